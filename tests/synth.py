@@ -1,0 +1,184 @@
+"""Deterministic synthetic weights/inputs for the Wan DiT and the Wan VAE.
+
+There are no checkpoints and no network here, so every parity test runs on seeded random
+weights of the reference architectures.  Weights come from numpy's legacy MT19937
+`RandomState` (bit-stable across numpy versions), NOT from torch's default init, so that the
+golden generator (run once, in the container that has /root/reference) and the tests (run
+anywhere) build bit-identical tensors without storing them.
+
+Parameter names and shapes follow the reference state dicts:
+  DiT: diffsynth/models/wan_video_dit.py:408-470 (WanModel.__init__), :321-336 (DiTBlock)
+  VAE: diffsynth/models/wan_video_vae.py:276-326 (Encoder3d), :379-430 (Decoder3d), :512-517
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------------- DiT
+def dit_param_shapes(dim: int, in_dim: int, ffn_dim: int, out_dim: int, text_dim: int, freq_dim: int,
+                     patch_size: Tuple[int, int, int], num_layers: int, has_image_input: bool) -> "OrderedDict[str, tuple]":
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def lin(name, o, i):
+        s[name + ".weight"] = (o, i)
+        s[name + ".bias"] = (o,)
+
+    s["patch_embedding.weight"] = (dim, in_dim, *patch_size)
+    s["patch_embedding.bias"] = (dim,)
+    lin("text_embedding.0", dim, text_dim)
+    lin("text_embedding.2", dim, dim)
+    lin("time_embedding.0", dim, freq_dim)
+    lin("time_embedding.2", dim, dim)
+    lin("time_projection.1", dim * 6, dim)
+    for i in range(num_layers):
+        b = f"blocks.{i}."
+        s[b + "modulation"] = (1, 6, dim)
+        for att in ("self_attn", "cross_attn"):
+            for nm in ("q", "k", "v", "o"):
+                lin(b + att + "." + nm, dim, dim)
+            s[b + att + ".norm_q.weight"] = (dim,)
+            s[b + att + ".norm_k.weight"] = (dim,)
+            if att == "cross_attn" and has_image_input:
+                lin(b + att + ".k_img", dim, dim)
+                lin(b + att + ".v_img", dim, dim)
+                s[b + att + ".norm_k_img.weight"] = (dim,)
+        s[b + "norm3.weight"] = (dim,)
+        s[b + "norm3.bias"] = (dim,)
+        lin(b + "ffn.0", ffn_dim, dim)
+        lin(b + "ffn.2", dim, ffn_dim)
+    s["head.modulation"] = (1, 2, dim)
+    lin("head.head", out_dim * int(np.prod(patch_size)), dim)
+    if has_image_input:
+        s["img_emb.proj.0.weight"] = (1280,)
+        s["img_emb.proj.0.bias"] = (1280,)
+        lin("img_emb.proj.1", 1280, 1280)
+        lin("img_emb.proj.3", dim, 1280)
+        s["img_emb.proj.4.weight"] = (dim,)
+        s["img_emb.proj.4.bias"] = (dim,)
+    return s
+
+
+def _fill(rs: np.random.RandomState, name: str, shape: tuple) -> np.ndarray:
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "modulation":
+        return (rs.standard_normal(shape) / math.sqrt(shape[-1])).astype(np.float32)
+    if leaf == "gamma" or (leaf == "weight" and len(shape) == 1):
+        return (1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32)      # norm gains
+    if leaf == "bias" and ("norm" in name or name.startswith("img_emb.proj.0") or name.startswith("img_emb.proj.4")):
+        return (0.1 * rs.standard_normal(shape)).astype(np.float32)
+    if leaf == "weight":
+        fan_in = int(np.prod(shape[1:]))
+        bound = 1.0 / math.sqrt(fan_in)
+        return rs.uniform(-bound, bound, size=shape).astype(np.float32)
+    if leaf == "bias":
+        return rs.uniform(-0.05, 0.05, size=shape).astype(np.float32)
+    raise KeyError(name)
+
+
+def dit_state_dict(seed: int, **cfg) -> Dict[str, np.ndarray]:
+    rs = np.random.RandomState(seed)
+    return OrderedDict((k, _fill(rs, k, shp)) for k, shp in dit_param_shapes(**cfg).items())
+
+
+TINY_DIT = dict(dim=128, in_dim=16, ffn_dim=256, out_dim=16, text_dim=64, freq_dim=256,
+                patch_size=(1, 2, 2), num_layers=2, has_image_input=False)
+TINY_DIT_I2V = dict(dim=128, in_dim=36, ffn_dim=256, out_dim=16, text_dim=64, freq_dim=256,
+                    patch_size=(1, 2, 2), num_layers=2, has_image_input=True)
+SMALL_DIT = dict(dim=256, in_dim=16, ffn_dim=768, out_dim=16, text_dim=128, freq_dim=256,
+                 patch_size=(1, 2, 2), num_layers=2, has_image_input=False)
+WAN_1_3B = dict(dim=1536, in_dim=16, ffn_dim=8960, out_dim=16, text_dim=4096, freq_dim=256,
+                patch_size=(1, 2, 2), num_layers=30, has_image_input=False)
+
+
+def num_heads_of(cfg: dict) -> int:
+    return cfg["dim"] // 128          # the 3-D RoPE split needs head_dim == 128
+
+
+# ----------------------------------------------------------------------------------- VAE
+def vae_param_shapes() -> "OrderedDict[str, tuple]":
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    base, z, mult = 96, 16, (1, 2, 4, 4)
+
+    def conv3(name, o, i, k=(3, 3, 3)):
+        s[name + ".weight"] = (o, i, *k)
+        s[name + ".bias"] = (o,)
+
+    def conv2(name, o, i, k=3):
+        s[name + ".weight"] = (o, i, k, k)
+        s[name + ".bias"] = (o,)
+
+    def res(p, i, o):
+        s[p + "residual.0.gamma"] = (i, 1, 1, 1)
+        conv3(p + "residual.2", o, i)
+        s[p + "residual.3.gamma"] = (o, 1, 1, 1)
+        conv3(p + "residual.6", o, o)
+        if i != o:
+            conv3(p + "shortcut", o, i, (1, 1, 1))
+
+    def attn(p, c):
+        s[p + "norm.gamma"] = (c, 1, 1)
+        conv2(p + "to_qkv", 3 * c, c, 1)
+        conv2(p + "proj", c, c, 1)
+
+    # encoder
+    e = "model.encoder."
+    dims = [base * u for u in (1,) + mult]
+    conv3(e + "conv1", dims[0], 3)
+    idx, tdown = 0, (False, True, True)
+    for i, (di, do) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(2):
+            res(f"{e}downsamples.{idx}.", di, do); idx += 1
+            di = do
+        if i != len(mult) - 1:
+            conv2(f"{e}downsamples.{idx}.resample.1", do, do)
+            if tdown[i]:
+                conv3(f"{e}downsamples.{idx}.time_conv", do, do, (3, 1, 1))
+            idx += 1
+    top = dims[-1]
+    res(e + "middle.0.", top, top); attn(e + "middle.1.", top); res(e + "middle.2.", top, top)
+    s[e + "head.0.gamma"] = (top, 1, 1, 1)
+    conv3(e + "head.2", 2 * z, top)
+    conv3("model.conv1", 2 * z, 2 * z, (1, 1, 1))
+    conv3("model.conv2", z, z, (1, 1, 1))
+    # decoder
+    d = "model.decoder."
+    dims = [base * u for u in (mult[-1],) + mult[::-1]]
+    conv3(d + "conv1", dims[0], z)
+    res(d + "middle.0.", dims[0], dims[0]); attn(d + "middle.1.", dims[0]); res(d + "middle.2.", dims[0], dims[0])
+    idx, tup = 0, tdown[::-1]
+    for i, (di, do) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            di = di // 2
+        for _ in range(3):
+            res(f"{d}upsamples.{idx}.", di, do); idx += 1
+            di = do
+        if i != len(mult) - 1:
+            conv2(f"{d}upsamples.{idx}.resample.1", do // 2, do)
+            if tup[i]:
+                conv3(f"{d}upsamples.{idx}.time_conv", do * 2, do, (3, 1, 1))
+            idx += 1
+    s[d + "head.0.gamma"] = (dims[-1], 1, 1, 1)
+    conv3(d + "head.2", 3, dims[-1])
+    return s
+
+
+def vae_state_dict(seed: int) -> Dict[str, np.ndarray]:
+    rs = np.random.RandomState(seed)
+    return OrderedDict((k, _fill(rs, k, shp)) for k, shp in vae_param_shapes().items())
+
+
+# ----------------------------------------------------------------------------------- inputs
+def randn(seed: int, *shape) -> np.ndarray:
+    return np.random.RandomState(seed).standard_normal(shape).astype(np.float32)
+
+
+def text_context(seed: int, tokens: int, text_dim: int, valid: int) -> np.ndarray:
+    """[1, tokens, text_dim] with the padded tail zeroed, like diffsynth/prompters/wan_prompter.py:107-108."""
+    c = randn(seed, 1, tokens, text_dim)
+    c[:, valid:] = 0
+    return c

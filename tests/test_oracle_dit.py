@@ -1,0 +1,117 @@
+"""The DiT / scheduler oracle against the reference's own outputs (tests/golden, made by gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import rel_l2
+from oracle import flow_match_oracle as fmo
+from oracle import wan_dit_oracle as wdo
+
+CASES = {
+    "tiny_t2v": (synth.TINY_DIT, (3, 4, 6), 20, 13, 637.5, 100),
+    "small_t2v": (synth.SMALL_DIT, (2, 5, 7), 24, 24, 991.7355, 150),
+    "tiny_i2v": (synth.TINY_DIT_I2V, (2, 4, 4), 16, 10, 92.5926, 200),
+}
+
+
+def make_cfg(c):
+    return wdo.DiTConfig(dim=c["dim"], in_dim=c["in_dim"], ffn_dim=c["ffn_dim"], out_dim=c["out_dim"],
+                         text_dim=c["text_dim"], freq_dim=c["freq_dim"], patch_size=c["patch_size"],
+                         num_heads=synth.num_heads_of(c), num_layers=c["num_layers"],
+                         has_image_input=c["has_image_input"])
+
+
+def inputs(c, grid, ctx_tokens, ctx_valid, seed):
+    f, h, w = grid
+    x = torch.from_numpy(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w))
+    ctx = torch.from_numpy(synth.text_context(seed + 2, ctx_tokens, c["text_dim"], ctx_valid))
+    kw = {}
+    if c["has_image_input"]:
+        kw["clip_feature"] = torch.from_numpy(synth.randn(seed + 3, 1, 257, 1280))
+        kw["y"] = torch.from_numpy(synth.randn(seed + 4, 1, c["in_dim"] - 16, f, 2 * h, 2 * w))
+    return x, ctx, kw
+
+
+def bf16_values(sd):
+    return {k: v.to(torch.bfloat16).to(torch.float32) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_fp32_matches_reference(golden, name):
+    c, grid, nt, nv, ts, seed = CASES[name]
+    g = golden(f"dit_{name}.npz")
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    out = wdo.dit_forward(sd, make_cfg(c), x, torch.tensor([ts]), ctx, **kw)
+    assert out.shape == g["out_fp32"].shape
+    assert rel_l2(out.numpy(), g["out_fp32"]) < 2e-5          # fp32 round-off only
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_block_fp32_matches_reference(golden, name):
+    c, grid, nt, nv, ts, seed = CASES[name]
+    f, h, w = grid
+    g = golden(f"dit_{name}.npz")
+    cfg = make_cfg(c)
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
+    L = f * h * w
+    bx = torch.from_numpy(synth.randn(seed + 5, 1, L, c["dim"]))
+    bctx = torch.from_numpy(synth.randn(seed + 6, 1, nt + (257 if c["has_image_input"] else 0), c["dim"]))
+    btm = torch.from_numpy(0.5 * synth.randn(seed + 7, 1, 6, c["dim"]))
+    rope = wdo.rope_table_3d(cfg.head_dim, grid)
+    assert np.allclose(torch.view_as_real(rope).numpy(), g["rope_table"], rtol=0, atol=1e-12)
+    out = wdo.dit_block(sd, "blocks.0.", bx, bctx, btm, rope, cfg)
+    assert rel_l2(out.numpy(), g["block0_fp32"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_bf16_rounding_mode_tracks_reference_bf16(golden, name):
+    """rounding="bf16" restates WHERE the reference's bf16 run rounds; it must sit much closer to the
+    reference's bf16 output than bf16 noise itself (the gap fp32 <-> bf16 of the reference)."""
+    c, grid, nt, nv, ts, seed = CASES[name]
+    g = golden(f"dit_{name}.npz")
+    sd = bf16_values({k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()})
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    out = wdo.dit_forward(sd, make_cfg(c), x, torch.tensor([ts]), ctx, rounding="bf16", **kw)
+    noise = rel_l2(g["out_bf16"], g["out_fp32"])
+    err = rel_l2(out.numpy(), g["out_bf16"])
+    assert err < 1e-2 and err < noise, (err, noise)
+
+
+def test_scheduler_known_answers(golden):
+    g = golden("flow_match.npz")
+    for n in (4, 10, 50):
+        sig = fmo.shifted_sigmas(n, 5.0)
+        assert np.array_equal(sig, g[f"sigmas_{n}"])
+        assert np.array_equal(fmo.timesteps_from_sigmas(sig), g[f"timesteps_{n}"])
+        x = torch.from_numpy(synth.randn(7, 2, 3))
+        v = torch.from_numpy(synth.randn(8, 2, 3))
+        for i in range(n):
+            x = x + v * fmo.euler_delta(sig, i)
+            assert np.allclose(x.numpy(), g[f"euler_traj_{n}"][i], rtol=0, atol=1e-6)
+    # literal values quoted in SURVEY.md §8c / BASELINE.md
+    s10 = fmo.shifted_sigmas(10, 5.0)
+    assert np.allclose(s10, [1.0, 0.978261, 0.952381, 0.921053, 0.882353, 0.833333, 0.769231, 0.681818,
+                             0.555556, 0.357143], atol=1e-6)
+    t50 = fmo.timesteps_from_sigmas(fmo.shifted_sigmas(50, 5.0))
+    assert np.allclose(t50[:3], [1000.0, 995.9349, 991.7355], atol=1e-3)
+    assert np.allclose(t50[-3:], [241.9355, 172.4138, 92.5926], atol=1e-3)
+
+
+def test_seeded_noise_is_torch_cpu_generator(golden):
+    g = golden("denoise_tiny.npz")
+    assert np.array_equal(fmo.seeded_noise((8,), 11).numpy(), g["noise_head"])
+
+
+def test_denoise_loop_matches_reference(golden):
+    g = golden("denoise_tiny.npz")
+    c, seed, grid = synth.TINY_DIT, 300, (2, 4, 4)
+    f, h, w = grid
+    cfg = make_cfg(c)
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
+    lat = fmo.seeded_noise((1, 16, f, 2 * h, 2 * w), 11)
+    pos = torch.from_numpy(synth.text_context(seed + 2, 16, c["text_dim"], 9))
+    neg = torch.from_numpy(synth.text_context(seed + 3, 16, c["text_dim"], 4))
+    out = fmo.denoise_loop(lambda x, t, ctx: wdo.dit_forward(sd, cfg, x, t, ctx), lat, pos, neg, 4, 5.0, 5.0)
+    assert rel_l2(out.numpy(), g["latents"]) < 5e-5
