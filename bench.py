@@ -1,0 +1,232 @@
+"""bench.py — denoised latent frames / second of the SVI rolling-window hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): Wan2.1-T2V-1.3B architecture, random-init bf16 weights,
+one 81-frame 832x480 clip = latents [1,16,21,60,104] -> 32760 tokens, text context [1,512,4096] (pos/neg), CFG 5.0,
+flow-match shift 5, 50 scheduler steps per clip.  A bench "step" is ONE scheduler step of the clip's denoise loop:
+cond forward + uncond forward through all 30 DiT blocks + CFG combine + Euler update, latents resident in HBM.
+With N ranks every rank denoises its own clip (weak scaling, SURVEY §8e axis 1: T2V clips are independent); the
+only data-path exchange is the all-gather of each clip's tail (motion) latents over RCCL at the end of the region.
+
+    value = N * 21 latent frames / (50 * step_time + vae_decode_time)        [latent frames / s]
+
+The VAE decode of the finished clip is timed in the same run (outside the K-step region, on the same stream) and
+its time is part of `value`; `config.dit_only_value` reports the a1-only variant.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = self-attention flash kernel: algorithmic 4*L^2*D FLOP per launch divided by
+                its mean launch time measured with HIP events on the launch stream inside the timed region.
+  cpu_baseline  the CPU oracle (a restatement of the reference, oracle/wan_dit_oracle.py) timed on this box's
+                host cores on a bounded sample (one of the 30 blocks of one of the 100 forwards, full size),
+                extrapolated to a clip.  Rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "stable-video-infinity_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (latent T, H, W), context tokens, steps per clip
+    "c2": dict(lat=(21, 60, 104), lc=512, steps_per_clip=50, desc="Wan2.1-T2V-1.3B 81f@832x480 50-step CFG5 single clip per GPU"),
+    "c1": dict(lat=(5, 32, 32), lc=512, steps_per_clip=10, desc="Wan2.1-T2V-1.3B 17f@256x256 10-step CFG5 (reference CPU-runnable case)"),
+}
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def device_weights(cfg: dict, seed: int, device) -> dict:
+    """Random-init weights of the named architecture, generated on the GPU (no checkpoints, no network)."""
+    import synth
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = {}
+    for name, shape in synth.dit_param_shapes(**cfg).items():
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "modulation":
+            t = torch.randn(shape, generator=g, device=device) / math.sqrt(shape[-1])
+        elif leaf == "weight" and len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        elif leaf == "bias" and "norm" in name:
+            t = 0.1 * torch.randn(shape, generator=g, device=device)
+        elif leaf == "weight":
+            bound = 1.0 / math.sqrt(float(torch.tensor(shape[1:]).prod()))
+            t = (torch.rand(shape, generator=g, device=device) * 2 - 1) * bound
+        else:
+            t = (torch.rand(shape, generator=g, device=device) * 2 - 1) * 0.05
+        out[name] = t.to(torch.bfloat16).contiguous()
+    return out
+
+
+def cpu_baseline(threads: int) -> dict:
+    """Time the oracle's DiTBlock at the full C2 size on the host cores; extrapolate to a clip (30 blocks x 100 forwards)."""
+    import synth
+    from oracle import wan_dit_oracle as wdo
+    torch.set_num_threads(threads)
+    c = dict(synth.WAN_1_3B)
+    c["num_layers"] = 1
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(0, **c).items()}
+    cfg = wdo.DiTConfig(num_layers=1)
+    L = 21 * 30 * 52
+    x = torch.from_numpy(synth.randn(1, 1, L, 1536))
+    ctx = torch.from_numpy(synth.randn(2, 1, 512, 1536))
+    tm = torch.from_numpy(0.1 * synth.randn(3, 1, 6, 1536))
+    rope = wdo.rope_table_3d(128, (21, 30, 52))
+    t0 = time.time()
+    with torch.no_grad():
+        wdo.dit_block(sd, "blocks.0.", x, ctx, tm, rope, cfg)
+    dt = time.time() - t0
+    clip_s = dt * 30 * 100
+    return {"value": 21.0 / clip_s, "unit": "latent frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 DiTBlock forward (fp32 oracle) at L=32760 took {dt:.1f}s; extrapolated x30 blocks x100 forwards per clip, VAE excluded"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import synth
+    import svi_hip
+    from svi_hip import _lib
+
+    wl = WORKLOADS[args.workload]
+    T, H, W = wl["lat"]
+    cfg = dict(synth.WAN_1_3B)
+    dit = svi_hip.WanDiT(eps=1e-6, num_heads=12, **cfg)
+    dit.bind(device_weights(cfg, 0, dev))
+    loop = svi_hip.DenoiseLoop(dit)
+    spc = wl["steps_per_clip"]
+    loop.scheduler.set_timesteps(spc, shift=5.0)
+
+    # clip `rank` of the rolling window: seed = chunk_idx * 42 (test_svi.py:425), noise from the CPU generator
+    lat = svi_hip.generate_noise((1, 16, T, H, W), seed=rank * 42, device="cpu", dtype=torch.float32).to(dev, torch.bfloat16)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    ctx_pos = torch.randn((1, wl["lc"], 4096), generator=gen, device=dev).to(torch.bfloat16)
+    ctx_neg = torch.randn((1, wl["lc"], 4096), generator=gen, device=dev).to(torch.bfloat16)
+    ctx_pos[:, 64:] = 0
+    ctx_neg[:, 32:] = 0
+    ts_dev = loop.scheduler.timesteps.to(dev, torch.float32)
+
+    def one_step(i: int) -> None:
+        j = i % spc
+        loop.step(lat, ts_dev[j:j + 1], loop.scheduler.step_delta(loop.scheduler.timesteps[j]), ctx_pos, ctx_neg, 5.0)
+
+    def sync() -> None:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    sync()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    if dist is not None:
+        # hand the clip's tail (motion) latents to every rank, as the rolling window stitches clips (test_svi.py:472-476)
+        tail = lat[:, :, -1:].contiguous()
+        gathered = [torch.empty_like(tail) for _ in range(world)]
+        dist.all_gather(gathered, tail)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.prof_summary()
+    _lib.prof_enable(False)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(lat.float()).all().item())
+
+    # VAE decode of the finished clip (fp32, as pipelines/svi_video.py:385-389), timed once on the same stream
+    vae_ms = None
+    if not args.no_vae:
+        try:
+            from svi_hip.vae import WanVideoVAE, device_vae_weights
+            vae = WanVideoVAE.from_state_dict(device_vae_weights(0, dev))
+            z = lat.float()
+            vae.decode(z, device=dev)                      # warm-up (workspace allocation)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            vid = vae.decode(z, device=dev)
+            e1.record()
+            torch.cuda.synchronize()
+            vae_ms = e0.elapsed_time(e1)
+            finite = finite and bool(torch.isfinite(vid).all().item())
+        except (ImportError, RuntimeError) as ex:          # VAE kernels not built yet -> DiT-only metric, said so below
+            vae_ms = None
+            vae_note = str(ex)[:120]
+
+    ms_per_step = elapsed * 1000.0 / args.steps
+    clip_s_dit = spc * ms_per_step / 1000.0
+    clip_s = clip_s_dit + (vae_ms or 0.0) / 1000.0
+    frames = float(T)
+    value = world * frames / clip_s
+    L = (T // 1) * (H // 2) * (W // 2)
+    flops_forward = 30 * (12 * L * 1536 ** 2 + 4 * L * L * 1536 + 4 * wl["lc"] * 1536 ** 2 + 4 * L * wl["lc"] * 1536 + 4 * L * 1536 * 8960)
+    fl = prof.get("flash_self", {"count": 0, "ms": 0.0})
+    roof = None
+    if fl["count"]:
+        per_launch_ms = fl["ms"] / fl["count"]
+        alg = 4.0 * L * L * 1536
+        ach = alg / (per_launch_ms * 1e-3) / 1e12
+        roof = {"kernel": "flash_fwd_kernel (self-attention)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4)}
+    line = {
+        "metric": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step" if args.workload == "c2" else "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",
+        "value": round(value, 5), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
+        "config": {"workload": wl["desc"], "step": "1 scheduler step = cond+uncond DiT forward (30 blocks) + CFG + Euler",
+                   "steps_per_clip": spc, "tokens": L, "clips_per_gpu": 1, "parallelism": f"clip-per-rank x{world}",
+                   "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
+                   "value_includes_vae_decode": vae_ms is not None,
+                   "dit_only_value": round(world * frames / clip_s_dit, 5),
+                   "dit_tflops": round(2 * flops_forward / (ms_per_step * 1e-3) / 1e12, 1),
+                   "outputs_finite": finite},
+        "roofline": roof,
+        "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

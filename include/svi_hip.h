@@ -1,0 +1,169 @@
+/* svi_hip.h — C ABI of libsvi_hip.so: the MI355X (gfx950) native backend for the
+ * Stable-Video-Infinity rolling-window denoising hot path (Wan DiT block stack + flow-match
+ * step + Wan 3-D causal VAE).
+ *
+ * The reference (vita-epfl/Stable-Video-Infinity) has no FFI: its boundary is a Python call
+ * surface.  Each entry point below names the reference function it stands in for
+ * (paths relative to the reference's diffsynth/ package); INTEGRATION.md shows the ctypes stub
+ * that binds it underneath the unchanged reference call surface.
+ *
+ * Conventions
+ *   - Plain C: opaque handles, raw DEVICE pointers, sizes.  No torch / HIP types in signatures
+ *     (svi_stream is a hipStream_t passed as void*; NULL = the null stream).
+ *   - Ownership: the caller owns every tensor (weights, inputs, outputs).  The library borrows
+ *     pointers for the duration of a call; weight pointers for the lifetime of the binding
+ *     (re-bind after a LoRA merge or any .to()/offload that moves storage).  The library owns
+ *     only its workspace (allocated at first use for a given problem size, never in steady state).
+ *   - All work is enqueued on the caller's stream; no internal synchronisation in steady state.
+ *   - Errors: integer status, never abort/throw across the ABI; message via svi_last_error()
+ *     (thread-local).  There is NO CPU fallback: with no usable GPU every compute call fails.
+ *   - Activations are bf16 (row-major, innermost dim contiguous) unless stated; accumulation fp32.
+ *   - Handles are not thread-safe; one handle per device.
+ */
+#ifndef SVI_HIP_H
+#define SVI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVI_HIP_ABI_VERSION 1
+
+typedef enum {
+    SVI_OK = 0,
+    SVI_ERR_INVALID = 1,      /* bad argument / shape */
+    SVI_ERR_UNBOUND = 2,      /* a required weight was never bound */
+    SVI_ERR_HIP = 3,          /* HIP runtime error (message has hipGetErrorString) */
+    SVI_ERR_UNSUPPORTED = 4,  /* valid in the reference, not implemented here */
+    SVI_ERR_OOM = 5
+} svi_status;
+
+typedef enum { SVI_BF16 = 0, SVI_F32 = 1 } svi_dtype;
+
+typedef void* svi_stream;
+typedef struct svi_dit svi_dit;
+typedef struct svi_vae svi_vae;
+
+/* Constructor arguments of models/wan_video_dit.py:408-421 (WanModel.__init__). head_dim must be 128. */
+typedef struct {
+    int32_t dim, in_dim, ffn_dim, out_dim, text_dim, freq_dim;
+    float eps;
+    int32_t patch_t, patch_h, patch_w;
+    int32_t num_heads, num_layers;
+    int32_t has_image_input;
+} svi_dit_config;
+
+/* GEMM epilogues (fused; see svi_gemm_bf16). */
+typedef enum {
+    SVI_EPI_BIAS = 0,           /* C = bf16(acc + bias)                                   nn.Linear            */
+    SVI_EPI_BIAS_GELU_TANH = 1, /* C = bf16(gelu_tanh(bf16(acc + bias)))                  ffn.0+GELU  dit:334  */
+    SVI_EPI_BIAS_GATE_RES = 2,  /* C = bf16(res + bf16(gate[n] * bf16(acc + bias)))       dit:369,370,373      */
+    SVI_EPI_BIAS_GELU_ERF = 3,  /* exact GELU                                             img_emb     dit:383  */
+    SVI_EPI_BIAS_SILU = 4       /* C = bf16(silu(bf16(acc+bias)))                         time_embedding       */
+} svi_epilogue;
+
+const char* svi_last_error(void);
+int32_t svi_abi_version(void);
+/* Number of visible HIP devices (0 => every compute entry point will fail with SVI_ERR_HIP). */
+int32_t svi_device_count(void);
+
+/* ------------------------------------------------------------------ DiT: whole model ------ */
+/* WanModel(...) construction (weights are bound afterwards, by reference state-dict key). */
+svi_status svi_dit_create(const svi_dit_config* cfg, svi_dit** out);
+svi_status svi_dit_destroy(svi_dit* h);
+/* name = reference state-dict key, e.g. "blocks.0.self_attn.q.weight" (models/wan_video_dit.py
+ * module tree).  dtype must be SVI_BF16 (the pipelines run the DiT in bf16, pipelines/svi_video.py:259).
+ * shape is checked against the config. */
+svi_status svi_dit_bind_weight(svi_dit* h, const char* name, const void* dev_ptr, svi_dtype dtype,
+                               const int64_t* shape, int32_t rank);
+/* Returns SVI_OK when every parameter the config requires has been bound; otherwise
+ * SVI_ERR_UNBOUND with the first missing key in svi_last_error(). */
+svi_status svi_dit_check_bound(svi_dit* h);
+
+/* model_fn_wan_video(dit, x, timestep, context, clip_feature, y, add_condition)
+ * (pipelines/svi_video.py:74-137; same math as WanModel.forward, models/wan_video_dit.py:486-567).
+ *   x            bf16 [B, 16, T, H, W]           latents
+ *   timestep     f32  [B]            (device)    flow-match timestep (pipelines/svi_video.py:397)
+ *   context      bf16 [B, Lc, text_dim]          T5 embeddings (un-projected)
+ *   clip_feature bf16 [B, 257, 1280] or NULL     I2V only
+ *   y            bf16 [B, in_dim-16, T, H, W] or NULL   I2V only (mask ‖ VAE latent)
+ *   add_condition bf16 [B, L, dim] or NULL       added to patch tokens (dance pose embedder)
+ *   out          bf16 [B, out_dim, T, H, W]      velocity prediction
+ * TeaCache and USP hooks of the reference function are not part of this entry point. */
+svi_status svi_dit_forward(svi_dit* h, const void* x, const float* timestep, const void* context,
+                           const void* clip_feature, const void* y, const void* add_condition,
+                           void* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc,
+                           svi_stream stream);
+
+/* DiTBlock.forward(x, context, t_mod, freqs) for block `layer` (models/wan_video_dit.py:354-374).
+ *   x_inout bf16 [L, dim] (L = f*h*w, updated in place); context bf16 [Lc(+257), dim] ALREADY
+ *   projected by text_embedding/img_emb; t_mod bf16 [6, dim]; freqs implied by the (f,h,w) grid. */
+svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_inout, const void* context,
+                                 const void* t_mod, int32_t f, int32_t hh, int32_t ww, int32_t Lc,
+                                 svi_stream stream);
+
+/* ------------------------------------------------------------------ operator seams -------- */
+/* flash_attention(q, k, v, num_heads) (models/wan_video_dit.py:116-147): layout [b, s, (n d)],
+ * unmasked softmax(q k^T / sqrt(d)) v, d must be 128.  out may not alias the inputs. */
+svi_status svi_attention_fwd(const void* q, const void* k, const void* v, void* out, int32_t b,
+                             int32_t s_q, int32_t s_kv, int32_t n, int32_t d, svi_stream stream);
+
+/* nn.LayerNorm(eps) [+ affine w,b] [+ modulate(x, shift, scale)] over rows of x[rows, dim]
+ * (models/wan_video_dit.py:150-151,331-333,358,372).  w,b,shift,scale are bf16 [dim] or NULL. */
+svi_status svi_layernorm_modulate(const void* x, void* out, int32_t rows, int32_t dim, float eps,
+                                  const void* w, const void* b, const void* shift, const void* scale,
+                                  svi_stream stream);
+
+/* RMSNorm over the full model dim, then (optionally) 3-D RoPE per head, in place on x[rows, ld]
+ * (models/wan_video_dit.py:186-197 then :178-183).  grid f*h*w must equal rows when rope != 0. */
+svi_status svi_rmsnorm_rope(void* x, int32_t ld, int32_t rows, int32_t dim, const void* weight, float eps,
+                            int32_t rope, int32_t num_heads, int32_t f, int32_t h, int32_t w,
+                            svi_stream stream);
+
+/* C[M,N] = epilogue(A[M,K] · W[N,K]^T)  — nn.Linear with the weight in its native [out,in] layout.
+ * bias bf16 [N] (or [M] when bias_along_m, used to emit V^T); gate f32 [N] or NULL; res bf16 [M,ldres]
+ * (may alias C).  K multiple of 8; lda/ldw/ldc multiples of 8 elements. */
+svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t ldc,
+                         int32_t M, int32_t N, int32_t K, const void* bias, int32_t bias_along_m,
+                         int32_t epilogue, const float* gate, const void* res, int32_t ldres,
+                         svi_stream stream);
+
+/* Classifier-free-guidance combine + FlowMatchScheduler.step, fused (pipelines/svi_video.py:410,420;
+ * schedulers/flow_match.py:53-64):  lat += (uncond + s*(cond-uncond)) * (sigma_next - sigma), bf16,
+ * rounded after every op exactly like the reference's bf16 tensor arithmetic.  uncond may be NULL
+ * (cfg_scale == 1 path). */
+svi_status svi_cfg_step(void* latents, const void* cond, const void* uncond, int64_t n, float cfg_scale,
+                        float dsigma, svi_stream stream);
+
+/* ------------------------------------------------------------------ measurement ----------- */
+/* Per-kernel timing with HIP events recorded on the launch stream (so it measures the kernels where
+ * they run, inside the caller's timed region).  Off by default; when on, every tagged launch inside
+ * svi_dit_forward / svi_vae_* is bracketed by an event pair.  svi_prof_summary synchronises the
+ * recorded events and writes one JSON object {"tag": {"count": n, "ms": total_ms}, ...} into buf. */
+svi_status svi_prof_enable(int32_t on);
+svi_status svi_prof_summary(char* buf, int64_t buflen);
+
+/* ------------------------------------------------------------------ VAE ------------------- */
+/* WanVideoVAE() (models/wan_video_vae.py:599-618): fixed architecture (dim 96, z 16, mult 1,2,4,4). */
+svi_status svi_vae_create(svi_vae** out);
+svi_status svi_vae_destroy(svi_vae* h);
+/* name = reference state-dict key ("model.decoder.conv1.weight", ...); dtype SVI_F32
+ * (the pipelines run the VAE in fp32: pipelines/svi_video.py:386-387,303-309). */
+svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const void* dev_ptr, svi_dtype dtype,
+                               const int64_t* shape, int32_t rank);
+svi_status svi_vae_check_bound(svi_vae* h);
+/* WanVideoVAE.decode -> single_decode -> VideoVAE_.decode (models/wan_video_vae.py:777-789,753-756,552-575)
+ *   latents f32 [16, T, h, w]  ->  video f32 [3, 1+4(T-1), 8h, 8w], clamped to [-1,1]. */
+svi_status svi_vae_decode(svi_vae* h, const float* latents, float* video, int32_t T, int32_t hh, int32_t ww,
+                          svi_stream stream);
+/* WanVideoVAE.encode -> single_encode -> VideoVAE_.encode (models/wan_video_vae.py:759-774,747-750,525-550)
+ *   video f32 [3, 1+4k, H, W]  ->  latents f32 [16, 1+k, H/8, W/8]  (normalised mean). */
+svi_status svi_vae_encode(svi_vae* h, const float* video, float* latents, int32_t T, int32_t H, int32_t W,
+                          svi_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVI_HIP_H */

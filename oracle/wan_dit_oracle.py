@@ -144,16 +144,28 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     return y if b is None else y + b
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
-    """[B,Lq,H*dh] x [B,Lk,H*dh] -> [B,Lq,H*dh]; unmasked softmax(QK^T/sqrt(dh))V (dit:116-147)."""
+def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int, q_chunk: int = 512) -> Tensor:
+    """[B,Lq,H*dh] x [B,Lk,H*dh] -> [B,Lq,H*dh]; unmasked softmax(QK^T/sqrt(dh))V (dit:116-147).
+    Queries are processed `q_chunk` rows at a time (exact; only bounds the size of the score matrix)."""
     b, lq, d = q.shape
     dh = d // num_heads
     qh = q.reshape(b, lq, num_heads, dh).permute(0, 2, 1, 3)
-    kh = k.reshape(b, -1, num_heads, dh).permute(0, 2, 1, 3)
+    kt = k.reshape(b, -1, num_heads, dh).permute(0, 2, 3, 1)
     vh = v.reshape(b, -1, num_heads, dh).permute(0, 2, 1, 3)
-    s = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
-    p = torch.softmax(s, dim=-1)
-    return (p @ vh).permute(0, 2, 1, 3).reshape(b, lq, d)
+    out = torch.empty_like(qh)
+    lk = kt.shape[-1]
+    q_chunk = max(1, min(q_chunk, lq))
+    sc = torch.empty((b, num_heads, q_chunk, lk), dtype=q.dtype)          # reused: avoids multi-GB realloc per chunk
+    scale = 1.0 / math.sqrt(dh)
+    for s0 in range(0, lq, q_chunk):
+        n = min(q_chunk, lq - s0)
+        s_ = sc[:, :, :n]
+        torch.matmul(qh[:, :, s0:s0 + n], kt, out=s_)
+        s_.mul_(scale)
+        s_.sub_(s_.amax(dim=-1, keepdim=True)).exp_()
+        s_.div_(s_.sum(dim=-1, keepdim=True))
+        torch.matmul(s_, vh, out=out[:, :, s0:s0 + n])
+    return out.permute(0, 2, 1, 3).reshape(b, lq, d)
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,203 @@
+// svi_api.hip — C-ABI glue of libsvi_hip.so: error plumbing and the operator-level entry points
+// (the seams the reference exposes: flash_attention, LayerNorm+modulate, RMSNorm+RoPE, Linear, CFG step).
+#include <stdlib.h>
+#include <string.h>
+
+#include "svi_common.h"
+
+static thread_local char g_err[512] = "";
+
+void svi_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* svi_last_error(void) { return g_err; }
+extern "C" int32_t svi_abi_version(void) { return SVI_HIP_ABI_VERSION; }
+extern "C" int32_t svi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ---- event profiler ------------------------------------------------------------------------------
+#include <vector>
+bool g_svi_prof_on = false;
+namespace {
+struct ProfRec { int tag; hipEvent_t a, b; };
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t g_prof_open[PROF_NTAGS];
+const char* kProfNames[PROF_NTAGS] = {"ln_modulate", "gemm_qkv", "rmsnorm_rope", "flash_self", "gemm_attn_out",
+                                      "gemm_cross", "flash_cross", "gemm_ffn1", "gemm_ffn2", "embed", "head",
+                                      "vae_conv", "vae_other"};
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+void svi_prof_begin_impl(int tag, hipStream_t st) {
+    hipEvent_t e = prof_event();
+    (void)hipEventRecord(e, st);
+    g_prof_open[tag] = e;
+}
+void svi_prof_end_impl(int tag, hipStream_t st) {
+    hipEvent_t e = prof_event();
+    (void)hipEventRecord(e, st);
+    g_prof_recs.push_back(ProfRec{tag, g_prof_open[tag], e});
+}
+extern "C" svi_status svi_prof_enable(int32_t on) {
+    for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+    g_prof_recs.clear();
+    g_svi_prof_on = on != 0;
+    return SVI_OK;
+}
+extern "C" svi_status svi_prof_summary(char* buf, int64_t buflen) {
+    SVI_REQUIRE(buf && buflen > 64, "svi_prof_summary: buffer too small");
+    double ms[PROF_NTAGS] = {0};
+    long cnt[PROF_NTAGS] = {0};
+    for (auto& r : g_prof_recs) {
+        SVI_CHECK_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        SVI_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.tag] += t; cnt[r.tag] += 1;
+    }
+    int64_t o = 0;
+    o += snprintf(buf + o, buflen - o, "{");
+    bool first = true;
+    for (int i = 0; i < PROF_NTAGS; ++i) {
+        if (!cnt[i]) continue;
+        if (buflen - o < 96) break;
+        o += snprintf(buf + o, buflen - o, "%s\"%s\": {\"count\": %ld, \"ms\": %.6f}", first ? "" : ", ", kProfNames[i], cnt[i], ms[i]);
+        first = false;
+    }
+    snprintf(buf + o, buflen - o, "}");
+    return SVI_OK;
+}
+
+// ---- scratch owned by the operator seams (grown on demand, never in steady state) ----------------
+namespace {
+struct Scratch {
+    char* p = nullptr;
+    size_t bytes = 0;
+};
+Scratch g_scratch;
+
+svi_status scratch_reserve(size_t bytes, char** out) {
+    if (g_scratch.bytes < bytes) {
+        if (g_scratch.p) { SVI_CHECK_HIP(hipFree(g_scratch.p)); g_scratch.p = nullptr; g_scratch.bytes = 0; }
+        hipError_t e = hipMalloc((void**)&g_scratch.p, bytes);
+        if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B scratch) failed: %s", bytes, hipGetErrorString(e)); return SVI_ERR_OOM; }
+        g_scratch.bytes = bytes;
+    }
+    *out = g_scratch.p;
+    return SVI_OK;
+}
+
+__global__ void f32_prepare_kernel(const bf16* __restrict__ in, float* __restrict__ out, int n, int one_plus) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = (float)in[i];
+    out[i] = one_plus ? rbf(1.0f + v) : v;
+}
+}  // namespace
+
+extern "C" svi_status svi_attention_fwd(const void* q, const void* k, const void* v, void* out, int32_t b, int32_t s_q,
+                                        int32_t s_kv, int32_t n, int32_t d, svi_stream stream) {
+    SVI_REQUIRE(q && k && v && out, "svi_attention_fwd: null argument");
+    SVI_REQUIRE(d == 128, "svi_attention_fwd: head dim %d unsupported (Wan DiT heads are 128 wide)", d);
+    SVI_REQUIRE(b > 0 && s_q > 0 && s_kv > 0 && n > 0, "svi_attention_fwd: bad sizes");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int D = n * d;
+    const int ldvt = ((s_kv + 7) / 8) * 8;
+    char* scr = nullptr;
+    SVI_TRY(scratch_reserve((size_t)D * ldvt * 2, &scr));
+    bf16* vt = reinterpret_cast<bf16*>(scr);
+    if (ldvt != s_kv) SVI_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)D * ldvt * 2, st));
+    for (int i = 0; i < b; ++i) {
+        const bf16* qi = reinterpret_cast<const bf16*>(q) + (size_t)i * s_q * D;
+        const bf16* ki = reinterpret_cast<const bf16*>(k) + (size_t)i * s_kv * D;
+        const bf16* vi = reinterpret_cast<const bf16*>(v) + (size_t)i * s_kv * D;
+        bf16* oi = reinterpret_cast<bf16*>(out) + (size_t)i * s_q * D;
+        SVI_TRY(svi_launch_transpose(vi, D, vt, ldvt, s_kv, D, st));
+        SVI_TRY(svi_launch_flash(qi, D, ki, D, vt, ldvt, oi, D, s_q, s_kv, n, st));
+    }
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_layernorm_modulate(const void* x, void* out, int32_t rows, int32_t dim, float eps, const void* w,
+                                             const void* b, const void* shift, const void* scale, svi_stream stream) {
+    SVI_REQUIRE(x && out, "svi_layernorm_modulate: null argument");
+    SVI_REQUIRE((shift == nullptr) == (scale == nullptr), "shift and scale must come together");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float *fs = nullptr, *fc = nullptr;
+    if (shift) {
+        char* scr = nullptr;
+        SVI_TRY(scratch_reserve((size_t)2 * dim * 4, &scr));
+        float* f = reinterpret_cast<float*>(scr);
+        hipLaunchKernelGGL(f32_prepare_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, reinterpret_cast<const bf16*>(shift), f, dim, 0);
+        hipLaunchKernelGGL(f32_prepare_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, reinterpret_cast<const bf16*>(scale), f + dim, dim, 1);
+        SVI_LAUNCH_CHECK();
+        fs = f; fc = f + dim;
+    }
+    return svi_launch_ln_mod(reinterpret_cast<const bf16*>(x), dim, reinterpret_cast<bf16*>(out), dim, rows, dim, eps,
+                             reinterpret_cast<const bf16*>(w), reinterpret_cast<const bf16*>(b), fs, fc, st);
+}
+
+extern "C" svi_status svi_rmsnorm_rope(void* x, int32_t ld, int32_t rows, int32_t dim, const void* weight, float eps,
+                                       int32_t rope, int32_t num_heads, int32_t f, int32_t h, int32_t w, svi_stream stream) {
+    SVI_REQUIRE(x && weight, "svi_rmsnorm_rope: null argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!rope)
+        return svi_launch_rmsnorm_rope(reinterpret_cast<bf16*>(x), ld, rows, dim, reinterpret_cast<const bf16*>(weight), eps, nullptr, st);
+    SVI_REQUIRE(num_heads > 0 && dim == num_heads * 128, "rope needs head_dim 128");
+    SVI_REQUIRE(f > 0 && h > 0 && w > 0 && f * h * w == rows, "rope grid %dx%dx%d != rows %d", f, h, w, rows);
+    // table built on the host in fp64 exactly as precompute_freqs_cis_3d does (dit:161-175)
+    const int dh = 128, d_hw = dh / 3, d_f = dh - 2 * d_hw;
+    const int npf = d_f / 2, nph = d_hw / 2, npw = d_hw / 2;
+    const size_t cnt = (size_t)f * npf + (size_t)h * nph + (size_t)w * npw;
+    float2* host = (float2*)malloc(cnt * sizeof(float2));
+    if (!host) { svi_set_error("out of host memory"); return SVI_ERR_OOM; }
+    size_t o = 0;
+    const int lens[3] = {f, h, w}, dims[3] = {d_f, d_hw, d_hw}, nps[3] = {npf, nph, npw};
+    for (int a = 0; a < 3; ++a)
+        for (int p = 0; p < lens[a]; ++p)
+            for (int i = 0; i < nps[a]; ++i) {
+                const double ang = (double)p / pow(10000.0, (double)(2 * i) / (double)dims[a]);
+                host[o++] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+    char* scr = nullptr;
+    svi_status s = scratch_reserve(cnt * sizeof(float2), &scr);
+    if (s != SVI_OK) { free(host); return s; }
+    hipError_t e = hipMemcpy(scr, host, cnt * sizeof(float2), hipMemcpyHostToDevice);
+    free(host);
+    if (e != hipSuccess) { svi_set_error("hipMemcpy(rope table) failed: %s", hipGetErrorString(e)); return SVI_ERR_HIP; }
+    SviRope r;
+    r.tab_f = reinterpret_cast<const float2*>(scr);
+    r.tab_h = r.tab_f + (size_t)f * npf;
+    r.tab_w = r.tab_h + (size_t)h * nph;
+    r.npf = npf; r.nph = nph; r.npw = npw; r.f = f; r.h = h; r.w = w;
+    return svi_launch_rmsnorm_rope(reinterpret_cast<bf16*>(x), ld, rows, dim, reinterpret_cast<const bf16*>(weight), eps, &r, st);
+}
+
+extern "C" svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t ldc, int32_t M,
+                                    int32_t N, int32_t K, const void* bias, int32_t bias_along_m, int32_t epilogue,
+                                    const float* gate, const void* res, int32_t ldres, svi_stream stream) {
+    SVI_REQUIRE(A && W && C, "svi_gemm_bf16: null argument");
+    SviGemmArgs g{reinterpret_cast<const bf16*>(A), lda, reinterpret_cast<const bf16*>(W), ldw, reinterpret_cast<bf16*>(C), ldc,
+                  M, N, K, reinterpret_cast<const bf16*>(bias), bias_along_m, epilogue, gate,
+                  reinterpret_cast<const bf16*>(res), ldres};
+    return svi_launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" svi_status svi_cfg_step(void* latents, const void* cond, const void* uncond, int64_t n, float cfg_scale,
+                                   float dsigma, svi_stream stream) {
+    SVI_REQUIRE(latents && cond, "svi_cfg_step: null argument");
+    return svi_launch_cfg_step(reinterpret_cast<bf16*>(latents), reinterpret_cast<const bf16*>(cond),
+                               reinterpret_cast<const bf16*>(uncond), n, cfg_scale, dsigma,
+                               reinterpret_cast<hipStream_t>(stream));
+}

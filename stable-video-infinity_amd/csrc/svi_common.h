@@ -1,0 +1,131 @@
+// svi_common.h — shared device helpers and host-side error plumbing for libsvi_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/svi_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define SVI_WAVE 64
+
+// ---- host: status + thread-local message -------------------------------------------------
+void svi_set_error(const char* fmt, ...);
+
+#define SVI_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            svi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SVI_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define SVI_REQUIRE(cond, ...)                                                                \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            svi_set_error(__VA_ARGS__);                                                       \
+            return SVI_ERR_INVALID;                                                           \
+        }                                                                                     \
+    } while (0)
+
+#define SVI_LAUNCH_CHECK()                                                                    \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess) {                                                               \
+            svi_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SVI_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define SVI_TRY(expr)                                                                         \
+    do {                                                                                      \
+        svi_status _s = (expr);                                                               \
+        if (_s != SVI_OK) return _s;                                                          \
+    } while (0)
+
+// ---- device helpers ----------------------------------------------------------------------
+#ifdef __HIPCC__
+// value of a float after a round trip through bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32):
+// the reference materialises a bf16 tensor after every op, this restates that rounding point.
+__device__ __forceinline__ float rbf(float v) { return (float)(bf16)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+#endif
+
+// ---- event profiler (svi_prof_enable / svi_prof_summary) ---------------------------------------
+enum SviProfTag {
+    PROF_LN = 0, PROF_GEMM_QKV, PROF_RMS_ROPE, PROF_FLASH_SELF, PROF_GEMM_O, PROF_GEMM_CROSS, PROF_FLASH_CROSS,
+    PROF_GEMM_FFN1, PROF_GEMM_FFN2, PROF_EMBED, PROF_HEAD, PROF_VAE_CONV, PROF_VAE_OTHER, PROF_NTAGS
+};
+extern bool g_svi_prof_on;
+void svi_prof_begin_impl(int tag, hipStream_t st);
+void svi_prof_end_impl(int tag, hipStream_t st);
+struct SviProfScope {
+    int tag; hipStream_t st;
+    SviProfScope(int t, hipStream_t s) : tag(t), st(s) { if (g_svi_prof_on) svi_prof_begin_impl(tag, st); }
+    ~SviProfScope() { if (g_svi_prof_on) svi_prof_end_impl(tag, st); }
+};
+
+// ---- kernel launchers shared between translation units (all enqueue on `st`) ----------------
+struct SviGemmArgs {
+    const bf16* A; int lda;
+    const bf16* W; int ldw;
+    bf16* C; int ldc;
+    int M, N, K;
+    const bf16* bias; int bias_along_m;
+    int epi;
+    const float* gate;
+    const bf16* res; int ldres;
+};
+svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
+
+// Q [Lq, ldq], K [Lk, ldk] token-major with head hd at column hd*128; VT [(n*128), ldvt] = V transposed
+// (row = channel, col = key; columns >= Lk up to the next multiple of 8 must be readable and finite).
+svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt,
+                            bf16* O, int ldo, int Lq, int Lk, int num_heads, hipStream_t st);
+
+svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int rows, int dim, float eps,
+                             const bf16* w, const bf16* b, const float* shift, const float* scale1p,
+                             hipStream_t st);
+struct SviRope {                // device tables of (cos,sin) pairs, fp32
+    const float2* tab_f; const float2* tab_h; const float2* tab_w;
+    int npf, nph, npw;          // complex pairs per head owned by the frame / height / width axis
+    int f, h, w;
+};
+svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
+                                   const SviRope* rope, hipStream_t st);
+svi_status svi_launch_transpose(const bf16* in, int ldi, bf16* out, int ldo, int rows, int cols, hipStream_t st);
+svi_status svi_launch_cfg_step(bf16* lat, const bf16* cond, const bf16* uncond, int64_t n, float s, float dsigma,
+                               hipStream_t st);
+svi_status svi_launch_add_bf16(bf16* a_inout, const bf16* b, int64_t n, hipStream_t st);

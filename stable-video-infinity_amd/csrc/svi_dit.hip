@@ -1,0 +1,461 @@
+// svi_dit.hip — the Wan DiT denoiser forward as ONE C call per forward: weight table bound by
+// reference state-dict key, static workspace in HBM, every kernel enqueued on the caller's stream.
+//
+// Stands in for model_fn_wan_video (pipelines/svi_video.py:74-137) == WanModel.forward
+// (models/wan_video_dit.py:486-567) and DiTBlock.forward (:354-374).
+//
+// HBM layout of one forward (bf16 unless noted; L = f*h*w tokens, D = dim, F = ffn_dim):
+//   X   [L, D]      residual stream (updated in place by the GEMM epilogues)
+//   Hb  [L, D]      normed+modulated GEMM input, then attention output
+//   QK  [L, 2D]     q | k, token-major; RMSNorm+RoPE in place
+//   VT  [D, L8]     V transposed (channel-major), emitted directly by the swapped V projection GEMM
+//   Fb  [L, F]      FFN hidden (GELU applied in the producing GEMM's epilogue)
+//   CTX [Lc(+257), D], CK [.., D], CVT [D, ..]   projected context and its per-block K / V^T
+//   modf f32 [layers][6][D]   (modulation + t_mod), bf16-rounded, with (1+scale) pre-added
+#include <map>
+#include <string>
+#include <vector>
+#include <math.h>
+#include <string.h>
+
+#include "svi_common.h"
+
+namespace {
+
+struct Lin { const bf16* w = nullptr; const bf16* b = nullptr; };
+struct AttnW {
+    Lin q, k, v, o;
+    const bf16* norm_q = nullptr;
+    const bf16* norm_k = nullptr;
+    Lin k_img, v_img;
+    const bf16* norm_k_img = nullptr;
+};
+struct BlockW {
+    const bf16* modulation = nullptr;
+    AttnW sa, ca;
+    const bf16* norm3_w = nullptr;
+    const bf16* norm3_b = nullptr;
+    Lin ffn0, ffn2;
+};
+struct Slot { const bf16** ptr; std::vector<int64_t> shape; };
+
+struct Workspace {
+    int L = 0, Lc = 0;
+    char* base = nullptr;
+    size_t bytes = 0;
+    bf16 *X, *Hb, *QK, *VT, *Fb, *CTX, *CTXH, *CK, *CVT, *CKi, *CVTi, *A2, *PATCH, *HO, *IMG0, *IMG1;
+    bf16 *e, *h1, *t, *st, *tmod;
+    float *modf, *headf;
+    int ldvt = 0, ldcvt = 0, ldcvti = 264, kpatch = 0;
+};
+
+}  // namespace
+
+struct svi_dit {
+    svi_dit_config cfg;
+    std::vector<BlockW> blocks;
+    const bf16 *patch_w = nullptr, *patch_b = nullptr;
+    Lin text0, text2, time0, time2, timeproj, head;
+    const bf16* head_mod = nullptr;
+    const bf16 *img_ln0_w = nullptr, *img_ln0_b = nullptr, *img_ln4_w = nullptr, *img_ln4_b = nullptr;
+    Lin img1, img3;
+    std::map<std::string, Slot> slots;
+    Workspace ws;
+    // rope
+    int rf = 0, rh = 0, rw = 0;
+    float2* rope_dev = nullptr;
+    SviRope rope{};
+};
+
+// ------------------------------------------------------------------------------------------------
+// small kernels private to the model forward
+// ------------------------------------------------------------------------------------------------
+// sinusoidal_embedding_1d (models/wan_video_dit.py:154-158): fp64 angle, cos half | sin half, -> bf16
+__global__ void sinusoid_kernel(const float* __restrict__ timestep, bf16* __restrict__ e, int freq_dim) {
+    const int half = freq_dim >> 1;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= half) return;
+    const double pos = (double)timestep[0];
+    const double ang = pos * pow(10000.0, -((double)j / (double)half));
+    e[j] = (bf16)(float)cos(ang);
+    e[half + j] = (bf16)(float)sin(ang);
+}
+
+__global__ void silu_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16)silu_f((float)in[i]);
+}
+
+// patch tokens: P[l][k], k = ((c*pt + a)*ph + b)*pw + cw ; token l = (fi*hh + hi)*ww + wi  (dit:473-477)
+__global__ void patch_gather_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y, bf16* __restrict__ P,
+                                    int Cx, int Cy, int T, int H, int W, int pt, int ph, int pw, int kp, int L) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)L * kp) return;
+    const int l = (int)(idx / kp), k = (int)(idx - (int64_t)l * kp);
+    const int hh = H / ph, ww = W / pw;
+    const int K = (Cx + Cy) * pt * ph * pw;
+    if (k >= K) { P[idx] = (bf16)0.f; return; }
+    const int cw = k % pw, b = (k / pw) % ph, a = (k / (pw * ph)) % pt, c = k / (pw * ph * pt);
+    const int wi = l % ww, hi = (l / ww) % hh, fi = l / (ww * hh);
+    const size_t sp = ((size_t)(fi * pt + a) * H + (hi * ph + b)) * W + (wi * pw + cw);
+    P[idx] = (c < Cx) ? x[(size_t)c * T * H * W + sp] : y[(size_t)(c - Cx) * T * H * W + sp];
+}
+
+// unpatchify 'b (f h w) (x y z c) -> b c (f x) (h y) (w z)'  (dit:479-484)
+__global__ void unpatchify_kernel(const bf16* __restrict__ ho, bf16* __restrict__ out, int C, int T, int H, int W,
+                                  int pt, int ph, int pw, int ldho) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)C * T * H * W;
+    if (idx >= n) return;
+    const int wq = (int)(idx % W), hq = (int)((idx / W) % H), tq = (int)((idx / ((int64_t)W * H)) % T);
+    const int c = (int)(idx / ((int64_t)W * H * T));
+    const int hh = H / ph, ww = W / pw;
+    const int fi = tq / pt, a = tq % pt, hi = hq / ph, b = hq % ph, wi = wq / pw, cw = wq % pw;
+    const int l = (fi * hh + hi) * ww + wi;
+    const int col = ((a * ph + b) * pw + cw) * C + c;
+    out[idx] = ho[(size_t)l * ldho + col];
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle construction / weight binding
+// ------------------------------------------------------------------------------------------------
+static void add_slot(svi_dit* h, const std::string& name, const bf16** p, std::vector<int64_t> shape) {
+    h->slots[name] = Slot{p, std::move(shape)};
+}
+static void add_lin(svi_dit* h, const std::string& name, Lin* l, int64_t o, int64_t i) {
+    add_slot(h, name + ".weight", &l->w, {o, i});
+    add_slot(h, name + ".bias", &l->b, {o});
+}
+
+extern "C" svi_status svi_dit_create(const svi_dit_config* c, svi_dit** out) {
+    SVI_REQUIRE(c && out, "svi_dit_create: null argument");
+    SVI_REQUIRE(c->num_heads > 0 && c->dim == c->num_heads * 128, "head_dim must be 128 (dim=%d heads=%d)", c->dim,
+                c->num_heads);
+    SVI_REQUIRE(c->dim % 8 == 0 && c->ffn_dim % 8 == 0 && c->text_dim % 8 == 0 && c->freq_dim % 8 == 0,
+                "dim/ffn_dim/text_dim/freq_dim must be multiples of 8");
+    SVI_REQUIRE(c->patch_t > 0 && c->patch_h > 0 && c->patch_w > 0 && c->num_layers > 0, "bad patch/layers");
+    SVI_REQUIRE((c->in_dim * c->patch_t * c->patch_h * c->patch_w) % 8 == 0, "in_dim*prod(patch) must be a multiple of 8");
+    SVI_REQUIRE(c->has_image_input ? c->in_dim > 16 : true, "has_image_input needs in_dim > 16");
+    svi_dit* h = new (std::nothrow) svi_dit();
+    if (!h) { svi_set_error("out of host memory"); return SVI_ERR_OOM; }
+    h->cfg = *c;
+    const int64_t D = c->dim, F = c->ffn_dim;
+    h->blocks.resize(c->num_layers);
+    add_slot(h, "patch_embedding.weight", &h->patch_w, {D, c->in_dim, c->patch_t, c->patch_h, c->patch_w});
+    add_slot(h, "patch_embedding.bias", &h->patch_b, {D});
+    add_lin(h, "text_embedding.0", &h->text0, D, c->text_dim);
+    add_lin(h, "text_embedding.2", &h->text2, D, D);
+    add_lin(h, "time_embedding.0", &h->time0, D, c->freq_dim);
+    add_lin(h, "time_embedding.2", &h->time2, D, D);
+    add_lin(h, "time_projection.1", &h->timeproj, 6 * D, D);
+    for (int i = 0; i < c->num_layers; ++i) {
+        BlockW& b = h->blocks[i];
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        add_slot(h, p + "modulation", &b.modulation, {1, 6, D});
+        for (int a = 0; a < 2; ++a) {
+            AttnW& w = a ? b.ca : b.sa;
+            const std::string ap = p + (a ? "cross_attn." : "self_attn.");
+            add_lin(h, ap + "q", &w.q, D, D);
+            add_lin(h, ap + "k", &w.k, D, D);
+            add_lin(h, ap + "v", &w.v, D, D);
+            add_lin(h, ap + "o", &w.o, D, D);
+            add_slot(h, ap + "norm_q.weight", &w.norm_q, {D});
+            add_slot(h, ap + "norm_k.weight", &w.norm_k, {D});
+            if (a && c->has_image_input) {
+                add_lin(h, ap + "k_img", &w.k_img, D, D);
+                add_lin(h, ap + "v_img", &w.v_img, D, D);
+                add_slot(h, ap + "norm_k_img.weight", &w.norm_k_img, {D});
+            }
+        }
+        add_slot(h, p + "norm3.weight", &b.norm3_w, {D});
+        add_slot(h, p + "norm3.bias", &b.norm3_b, {D});
+        add_lin(h, p + "ffn.0", &b.ffn0, F, D);
+        add_lin(h, p + "ffn.2", &b.ffn2, D, F);
+    }
+    add_slot(h, "head.modulation", &h->head_mod, {1, 2, D});
+    add_lin(h, "head.head", &h->head, (int64_t)c->out_dim * c->patch_t * c->patch_h * c->patch_w, D);
+    if (c->has_image_input) {
+        add_slot(h, "img_emb.proj.0.weight", &h->img_ln0_w, {1280});
+        add_slot(h, "img_emb.proj.0.bias", &h->img_ln0_b, {1280});
+        add_lin(h, "img_emb.proj.1", &h->img1, 1280, 1280);
+        add_lin(h, "img_emb.proj.3", &h->img3, D, 1280);
+        add_slot(h, "img_emb.proj.4.weight", &h->img_ln4_w, {D});
+        add_slot(h, "img_emb.proj.4.bias", &h->img_ln4_b, {D});
+    }
+    *out = h;
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_destroy(svi_dit* h) {
+    if (!h) return SVI_OK;
+    if (h->ws.base) (void)hipFree(h->ws.base);
+    if (h->rope_dev) (void)hipFree(h->rope_dev);
+    delete h;
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_bind_weight(svi_dit* h, const char* name, const void* dev_ptr, svi_dtype dtype,
+                                          const int64_t* shape, int32_t rank) {
+    SVI_REQUIRE(h && name && dev_ptr && shape, "svi_dit_bind_weight: null argument");
+    auto it = h->slots.find(name);
+    if (it == h->slots.end()) { svi_set_error("unknown DiT parameter '%s'", name); return SVI_ERR_INVALID; }
+    SVI_REQUIRE(dtype == SVI_BF16, "DiT parameter '%s' must be bf16", name);
+    const std::vector<int64_t>& want = it->second.shape;
+    bool ok = (int)want.size() == rank;
+    for (int i = 0; ok && i < rank; ++i) ok = want[i] == shape[i];
+    if (!ok) { svi_set_error("shape mismatch for '%s'", name); return SVI_ERR_INVALID; }
+    SVI_REQUIRE(((uintptr_t)dev_ptr % 16) == 0, "parameter '%s' is not 16-byte aligned", name);
+    *it->second.ptr = reinterpret_cast<const bf16*>(dev_ptr);
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_check_bound(svi_dit* h) {
+    SVI_REQUIRE(h, "null handle");
+    for (auto& kv : h->slots)
+        if (*kv.second.ptr == nullptr) { svi_set_error("parameter '%s' was never bound", kv.first.c_str()); return SVI_ERR_UNBOUND; }
+    return SVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace and rope tables (allocation only when the problem size changes — never in steady state)
+// ------------------------------------------------------------------------------------------------
+static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static svi_status ensure_workspace(svi_dit* h, int L, int Lc) {
+    Workspace& w = h->ws;
+    if (w.base && w.L == L && w.Lc == Lc) return SVI_OK;
+    const svi_dit_config& c = h->cfg;
+    const size_t D = c.dim, F = c.ffn_dim;
+    const int img = c.has_image_input ? 257 : 0;
+    const size_t Lctx = (size_t)Lc + img;
+    const int ldvt = ((L + 7) / 8) * 8, ldcvt = ((Lc + 7) / 8) * 8;
+    const int kpatch = c.in_dim * c.patch_t * c.patch_h * c.patch_w;
+    const size_t ho = (size_t)c.out_dim * c.patch_t * c.patch_h * c.patch_w;
+    const size_t ho_ld = (ho + 7) / 8 * 8;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t oX = take((size_t)L * D * 2), oH = take((size_t)L * D * 2), oQK = take((size_t)L * 2 * D * 2);
+    const size_t oVT = take(D * ldvt * 2), oF = take((size_t)L * F * 2);
+    const size_t oCTX = take(Lctx * D * 2), oCTXH = take((size_t)Lc * D * 2), oCK = take(Lctx * D * 2);
+    const size_t oCVT = take(D * ldcvt * 2), oCKi = take((size_t)264 * D * 2), oCVTi = take(D * 264 * 2);
+    const size_t oA2 = take(img ? (size_t)L * D * 2 : 256);
+    const size_t oP = take((size_t)L * kpatch * 2), oHO = take((size_t)L * ho_ld * 2);
+    const size_t oI0 = take((size_t)264 * 1280 * 2), oI1 = take((size_t)264 * 1280 * 2);
+    const size_t oe = take(c.freq_dim * 2), oh1 = take(D * 2), ot = take(D * 2), ost = take(D * 2), otm = take(6 * D * 2);
+    const size_t omodf = take((size_t)c.num_layers * 6 * D * 4), oheadf = take(2 * D * 4);
+    if (w.base) { SVI_CHECK_HIP(hipFree(w.base)); w.base = nullptr; }
+    hipError_t e = hipMalloc((void**)&w.base, off);
+    if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B workspace) failed: %s", off, hipGetErrorString(e)); return SVI_ERR_OOM; }
+    SVI_CHECK_HIP(hipMemset(w.base, 0, off));           // V^T pad columns must read as zeros
+    w.bytes = off; w.L = L; w.Lc = Lc; w.ldvt = ldvt; w.ldcvt = ldcvt; w.kpatch = kpatch;
+    auto P = [&](size_t o) { return reinterpret_cast<bf16*>(w.base + o); };
+    w.X = P(oX); w.Hb = P(oH); w.QK = P(oQK); w.VT = P(oVT); w.Fb = P(oF); w.CTX = P(oCTX); w.CTXH = P(oCTXH);
+    w.CK = P(oCK); w.CVT = P(oCVT); w.CKi = P(oCKi); w.CVTi = P(oCVTi); w.A2 = P(oA2); w.PATCH = P(oP); w.HO = P(oHO);
+    w.IMG0 = P(oI0); w.IMG1 = P(oI1); w.e = P(oe); w.h1 = P(oh1); w.t = P(ot); w.st = P(ost); w.tmod = P(otm);
+    w.modf = reinterpret_cast<float*>(w.base + omodf);
+    w.headf = reinterpret_cast<float*>(w.base + oheadf);
+    return SVI_OK;
+}
+
+// precompute_freqs_cis_3d (models/wan_video_dit.py:161-175): fp64 angles, stored as fp32 (cos, sin)
+static svi_status ensure_rope(svi_dit* h, int f, int hh, int ww) {
+    if (h->rope_dev && h->rf == f && h->rh == hh && h->rw == ww) return SVI_OK;
+    const int dh = 128, d_hw = dh / 3, d_f = dh - 2 * d_hw;
+    const int npf = d_f / 2, nph = d_hw / 2, npw = d_hw / 2;
+    std::vector<float2> host((size_t)f * npf + (size_t)hh * nph + (size_t)ww * npw);
+    size_t o = 0;
+    auto fill = [&](int len, int axis_dim, int np) {
+        for (int p = 0; p < len; ++p)
+            for (int i = 0; i < np; ++i) {
+                const double inv = 1.0 / pow(10000.0, (double)(2 * i) / (double)axis_dim);
+                const double ang = (double)p * inv;
+                host[o++] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+    };
+    fill(f, d_f, npf); fill(hh, d_hw, nph); fill(ww, d_hw, npw);
+    if (h->rope_dev) { SVI_CHECK_HIP(hipFree(h->rope_dev)); h->rope_dev = nullptr; }
+    SVI_CHECK_HIP(hipMalloc((void**)&h->rope_dev, host.size() * sizeof(float2)));
+    SVI_CHECK_HIP(hipMemcpy(h->rope_dev, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
+    h->rf = f; h->rh = hh; h->rw = ww;
+    h->rope.tab_f = h->rope_dev;
+    h->rope.tab_h = h->rope_dev + (size_t)f * npf;
+    h->rope.tab_w = h->rope.tab_h + (size_t)hh * nph;
+    h->rope.npf = npf; h->rope.nph = nph; h->rope.npw = npw;
+    h->rope.f = f; h->rope.h = hh; h->rope.w = ww;
+    return SVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static svi_status linear(const bf16* A, int lda, const Lin& l, bf16* C, int ldc, int M, int N, int K, int epi,
+                         hipStream_t st, const float* gate = nullptr, const bf16* res = nullptr, int ldres = 0) {
+    SviGemmArgs g{A, lda, l.w, K, C, ldc, M, N, K, l.b, 0, epi, gate, res, ldres};
+    return svi_launch_gemm(g, st);
+}
+// V^T[D, n_tok] = Wv · X^T + bv (bias along rows): same GEMM with the operands swapped.
+static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16* CT, int ldct, int n_tok, int N, int K,
+                                    hipStream_t st) {
+    SviGemmArgs g{l.w, K, Xin, ldx, CT, ldct, N, n_tok, K, l.b, 1, SVI_EPI_BIAS, nullptr, nullptr, 0};
+    return svi_launch_gemm(g, st);
+}
+
+static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
+                            hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const BlockW& b = h->blocks[layer];
+    Workspace& w = h->ws;
+    const int D = c.dim, F = c.ffn_dim, H = c.num_heads;
+    const int img = c.has_image_input ? 257 : 0;
+    const bf16* ctx_txt = CTX + (size_t)img * D;
+    const float *sh_a = modf, *sc_a = modf + D, *g_a = modf + 2 * D, *sh_m = modf + 3 * D, *sc_m = modf + 4 * D,
+                *g_m = modf + 5 * D;
+    // --- self attention: x += gate_msa * o(attn(rope(rms(q)), rope(rms(k)), v))     dit:358,369,226-242
+    { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_a, sc_a, st)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, w.QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, w.VT, w.ldvt, L, D, D, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.sa.norm_q, c.eps, &h->rope, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK + D, 2 * D, L, D, b.sa.norm_k, c.eps, &h->rope, st)); }
+    { SviProfScope _p(PROF_FLASH_SELF, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.QK + D, 2 * D, w.VT, w.ldvt, w.Hb, D, L, L, H, st)); }
+    { SviProfScope _p(PROF_GEMM_O, st); SVI_TRY(linear(w.Hb, D, b.sa.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D)); }
+    // --- cross attention: x += o(attn(rms(q(norm3 x)), rms(k ctx), v ctx) [+ image branch])   dit:370,266-303
+    { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, b.norm3_w, b.norm3_b, nullptr, nullptr, st)); }
+    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.ca.norm_q, c.eps, nullptr, st)); }
+    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(ctx_txt, D, b.ca.k, w.CK, D, Lc, D, D, SVI_EPI_BIAS, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, st)); }
+    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, w.CVT, w.ldcvt, Lc, D, D, st)); }
+    { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.CK, D, w.CVT, w.ldcvt, w.Hb, D, L, Lc, H, st)); }
+    if (img) {
+        SVI_TRY(linear(CTX, D, b.ca.k_img, w.CKi, D, img, D, D, SVI_EPI_BIAS, st));
+        SVI_TRY(svi_launch_rmsnorm_rope(w.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, st));
+        SVI_TRY(linear_transposed(CTX, D, b.ca.v_img, w.CVTi, w.ldcvti, img, D, D, st));
+        SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.CKi, D, w.CVTi, w.ldcvti, w.A2, D, L, img, H, st));
+        SVI_TRY(svi_launch_add_bf16(w.Hb, w.A2, (int64_t)L * D, st));
+    }
+    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D)); }
+    // --- MLP: x += gate_mlp * W2 gelu_tanh(W1 modulate(norm2 x))                  dit:372-373,334-335
+    { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_m, sc_m, st)); }
+    { SviProfScope _p(PROF_GEMM_FFN1, st); SVI_TRY(linear(w.Hb, D, b.ffn0, w.Fb, F, L, F, D, SVI_EPI_BIAS_GELU_TANH, st)); }
+    { SviProfScope _p(PROF_GEMM_FFN2, st); SVI_TRY(linear(w.Fb, F, b.ffn2, X, D, L, D, F, SVI_EPI_BIAS_GATE_RES, st, g_m, X, D)); }
+    return SVI_OK;
+}
+
+// modf[i][c] = bf16(modulation[i][c] + t_mod[i][c]); rows in scale_mask store bf16(1 + that)
+// (DiTBlock.forward models/wan_video_dit.py:356-357, modulate :150-151, Head.forward :402)
+__global__ void mod_prepare_one_kernel(const bf16* __restrict__ modulation, const bf16* __restrict__ tmod,
+                                       float* __restrict__ modf, int D, int rows, int scale_mask, int tmod_rows) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * D) return;
+    const int i = idx / D, c = idx - i * D;
+    const float t = (float)tmod[(tmod_rows == 1 ? 0 : i) * D + c];
+    float m = rbf((float)modulation[idx] + t);
+    if ((scale_mask >> i) & 1) m = rbf(1.0f + m);
+    modf[idx] = m;
+}
+
+static svi_status mod_one(const bf16* modulation, const bf16* tmod, float* modf, int D, int rows, int scale_mask,
+                          int tmod_rows, hipStream_t st) {
+    const int n = rows * D;
+    hipLaunchKernelGGL(mod_prepare_one_kernel, dim3((n + 255) / 256), dim3(256), 0, st, modulation, tmod, modf, D, rows,
+                       scale_mask, tmod_rows);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, const bf16* context, const bf16* clip,
+                              const bf16* y, const bf16* addc, bf16* out, int T, int H, int W, int Lc, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const int D = c.dim;
+    const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
+    const int L = f * hh * ww;
+    SVI_TRY(ensure_workspace(h, L, Lc));
+    SVI_TRY(ensure_rope(h, f, hh, ww));
+    Workspace& w = h->ws;
+    const int img = c.has_image_input ? 257 : 0;
+    // --- timestep embedding -> t, t_mod                              svi_video.py:92-93
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((c.freq_dim / 2 + 63) / 64), dim3(64), 0, st, timestep, w.e, c.freq_dim);
+    SVI_LAUNCH_CHECK();
+    SVI_TRY(linear(w.e, c.freq_dim, h->time0, w.h1, D, 1, D, c.freq_dim, SVI_EPI_BIAS_SILU, st));
+    SVI_TRY(linear(w.h1, D, h->time2, w.t, D, 1, D, D, SVI_EPI_BIAS, st));
+    hipLaunchKernelGGL(silu_kernel, dim3((D + 255) / 256), dim3(256), 0, st, w.t, w.st, D);
+    SVI_LAUNCH_CHECK();
+    SVI_TRY(linear(w.st, D, h->timeproj, w.tmod, 6 * D, 1, 6 * D, D, SVI_EPI_BIAS, st));
+    for (int l = 0; l < c.num_layers; ++l)
+        SVI_TRY(mod_one(h->blocks[l].modulation, w.tmod, w.modf + (size_t)l * 6 * D, D, 6, (1 << 1) | (1 << 4), 6, st));
+    SVI_TRY(mod_one(h->head_mod, w.t, w.headf, D, 2, 1 << 1, 1, st));
+    // --- text (and CLIP image) context                                svi_video.py:94-99
+    SVI_TRY(linear(context, c.text_dim, h->text0, w.CTXH, D, Lc, D, c.text_dim, SVI_EPI_BIAS_GELU_TANH, st));
+    SVI_TRY(linear(w.CTXH, D, h->text2, w.CTX + (size_t)img * D, D, Lc, D, D, SVI_EPI_BIAS, st));
+    if (img) {
+        SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
+        SVI_TRY(svi_launch_ln_mod(clip, 1280, w.IMG0, 1280, 257, 1280, 1e-5f, h->img_ln0_w, h->img_ln0_b, nullptr, nullptr, st));
+        SVI_TRY(linear(w.IMG0, 1280, h->img1, w.IMG1, 1280, 257, 1280, 1280, SVI_EPI_BIAS_GELU_ERF, st));
+        SVI_TRY(linear(w.IMG1, 1280, h->img3, w.Hb, D, 257, D, 1280, SVI_EPI_BIAS, st));
+        SVI_TRY(svi_launch_ln_mod(w.Hb, D, w.CTX, D, 257, D, 1e-5f, h->img_ln4_w, h->img_ln4_b, nullptr, nullptr, st));
+    }
+    // --- patchify                                                     svi_video.py:101, dit:473-477
+    {
+        const int64_t n = (int64_t)L * w.kpatch;
+        hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, w.PATCH, 16,
+                           c.in_dim - 16, T, H, W, c.patch_t, c.patch_h, c.patch_w, w.kpatch, L);
+        SVI_LAUNCH_CHECK();
+        Lin pe{h->patch_w, h->patch_b};
+        SVI_TRY(linear(w.PATCH, w.kpatch, pe, w.X, D, L, D, w.kpatch, SVI_EPI_BIAS, st));
+        if (addc) SVI_TRY(svi_launch_add_bf16(w.X, addc, (int64_t)L * D, st));
+    }
+    // --- blocks
+    for (int l = 0; l < c.num_layers; ++l)
+        SVI_TRY(run_block(h, l, w.X, w.CTX, w.modf + (size_t)l * 6 * D, L, Lc, st));
+    // --- head + unpatchify                                            dit:401-404,479-484
+    {
+        const int ho = c.out_dim * c.patch_t * c.patch_h * c.patch_w;
+        const int ho_ld = (ho + 7) / 8 * 8;
+        SVI_TRY(svi_launch_ln_mod(w.X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, w.headf, w.headf + D, st));
+        SVI_TRY(linear(w.Hb, D, h->head, w.HO, ho_ld, L, ho, D, SVI_EPI_BIAS, st));
+        const int64_t n = (int64_t)c.out_dim * T * H * W;
+        hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.HO, out, c.out_dim, T,
+                           H, W, c.patch_t, c.patch_h, c.patch_w, ho_ld);
+        SVI_LAUNCH_CHECK();
+    }
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_forward(svi_dit* h, const void* x, const float* timestep, const void* context,
+                                      const void* clip_feature, const void* y, const void* add_condition, void* out,
+                                      int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc, svi_stream stream) {
+    SVI_REQUIRE(h && x && timestep && context && out, "svi_dit_forward: null argument");
+    SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward: bad sizes");
+    const svi_dit_config& c = h->cfg;
+    SVI_REQUIRE(T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0,
+                "latent size %dx%dx%d is not divisible by the patch size", T, H, W);
+    SVI_TRY(svi_dit_check_bound(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t thw = (size_t)T * H * W;
+    const int L = (T / c.patch_t) * (H / c.patch_h) * (W / c.patch_w);
+    for (int b = 0; b < B; ++b) {
+        const bf16* xb = reinterpret_cast<const bf16*>(x) + b * 16 * thw;
+        const bf16* cb = reinterpret_cast<const bf16*>(context) + (size_t)b * Lc * c.text_dim;
+        const bf16* clb = clip_feature ? reinterpret_cast<const bf16*>(clip_feature) + (size_t)b * 257 * 1280 : nullptr;
+        const bf16* yb = y ? reinterpret_cast<const bf16*>(y) + b * (size_t)(c.in_dim - 16) * thw : nullptr;
+        const bf16* ab = add_condition ? reinterpret_cast<const bf16*>(add_condition) + (size_t)b * L * c.dim : nullptr;
+        bf16* ob = reinterpret_cast<bf16*>(out) + b * (size_t)c.out_dim * thw;
+        SVI_TRY(forward_one(h, xb, timestep + b, cb, clb, yb, ab, ob, T, H, W, Lc, st));
+    }
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_inout, const void* context,
+                                            const void* t_mod, int32_t f, int32_t hh, int32_t ww, int32_t Lc,
+                                            svi_stream stream) {
+    SVI_REQUIRE(h && x_inout && context && t_mod, "svi_dit_block_forward: null argument");
+    SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers, "layer %d out of range", layer);
+    SVI_REQUIRE(f > 0 && hh > 0 && ww > 0 && Lc > 0, "bad grid");
+    SVI_TRY(svi_dit_check_bound(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int L = f * hh * ww, D = h->cfg.dim;
+    SVI_TRY(ensure_workspace(h, L, Lc));
+    SVI_TRY(ensure_rope(h, f, hh, ww));
+    float* modf = h->ws.modf + (size_t)layer * 6 * D;
+    SVI_TRY(mod_one(h->blocks[layer].modulation, reinterpret_cast<const bf16*>(t_mod), modf, D, 6, (1 << 1) | (1 << 4), 6, st));
+    return run_block(h, layer, reinterpret_cast<bf16*>(x_inout), reinterpret_cast<const bf16*>(context), modf, L, Lc, st);
+}

@@ -1,0 +1,259 @@
+// svi_elementwise.hip — HBM-bound row kernels of the DiT block (gfx950).
+//
+// All of these stream a [rows, dim] bf16 activation once: one 64-lane wave owns one row, each lane
+// holds 16-byte (8 x bf16) chunks of it in registers, statistics are reduced across the wave, and
+// the row is written once.  Algorithmic traffic = 2 * rows * dim * 2 bytes (read + write); that is
+// the figure the roofline fraction of these kernels is quoted against.
+//
+// Rounding: the reference runs these ops as separate bf16 tensor ops; `rbf()` marks each point
+// where it materialises a bf16 tensor so results track it to within accumulation-order noise.
+#include "svi_common.h"
+
+#define ROWS_PER_BLOCK 4      // 4 waves / 256 threads per workgroup
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (no affine | affine) [+ modulate]:  out = ((x-mean)*rstd [*w+b]) [*(1+scale)+shift]
+// reference: nn.LayerNorm(eps=1e-6) + modulate(), models/wan_video_dit.py:150-151,331-333,358,370,372
+// ------------------------------------------------------------------------------------------------
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ out,
+                                                     int ldo, int rows, int dim, float eps,
+                                                     const bf16* __restrict__ w, const bf16* __restrict__ b,
+                                                     const float* __restrict__ shift,
+                                                     const float* __restrict__ scale1p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = dim >> 3;
+    const bf16* xr = x + (size_t)row * ldx;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+            bf16x8 t = ld_bf16x8(xr + ci * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[c][j] = (float)t[j]; s += v[c][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float d = v[c][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+    bf16* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+            const int col = ci * 8;
+            bf16x8 o;
+            bf16x8 wv, bv;
+            if (w) { wv = ld_bf16x8(w + col); bv = ld_bf16x8(b + col); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = (v[c][j] - mean) * rstd;
+                if (w) y = y * (float)wv[j] + (float)bv[j];
+                y = rbf(y);
+                if (scale1p) y = rbf(rbf(y * scale1p[col + j]) + shift[col + j]);
+                o[j] = (bf16)y;
+            }
+            st_bf16x8(orow + col, o);
+        }
+    }
+}
+
+svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int rows, int dim, float eps,
+                             const bf16* w, const bf16* b, const float* shift, const float* scale1p,
+                             hipStream_t st) {
+    SVI_REQUIRE(dim % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "layernorm: dim/ld must be multiples of 8 (dim=%d)", dim);
+    SVI_REQUIRE(dim <= 8192, "layernorm: dim %d > 8192 unsupported", dim);
+    SVI_REQUIRE((w == nullptr) == (b == nullptr), "layernorm: affine weight and bias must come together");
+    SVI_REQUIRE((shift == nullptr) == (scale1p == nullptr), "layernorm: shift and scale must come together");
+    if (rows <= 0) return SVI_OK;
+    dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+    const int nchunk = dim / 8;
+    if (nchunk <= 64 * 3)
+        hipLaunchKernelGGL(ln_mod_kernel<3>, grid, block, 0, st, x, ldx, out, ldo, rows, dim, eps, w, b, shift, scale1p);
+    else if (nchunk <= 64 * 10)
+        hipLaunchKernelGGL(ln_mod_kernel<10>, grid, block, 0, st, x, ldx, out, ldo, rows, dim, eps, w, b, shift, scale1p);
+    else
+        hipLaunchKernelGGL(ln_mod_kernel<16>, grid, block, 0, st, x, ldx, out, ldo, rows, dim, eps, w, b, shift, scale1p);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm over the full model dim (all heads jointly) [+ 3-D RoPE per head], in place.
+// reference: RMSNorm.forward models/wan_video_dit.py:192-197; rope_apply :178-183 with the table of
+// :161-175 gathered per token at pipelines/svi_video.py:106-110.  The reference rotates in fp64;
+// here cos/sin come from a host-built fp64->fp32 table and the 2x2 rotate runs in fp32 — the result
+// is rounded to bf16 either way (difference <= 1 bf16 ulp on rounding ties only).
+// ------------------------------------------------------------------------------------------------
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x, int ld, int rows, int dim,
+                                                           const bf16* __restrict__ weight, float eps, int use_rope,
+                                                           SviRope r) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = dim >> 3;
+    bf16* xr = x + (size_t)row * ld;
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+            bf16x8 t = ld_bf16x8(xr + ci * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[c][j] = (float)t[j]; ss += v[c][j] * v[c][j]; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(ss) / (float)dim + eps);
+    int pf = 0, ph = 0, pw = 0;
+    if (use_rope) {
+        const int hw = r.h * r.w;
+        pf = row / hw;
+        const int rem = row - pf * hw;
+        ph = rem / r.w;
+        pw = rem - ph * r.w;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+            const int col = ci * 8;
+            bf16x8 wv = ld_bf16x8(weight + col);
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[c][j] * rs) * (float)wv[j]);
+            bf16x8 o;
+            if (use_rope) {
+                const int pair0 = (col & 127) >> 1;            // complex-pair index inside the head
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int pi = pair0 + p;
+                    float2 cs;
+                    if (pi < r.npf) cs = r.tab_f[pf * r.npf + pi];
+                    else if (pi < r.npf + r.nph) cs = r.tab_h[ph * r.nph + (pi - r.npf)];
+                    else cs = r.tab_w[pw * r.npw + (pi - r.npf - r.nph)];
+                    const float a = y[2 * p], bq = y[2 * p + 1];
+                    o[2 * p] = (bf16)(a * cs.x - bq * cs.y);
+                    o[2 * p + 1] = (bf16)(a * cs.y + bq * cs.x);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)y[j];
+            }
+            st_bf16x8(xr + col, o);
+        }
+    }
+}
+
+svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
+                                   const SviRope* rope, hipStream_t st) {
+    SVI_REQUIRE(dim % 8 == 0 && ld % 8 == 0, "rmsnorm: dim/ld must be multiples of 8");
+    SVI_REQUIRE(dim <= 8192, "rmsnorm: dim %d > 8192 unsupported", dim);
+    if (rows <= 0) return SVI_OK;
+    SviRope r{};
+    if (rope) {
+        r = *rope;
+        SVI_REQUIRE(dim % 128 == 0 && r.npf + r.nph + r.npw == 64, "rope needs head_dim 128");
+        SVI_REQUIRE(r.f * r.h * r.w == rows, "rope grid %dx%dx%d != rows %d", r.f, r.h, r.w, rows);
+    }
+    dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+    const int nchunk = dim / 8;
+    const int use = rope ? 1 : 0;
+    if (nchunk <= 64 * 3)
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r);
+    else if (nchunk <= 64 * 10)
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<10>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r);
+    else
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<16>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 transpose through LDS (64x64 tiles): out[c][r] = in[r][c].  Used by the flash_attention seam
+// to present V as V^T (the DiT forward never needs it: its V^T comes straight out of a swapped GEMM).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ in, int ldi, bf16* __restrict__ out,
+                                                        int ldo, int rows, int cols) {
+    __shared__ bf16 tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ldi + c] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * ldo + r] = tile[tx][i];
+    }
+}
+
+svi_status svi_launch_transpose(const bf16* in, int ldi, bf16* out, int ldo, int rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return SVI_OK;
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64), block(256);
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, in, ldi, out, ldo, rows, cols);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFG combine + flow-match Euler step (pipelines/svi_video.py:410,420; schedulers/flow_match.py:63)
+//   v   = uncond + s*(cond-uncond)        (bf16 tensor ops: each result rounded)
+//   lat = lat + v*(sigma_next - sigma)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg_step_kernel(bf16* __restrict__ lat, const bf16* __restrict__ cond,
+                                                       const bf16* __restrict__ uncond, int64_t n, float s,
+                                                       float dsigma) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float c = (float)cond[i];
+        float v = c;
+        if (uncond) {
+            const float u = (float)uncond[i];
+            v = rbf(u + rbf(s * rbf(c - u)));
+        }
+        lat[i] = (bf16)((float)lat[i] + rbf(v * dsigma));
+    }
+}
+
+svi_status svi_launch_cfg_step(bf16* lat, const bf16* cond, const bf16* uncond, int64_t n, float s, float dsigma,
+                               hipStream_t st) {
+    if (n <= 0) return SVI_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cfg_step_kernel, dim3(blocks), dim3(256), 0, st, lat, cond, uncond, n, s, dsigma);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+__global__ __launch_bounds__(256) void add_bf16_kernel(bf16* __restrict__ a, const bf16* __restrict__ b, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        a[i] = (bf16)((float)a[i] + (float)b[i]);
+}
+
+svi_status svi_launch_add_bf16(bf16* a, const bf16* b, int64_t n, hipStream_t st) {
+    if (n <= 0) return SVI_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(blocks), dim3(256), 0, st, a, b, n);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}

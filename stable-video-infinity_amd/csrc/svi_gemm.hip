@@ -1,0 +1,225 @@
+// svi_gemm.hip — bf16 MFMA GEMM for nn.Linear on gfx950:  C[M,N] = epi(A[M,K] · W[N,K]^T)
+//
+// Both operands are K-contiguous ("NT"), which is the natural layout of an activation matrix and of a
+// PyTorch Linear weight, and exactly what a v_mfma_f32_32x32x16_bf16 fragment wants: lane l holds 8
+// consecutive k of row (l & 31), k-block (l >> 5).
+//
+// Tile: 128(M) x 128(N) x 64(K) per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA
+// tiles, 64 accumulator VGPRs).  The MFMA is issued with the WEIGHT fragment as A-operand and the
+// ACTIVATION fragment as B-operand, so a lane's accumulator holds 4 consecutive n of ONE activation
+// row m = (l & 31): the epilogue then packs 8-byte row pieces instead of 2-byte column pieces.
+//
+// LDS: two stages x (A tile 16 KiB + W tile 16 KiB) = 64 KiB -> 2 workgroups per CU.  Rows are
+// 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 so that the 16 rows a
+// ds_read_b128 lane group touches land on 16 distinct 16-byte slots of the 256-byte bank row
+// (MI355X_MICROARCH.md §LDS; cdna_hip_programming.md T2).  Global->LDS goes through registers
+// (issue the next tile's loads before the MFMAs, write them after; one barrier per K tile).
+//
+// Epilogue: y = bf16(acc + bias) in registers -> staged through LDS as a bf16 [128][136] tile ->
+// re-read row-contiguously (16 B per lane, 256 B per row segment) -> activation / gate / residual ->
+// coalesced 16-byte stores.  Residual may alias C (x += gate * y in place).
+//
+// Workgroup ids are remapped so that the 8 XCDs each own a contiguous band of tiles (per-XCD L2 keeps
+// the shared A row-panel hot; cdna_hip_programming.md T1, bijective form).
+#include "svi_common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define STAGE_BYTES (BM * BK * 2)      // 16 KiB per operand tile
+#define CS_LD 136                      // bf16 elements per staged C row (272 B: 16-B aligned, odd*16)
+
+__device__ __forceinline__ int lds_tile_off(int row, int chunk) {   // byte offset inside a [128][64] bf16 tile
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware, bijective remap of the linear workgroup id
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // global -> register staging assignment: 1024 16-byte chunks per operand tile, 4 per thread
+    const int ld_row = tid >> 3;            // + 32*j
+    const int ld_chunk = tid & 7;
+    const bf16* a_ptr[4];
+    const bf16* w_ptr[4];
+    bool a_ok[4], w_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = ld_row + 32 * j;
+        a_ok[j] = (m0 + r) < g.M;
+        w_ok[j] = (n0 + r) < g.N;
+        a_ptr[j] = g.A + (size_t)(a_ok[j] ? (m0 + r) : 0) * g.lda + ld_chunk * 8;
+        w_ptr[j] = g.W + (size_t)(w_ok[j] ? (n0 + r) : 0) * g.ldw + ld_chunk * 8;
+    }
+    const int nk = (g.K + BK - 1) / BK;
+    u32x4 ra[4], rw[4];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_tile = [&](int kt) {
+        const int kbase = kt * BK + ld_chunk * 8;
+        const bool kin = kbase < g.K;          // K % 8 == 0: a chunk is entirely inside or outside
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = (a_ok[j] && kin) ? *reinterpret_cast<const u32x4*>(a_ptr[j] + kt * BK) : zero4;
+            rw[j] = (w_ok[j] && kin) ? *reinterpret_cast<const u32x4*>(w_ptr[j] + kt * BK) : zero4;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* As = smem + buf * 2 * STAGE_BYTES;
+        char* Ws = As + STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = lds_tile_off(ld_row + 32 * j, ld_chunk);
+            *reinterpret_cast<u32x4*>(As + off) = ra[j];
+            *reinterpret_cast<u32x4*>(Ws + off) = rw[j];
+        }
+    };
+
+    f32x16 acc[2][2];                       // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* As = smem + cur * 2 * STAGE_BYTES;
+        const char* Ws = As + STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 xa[2], wb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xa[i] = *reinterpret_cast<const bf16x8*>(As + lds_tile_off(wm * 64 + i * 32 + l31, 2 * kk + hi));
+                wb[i] = *reinterpret_cast<const bf16x8*>(Ws + lds_tile_off(wn * 64 + i * 32 + l31, 2 * kk + hi));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue part 1: y = bf16(acc + bias) -> LDS [128 m][CS_LD] bf16 --------------------------
+    // acc[ni][mi][r] is C[m = m0 + wm*64 + mi*32 + l31][n = n0 + wn*64 + ni*32 + (r&3) + 8*(r>>2) + 4*hi]
+    bf16* Cs = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int ml = wm * 64 + mi * 32 + l31;
+            float bm = 0.f;
+            if (g.bias && g.bias_along_m) bm = (m0 + ml < g.M) ? (float)g.bias[m0 + ml] : 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int nl = wn * 64 + ni * 32 + 8 * rg + 4 * hi;
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bv = bm;
+                    if (g.bias && !g.bias_along_m) bv = (n0 + nl + e < g.N) ? (float)g.bias[n0 + nl + e] : 0.f;
+                    pk[e] = (bf16)(acc[ni][mi][rg * 4 + e] + bv);
+                }
+                *reinterpret_cast<bf16x4*>(Cs + ml * CS_LD + nl) = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue part 2: row-contiguous read-back, activation / gate / residual, coalesced store ----
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int id = tid + 256 * it;
+        const int ml = id >> 4, cc = id & 15;
+        const int m = m0 + ml, n = n0 + cc * 8;
+        if (m >= g.M || n >= g.N) continue;
+        bf16x8 yv = *reinterpret_cast<const bf16x8*>(Cs + ml * CS_LD + cc * 8);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (float)yv[e];
+        const bool full = (n + 8 <= g.N);
+        if (g.epi == SVI_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = gelu_tanh_f(y[e]);
+        } else if (g.epi == SVI_EPI_BIAS_GELU_ERF) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = gelu_erf_f(y[e]);
+        } else if (g.epi == SVI_EPI_BIAS_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+        } else if (g.epi == SVI_EPI_BIAS_GATE_RES) {
+            const bf16* rp = g.res + (size_t)m * g.ldres + n;
+            float rv[8];
+            if (full) {
+                bf16x8 t = ld_bf16x8(rp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[e] = (float)t[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[e] = (n + e < g.N) ? (float)rp[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = y[e];
+                if (g.gate) t = rbf(((n + e < g.N) ? g.gate[n + e] : 0.f) * t);
+                y[e] = rv[e] + t;
+            }
+        }
+        bf16* cp = g.C + (size_t)m * g.ldc + n;
+        if (full) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
+            st_bf16x8(cp, o);
+        } else {
+            for (int e = 0; e < 8 && n + e < g.N; ++e) cp[e] = (bf16)y[e];
+        }
+    }
+}
+
+svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
+    SVI_REQUIRE(g.M >= 0 && g.N >= 0 && g.K > 0, "gemm: bad sizes M=%d N=%d K=%d", g.M, g.N, g.K);
+    if (g.M == 0 || g.N == 0) return SVI_OK;
+    SVI_REQUIRE(g.K % 8 == 0, "gemm: K=%d must be a multiple of 8", g.K);
+    SVI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0 && g.ldc % 8 == 0, "gemm: leading dims must be multiples of 8");
+    SVI_REQUIRE(g.lda >= g.K && g.ldw >= g.K && g.ldc >= g.N, "gemm: leading dims too small");
+    SVI_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && ((uintptr_t)g.C % 16) == 0,
+                "gemm: operands must be 16-byte aligned");
+    SVI_REQUIRE(g.epi >= 0 && g.epi <= SVI_EPI_BIAS_SILU, "gemm: unknown epilogue %d", g.epi);
+    if (g.epi == SVI_EPI_BIAS_GATE_RES) {
+        SVI_REQUIRE(g.res != nullptr && g.ldres % 8 == 0 && ((uintptr_t)g.res % 16) == 0,
+                    "gemm: gate/residual epilogue needs an aligned residual");
+    }
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m,
+                       tiles_n);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}

@@ -1,0 +1,14 @@
+"""svi_hip — MI355X-native backend for the Stable-Video-Infinity rolling-window denoising hot path.
+
+Python is plumbing only (pointers, streams, torch.distributed); the arithmetic lives in libsvi_hip.so
+(hand-written HIP for gfx950, C ABI in include/svi_hip.h).  Importing this package never imports the
+oracle and never falls back to PyTorch math.
+"""
+from . import _lib
+from .dit import WanDiT, model_fn_wan_video
+from .ops import cfg_step_, flash_attention, layernorm_modulate, linear, rmsnorm_rope_
+from .pipeline import DenoiseLoop, generate_noise, install
+from .scheduler import FlowMatchScheduler
+
+__all__ = ["WanDiT", "model_fn_wan_video", "flash_attention", "layernorm_modulate", "rmsnorm_rope_", "linear",
+           "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "_lib"]

@@ -1,0 +1,100 @@
+"""ctypes binding of libsvi_hip.so (declared in include/svi_hip.h).
+
+There is no fallback: if the shared object is missing or a call fails, a RuntimeError carrying
+svi_last_error() is raised.  Nothing here touches oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvi_hip.so")
+
+SVI_OK = 0
+SVI_BF16, SVI_F32 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RES, EPI_BIAS_GELU_ERF, EPI_BIAS_SILU = 0, 1, 2, 3, 4
+
+# every symbol include/svi_hip.h declares: (name, restype, argtypes)
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class DitConfig(C.Structure):
+    _fields_ = [("dim", _i32), ("in_dim", _i32), ("ffn_dim", _i32), ("out_dim", _i32), ("text_dim", _i32),
+                ("freq_dim", _i32), ("eps", _f32), ("patch_t", _i32), ("patch_h", _i32), ("patch_w", _i32),
+                ("num_heads", _i32), ("num_layers", _i32), ("has_image_input", _i32)]
+
+
+SYMBOLS = [
+    ("svi_last_error", C.c_char_p, []),
+    ("svi_abi_version", _i32, []),
+    ("svi_device_count", _i32, []),
+    ("svi_dit_create", _i32, [C.POINTER(DitConfig), C.POINTER(_vp)]),
+    ("svi_dit_destroy", _i32, [_vp]),
+    ("svi_dit_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
+    ("svi_dit_check_bound", _i32, [_vp]),
+    ("svi_dit_forward", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_dit_block_forward", _i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_attention_fwd", _i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_layernorm_modulate", _i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    ("svi_rmsnorm_rope", _i32, [_vp, _i32, _i32, _i32, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_gemm_bf16", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    ("svi_cfg_step", _i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
+    ("svi_prof_enable", _i32, [_i32]),
+    ("svi_prof_summary", _i32, [C.c_char_p, _i64]),
+    ("svi_vae_create", _i32, [C.POINTER(_vp)]),
+    ("svi_vae_destroy", _i32, [_vp]),
+    ("svi_vae_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
+    ("svi_vae_check_bound", _i32, [_vp]),
+    ("svi_vae_decode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("svi_vae_encode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the native library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950).  svi_hip has no CPU or PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(l, name)          # AttributeError here == ABI drift; let it surface
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().svi_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(status: int, what: str = "") -> None:
+    if status != SVI_OK:
+        raise RuntimeError(f"svi_hip{': ' + what if what else ''} failed (status {status}): {last_error()}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().svi_prof_enable(1 if on else 0), "svi_prof_enable")
+
+
+def prof_summary() -> dict:
+    """{tag: {"count": launches, "ms": total milliseconds}} for the launches since prof_enable(True)."""
+    import json
+    buf = C.create_string_buffer(8192)
+    check(lib().svi_prof_summary(buf, len(buf)), "svi_prof_summary")
+    return json.loads(buf.value.decode())

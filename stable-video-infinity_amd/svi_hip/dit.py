@@ -1,0 +1,127 @@
+"""Host-side mirror of the reference DiT call surface, running on libsvi_hip.
+
+    WanDiT.from_state_dict(sd, **cfg)      <- WanModel(**cfg).load_state_dict(sd)   models/wan_video_dit.py:407-470
+    WanDiT.from_module(wan_model)          <- an existing reference WanModel (weights borrowed, not copied)
+    model_fn_wan_video(dit, x, timestep, context, clip_feature, y, ...)             pipelines/svi_video.py:74-137
+    WanDiT.block_forward(i, x, context, t_mod, grid)   <- dit.blocks[i](x, context, t_mod, freqs)    dit:354-374
+
+The handle borrows the device pointers of the bound tensors; this object keeps those tensors alive and
+re-binds them on `rebind()` (call it after a LoRA merge or any operation that moves parameter storage).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+class WanDiT:
+    def __init__(self, dim: int, in_dim: int, ffn_dim: int, out_dim: int, text_dim: int, freq_dim: int, eps: float,
+                 patch_size: Tuple[int, int, int], num_heads: int, num_layers: int, has_image_input: bool):
+        self.dim, self.in_dim, self.ffn_dim, self.out_dim = dim, in_dim, ffn_dim, out_dim
+        self.text_dim, self.freq_dim, self.eps, self.patch_size = text_dim, freq_dim, eps, tuple(patch_size)
+        self.num_heads, self.num_layers, self.has_image_input = num_heads, num_layers, bool(has_image_input)
+        cfg = L.DitConfig(dim, in_dim, ffn_dim, out_dim, text_dim, freq_dim, eps, *self.patch_size, num_heads,
+                          num_layers, int(self.has_image_input))
+        h = C.c_void_p()
+        L.check(L.lib().svi_dit_create(C.byref(cfg), C.byref(h)), "svi_dit_create")
+        self._h = h
+        self._params: Dict[str, torch.Tensor] = {}
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, state_dict: Dict[str, torch.Tensor], device="cuda", **cfg) -> "WanDiT":
+        m = cls(**cfg)
+        m.bind({k: v.to(device=device, dtype=torch.bfloat16).contiguous() for k, v in state_dict.items()})
+        return m
+
+    @classmethod
+    def from_module(cls, wan_model) -> "WanDiT":
+        """Borrow the parameters of a reference `WanModel` (already on the GPU, bf16)."""
+        blk = wan_model.blocks[0]
+        pe = wan_model.patch_embedding
+        m = cls(dim=wan_model.dim, in_dim=pe.in_channels, ffn_dim=blk.ffn_dim, out_dim=wan_model.head.head.out_features
+                // (pe.kernel_size[0] * pe.kernel_size[1] * pe.kernel_size[2]),
+                text_dim=wan_model.text_embedding[0].in_features, freq_dim=wan_model.freq_dim,
+                eps=blk.norm1.eps, patch_size=tuple(pe.kernel_size), num_heads=blk.num_heads,
+                num_layers=len(wan_model.blocks), has_image_input=wan_model.has_image_input)
+        m.bind(dict(wan_model.state_dict()))
+        return m
+
+    def bind(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        lib = L.lib()
+        for name, t in state_dict.items():
+            if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+                raise RuntimeError(f"parameter {name} must be a contiguous CUDA bf16 tensor (got {t.device}, {t.dtype})")
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            L.check(lib.svi_dit_bind_weight(self._h, name.encode(), t.data_ptr(), L.SVI_BF16, shape, t.dim()),
+                    f"bind {name}")
+            self._params[name] = t
+        L.check(lib.svi_dit_check_bound(self._h), "svi_dit_check_bound")
+
+    def rebind(self) -> None:
+        self.bind(dict(self._params))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().svi_dit_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, timestep: torch.Tensor, context: torch.Tensor,
+                clip_feature: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
+                add_condition: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("svi_hip runs on the GPU only")
+        x = x.to(torch.bfloat16).contiguous()
+        context = context.to(torch.bfloat16).contiguous()
+        timestep = timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        B, _, T, H, W = x.shape
+        if timestep.numel() != B:
+            timestep = timestep.expand(B).contiguous()
+        if clip_feature is not None:
+            clip_feature = clip_feature.to(torch.bfloat16).contiguous()
+        if y is not None:
+            y = y.to(torch.bfloat16).contiguous()
+        if add_condition is not None:
+            add_condition = add_condition.to(torch.bfloat16).contiguous()
+        if out is None:
+            out = torch.empty((B, self.out_dim, T, H, W), dtype=torch.bfloat16, device=x.device)
+        L.check(L.lib().svi_dit_forward(self._h, L.ptr(x), L.ptr(timestep), L.ptr(context), L.ptr(clip_feature), L.ptr(y),
+                                        L.ptr(add_condition), L.ptr(out), B, T, H, W, context.shape[1],
+                                        L.current_stream()), "svi_dit_forward")
+        return out
+
+    __call__ = forward
+
+    def block_forward(self, layer: int, x: torch.Tensor, context: torch.Tensor, t_mod: torch.Tensor,
+                      grid: Tuple[int, int, int]) -> torch.Tensor:
+        """x [1, L, dim] (not modified; a copy is updated and returned), context [1, Lc(+257), dim] already
+        projected, t_mod [1, 6, dim]."""
+        f, h, w = grid
+        xo = x.to(torch.bfloat16).contiguous().clone()
+        context = context.to(torch.bfloat16).contiguous()
+        t_mod = t_mod.to(torch.bfloat16).contiguous()
+        lc = context.shape[-2] - (257 if self.has_image_input else 0)
+        L.check(L.lib().svi_dit_block_forward(self._h, layer, L.ptr(xo), L.ptr(context), L.ptr(t_mod), f, h, w, lc,
+                                              L.current_stream()), "svi_dit_block_forward")
+        return xo
+
+
+def model_fn_wan_video(dit: WanDiT, x: torch.Tensor, timestep: torch.Tensor, context: torch.Tensor,
+                       clip_feature: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
+                       tea_cache=None, add_condition=None, use_unified_sequence_parallel: bool = False,
+                       **kwargs) -> torch.Tensor:
+    """Same signature as pipelines/svi_video.py:74-85.  TeaCache and USP are reference options this backend does not
+    serve: asking for them is an error rather than a silent change of results."""
+    if tea_cache is not None:
+        raise NotImplementedError("TeaCache is not implemented by the HIP backend (pass tea_cache=None)")
+    if use_unified_sequence_parallel:
+        raise NotImplementedError("USP is not implemented by the HIP backend; clips/CFG shard over ranks instead")
+    return dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition)

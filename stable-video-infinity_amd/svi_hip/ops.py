@@ -1,0 +1,108 @@
+"""Operator seams of the reference, served by the HIP kernels.
+
+Same names and argument meaning as the reference's own functions so that parity tests read like
+calls into the reference:
+    flash_attention(q, k, v, num_heads)                    models/wan_video_dit.py:116-147
+    modulate / LayerNorm  -> layernorm_modulate            models/wan_video_dit.py:150-151,331-333
+    RMSNorm + rope_apply  -> rmsnorm_rope                  models/wan_video_dit.py:186-197,178-183
+    nn.Linear (+ fused epilogues) -> linear                models/wan_video_dit.py:227-229,242,334-335
+    CFG combine + FlowMatchScheduler.step -> cfg_step      pipelines/svi_video.py:410,420
+All tensors must be CUDA(HIP) bf16 and contiguous unless noted.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.bfloat16):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (svi_hip has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
+                    compatibility_mode: bool = False) -> torch.Tensor:
+    """[b, s, (n d)] layout in and out; d = 128."""
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
+    b, sq, dim = q.shape
+    skv = k.shape[1]
+    out = torch.empty_like(q)
+    L.check(L.lib().svi_attention_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), b, sq, skv, num_heads,
+                                      dim // num_heads, L.current_stream()), "flash_attention")
+    return out
+
+
+def layernorm_modulate(x: torch.Tensor, eps: float = 1e-6, weight: Optional[torch.Tensor] = None,
+                       bias: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+                       scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm over the last dim [+ affine] [+ x*(1+scale)+shift]; shift/scale are [dim] vectors."""
+    _chk(x, "x")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    out = torch.empty_like(x)
+    for t, n in ((weight, "weight"), (bias, "bias"), (shift, "shift"), (scale, "scale")):
+        if t is not None:
+            _chk(t, n)
+            if t.numel() != dim:
+                raise ValueError(f"{n} must have {dim} elements")
+    L.check(L.lib().svi_layernorm_modulate(L.ptr(x), L.ptr(out), rows, dim, eps, L.ptr(weight), L.ptr(bias),
+                                           L.ptr(shift), L.ptr(scale), L.current_stream()), "layernorm_modulate")
+    return out
+
+
+def rmsnorm_rope_(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, grid=None, num_heads: int = 0) -> torch.Tensor:
+    """In place on x [rows, dim]: RMSNorm over dim, then 3-D RoPE for the (f, h, w) token grid if given."""
+    _chk(x, "x"); _chk(weight, "weight")
+    rows, dim = x.shape[-2], x.shape[-1]
+    f, h, w = grid if grid is not None else (0, 0, 0)
+    L.check(L.lib().svi_rmsnorm_rope(L.ptr(x), dim, rows, dim, L.ptr(weight), eps, 1 if grid is not None else 0,
+                                      num_heads, f, h, w, L.current_stream()), "rmsnorm_rope")
+    return x
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = L.EPI_BIAS,
+           gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           transpose_out: bool = False) -> torch.Tensor:
+    """y = epilogue(x @ weight.T + bias).  x [M, K], weight [N, K].  transpose_out returns y^T [N, M8]
+    (M8 = M rounded up to 8; the form the attention kernel wants V in)."""
+    _chk(x, "x"); _chk(weight, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    if bias is not None:
+        _chk(bias, "bias")
+    if gate is not None:
+        _chk(gate, "gate", torch.float32)
+    st = L.current_stream()
+    if transpose_out:
+        ld = (M + 7) // 8 * 8
+        out = torch.zeros((N, ld), dtype=torch.bfloat16, device=x.device)
+        L.check(L.lib().svi_gemm_bf16(L.ptr(weight), K, L.ptr(x), K, L.ptr(out), ld, N, M, K, L.ptr(bias), 1,
+                                      epilogue, None, None, 0, st), "linear^T")
+        return out
+    ldc = (N + 7) // 8 * 8
+    out = torch.empty((M, ldc), dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        _chk(residual, "residual")
+    L.check(L.lib().svi_gemm_bf16(L.ptr(x), K, L.ptr(weight), K, L.ptr(out), ldc, M, N, K, L.ptr(bias), 0, epilogue,
+                                  L.ptr(gate), L.ptr(residual), residual.shape[-1] if residual is not None else 0, st),
+            "linear")
+    return out if ldc == N else out[:, :N].contiguous()
+
+
+def cfg_step_(latents: torch.Tensor, cond: torch.Tensor, uncond: Optional[torch.Tensor], cfg_scale: float,
+              dsigma: float) -> torch.Tensor:
+    """latents += (uncond + cfg_scale*(cond-uncond)) * dsigma, in place, bf16 op-by-op rounding."""
+    _chk(latents, "latents"); _chk(cond, "cond")
+    if uncond is not None:
+        _chk(uncond, "uncond")
+    L.check(L.lib().svi_cfg_step(L.ptr(latents), L.ptr(cond), L.ptr(uncond), latents.numel(), float(cfg_scale),
+                                 float(dsigma), L.current_stream()), "cfg_step")
+    return latents

@@ -1,0 +1,106 @@
+"""The rolling-window denoising loop on the HIP backend, and `install(pipe)` — the drop-in swap.
+
+    DenoiseLoop.sample(...)     <- SVIVideoPipeline._sample_with_regular_video   pipelines/svi_video.py:392-421
+                                   (== the loop in WanVideoPipeline.__call__, pipelines/wan_video.py:266-278)
+    generate_noise(...)         <- BasePipeline.generate_noise                  pipelines/base.py:140-143
+    install(pipe)               <- the reference's own swap idioms: module-attribute / bound-method rebinding
+                                   (pipelines/svi_video.py:265-273 does the same for USP)
+"""
+from __future__ import annotations
+
+import sys
+import types
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import ops
+from .dit import WanDiT, model_fn_wan_video
+from .scheduler import FlowMatchScheduler
+
+
+def generate_noise(shape, seed=None, device="cpu", dtype=torch.float16):
+    """Seeded noise comes from torch's CPU generator in the reference; keeping that is what makes seeds portable."""
+    generator = None if seed is None else torch.Generator(device).manual_seed(seed)
+    return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+
+class DenoiseLoop:
+    """50 x { cond forward, uncond forward, CFG combine, Euler step } with latents resident in HBM."""
+
+    def __init__(self, dit: WanDiT, scheduler: Optional[FlowMatchScheduler] = None):
+        self.dit = dit
+        self.scheduler = scheduler or FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        self._cond = self._uncond = None
+
+    def step(self, latents: torch.Tensor, timestep: torch.Tensor, dsigma: float, ctx_pos: torch.Tensor,
+             ctx_neg: Optional[torch.Tensor], cfg_scale: float, **cond) -> torch.Tensor:
+        """One scheduler step, in place on `latents` (bf16 [B,16,T,H,W])."""
+        if self._cond is None or self._cond.shape != latents.shape:
+            self._cond = torch.empty_like(latents)
+            self._uncond = torch.empty_like(latents)
+        self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
+        if cfg_scale != 1.0:
+            self.dit.forward(latents, timestep, ctx_neg, out=self._uncond, **cond)
+            ops.cfg_step_(latents, self._cond, self._uncond, cfg_scale, dsigma)
+        else:
+            ops.cfg_step_(latents, self._cond, None, 1.0, dsigma)
+        return latents
+
+    @torch.no_grad()
+    def sample(self, latents: torch.Tensor, ctx_pos: torch.Tensor, ctx_neg: Optional[torch.Tensor],
+               num_inference_steps: int = 50, cfg_scale: float = 5.0, sigma_shift: float = 5.0,
+               denoising_strength: float = 1.0, progress_bar_cmd: Callable = lambda x: x, **cond) -> torch.Tensor:
+        self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
+        latents = latents.to(torch.bfloat16).contiguous().clone()
+        ts_dev = self.scheduler.timesteps.to(device=latents.device, dtype=torch.float32)
+        for i, t in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
+            self.step(latents, ts_dev[i:i + 1], self.scheduler.step_delta(t), ctx_pos, ctx_neg, cfg_scale, **cond)
+        return latents
+
+
+# ------------------------------------------------------------------------------------------------------
+_INSTALLED: Dict[int, WanDiT] = {}
+
+
+def _hip_model_fn(dit_module, x, timestep, context, clip_feature=None, y=None, tea_cache=None, add_condition=None,
+                  use_unified_sequence_parallel=False, **kwargs):
+    """model_fn_wan_video with the reference's exact signature; `dit_module` is the reference WanModel the
+    pipeline still owns (so state_dict()/LoRA loading keep working); its HIP twin is looked up by identity."""
+    hip = _INSTALLED.get(id(dit_module))
+    if hip is None:
+        raise RuntimeError("this WanModel was not passed through svi_hip.install(); refusing to fall back to PyTorch")
+    return model_fn_wan_video(hip, x, timestep, context, clip_feature=clip_feature, y=y, tea_cache=tea_cache,
+                              add_condition=add_condition, use_unified_sequence_parallel=use_unified_sequence_parallel)
+
+
+def install(pipe, vae: bool = True):
+    """Route `pipe`'s hot path (SVIVideoPipeline / WanVideoPipeline of the reference) through libsvi_hip.
+
+    * `model_fn_wan_video` in the pipeline's defining module is replaced by the HIP-backed function
+      (every call site in that module — the cond/uncond forwards of the sampler — picks it up);
+    * `pipe.vae.encode/decode` are rebound to the HIP VAE (same signatures), when `vae` is true;
+    * `pipe.dit` stays the reference nn.Module: weights are borrowed, so call `install` again (or
+      `pipe._svi_hip_dit.rebind()`) after `load_lora_v2`, `.to()` or any offload that moves storage.
+    CPU offload / VRAM management must stay off (288 GB HBM holds every model resident).
+    """
+    dit_module = pipe.dit
+    p = next(dit_module.parameters())
+    if not p.is_cuda or p.dtype != torch.bfloat16:
+        raise RuntimeError("install(): move the DiT to the GPU in bf16 first (pipe.dit.to('cuda', torch.bfloat16))")
+    hip = WanDiT.from_module(dit_module)
+    _INSTALLED[id(dit_module)] = hip
+    pipe._svi_hip_dit = hip
+    mod = sys.modules[type(pipe).__module__]
+    if not hasattr(mod, "_svi_hip_original_model_fn"):
+        mod._svi_hip_original_model_fn = getattr(mod, "model_fn_wan_video", None)
+    mod.model_fn_wan_video = _hip_model_fn
+    if vae and getattr(pipe, "vae", None) is not None:
+        from .vae import WanVideoVAE
+        hv = WanVideoVAE.from_module(pipe.vae)
+        pipe._svi_hip_vae = hv
+        pipe.vae.encode = types.MethodType(lambda self, videos, device=None, tiled=False, tile_size=(34, 34),
+                                           tile_stride=(18, 16): hv.encode(videos, device, tiled, tile_size, tile_stride), pipe.vae)
+        pipe.vae.decode = types.MethodType(lambda self, hidden_states, device=None, tiled=False, tile_size=(34, 34),
+                                           tile_stride=(18, 16): hv.decode(hidden_states, device, tiled, tile_size, tile_stride), pipe.vae)
+    return pipe

@@ -1,0 +1,75 @@
+"""The C-ABI boundary without a GPU: the library loads, exports every symbol include/svi_hip.h declares,
+the ctypes table matches the header, and host-only entry points behave (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from svi_hip import _lib as L
+
+HEADER = os.path.join(ROOT, "include", "svi_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.lib()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in svi_hip.h but not exported by libsvi_hip.so"
+
+
+def test_ctypes_table_matches_header():
+    assert sorted(n for n, _, _ in L.SYMBOLS) == declared_symbols()
+
+
+def test_abi_version():
+    assert L.lib().svi_abi_version() == 1
+
+
+def test_dit_handle_lifecycle_and_errors():
+    lib = L.lib()
+    cfg = L.DitConfig(128, 16, 256, 16, 64, 256, 1e-6, 1, 2, 2, 1, 2, 0)
+    h = C.c_void_p()
+    assert lib.svi_dit_create(C.byref(cfg), C.byref(h)) == 0
+    # nothing bound yet -> UNBOUND with the first missing key named
+    assert lib.svi_dit_check_bound(h) == 2
+    assert "never bound" in L.last_error()
+    # unknown key and wrong shape are rejected
+    shape = (C.c_int64 * 2)(128, 128)
+    assert lib.svi_dit_bind_weight(h, b"blocks.0.nope.weight", 16, L.SVI_BF16, shape, 2) == 1
+    bad = (C.c_int64 * 2)(64, 128)
+    assert lib.svi_dit_bind_weight(h, b"blocks.0.self_attn.q.weight", 16, L.SVI_BF16, bad, 2) == 1
+    assert "shape mismatch" in L.last_error()
+    assert lib.svi_dit_bind_weight(h, b"blocks.0.self_attn.q.weight", 16, L.SVI_F32, shape, 2) == 1
+    assert lib.svi_dit_destroy(h) == 0
+    # head_dim must be 128
+    cfg2 = L.DitConfig(128, 16, 256, 16, 64, 256, 1e-6, 1, 2, 2, 2, 2, 0)
+    assert lib.svi_dit_create(C.byref(cfg2), C.byref(h)) == 1
+    assert "head_dim" in L.last_error()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "stable-video-infinity_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "/root/reference" not in txt, f
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import svi_hip
+    x = torch.zeros(4, 128, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        svi_hip.layernorm_modulate(x)

@@ -1,0 +1,131 @@
+"""-m gpu: DiT block / whole forward / denoise loop on the HIP path against the golden vectors of the
+reference and against the oracle.
+
+Stated tolerances (rel-L2 over the whole output tensor):
+  block   vs oracle(bf16 rounding) <= 6e-3 ;  vs reference fp32 golden <= 1.5e-2
+  forward vs reference bf16 golden  <= 2e-2  (and not worse than 2x the reference's own bf16-vs-fp32 gap)
+  4-step CFG denoise loop vs reference fp32 golden <= 5e-2   (SURVEY §8c suggested bounds)
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gpu_util import bf16r, dev, errs, host, report
+from oracle import flow_match_oracle as fmo
+from oracle import wan_dit_oracle as wdo
+from test_oracle_dit import CASES, inputs, make_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def build(hip, c, seed):
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    return m, {k: bf16r(v) for k, v in sd.items()}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import svi_hip
+    return svi_hip
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_block_forward(hip, golden, name):
+    c, grid, nt, nv, ts, seed = CASES[name]
+    f, h, w = grid
+    g = golden(f"dit_{name}.npz")
+    m, sdb = build(hip, c, seed)
+    L = f * h * w
+    bx = torch.from_numpy(synth.randn(seed + 5, 1, L, c["dim"]))
+    bctx = torch.from_numpy(synth.randn(seed + 6, 1, nt + (257 if c["has_image_input"] else 0), c["dim"]))
+    btm = torch.from_numpy(0.5 * synth.randn(seed + 7, 1, 6, c["dim"]))
+    got = m.block_forward(0, dev(bx), dev(bctx), dev(btm), grid)
+    cfg = make_cfg(c)
+    want_b = wdo.dit_block(sdb, "blocks.0.", bf16r(bx), bf16r(bctx), bf16r(btm), wdo.rope_table_3d(128, grid), cfg, "bf16")
+    r_or, mx_or, _ = errs(got, want_b)
+    r_ref32, _, _ = errs(got, g["block0_fp32"])
+    r_ref16, _, _ = errs(got, g["block0_bf16"])
+    report("dit_block", case=name, vs_oracle_bf16=r_or, vs_ref_fp32=r_ref32, vs_ref_bf16=r_ref16, max_abs=mx_or)
+    assert r_or < 6e-3 and r_ref32 < 1.5e-2, (r_or, r_ref32, r_ref16)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward(hip, golden, name):
+    c, grid, nt, nv, ts, seed = CASES[name]
+    g = golden(f"dit_{name}.npz")
+    m, sdb = build(hip, c, seed)
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    got = m.forward(dev(x), torch.tensor([ts]), dev(ctx), **{k: dev(v) for k, v in kw.items()})
+    want_b = wdo.dit_forward(sdb, make_cfg(c), x, torch.tensor([ts]), ctx, rounding="bf16", **kw)
+    r_or, mx, _ = errs(got, want_b)
+    r_ref16, _, _ = errs(got, g["out_bf16"])
+    r_ref32, _, _ = errs(got, g["out_fp32"])
+    from conftest import rel_l2
+    noise = rel_l2(g["out_bf16"], g["out_fp32"])
+    report("dit_forward", case=name, vs_oracle_bf16=r_or, vs_ref_bf16=r_ref16, vs_ref_fp32=r_ref32, ref_bf16_vs_fp32=noise)
+    assert got.shape == g["out_fp32"].shape
+    assert r_ref16 < 2e-2 and r_ref32 < max(2e-2, 2 * noise), (r_or, r_ref16, r_ref32, noise)
+
+
+def test_model_fn_signature_and_refusals(hip):
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    m, _ = build(hip, c, seed)
+    x, ctx, _ = inputs(c, grid, nt, nv, seed)
+    a = hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx))
+    b = m.forward(dev(x), torch.tensor([ts]), dev(ctx))
+    assert torch.equal(a, b)                       # deterministic: same kernels, same order
+    with pytest.raises(NotImplementedError):
+        hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx), tea_cache=object())
+    with pytest.raises(NotImplementedError):
+        hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx), use_unified_sequence_parallel=True)
+
+
+def test_add_condition_and_batch(hip):
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    f, h, w = grid
+    m, sdb = build(hip, c, seed)
+    x, ctx, _ = inputs(c, grid, nt, nv, seed)
+    add = torch.from_numpy(0.1 * synth.randn(9, 1, f * h * w, c["dim"]))
+    got = m.forward(dev(x), torch.tensor([ts]), dev(ctx), add_condition=dev(add))
+    want = wdo.dit_forward(sdb, make_cfg(c), x, torch.tensor([ts]), ctx, add_condition=bf16r(add), rounding="bf16")
+    assert errs(got, want)[0] < 1e-2
+    xb = torch.cat([x, x.flip(-1)]); cb = torch.cat([ctx, ctx])
+    gb = m.forward(dev(xb), torch.tensor([ts, ts]), dev(cb))
+    g0 = m.forward(dev(x), torch.tensor([ts]), dev(ctx))
+    assert torch.equal(gb[0:1], g0)
+
+
+def test_denoise_loop_matches_reference(hip, golden):
+    g = golden("denoise_tiny.npz")
+    c, seed, grid = synth.TINY_DIT, 300, (2, 4, 4)
+    f, h, w = grid
+    m, sdb = build(hip, c, seed)
+    lat = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=11, device="cpu", dtype=torch.float32)
+    pos = torch.from_numpy(synth.text_context(seed + 2, 16, c["text_dim"], 9))
+    neg = torch.from_numpy(synth.text_context(seed + 3, 16, c["text_dim"], 4))
+    loop = hip.DenoiseLoop(m)
+    out = loop.sample(dev(lat), dev(pos), dev(neg), num_inference_steps=4, cfg_scale=5.0, sigma_shift=5.0)
+    cfg = make_cfg(c)
+    want_b = fmo.denoise_loop(lambda x, t, cx: wdo.dit_forward(sdb, cfg, x, t, cx, rounding="bf16"), lat, pos, neg, 4, 5.0, 5.0, "bf16")
+    r_or = errs(out, want_b)[0]
+    r_ref = errs(out, g["latents"])[0]
+    report("denoise_loop", vs_oracle_bf16=r_or, vs_ref_fp32=r_ref)
+    assert r_ref < 5e-2 and r_or < 3e-2, (r_or, r_ref)
+
+
+def test_c1_scale_forward_vs_oracle(hip):
+    """Config C1 geometry (17f 256x256 -> L=1280) at a 2-layer, 2-head width: multi-tile GEMMs and 20 key tiles."""
+    c = dict(synth.SMALL_DIT)
+    m, sdb = build(hip, c, 700)
+    x = torch.from_numpy(synth.randn(701, 1, 16, 5, 32, 32))
+    ctx = torch.from_numpy(synth.text_context(702, 512, c["text_dim"], 60))
+    ts = torch.tensor([833.3333])
+    got = m.forward(dev(x), ts, dev(ctx))
+    want = wdo.dit_forward(sdb, make_cfg(c), x, ts, ctx, rounding="bf16")
+    want32 = wdo.dit_forward({k: torch.from_numpy(v) for k, v in synth.dit_state_dict(700, **c).items()}, make_cfg(c), x, ts, ctx)
+    r, mx, _ = errs(got, want)
+    r32 = errs(got, want32)[0]
+    report("dit_forward_c1grid", vs_oracle_bf16=r, vs_oracle_fp32=r32, max_abs=mx)
+    assert r < 1e-2 and r32 < 2e-2, (r, r32)

@@ -1,0 +1,210 @@
+"""-m gpu: every HIP operator, called through the C ABI, against the oracle's statement of the same op.
+
+Tolerances (stated per test): inputs are bf16, accumulation fp32, outputs bf16.  Against the oracle's
+"bf16 rounding" statement the only differences are accumulation order and a few fused roundings, so
+rel-L2 <= 4e-3 (one bf16 ulp is 2^-8 = 3.9e-3 relative); against plain fp32 math, rel-L2 <= 1e-2.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gpu_util import bf16r, dev, errs, host, report
+from oracle import wan_dit_oracle as wdo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import svi_hip
+    assert svi_hip._lib.lib().svi_device_count() >= 1
+    return svi_hip
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [
+    (128, 128, 64), (256, 384, 128), (1, 1536, 256), (72, 128, 128), (257, 1280, 1280), (333, 200, 72),
+    (1000, 1536, 1536), (512, 8960, 1536), (640, 1536, 8960), (130, 64, 1536),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bias(hip, M, N, K):
+    """A=I-style transposition traps are covered by asymmetric random operands and a non-square shape."""
+    x = bf16r(torch.from_numpy(synth.randn(1, M, K)))
+    w = bf16r(torch.from_numpy(synth.randn(2, N, K)) / math.sqrt(K))
+    b = bf16r(torch.from_numpy(synth.randn(3, N)))
+    want = (x.double() @ w.double().t() + b.double()).float()
+    got = hip.linear(dev(x), dev(w), dev(b))
+    r, mx, sc = errs(got, want)
+    report("gemm_bias", M=M, N=N, K=K, rel_l2=r, max_abs=mx, scale=sc)
+    assert got.shape == (M, N)
+    assert r < 4e-3 and mx < 2 ** -7 * sc * 2, (r, mx, sc)
+
+
+def test_gemm_identity_detects_transposes(hip):
+    """W = shifted identity with asymmetric scaling: any swap of row/col or k-order shows up exactly."""
+    K = N = 256
+    M = 192
+    x = bf16r(torch.from_numpy(synth.randn(5, M, K)))
+    w = torch.zeros(N, K)
+    for n in range(N):
+        w[n, (n * 7 + 3) % K] = float(1 + (n % 5))
+    got = host(hip.linear(dev(x), dev(w), None))
+    want = bf16r(x @ w.t())
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("epi", ["gelu_tanh", "gelu_erf", "silu", "gate_res", "res_nogate", "transposed"])
+def test_gemm_epilogues(hip, epi):
+    L = hip._lib
+    M, N, K = 200, 264, 136
+    x = bf16r(torch.from_numpy(synth.randn(11, M, K)))
+    w = bf16r(torch.from_numpy(synth.randn(12, N, K)) / math.sqrt(K))
+    b = bf16r(torch.from_numpy(synth.randn(13, N)))
+    y = bf16r(x @ w.t() + b)
+    if epi == "gelu_tanh":
+        want = bf16r(wdo.gelu_tanh(y)); got = hip.linear(dev(x), dev(w), dev(b), epilogue=L.EPI_BIAS_GELU_TANH)
+    elif epi == "gelu_erf":
+        want = bf16r(0.5 * y * (1 + torch.erf(y / math.sqrt(2)))); got = hip.linear(dev(x), dev(w), dev(b), epilogue=L.EPI_BIAS_GELU_ERF)
+    elif epi == "silu":
+        want = bf16r(y * torch.sigmoid(y)); got = hip.linear(dev(x), dev(w), dev(b), epilogue=L.EPI_BIAS_SILU)
+    elif epi in ("gate_res", "res_nogate"):
+        res = bf16r(torch.from_numpy(synth.randn(14, M, N)))
+        gate = bf16r(torch.from_numpy(synth.randn(15, N))) if epi == "gate_res" else None
+        t = bf16r(gate * y) if gate is not None else y
+        want = bf16r(res + t)
+        got = hip.linear(dev(x), dev(w), dev(b), epilogue=L.EPI_BIAS_GATE_RES,
+                         gate=None if gate is None else dev(gate, torch.float32), residual=dev(res))
+    else:
+        bm = b                      # bias runs along the rows of the transposed output
+        want = bf16r((x @ w.t() + bm)).t()
+        got = hip.linear(dev(x), dev(w), dev(b), transpose_out=True)[:, :M]
+    r, mx, sc = errs(got, want)
+    report("gemm_epilogue", epi=epi, rel_l2=r, max_abs=mx)
+    assert r < 4e-3, (epi, r, mx)
+
+
+def test_gemm_inplace_residual(hip):
+    """x += gate*(h W^T + b) with the residual aliasing the output, as the block does (dit:369,373)."""
+    L = hip._lib
+    M, N, K = 300, 256, 128
+    h = dev(synth.randn(21, M, K)); w = dev(synth.randn(22, N, K) / math.sqrt(K)); b = dev(synth.randn(23, N))
+    gate = dev(synth.randn(24, N), torch.float32)
+    x = dev(synth.randn(25, M, N))
+    ref = hip.linear(h, w, b, epilogue=L.EPI_BIAS_GATE_RES, gate=gate, residual=x.clone())
+    xin = x.clone()
+    L.check(L.lib().svi_gemm_bf16(h.data_ptr(), K, w.data_ptr(), K, xin.data_ptr(), N, M, N, K, b.data_ptr(), 0,
+                                  L.EPI_BIAS_GATE_RES, gate.data_ptr(), xin.data_ptr(), N, L.current_stream()))
+    assert torch.equal(xin, ref)
+
+
+# ------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("rows,dim", [(1, 128), (7, 1536), (130, 1280), (33, 5120), (5, 8192)])
+@pytest.mark.parametrize("mode", ["plain", "affine", "mod"])
+def test_layernorm_modulate(hip, rows, dim, mode):
+    x = bf16r(torch.from_numpy(3 * synth.randn(31, rows, dim) + 0.5))
+    kw, want = {}, bf16r(wdo.layer_norm(x, 1e-6))
+    if mode == "affine":
+        w = bf16r(torch.from_numpy(1 + 0.1 * synth.randn(32, dim))); b = bf16r(torch.from_numpy(0.1 * synth.randn(33, dim)))
+        want = bf16r(wdo.layer_norm(x, 1e-6, w, b)); kw = dict(weight=dev(w), bias=dev(b))
+    elif mode == "mod":
+        sh = bf16r(torch.from_numpy(0.3 * synth.randn(34, dim))); sc = bf16r(torch.from_numpy(0.3 * synth.randn(35, dim)))
+        want = wdo.modulated_norm(x[None], sh[None, None], sc[None, None], 1e-6, bf16r)[0]
+        kw = dict(shift=dev(sh), scale=dev(sc))
+    got = hip.layernorm_modulate(dev(x), 1e-6, **kw)
+    r, mx, sc_ = errs(got, want)
+    report("layernorm", rows=rows, dim=dim, mode=mode, rel_l2=r, max_abs=mx)
+    assert r < 2e-3, (r, mx)
+
+
+@pytest.mark.parametrize("grid,heads", [((1, 1, 1), 1), ((3, 4, 6), 1), ((2, 5, 7), 2), ((2, 3, 5), 12), ((21, 2, 3), 2)])
+def test_rmsnorm_rope(hip, grid, heads):
+    f, h, w = grid
+    L, dim = f * h * w, heads * 128
+    x = bf16r(torch.from_numpy(2 * synth.randn(41, L, dim)))
+    wt = bf16r(torch.from_numpy(1 + 0.1 * synth.randn(42, dim)))
+    n = wdo.rms_norm_full(x[None], wt, 1e-6, bf16r)
+    want_norm = n[0]
+    want_rope = bf16r(wdo.apply_rope(n, wdo.rope_table_3d(128, grid), heads))[0]
+    got_norm = hip.rmsnorm_rope_(dev(x), dev(wt), 1e-6)
+    got_rope = hip.rmsnorm_rope_(dev(x), dev(wt), 1e-6, grid=grid, num_heads=heads)
+    r0, m0, _ = errs(got_norm, want_norm)
+    r1, m1, _ = errs(got_rope, want_rope)
+    report("rmsnorm_rope", grid=list(grid), heads=heads, rel_l2_norm=r0, rel_l2_rope=r1, max_abs_rope=m1)
+    assert r0 < 2e-3 and r1 < 2e-3, (r0, r1)
+
+
+def test_rmsnorm_strided_view(hip):
+    """The block normalises q and k in place inside the [L, 2D] q|k buffer (ld = 2D)."""
+    L_, D = 50, 256
+    qk = dev(synth.randn(43, L_, 2 * D))
+    wt = dev(1 + 0.1 * synth.randn(44, D))
+    ref = hip.rmsnorm_rope_(qk[:, D:].contiguous(), wt, 1e-6)
+    lib = hip._lib
+    before_q = qk[:, :D].clone()
+    lib.check(lib.lib().svi_rmsnorm_rope(qk.data_ptr() + D * 2, 2 * D, L_, D, wt.data_ptr(), 1e-6, 0, 0, 0, 0, 0,
+                                         lib.current_stream()))
+    assert torch.equal(qk[:, D:], ref) and torch.equal(qk[:, :D], before_q)
+
+
+# ------------------------------------------------------------------------------------------ attention
+ATT_SHAPES = [(64, 64, 1), (128, 512, 2), (100, 77, 1), (1280, 1280, 2), (333, 257, 3), (72, 72, 12), (1, 1, 1),
+              (4096, 4096, 1), (130, 1000, 2)]
+
+
+@pytest.mark.parametrize("Lq,Lk,heads", ATT_SHAPES)
+def test_flash_attention(hip, Lq, Lk, heads):
+    """vs softmax(QK^T/sqrt(128))V in fp64 on the same bf16 inputs.  P is rounded to bf16 before PV inside the
+    kernel (as every flash-attention does), so the bound is a little over one bf16 ulp: rel-L2 <= 6e-3."""
+    D = heads * 128
+    q = bf16r(torch.from_numpy(synth.randn(51, 1, Lq, D)))
+    k = bf16r(torch.from_numpy(synth.randn(52, 1, Lk, D)))
+    v = bf16r(torch.from_numpy(synth.randn(53, 1, Lk, D)))
+    want = wdo.attention(q.double(), k.double(), v.double(), heads).float()
+    got = hip.flash_attention(dev(q), dev(k), dev(v), heads)
+    r, mx, sc = errs(got, want)
+    report("flash_attention", Lq=Lq, Lk=Lk, heads=heads, rel_l2=r, max_abs=mx, scale=sc)
+    assert r < 6e-3, (r, mx)
+
+
+def test_flash_attention_online_softmax_rescale(hip):
+    """Force the running max to jump late in the key axis (a spiked key in the last tile) and early (first tile):
+    exercises the O/l rescale branch that bounded random data barely touches."""
+    Lq, Lk, heads = 96, 448, 1
+    q = bf16r(torch.from_numpy(synth.randn(61, 1, Lq, 128)))
+    k = bf16r(torch.from_numpy(synth.randn(62, 1, Lk, 128)))
+    v = bf16r(torch.from_numpy(synth.randn(63, 1, Lk, 128)))
+    k[0, 430] = q[0, 17] * 4.0          # row 17's max jumps by ~45 logits at the last tile
+    k[0, 3] = q[0, 40] * 4.0            # row 40 peaks in the first tile, everything later is rescaled against it
+    want = wdo.attention(q.double(), k.double(), v.double(), heads).float()
+    got = hip.flash_attention(dev(q), dev(k), dev(v), heads)
+    r, mx, _ = errs(got, want)
+    report("flash_attention_spike", rel_l2=r, max_abs=mx)
+    assert r < 6e-3 and mx < 0.05, (r, mx)
+
+
+def test_flash_attention_batch_and_linearity_in_v(hip):
+    """Size-independent property: attention is linear in V;  attn(q,k,a*v1+v2) == a*attn(q,k,v1)+attn(q,k,v2)."""
+    q = dev(synth.randn(71, 2, 200, 256)); k = dev(synth.randn(72, 2, 300, 256))
+    v1 = dev(synth.randn(73, 2, 300, 256)); v2 = dev(synth.randn(74, 2, 300, 256))
+    o1 = hip.flash_attention(q, k, v1, 2).float(); o2 = hip.flash_attention(q, k, v2, 2).float()
+    o12 = hip.flash_attention(q, k, (2 * v1.float() + v2.float()).to(torch.bfloat16), 2).float()
+    r, mx, _ = errs(o12, 2 * o1 + o2)
+    assert r < 1e-2, r
+
+
+# ------------------------------------------------------------------------------------------ cfg step
+def test_cfg_step_bit_exact(hip):
+    n = 16 * 5 * 32 * 32 + 3
+    lat = bf16r(torch.from_numpy(synth.randn(81, n))); c = bf16r(torch.from_numpy(synth.randn(82, n))); u = bf16r(torch.from_numpy(synth.randn(83, n)))
+    s, ds = 5.0, -0.021739
+    want = bf16r(lat + bf16r(bf16r(u + bf16r(s * bf16r(c - u))) * ds))
+    got = host(hip.cfg_step_(dev(lat), dev(c), dev(u), s, ds))
+    assert torch.equal(got, want)
+    want1 = bf16r(lat + bf16r(c * ds))
+    got1 = host(hip.cfg_step_(dev(lat), dev(c), None, 1.0, ds))
+    assert torch.equal(got1, want1)
