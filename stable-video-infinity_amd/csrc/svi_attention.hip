@@ -40,6 +40,8 @@ __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((
 // MFMA row i of a 32-key block reads key perm23(i): bits 2 and 3 swapped.
 __device__ __forceinline__ int perm23(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
+// TAG only names the instantiation (0 = self-attention, 1 = cross-attention) so that profiles tell them apart.
+template <int TAG>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restrict__ Q, int ldq,
                                                            const bf16* __restrict__ K, int ldk,
                                                            const bf16* __restrict__ VT, int ldvt,
@@ -206,13 +208,18 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     static bool attr_set = false;
     const int lds = 2 * (KT_BYTES + VT_BYTES);
     if (!attr_set) {
-        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel),
+        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid((Lq + QB - 1) / QB, num_heads), block(256);
-    hipLaunchKernelGGL(flash_fwd_kernel, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
+    if (Lq == Lk)
+        hipLaunchKernelGGL(flash_fwd_kernel<0>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
+    else
+        hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
