@@ -27,6 +27,8 @@
 // written after them (one barrier per tile).
 //
 // Algorithmic work: 4 * Lq * Lk * 128 FLOP per head (QK^T + PV, multiply-add = 2).
+#include <type_traits>
+
 #include "svi_common.h"
 
 #define QB 128            // query rows per workgroup
@@ -73,20 +75,21 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
     const int kr = tid >> 4, kc = tid & 15;          // + 16 rows per j
     const int vr = tid >> 3, vc = tid & 7;           // + 32 rows per j
     const bf16* kbase = K + head * DH + kc * 8;
-    const bf16* vbase = VT + (size_t)(head * DH) * ldvt + vc * 8;
+    const bf16* vrow = VT + (size_t)(head * DH) * ldvt;
     u32x4 rk[4], rv[4];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int ntiles = (Lk + KB - 1) / KB;
 
+    // Tile loads are unconditional: out-of-range keys are clamped to the last valid key / key-chunk, so the tail
+    // tile reads finite duplicates that the -inf mask (scores) and P == 0 (values) remove exactly.
+    const int last_key = Lk - 1, last_chunk = (Lk - 1) & ~7;
     auto load_tile = [&](int t) {
         const int key0 = t * KB;
+        const int kcol = min(key0 + vc * 8, last_chunk);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int key = key0 + kr + 16 * j;
-            rk[j] = (key < Lk) ? *reinterpret_cast<const u32x4*>(kbase + (size_t)key * ldk) : zero4;
-            const int kcol = key0 + vc * 8;          // first key of this 8-key chunk; pad keys hold zeros
-            rv[j] = (kcol < Lk) ? *reinterpret_cast<const u32x4*>(vbase + (size_t)(vr + 32 * j) * ldvt + key0)
-                                : zero4;
+            const int key = min(key0 + kr + 16 * j, last_key);
+            rk[j] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * ldk);
+            rv[j] = *reinterpret_cast<const u32x4*>(vrow + (size_t)(vr + 32 * j) * ldvt + kcol);
         }
     };
     auto store_tile = [&](int buf) {
@@ -107,17 +110,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
     float m_run = -INFINITY, l_run = 0.f;
     const int krow = perm23(l31);
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ntiles) load_tile(t + 1);
+    // One 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  MASKED is a compile-time flag so that the
+    // key-range test exists only in the peeled last tile (as a runtime `if` the compiler if-converts it into ~110
+    // predicated VALU ops per tile).
+    auto tile = [&](int t, int cur, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const char* Ks = smem + cur * (KT_BYTES + VT_BYTES);
         const char* Vs = Ks + KT_BYTES;
-
-        // ---- S^T = K Q^T (2 blocks of 32 keys) ------------------------------------------------------
         f32x16 s[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
             }
         }
         // register r of s[tt] is key  t*64 + 32*tt + 16*(r>>3) + 8*hi + (r&7)
-        if ((t + 1) * KB > Lk) {
+        if (MASKED) {
             const int kb = t * KB + 8 * hi;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
@@ -138,34 +137,36 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
                 for (int r = 0; r < 16; ++r)
                     if (kb + 32 * tt + 16 * (r >> 3) + (r & 7) >= Lk) s[tt][r] = -INFINITY;
         }
-
         // ---- online softmax (per query = per (l & 31); the other 32 keys live in lane ^ 32) -----------
-        float mx = s[0][0];
+        float m8[8];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        for (int r = 0; r < 8; ++r) m8[r] = fmaxf(fmaxf(s[0][r], s[0][r + 8]), fmaxf(s[1][r], s[1][r + 8]));
+        float mx = fmaxf(fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3])), fmaxf(fmaxf(m8[4], m8[5]), fmaxf(m8[6], m8[7])));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-        const float mneg = -m_new * scale_log2e;
-        float psum = 0.f;
+        // Rescale O and l only when some row's running max actually grew in this tile (wave-uniform branch).
+        // This is exact, not a threshold: when no max grows alpha == exp2(0) == 1 for every row.
+        if (__any(mx > m_run)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        const float mneg = -m_run * scale_log2e;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
         bf16x8 pf[2][2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale_log2e, mneg));
-                psum += p;
+                ps[r & 3] += p;
                 pf[tt][r >> 3][r & 7] = (bf16)p;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         // ---- O^T += V^T P^T ------------------------------------------------------------------------
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
@@ -176,10 +177,20 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
                     bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + v_off(32 * d + l31, 4 * tt + 2 * sb + hi));
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tt][sb], o[d], 0, 0, 0);
                 }
+    };
 
-        if (t + 1 < ntiles) store_tile(cur ^ 1);
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        const int cur = t & 1;
+        load_tile(t + 1);
+        tile(t, cur, std::false_type{});
+        store_tile(cur ^ 1);
         __syncthreads();
     }
+    if (Lk & (KB - 1)) tile(ntiles - 1, (ntiles - 1) & 1, std::true_type{});
+    else tile(ntiles - 1, (ntiles - 1) & 1, std::false_type{});
 
     // ---- normalise and store: lane holds O[q_row][32 d + (r&3) + 8 (r>>2) + 4 hi] --------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);

@@ -74,10 +74,14 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 
+// gelu_tanh(x) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi)(x + 0.044715 x^3).  1 + tanh(u) = 2 sigmoid(2u), so
+// gelu_tanh(x) = x / (1 + exp(-2u)): one v_exp + one v_rcp instead of a tanhf expansion (fp32-accurate;
+// the result is rounded to bf16 by the caller).
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+    const float u = k0 * (x + k1 * x * x * x);
+    const float e = __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

@@ -60,12 +60,17 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16* __restrict__ x,
             bf16x8 o;
             bf16x8 wv, bv;
             if (w) { wv = ld_bf16x8(w + col); bv = ld_bf16x8(b + col); }
+            f32x4 sc0, sc1, sh0, sh1;
+            if (scale1p) {
+                sc0 = *reinterpret_cast<const f32x4*>(scale1p + col); sc1 = *reinterpret_cast<const f32x4*>(scale1p + col + 4);
+                sh0 = *reinterpret_cast<const f32x4*>(shift + col); sh1 = *reinterpret_cast<const f32x4*>(shift + col + 4);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float y = (v[c][j] - mean) * rstd;
                 if (w) y = y * (float)wv[j] + (float)bv[j];
                 y = rbf(y);
-                if (scale1p) y = rbf(rbf(y * scale1p[col + j]) + shift[col + j]);
+                if (scale1p) y = rbf(rbf(y * (j < 4 ? sc0[j & 3] : sc1[j & 3])) + (j < 4 ? sh0[j & 3] : sh1[j & 3]));
                 o[j] = (bf16)y;
             }
             st_bf16x8(orow + col, o);

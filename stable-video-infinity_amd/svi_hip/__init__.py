@@ -9,6 +9,7 @@ from .dit import WanDiT, model_fn_wan_video
 from .ops import cfg_step_, flash_attention, layernorm_modulate, linear, rmsnorm_rope_
 from .pipeline import DenoiseLoop, generate_noise, install
 from .scheduler import FlowMatchScheduler
+from .vae import WanVideoVAE
 
 __all__ = ["WanDiT", "model_fn_wan_video", "flash_attention", "layernorm_modulate", "rmsnorm_rope_", "linear",
-           "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "_lib"]
+           "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "WanVideoVAE", "_lib"]

@@ -1,0 +1,109 @@
+"""Multi-GPU execution of the rolling window: one process per GPU, clips sharded over ranks, RCCL over xGMI.
+
+What shards: for the T2V model the clip-to-clip hand-off never reaches the network
+(pipelines/svi_video.py:481,493-494 ignore `input_image` without an image encoder), so clip k depends only on
+(prompt_k, seed_k = k * seed_times) (test_svi.py:424-476).  Clips are therefore independent units:
+
+    clip k  ->  rank k mod P      (weights replicated: 2.8 GB bf16 on 288 GB)
+
+There is NO collective inside the 50-step denoise loop.  The only exchange is at the end of a round of clips:
+an all-gather of each clip's final latents ([16,21,h,w] bf16 = 4.2 MB) — which contains the tail (motion) latent
+frames every rank needs to know where the next clip of the window starts — so that any rank can decode and
+stitch the window in order with the reference's stitching rule (drop the last `num_motion_frames` frames of every
+clip but the last, test_svi.py:472-476).  Over xGMI a 4.2 MB all-gather on 8 GPUs is ~30 us of wire time; it is a
+per-clip (every ~40 s) event.
+
+For I2V (image-conditioned) streams clip k+1 needs clip k's decoded frames, which is sequential by definition;
+those shard over *samples* with the same code (`units` are then whole samples).
+
+Backends: "nccl" (= RCCL on ROCm) on GPUs; "gloo" on CPU for the world_size-2 tests of the sharding/stitching logic.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_units(num_units: int, rank: int, world: int) -> List[int]:
+    """Round-robin: unit k -> rank k mod world (keeps every rank's load within one clip of the others)."""
+    return [k for k in range(num_units) if k % world == rank]
+
+
+def clip_seed(chunk_idx: int, seed_times: int = 42) -> Optional[int]:
+    """seed = chunk_idx * seed_times; seed_times == -1 means unseeded (test_svi.py:425-428)."""
+    return None if seed_times == -1 else int(chunk_idx * seed_times)
+
+
+def clip_prompt_index(chunk_idx: int, num_prompts: int, prompt_repeat_times: int = 1, use_first_prompt_only: bool = False) -> int:
+    """Prompt cycling of the clip loop (test_svi.py:430-438)."""
+    if use_first_prompt_only:
+        return 0
+    return (chunk_idx // prompt_repeat_times) % num_prompts
+
+
+class ClipParallel:
+    """Process-group wrapper: who am I, which clips are mine, and the end-of-round all-gather."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        self.world = dist.get_world_size(group) if self.enabled else 1
+
+    def my_clips(self, num_clips: int) -> List[int]:
+        return shard_units(num_clips, self.rank, self.world)
+
+    def all_gather_clips(self, local: Dict[int, torch.Tensor], num_clips: int, like: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+        """Every rank contributes the latents of its clips; every rank receives all `num_clips`, in clip order.
+
+        One all-gather per round r (clips r*P .. r*P+P-1): a rank with no clip in the last, partial round
+        contributes a zero tensor that is dropped on receipt (all ranks must enter the collective)."""
+        if not self.enabled or self.world == 1:
+            return [local[k] for k in range(num_clips)]
+        proto = like if like is not None else next(iter(local.values()))
+        out: List[Optional[torch.Tensor]] = [None] * num_clips
+        rounds = (num_clips + self.world - 1) // self.world
+        for r in range(rounds):
+            k = r * self.world + self.rank
+            mine = local[k].contiguous() if k < num_clips else torch.zeros_like(proto)
+            bucket = [torch.empty_like(proto) for _ in range(self.world)]
+            dist.all_gather(bucket, mine, group=self.group)
+            for src in range(self.world):
+                kk = r * self.world + src
+                if kk < num_clips:
+                    out[kk] = bucket[src]
+        return out  # type: ignore[return-value]
+
+    def all_gather_motion_tails(self, local: Dict[int, torch.Tensor], num_clips: int, num_motion_latents: int = 1) -> List[torch.Tensor]:
+        """Only the last `num_motion_latents` latent frames of each clip ([16, n, h, w]); what the next clip's
+        conditioning would be built from.  Same collective shape as all_gather_clips, 1/21 of the bytes."""
+        tails = {k: v[..., -num_motion_latents:, :, :].contiguous() for k, v in local.items()}
+        return self.all_gather_clips(tails, num_clips)
+
+
+def stitch_window(clips: Sequence[Sequence], num_motion_frames: int) -> list:
+    """The reference's stitching rule (test_svi.py:472-476): every clip but the last loses its final
+    `num_motion_frames` frames (they are re-generated as the head of the next clip)."""
+    frames: list = []
+    n = len(clips)
+    for i, c in enumerate(clips):
+        c = list(c)
+        frames += c[:-num_motion_frames] if (i < n - 1 and num_motion_frames > 0) else c
+    return frames
+
+
+def run_window(denoise_clip: Callable[[int], torch.Tensor], num_clips: int, par: Optional[ClipParallel] = None,
+               ) -> List[torch.Tensor]:
+    """Denoise `num_clips` independent clips across the ranks of `par`; returns all final latents, in clip order, on
+    every rank.  `denoise_clip(k)` must depend only on k (seed/prompt derive from k) — that is what makes the result
+    identical for any number of ranks."""
+    par = par or ClipParallel()
+    local = {k: denoise_clip(k) for k in par.my_clips(num_clips)}
+    proto = None
+    if not local:                                  # more ranks than clips: still join the collective
+        proto = denoise_clip.__dict__.get("proto")
+        if proto is None:
+            raise RuntimeError("rank without clips needs denoise_clip.proto (a tensor shaped like a clip's latents)")
+    return par.all_gather_clips(local, num_clips, like=proto)

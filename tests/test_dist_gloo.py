@@ -1,0 +1,95 @@
+"""Multi-process (gloo, world_size 2, CPU) tests of the N>1 path: clip sharding, the end-of-round all-gather and the
+stitching rule.  The property under test: the gathered window is identical for any number of ranks."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd"))
+from svi_hip import parallel  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _clip(k):
+    """Stand-in for a denoised clip that depends only on k — like seed = k*42 does (test_svi.py:425)."""
+    g = torch.Generator("cpu").manual_seed(parallel.clip_seed(k))
+    return torch.randn((16, 3, 4, 4), generator=g).to(torch.bfloat16)
+
+
+_clip.proto = torch.zeros((16, 3, 4, 4), dtype=torch.bfloat16)
+
+
+def _worker(rank, world, port, num_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = parallel.ClipParallel()
+        mine = par.my_clips(num_clips)
+        window = parallel.run_window(_clip, num_clips, par)
+        tails = par.all_gather_motion_tails({k: _clip(k) for k in mine}, num_clips, 1) if mine else None
+        q.put((rank, mine, [w.float() for w in window], None if tails is None else [t.float() for t in tails]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_clips", [2, 5])
+def test_two_ranks_reproduce_single_rank_window(num_clips):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, num_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    serial = [_clip(k).float() for k in range(num_clips)]
+    seen = []
+    for rank, mine, window, tails in res:
+        assert mine == [k for k in range(num_clips) if k % 2 == rank]
+        seen += mine
+        assert len(window) == num_clips
+        for k in range(num_clips):
+            assert torch.equal(window[k], serial[k])          # bit-identical to the 1-rank order
+        if tails is not None:
+            for k in range(num_clips):
+                assert torch.equal(tails[k], serial[k][:, -1:])
+    assert sorted(seen) == list(range(num_clips))
+
+
+def test_single_process_paths():
+    par = parallel.ClipParallel()
+    assert (par.rank, par.world) == (0, 1) and par.my_clips(3) == [0, 1, 2]
+    w = parallel.run_window(_clip, 3, par)
+    assert all(torch.equal(w[k], _clip(k)) for k in range(3))
+    assert parallel.shard_units(8, 3, 8) == [3] and parallel.shard_units(3, 5, 8) == []
+    assert sorted(sum((parallel.shard_units(11, r, 4) for r in range(4)), [])) == list(range(11))
+
+
+def test_seed_and_prompt_schedule_match_reference_loop():
+    assert [parallel.clip_seed(k) for k in range(3)] == [0, 42, 84]          # test_svi.py:425, seed_times=42
+    assert parallel.clip_seed(7, -1) is None
+    assert [parallel.clip_prompt_index(k, 3, 2) for k in range(8)] == [0, 0, 1, 1, 2, 2, 0, 0]
+    assert parallel.clip_prompt_index(5, 3, 1, use_first_prompt_only=True) == 0
+
+
+def test_stitching_rule():
+    clips = [list(range(10 * i, 10 * i + 5)) for i in range(3)]
+    assert parallel.stitch_window(clips, 1) == [0, 1, 2, 3, 10, 11, 12, 13, 20, 21, 22, 23, 24]   # test_svi.py:472-476
+    assert parallel.stitch_window(clips[:1], 1) == clips[0]
+    assert len(parallel.stitch_window(clips, 0)) == 15
