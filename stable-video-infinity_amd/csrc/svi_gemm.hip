@@ -21,6 +21,8 @@
 //
 // Workgroup ids are remapped so that the 8 XCDs each own a contiguous band of tiles (per-XCD L2 keeps
 // the shared A row-panel hot; cdna_hip_programming.md T1, bijective form).
+#include <stdlib.h>
+
 #include "svi_common.h"
 
 #define BM 128
@@ -198,6 +200,188 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
     }
 }
 
+
+// =================================================================================================
+// Large-problem kernel: 256(M) x 256(N) x 64(K) per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per
+// wave = 4x2 MFMA tiles, 128 accumulator VGPRs), ONE workgroup per CU.
+//
+// Why a second kernel: with the 128^2 tile a K step gives a wave only 16 MFMAs (512 cycles) of cover for the
+// next tile's global loads, so the loop runs at L2/HBM latency, not at MFMA rate (measured 530-610 TFLOP/s).
+// Here a K step is 32 MFMAs per wave and two waves share a SIMD -> 2048 cycles of matrix work per barrier,
+// and the next tile is fetched by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass)
+// issued BEFORE the MFMAs of the current tile (cdna_hip_programming.md §5 "glds vs register staging").
+//
+// LDS image: per stage A tile [256 rows][128 B] + W tile [256][128 B] = 64 KiB, two stages = 128 KiB.
+// LDS-DMA writes lane-linear (wave-uniform base + lane*16), so the bank swizzle sits on the SOURCE address:
+// LDS slot (row r, position p) receives global 16-byte chunk p ^ ((r >> 1) & 7) of row r; the fragment read
+// applies the same XOR (rule 21: source permutation == read permutation, destination linear).  A wave
+// instruction covers 8 whole 128-byte rows, so the permutation stays inside full cache lines.
+//
+// Epilogue as in the 128^2 kernel, the staged C tile is [256][264] bf16 (132 KiB, the LDS is otherwise idle).
+// Tile order: 8 XCD bands (bijective), inside a band groups of 8 row panels walk the column panels, so the 32
+// tiles an XCD runs at once are ~8 row panels x 4 column panels: 12 operand panels for 32 tiles in its L2.
+// =================================================================================================
+#define TM 256
+#define TN 256
+#define T_STAGE (TM * BK * 2)          // 32 KiB per operand tile
+#define C2_LD 264
+#define LDS256_BYTES (TM * C2_LD * 2)  // 135168 >= 4 * T_STAGE
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    const int GM = 8;
+    const int group = swz / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = swz - group * GM * tiles_n;
+    const int tile_n = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n * gm);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+    // ---- LDS-DMA assignment: operand tile = 32 pieces of 1 KiB (8 rows); wave w issues pieces w, w+8, w+16, w+24
+    unsigned a_off[4], w_off[4];         // element offsets of this lane's source chunk at k = 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 8;
+        w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 8;
+    }
+    const int nk = g.K / BK;
+    auto stage = [&](int kt, int buf) {
+        char* As = smem + buf * 2 * T_STAGE;
+        char* Ws = As + T_STAGE;
+        const bf16* ak = g.A + kt * BK;
+        const bf16* wk = g.W + kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ak + a_off[j]), (lptr_t)(As + (j * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wk + w_off[j]), (lptr_t)(Ws + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][4];                       // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const char* As = smem + cur * 2 * T_STAGE;
+        const char* Ws = As + T_STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 xa[4], wb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xa[i] = *reinterpret_cast<const bf16x8*>(As + lds_tile_off(wm * 128 + i * 32 + l31, 2 * kk + hi));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wb[i] = *reinterpret_cast<const bf16x8*>(Ws + lds_tile_off(wn * 64 + i * 32 + l31, 2 * kk + hi));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();                    // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
+    }
+
+    // ---- epilogue part 1: y = bf16(acc + bias) -> LDS [256 m][C2_LD] bf16 ---------------------------
+    bf16* Cs = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int ml = wm * 128 + mi * 32 + l31;
+            float bm = 0.f;
+            if (g.bias && g.bias_along_m) bm = (m0 + ml < g.M) ? (float)g.bias[m0 + ml] : 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int nl = wn * 64 + ni * 32 + 8 * rg + 4 * hi;
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bv = bm;
+                    if (g.bias && !g.bias_along_m) bv = (n0 + nl + e < g.N) ? (float)g.bias[n0 + nl + e] : 0.f;
+                    pk[e] = (bf16)(acc[ni][mi][rg * 4 + e] + bv);
+                }
+                *reinterpret_cast<bf16x4*>(Cs + ml * C2_LD + nl) = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue part 2: row-contiguous read-back (512 B per row), activation / gate / residual, coalesced store
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int id = tid + 512 * it;
+        const int ml = id >> 5, cc = id & 31;
+        const int m = m0 + ml, n = n0 + cc * 8;
+        if (m >= g.M || n >= g.N) continue;
+        bf16x8 yv = *reinterpret_cast<const bf16x8*>(Cs + ml * C2_LD + cc * 8);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (float)yv[e];
+        const bool full = (n + 8 <= g.N);
+        if (g.epi == SVI_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = gelu_tanh_f(y[e]);
+        } else if (g.epi == SVI_EPI_BIAS_GELU_ERF) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = gelu_erf_f(y[e]);
+        } else if (g.epi == SVI_EPI_BIAS_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+        } else if (g.epi == SVI_EPI_BIAS_GATE_RES) {
+            const bf16* rp = g.res + (size_t)m * g.ldres + n;
+            float rv[8];
+            if (full) {
+                bf16x8 t = ld_bf16x8(rp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[e] = (float)t[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[e] = (n + e < g.N) ? (float)rp[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = y[e];
+                if (g.gate) t = rbf(((n + e < g.N) ? g.gate[n + e] : 0.f) * t);
+                y[e] = rv[e] + t;
+            }
+        }
+        bf16* cp = g.C + (size_t)m * g.ldc + n;
+        if (full) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
+            st_bf16x8(cp, o);
+        } else {
+            for (int e = 0; e < 8 && n + e < g.N; ++e) cp[e] = (bf16)y[e];
+        }
+    }
+}
+
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     SVI_REQUIRE(g.M >= 0 && g.N >= 0 && g.K > 0, "gemm: bad sizes M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0 || g.N == 0) return SVI_OK;
@@ -210,6 +394,25 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     if (g.epi == SVI_EPI_BIAS_GATE_RES) {
         SVI_REQUIRE(g.res != nullptr && g.ldres % 8 == 0 && ((uintptr_t)g.res % 16) == 0,
                     "gemm: gate/residual epilogue needs an aligned residual");
+    }
+    // 256^2 LDS-DMA kernel when the problem fills at least half the chip with 256^2 tiles (and K tiles are whole)
+    {
+        const long t256 = (long)((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN);
+        const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
+        const char* force = getenv("SVI_GEMM_KERNEL");      // "128" / "256": A/B switch for tools/kernel_probe.py
+        const bool want256 = force ? (force[0] == '2') : (t256 >= 128);
+        if (want256 && g.K % BK == 0 && fits32) {
+            static bool attr256 = false;
+            if (!attr256) {
+                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
+                attr256 = true;
+            }
+            const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
+            hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn);
+            SVI_LAUNCH_CHECK();
+            return SVI_OK;
+        }
     }
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     static bool attr_set = false;
