@@ -27,6 +27,7 @@
 // written after them (one barrier per tile).
 //
 // Algorithmic work: 4 * Lq * Lk * 128 FLOP per head (QK^T + PV, multiply-add = 2).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "svi_common.h"
@@ -209,6 +210,476 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
     }
 }
 
+
+// =================================================================================================
+// v2 — 256 query rows per workgroup: 4 waves x 64 rows (two 32-row groups g = 0,1 per wave), ONE wave per SIMD
+// (__launch_bounds__(256, 1): the wave owns the SIMD's whole 512-entry register file).
+//
+// Why: v1 runs at 49 % in-clock MFMA utilisation because each wave serialises QK^T -> softmax -> PV and the only
+// overlap is whatever a second, unsynchronised wave on the SIMD happens to provide (rocprof: 25 % of wave cycles in
+// s_waitcnt/barrier, 36 % in issue stalls).  Here the overlap is built into ONE instruction stream:
+//   * both row groups share every K / V^T fragment read (half the LDS traffic and ds_read count per MFMA);
+//   * software pipeline over key tiles, two phases per tile t, 32 MFMAs each:
+//       phase 1   S(t) = K(t)·Q^T              with, in its MFMA gaps, B(t-1): exp / row-sum / bf16 pack of tile t-1
+//       phase 2   O   += V(t-1)·P(t-1)         with, in its gaps,         A(t):   row max, new running max, alpha
+//     so the VALU-heavy half of the softmax of one tile hides under the QK^T of the next, the light half under PV;
+//     two score tiles are live (sA/sB alternate by name), one P tile;
+//   * the order is pinned: every MFMA and every filler group is chained through a dummy register `tok`
+//     (TIE()), so hipcc only allocates registers and places waitcnts — it does not get to cluster the VALU work away
+//     from the MFMAs (which is what it does when left alone: 124 VALU in one block, then 64 bare MFMAs);
+//   * K / V^T tiles arrive by LDS-DMA (global_load_lds_dwordx4, swizzle on the SOURCE address), two stages each, one
+//     barrier per tile; no staging registers, no ds_write pass;
+//   * row max with v_max3_f32, half-wave exchange with v_permlane32_swap (no LDS round trip in the softmax).
+// Same MFMA operand mapping and key permutation as v1 (see the file header).  The online-softmax rescale stays exact
+// (taken only when some row's max grew).  Tiles are processed in pairs; a tile index past the last real tile is a
+// fully masked tile (scores -inf -> P = 0), its loads are clamped to the last valid key.
+// =================================================================================================
+#define QB2 256
+#define SVI_RESCALE_THR 8.0f
+
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Register ownership.  Three quarters of the accumulation half of the register file are owned by this file, not by hipcc:
+//   a[0:63]     left to hipcc (it parks a few address registers there when its 256 arch VGPRs run out)
+//   a[64:191]   O^T accumulators, a[64 + (g*4 + d)*16 + r]  (g = row group, d = 32-channel block)
+//   a[192:255]  Q fragments (MFMA B operands), a[192 + (g*8 + kk)*4 + 0..3]
+// hipcc will not keep an MFMA *input* in AGPRs on its own (it spilled Q to scratch and reloaded it in front of every
+// QK^T MFMA) and it shuttles accumulators through v_accvgpr_* whenever a VALU touches them, so both the QK^T and the PV
+// MFMAs are inline asm naming these registers literally, and only scores / probabilities / fragments live in hipcc's
+// 256 arch VGPRs.  Contract (tools/audit_flash2.py checks the .s after every edit): every compiler-generated
+// v_accvgpr_* names an AGPR below a64, and nothing is spilled to scratch inside the tile loop.  The one statement that lists
+// a0..a255 as clobbers makes the kernel descriptor allocate them.  Wait states that hipcc would insert around its own
+// MFMAs are written out by hand next to each use (cdna_hip_programming.md §5.7).
+#define SVI_OREG0 64
+#define SVI_QREG0 192
+#define SVI_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define SVI_ALL_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", SVI_A8(1), SVI_A8(2), SVI_A8(3), SVI_A8(4), \
+    SVI_A8(5), SVI_A8(6), SVI_A8(7), SVI_A8(8), SVI_A8(9), SVI_A8(10), SVI_A8(11), SVI_A8(12), SVI_A8(13), SVI_A8(14),        \
+    SVI_A8(15), SVI_A8(16), SVI_A8(17), SVI_A8(18), SVI_A8(19), SVI_A8(20), SVI_A8(21), SVI_A8(22), SVI_A8(23), SVI_A8(24),   \
+    "a250", "a251", "a252", "a253", "a254", "a255"
+
+// `tok` is a dummy VGPR threaded through every statement that touches registers hipcc cannot see (the O accumulators):
+// it gives the compiler their ordering and liveness without making the statements volatile.
+template <int R>
+__device__ __forceinline__ void q_put(bf16x8 v) {              // a[R:R+3] = v
+    const u32x4 u = __builtin_bit_cast(u32x4, v);
+    asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
+                 "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+                 :: "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
+}
+// One QK^T MFMA:  s (+)= K-fragment x Q-fragment(a[R:R+3]).  `apin` (the LDS address of a later fragment read) is
+// listed in/out only to keep that read behind this MFMA.
+template <int R, bool FIRST>
+__device__ __forceinline__ void qk_mfma(int& tok, f32x16& s, u32x4 kf, int& apin) {
+    if constexpr (FIRST)
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], 0"
+            : [s] "=&v"(s), [tok] "+v"(tok), [ap] "+v"(apin) : [kf] "v"(kf), [q0] "n"(R), [q1] "n"(R + 3));
+    else
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]"
+            : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin) : [kf] "v"(kf), [q0] "n"(R), [q1] "n"(R + 3));
+}
+// The same MFMA followed, in ONE statement, by the softmax "B" work of two scores of the PREVIOUS tile:
+//   p = exp2(x * c + mneg);  rowsum += p;  w = pack_bf16(p0, p1)
+// Written out as instructions so that the seven VALU ops sit exactly in this MFMA's shadow (hipcc otherwise clusters
+// them away from the MFMAs).  v_exp results are consumed two instructions later (trans -> VALU use needs one).
+template <int R, bool FIRST>
+__device__ __forceinline__ void qk_mfma_b(int& tok, f32x16& s, u32x4 kf, int& apin, float x0, float x1, float c,
+                                          float mn, float& sum0, float& sum1, unsigned& w) {
+    float t0, t1;
+    if constexpr (FIRST)
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], 0\n\t"
+            "v_fma_f32 %[t0], %[x0], %[c], %[mn]\n\tv_fma_f32 %[t1], %[x1], %[c], %[mn]\n\t"
+            "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"
+            "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"
+            "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
+            : [s] "=&v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
+            : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [mn] "v"(mn), [q0] "n"(R), [q1] "n"(R + 3));
+    else
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t"
+            "v_fma_f32 %[t0], %[x0], %[c], %[mn]\n\tv_fma_f32 %[t1], %[x1], %[c], %[mn]\n\t"
+            "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"
+            "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"
+            "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
+            : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
+            : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [mn] "v"(mn), [q0] "n"(R), [q1] "n"(R + 3));
+}
+// One PV MFMA:  a[R:R+15] += V^T-fragment x P-fragment
+template <int R>
+__device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) {
+    asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]"
+        : [tok] "+v"(tok), [ap] "+v"(apin) : [vf] "v"(vf), [p] "v"(p), [o0] "n"(R), [o1] "n"(R + 15));
+}
+// ... followed by the softmax "A" work of four scores of the CURRENT tile: two running v_max3 chains
+template <int R>
+__device__ __forceinline__ void pv_mfma_a(int& tok, u32x4 vf, u32x4 p, int& apin, float& ma, float& mb, float y0, float y1,
+                                          float z0, float z1) {
+    asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t"
+        "v_max3_f32 %[ma], %[ma], %[y0], %[y1]\n\tv_max3_f32 %[mb], %[mb], %[z0], %[z1]"
+        : [tok] "+v"(tok), [ap] "+v"(apin), [ma] "+v"(ma), [mb] "+v"(mb)
+        : [vf] "v"(vf), [p] "v"(p), [y0] "v"(y0), [y1] "v"(y1), [z0] "v"(z0), [z1] "v"(z1), [o0] "n"(R), [o1] "n"(R + 15));
+}
+// ... or followed by the "B" work of two scores of the previous tile (see qk_mfma_b)
+template <int R>
+__device__ __forceinline__ void pv_mfma_b(int& tok, u32x4 vf, u32x4 p, int& apin, float x0, float x1, float c, float mn,
+                                          float& sum0, float& sum1, unsigned& w) {
+    float t0, t1;
+    asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t"
+        "v_fma_f32 %[t0], %[x0], %[c], %[mn]\n\tv_fma_f32 %[t1], %[x1], %[c], %[mn]\n\t"
+        "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"
+        "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"
+        "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
+        : [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
+        : [vf] "v"(vf), [p] "v"(p), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [mn] "v"(mn), [o0] "n"(R), [o1] "n"(R + 15));
+}
+template <int R>
+__device__ __forceinline__ void o_zero(int& tok) {
+    asm("v_accvgpr_write_b32 a[%c1], 0" : "+v"(tok) : "n"(R));
+}
+template <int R>
+__device__ __forceinline__ void o_scale4(int& tok, float alpha) {          // a[R..R+3] *= alpha
+    float t0, t1, t2, t3;
+    asm("v_accvgpr_read_b32 %[t0], a[%c[r0]]\n\tv_accvgpr_read_b32 %[t1], a[%c[r1]]\n\t"
+        "v_accvgpr_read_b32 %[t2], a[%c[r2]]\n\tv_accvgpr_read_b32 %[t3], a[%c[r3]]\n\t"
+        "v_mul_f32 %[t0], %[t0], %[al]\n\tv_mul_f32 %[t1], %[t1], %[al]\n\t"
+        "v_mul_f32 %[t2], %[t2], %[al]\n\tv_mul_f32 %[t3], %[t3], %[al]\n\t"
+        "v_accvgpr_write_b32 a[%c[r0]], %[t0]\n\tv_accvgpr_write_b32 a[%c[r1]], %[t1]\n\t"
+        "v_accvgpr_write_b32 a[%c[r2]], %[t2]\n\tv_accvgpr_write_b32 a[%c[r3]], %[t3]"
+        : [tok] "+v"(tok), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [al] "v"(alpha), [r0] "n"(R), [r1] "n"(R + 1), [r2] "n"(R + 2), [r3] "n"(R + 3));
+}
+template <int R>
+__device__ __forceinline__ float o_get(int& tok) {
+    float x;
+    asm("v_accvgpr_read_b32 %1, a[%c2]" : "+v"(tok), "=v"(x) : "n"(R));
+    return x;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    bf16x2 t;
+    t[0] = (bf16)lo;
+    t[1] = (bf16)hi;
+    return __builtin_bit_cast(unsigned, t);
+}
+typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_t;
+
+// ABL: timing-only ablation mask for tools/attn_ab.py (results are WRONG when non-zero): 1 = no B fillers, 2 = no A
+// fillers, 4 = fragment reads only at the start of each phase, 8 = no LDS-DMA staging and no barrier in the tile loop.
+template <int TAG, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restrict__ Q, int ldq,
+                                                            const bf16* __restrict__ K, int ldk,
+                                                            const bf16* __restrict__ VT, int ldvt,
+                                                            bf16* __restrict__ O, int ldo, int Lq, int Lk,
+                                                            float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Kst = smem;                       // 2 stages x 16 KiB
+    char* const Vst = smem + 2 * KT_BYTES;        // 2 stages x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int head = blockIdx.y;
+    const int row0 = blockIdx.x * QB2 + wave * 64 + l31;
+
+    // ---- Q fragments of both row groups -> a[192:255]; O accumulators a[64:191] = 0 ----------------------------
+    static_for<0, 2>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        const int qr = row0 + 32 * g;
+        const bf16* qp = Q + (size_t)min(qr, Lq - 1) * ldq + head * DH + hi * 8;
+        static_for<0, 8>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
+            bf16x8 v = ld_bf16x8(qp + kk * 16);
+            if (qr >= Lq) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            }
+            q_put<SVI_QREG0 + (g * 8 + kk) * 4>(v);
+        });
+    });
+    int tok = 0;
+    asm volatile("; reserve the accumulation half" ::: SVI_ALL_AGPRS);
+    static_for<0, 128>([&](auto rc) { o_zero<SVI_OREG0 + decltype(rc)::value>(tok); });
+    asm volatile("s_nop 4" : "+v"(tok));        // v_accvgpr_write -> MFMA operand wait states
+
+    // ---- LDS-DMA assignment: a tile is 16 pieces of 1 KiB; wave w moves pieces w, w+4, w+8, w+12 ------------
+    // buffer_load ... lds: the descriptor bounds every access, so key rows past the end of K read as zeros and need no
+    // clamping; V^T key columns past Lk read the row's pad / the next row (finite by contract) and are multiplied by P = 0.
+    const int ntiles = (Lk + KB - 1) / KB;
+    const int npairs = (ntiles + 1) >> 1;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(K), 0, (int)(((size_t)(Lk - 1) * ldk + (size_t)(head + 1) * DH) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(VT), 0, (int)(((size_t)((head + 1) * DH - 1) * ldvt + (size_t)ldvt) * 2), 0x00020000);
+    int koff[4], voff[4];                          // byte offsets of this lane's source chunk inside tile 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pc = wave + 4 * j;
+        const int kr_ = 4 * pc + (lane >> 4);                  // K tile: 4 rows of 256 B per piece
+        koff[j] = (kr_ * ldk + head * DH + (((lane & 15) ^ (kr_ & 15)) << 3)) * 2;
+        const int vr_ = 8 * pc + (lane >> 3);                  // V^T tile: 8 rows of 128 B per piece
+        voff[j] = ((head * DH + vr_) * ldvt + (((lane & 7) ^ ((vr_ >> 1) & 7)) << 3)) * 2;
+    }
+    auto stage_k = [&](int t, int st) {             // K tile t -> K stage st
+        char* dst = Kst + st * KT_BYTES;
+        const int soff = t * KB * ldk * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(dst + (wave + 4 * j) * 1024), 16, koff[j], soff, 0, 0);
+    };
+    auto stage_v = [&](int t, int st) {             // V^T tile t -> V stage st
+        char* dst = Vst + st * VT_BYTES;
+        const int soff = t * KB * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(dst + (wave + 4 * j) * 1024), 16, voff[j], soff, 0, 0);
+    };
+
+    // ---- per-row-group softmax state ---------------------------------------------------------------------
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float mneg[2] = {0.f, 0.f};                  // -m(t) * scale_log2e of the tile whose B phase is pending
+    float alpha[2] = {1.f, 1.f};                 // exp2((m(t-1) - m(t)) * scale_log2e) of that tile
+    u32x4 pw[2][2][2];                           // P(t-1) as MFMA B operands: [g][tt][sb], 8 bf16 each
+    const int krow = perm23(l31);
+    // Absolute LDS byte addresses of this lane's fragments in stage 0: the swizzle XOR makes the 8 k-steps (K) and the
+    // 4 (tt, sb) key blocks (V^T) non-additive; tt / d (+32 rows) and the stage fold into the instruction's immediate.
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    int kaddr[8], vaddr[4];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) kaddr[kk] = lds0 + k_off(krow, 2 * kk + hi);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vaddr[c] = lds0 + 2 * KT_BYTES + v_off(l31, 2 * c + hi);
+
+    // The 32 score pairs of a tile (per row group g: tb in {0,1}, word w in 0..7 = scores 2w, 2w+1 of s[g][tb]) become
+    // the 32 packed P words pw[g][tb][w >> 2][w & 3].  B work (exp / row-sum / pack) of tile t-1 is spread over the MFMA
+    // statements of tile t: 24 pairs ride on phase 1 (3 of every 4 MFMAs: all of tb = 0, then tb = 1 words 0..3), the last
+    // 8 (tb = 1, words 4..7, first needed by PV fragment 12) on the odd MFMAs of the first half of phase 2.
+    float ps[2][2];
+    // phase 1 of tile t: S(t) -> sn from K stage kst.  Fragment f = tt*8 + kk feeds MFMAs (f, g=0), (f, g=1); fragment f+3
+    // is read behind MFMA (f, 0).  WITH_B is false only for tile 0.
+    auto phase1 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], int kst, auto with_b) {
+        constexpr bool WITH_B = decltype(with_b)::value && !(ABL & 1);
+        const int ks = kst * KT_BYTES;
+        ps[0][0] = ps[0][1] = ps[1][0] = ps[1][1] = 0.f;
+        u32x4 kf[4];
+        kf[0] = *(lds_u32x4_t)(kaddr[0] + ks);
+        kf[1] = *(lds_u32x4_t)(kaddr[1] + ks);
+        kf[2] = *(lds_u32x4_t)(kaddr[2] + ks);
+        static_for<0, 16>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int tt = f >> 3, kk = f & 7, f3 = (f + 3) & 15;
+            static_for<0, 2>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int k = 2 * f + g;                         // MFMA statement index in the phase
+                if constexpr (WITH_B && (k & 3) != 3) {
+                    constexpr int pi = k - (k >> 2);                 // pair 0..23: (w, g') fastest g'
+                    constexpr int pg = pi & 1, pj = pi >> 1;         // pj 0..11: 0..7 -> tb 0 word pj; 8..11 -> tb 1 word pj-8
+                    constexpr int tb = pj >> 3, w = pj & 7, r0 = 2 * w;
+                    unsigned wd;
+                    qk_mfma_b<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0>(tok, sn[g][tt], kf[f & 3], kaddr[f3 & 7], so[pg][tb][r0],
+                                                                     so[pg][tb][r0 + 1], scale_log2e, mneg[pg], ps[pg][0], ps[pg][1], wd);
+                    pw[pg][tb][w >> 2][w & 3] = wd;
+                } else {
+                    qk_mfma<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0>(tok, sn[g][tt], kf[f & 3], kaddr[f3 & 7]);
+                }
+                if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
+                    kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ks + ((f + 3) >> 3) * 32 * 256);
+                if constexpr (g == 0 && f + 3 < 16 && (ABL & 4)) kf[(f + 3) & 3] = kf[f & 3];
+            });
+        });
+    };
+    // phase 2 of tile t: O += V(t-1)·P(t-1) from V stage vst, with A(t) (row max of sn) on the even MFMAs and the last 8 B
+    // pairs of tile t-1 on the odd MFMAs of fragments 0..7.  Leaves the candidate maxima in m_cand and returns whether some
+    // row's maximum outgrew the reference by more than SVI_RESCALE_THR.  WITH_PV is false only for tile 0.
+    float m_cand[2];
+    auto phase2 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], int vst, int key_base, auto masked_tag, auto with_pv) -> bool {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool WITH_PV = decltype(with_pv)::value;
+        constexpr bool WITH_B = WITH_PV && !(ABL & 1);
+        const int vs = vst * VT_BYTES;
+        // MFMA result (the last QK^T MFMAs) -> VALU read, and VALU-written P -> MFMA operand: wait states by hand
+        asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
+        if (MASKED) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key_base + 8 * hi + 32 * tt + 16 * (r >> 3) + (r & 7) >= Lk) sn[g][tt][r] = -INFINITY;
+        }
+        u32x4 vf[4];
+        float ma[2] = {-INFINITY, -INFINITY}, mb[2] = {-INFINITY, -INFINITY};
+        bool need = false;
+        if constexpr (WITH_PV) {
+            vf[0] = *(lds_u32x4_t)(vaddr[0] + vs);
+            vf[1] = *(lds_u32x4_t)(vaddr[0] + vs + 32 * 128);
+            vf[2] = *(lds_u32x4_t)(vaddr[0] + vs + 64 * 128);
+        }
+        auto finish = [&](int g) {               // running max of group g complete: candidate reference, growth test
+            const float mx = vmax3(ma[g], mb[g], mb[g]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            m_cand[g] = vmax3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), m_run[g]);
+            need = need || ((m_cand[g] - m_run[g]) * scale_log2e > SVI_RESCALE_THR);
+        };
+        // fragment f = (tt*2 + sb)*4 + d feeds MFMAs (f, g=0), (f, g=1); MFMA (f, 0) carries step f&7 of group f>>3's max
+        static_for<0, 16>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int tt = f >> 3, sb = (f >> 2) & 1, d = f & 3, f3 = (f + 3) & 15;
+            constexpr int ga = f >> 3, r = 2 * (f & 7);
+            if constexpr (WITH_PV) {
+                if constexpr (ABL & 2)
+                    pv_mfma<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], vaddr[f3 >> 2]);
+                else
+                    pv_mfma_a<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], vaddr[f3 >> 2], ma[ga], mb[ga],
+                                                            sn[ga][0][r], sn[ga][0][r + 1], sn[ga][1][r], sn[ga][1][r + 1]);
+                if constexpr (f + 3 < 16 && !(ABL & 4))
+                    vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
+                if constexpr (f + 3 < 16 && (ABL & 4)) vf[(f + 3) & 3] = vf[f & 3];
+                if constexpr (WITH_B && f < 8) {
+                    constexpr int pg = f & 1, w = 4 + (f >> 1), r0 = 2 * w;      // tb = 1, words 4..7
+                    unsigned wd;
+                    pv_mfma_b<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vf[f & 3], pw[1][tt][sb], vaddr[f3 >> 2], so[pg][1][r0], so[pg][1][r0 + 1],
+                                                            scale_log2e, mneg[pg], ps[pg][0], ps[pg][1], wd);
+                    pw[pg][1][w >> 2][w & 3] = wd;
+                } else {
+                    pv_mfma<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vf[f & 3], pw[1][tt][sb], vaddr[f3 >> 2]);
+                }
+                if constexpr (WITH_B && f == 7) {                    // all 32 pairs of tile t-1 are done: fold the row sums
+                    l_run[0] = l_run[0] * alpha[0] + (ps[0][0] + ps[0][1]);
+                    l_run[1] = l_run[1] * alpha[1] + (ps[1][0] + ps[1][1]);
+                }
+            } else {
+                ma[ga] = vmax3(ma[ga], sn[ga][0][r], sn[ga][0][r + 1]);
+                mb[ga] = vmax3(mb[ga], sn[ga][1][r], sn[ga][1][r + 1]);
+            }
+            if constexpr ((f & 7) == 7 && !(ABL & 2)) finish(ga);
+        });
+        return need;
+    };
+    // adopt the candidate maxima as the new reference: alpha rescales everything accumulated against the old one
+    auto commit = [&]() {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            alpha[g] = __builtin_amdgcn_exp2f((m_run[g] - m_cand[g]) * scale_log2e);
+            m_run[g] = m_cand[g];
+            mneg[g] = -m_cand[g] * scale_log2e;
+        }
+    };
+    // Deferred rescale (cdna_hip_programming.md T13): the reference maximum only moves when some row of the wave outgrew
+    // it by more than SVI_RESCALE_THR (in log2 units), so P stays <= 2^THR and the 128-register O rescale — and the
+    // barrier skew it causes when only one wave of the workgroup takes it — all but disappears.  The result is the same
+    // softmax: numerator and denominator carry the same reference.
+    auto rescale = [&](bool need) {
+        alpha[0] = alpha[1] = 1.0f;
+        if (__any(need)) {
+            commit();
+            asm("s_nop 15" : "+v"(tok));        // MFMA result -> v_accvgpr_read wait states
+            static_for<0, 2>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                static_for<0, 16>([&](auto rc) { o_scale4<SVI_OREG0 + g * 64 + 4 * decltype(rc)::value>(tok, alpha[g]); });
+            });
+            asm("s_nop 4" : "+v"(tok));         // v_accvgpr_write -> MFMA SrcC wait states
+        }
+    };
+    // one tile t >= 1: loads K(t+1), V(t); phase 1 (S(t) | B(t-1)); phase 2 (PV(t-1) | A(t)); rescale; barrier
+    auto tile = [&](int t, int par, f32x16 (&sn)[2][2], f32x16 (&so)[2][2], auto masked_tag) {
+        constexpr bool STEADY = !decltype(masked_tag)::value;
+        if constexpr (!(STEADY && (ABL & 8))) {
+            stage_k(t + 1, par ^ 1);
+            stage_v(t, par);
+        }
+        phase1(sn, so, par, std::true_type{});
+        const bool need = phase2(sn, so, par ^ 1, t * KB, masked_tag, std::true_type{});
+        rescale(need);
+        if constexpr (!(STEADY && (ABL & 8))) __syncthreads();
+    };
+
+    // ---- prologue: tile 0 (no B, no PV) ---------------------------------------------------------------------------
+    f32x16 sA[2][2], sB[2][2];
+    stage_k(0, 0);
+    __syncthreads();
+    stage_k(1, 1);
+    stage_v(0, 0);
+    phase1(sA, sB, 0, std::false_type{});
+    (void)phase2(sA, sB, 1, 0, std::true_type{}, std::false_type{});
+    commit();                                                          // first reference; alpha = exp2(-inf) = 0, O and l are 0
+    __syncthreads();
+
+    // ---- tiles 1 .. 2*npairs-1: odd tiles write sB / consume sA, even tiles the reverse; the last two are masked ----
+    const int last = 2 * npairs - 1;
+    int t = 1;
+    for (; last - t >= 4; t += 2) {
+        tile(t, 1, sB, sA, std::false_type{});
+        tile(t + 1, 0, sA, sB, std::false_type{});
+    }
+    if (last - t == 2) {
+        tile(t, 1, sB, sA, std::false_type{});
+        tile(t + 1, 0, sA, sB, std::true_type{});
+        t += 2;
+    }
+    tile(t, 1, sB, sA, std::true_type{});                              // t == last (odd): S(last) in sB
+    // ---- drain: B(last), then O += V(last)·P(last) ------------------------------------------------------------------
+    {
+        float ps[2] = {0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(sB[g][tt][r], scale_log2e, mneg[g]));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(sB[g][tt][r + 1], scale_log2e, mneg[g]));
+                    ps[g] += p0 + p1;
+                    pw[g][tt][r >> 3][(r & 7) >> 1] = pack_bf16x2(p0, p1);
+                }
+            l_run[g] = l_run[g] * alpha[g] + ps[g];
+        }
+        asm("s_nop 1" : "+v"(tok), "+v"(pw[0][0][0]), "+v"(pw[0][0][1]), "+v"(pw[0][1][0]), "+v"(pw[0][1][1]));
+        asm("s_nop 1" : "+v"(tok), "+v"(pw[1][0][0]), "+v"(pw[1][0][1]), "+v"(pw[1][1][0]), "+v"(pw[1][1][1]));
+        static_for<0, 16>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int tt = f >> 3, sb = (f >> 2) & 1, d = f & 3;
+            const u32x4 vfr = *(lds_u32x4_t)(vaddr[f >> 2] + VT_BYTES + d * 32 * 128);   // V(last) sits in stage last & 1 == 1
+            pv_mfma<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vfr, pw[0][tt][sb], vaddr[0]);
+            pv_mfma<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vfr, pw[1][tt][sb], vaddr[0]);
+        });
+    }
+
+    // ---- normalise and store: a[(g*4+d)*16 + r] is O[row][32 d + (r&3) + 8 (r>>2) + 4 hi] ----------------------
+    asm("s_nop 15" : "+v"(tok));                // last MFMA result -> v_accvgpr_read wait states
+    static_for<0, 2>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[g]), __float_as_uint(l_run[g]), false, false);
+        const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+        const int qr = row0 + 32 * g;
+        bf16* op = O + (size_t)min(qr, Lq - 1) * ldo + head * DH + 4 * hi;
+        static_for<0, 4>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            static_for<0, 4>([&](auto qc) {
+                constexpr int rg = decltype(qc)::value;
+                bf16x4 pk;
+                pk[0] = (bf16)(o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 0>(tok) * inv);
+                pk[1] = (bf16)(o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 1>(tok) * inv);
+                pk[2] = (bf16)(o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 2>(tok) * inv);
+                pk[3] = (bf16)(o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 3>(tok) * inv);
+                if (qr < Lq) *reinterpret_cast<bf16x4*>(op + 32 * d + 8 * rg) = pk;
+            });
+        });
+    });
+}
+
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt, bf16* O,
                             int ldo, int Lq, int Lk, int num_heads, hipStream_t st) {
     SVI_REQUIRE(Lq > 0 && Lk > 0 && num_heads > 0, "attention: bad sizes Lq=%d Lk=%d heads=%d", Lq, Lk, num_heads);
@@ -226,6 +697,31 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         attr_set = true;
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
+    {
+        const char* force = getenv("SVI_FLASH_KERNEL");            // "1" / "2": A/B switch for tools/attn_ab.py
+        const bool v2 = force ? force[0] == '2' : (Lk >= 2048);     // short key axes (text context) are prologue-bound: v1
+        if (v2) {
+            const char* ab = getenv("SVI_FLASH_ABL");              // timing-only ablations, see the kernel's ABL parameter
+            const int abl = ab ? atoi(ab) : 0;
+            typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float);
+            kern_t kern = Lq == Lk ? flash_fwd2_kernel<0, 0> : flash_fwd2_kernel<1, 0>;
+            switch (abl) {
+                case 1: kern = flash_fwd2_kernel<0, 1>; break;
+                case 2: kern = flash_fwd2_kernel<0, 2>; break;
+                case 3: kern = flash_fwd2_kernel<0, 3>; break;
+                case 4: kern = flash_fwd2_kernel<0, 4>; break;
+                case 7: kern = flash_fwd2_kernel<0, 7>; break;
+                case 8: kern = flash_fwd2_kernel<0, 8>; break;
+                case 15: kern = flash_fwd2_kernel<0, 15>; break;
+                default: break;
+            }
+            SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
+            hipLaunchKernelGGL(kern, grid2, block2, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
+            SVI_LAUNCH_CHECK();
+            return SVI_OK;
+        }
+    }
     dim3 grid((Lq + QB - 1) / QB, num_heads), block(256);
     if (Lq == Lk)
         hipLaunchKernelGGL(flash_fwd_kernel<0>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);

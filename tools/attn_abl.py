@@ -1,0 +1,37 @@
+"""Timing-only ablations of flash_fwd2_kernel at the C2 self-attention shape (results are wrong for ABL != 0).
+    python tools/attn_abl.py [rounds]
+ABL bits: 1 no B fillers (exp/sum/pack), 2 no A fillers (row max), 4 fragment reads only at phase start, 8 no staging/barrier."""
+import os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd"))
+import torch
+import svi_hip
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dev = torch.device("cuda")
+g = torch.Generator(device=dev).manual_seed(0)
+sq = sk = 32760; n = 12
+q, k, v = [(torch.randn((1, sq, n * 128), generator=g, device=dev)).to(torch.bfloat16) for _ in range(3)]
+os.environ["SVI_FLASH_KERNEL"] = "2"
+variants = ["v1", "0", "1", "2", "3", "4", "7", "8", "15"]
+times = {a: [] for a in variants}
+def run(a):
+    if a == "v1":
+        os.environ["SVI_FLASH_KERNEL"] = "1"
+    else:
+        os.environ["SVI_FLASH_KERNEL"] = "2"; os.environ["SVI_FLASH_ABL"] = a
+    return svi_hip.flash_attention(q, k, v, n)
+for a in variants:
+    run(a)
+torch.cuda.synchronize()
+for _ in range(rounds):
+    for a in variants:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            run(a)
+        e1.record(); torch.cuda.synchronize()
+        times[a].append(e0.elapsed_time(e1) / 2)
+fl = 4.0 * sq * sk * n * 128
+for a in variants:
+    med = statistics.median(times[a])
+    print(f"ABL={a:>3}: med {med:.3f} ms  ({fl/med/1e9:.0f} TF-equivalent)  min {min(times[a]):.3f}")
