@@ -124,7 +124,8 @@ extern "C" svi_status svi_attention_fwd(const void* q, const void* k, const void
         const bf16* vi = reinterpret_cast<const bf16*>(v) + (size_t)i * s_kv * D;
         bf16* oi = reinterpret_cast<bf16*>(out) + (size_t)i * s_q * D;
         SVI_TRY(svi_launch_transpose(vi, D, vt, ldvt, s_kv, D, st));
-        SVI_TRY(svi_launch_flash(qi, D, ki, D, vt, ldvt, oi, D, s_q, s_kv, n, st));
+        // SVI_FLASH_ASSUME_PRESCALED is a timing aid for tools/attn_abl.py only (it makes the results wrong by the scale factor)
+        SVI_TRY(svi_launch_flash(qi, D, ki, D, vt, ldvt, oi, D, s_q, s_kv, n, getenv("SVI_FLASH_ASSUME_PRESCALED") ? 1 : 0, st));
     }
     return SVI_OK;
 }
@@ -153,7 +154,7 @@ extern "C" svi_status svi_rmsnorm_rope(void* x, int32_t ld, int32_t rows, int32_
     SVI_REQUIRE(x && weight, "svi_rmsnorm_rope: null argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!rope)
-        return svi_launch_rmsnorm_rope(reinterpret_cast<bf16*>(x), ld, rows, dim, reinterpret_cast<const bf16*>(weight), eps, nullptr, st);
+        return svi_launch_rmsnorm_rope(reinterpret_cast<bf16*>(x), ld, rows, dim, reinterpret_cast<const bf16*>(weight), eps, nullptr, 1.0f, st);
     SVI_REQUIRE(num_heads > 0 && dim == num_heads * 128, "rope needs head_dim 128");
     SVI_REQUIRE(f > 0 && h > 0 && w > 0 && f * h * w == rows, "rope grid %dx%dx%d != rows %d", f, h, w, rows);
     // table built on the host in fp64 exactly as precompute_freqs_cis_3d does (dit:161-175)
@@ -181,7 +182,7 @@ extern "C" svi_status svi_rmsnorm_rope(void* x, int32_t ld, int32_t rows, int32_
     r.tab_h = r.tab_f + (size_t)f * npf;
     r.tab_w = r.tab_h + (size_t)h * nph;
     r.npf = npf; r.nph = nph; r.npw = npw; r.f = f; r.h = h; r.w = w;
-    return svi_launch_rmsnorm_rope(reinterpret_cast<bf16*>(x), ld, rows, dim, reinterpret_cast<const bf16*>(weight), eps, &r, st);
+    return svi_launch_rmsnorm_rope(reinterpret_cast<bf16*>(x), ld, rows, dim, reinterpret_cast<const bf16*>(weight), eps, &r, 1.0f, st);
 }
 
 extern "C" svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t ldc, int32_t M,

@@ -229,7 +229,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
 //     from the MFMAs (which is what it does when left alone: 124 VALU in one block, then 64 bare MFMAs);
 //   * K / V^T tiles arrive by LDS-DMA (global_load_lds_dwordx4, swizzle on the SOURCE address), two stages each, one
 //     barrier per tile; no staging registers, no ds_write pass;
-//   * row max with v_max3_f32, half-wave exchange with v_permlane32_swap (no LDS round trip in the softmax).
+//   * row max with v_max3_f32, half-wave exchange with v_permlane32_swap (no LDS round trip in the softmax);
+//   * the scores leave the MFMA already in the form the exponential wants: Q is pre-multiplied by
+//     softmax_scale*log2(e) when it is loaded (one extra bf16 rounding of q), and the first MFMA of every
+//     score chain takes  C = -M  (the row's current reference maximum, in log2 units, kept as a 16-register tuple per
+//     row group) instead of 0, so  x = s*c - M  needs no VALU at all: B is exp, add, pack.
 // Same MFMA operand mapping and key permutation as v1 (see the file header).  The online-softmax rescale stays exact
 // (taken only when some row's max grew).  Tiles are processed in pairs; a tile index past the last real tile is a
 // fully masked tile (scores -inf -> P = 0), its loads are clamped to the last valid key.
@@ -255,7 +259,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // Register ownership.  Three quarters of the accumulation half of the register file are owned by this file, not by hipcc:
-//   a[0:63]     left to hipcc (it parks a few address registers there when its 256 arch VGPRs run out)
+//   a[0:63]     left to hipcc (unused today; it parks values there when its 256 arch VGPRs run out)
 //   a[64:191]   O^T accumulators, a[64 + (g*4 + d)*16 + r]  (g = row group, d = 32-channel block)
 //   a[192:255]  Q fragments (MFMA B operands), a[192 + (g*8 + kk)*4 + 0..3]
 // hipcc will not keep an MFMA *input* in AGPRs on its own (it spilled Q to scratch and reloaded it in front of every
@@ -282,41 +286,52 @@ __device__ __forceinline__ void q_put(bf16x8 v) {              // a[R:R+3] = v
                  "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
                  :: "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
 }
-// One QK^T MFMA:  s (+)= K-fragment x Q-fragment(a[R:R+3]).  `apin` (the LDS address of a later fragment read) is
-// listed in/out only to keep that read behind this MFMA.
+// One QK^T MFMA:  s (+)= K-fragment x Q-fragment(a[R:R+3]); the first of a chain starts from the -M tuple `cneg`
+// (it has to be a VGPR tuple: an MFMA's C and D operands must be in the same half of the register file).
+// `apin` (the LDS address of a later fragment read) is listed in/out only to keep that read behind this MFMA.
 template <int R, bool FIRST>
-__device__ __forceinline__ void qk_mfma(int& tok, f32x16& s, u32x4 kf, int& apin) {
+__device__ __forceinline__ void qk_mfma(int& tok, f32x16& s, u32x4 kf, int& apin, const f32x16& cneg) {
     if constexpr (FIRST)
-        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], 0"
-            : [s] "=&v"(s), [tok] "+v"(tok), [ap] "+v"(apin) : [kf] "v"(kf), [q0] "n"(R), [q1] "n"(R + 3));
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[c]"
+            : [s] "=&v"(s), [tok] "+v"(tok), [ap] "+v"(apin) : [kf] "v"(kf), [c] "v"(cneg), [q0] "n"(R), [q1] "n"(R + 3));
     else
         asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]"
             : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin) : [kf] "v"(kf), [q0] "n"(R), [q1] "n"(R + 3));
 }
-// The same MFMA followed, in ONE statement, by the softmax "B" work of two scores of the PREVIOUS tile:
-//   p = exp2(x * c + mneg);  rowsum += p;  w = pack_bf16(p0, p1)
-// Written out as instructions so that the seven VALU ops sit exactly in this MFMA's shadow (hipcc otherwise clusters
+// The same MFMA followed, in ONE statement, by the softmax "B" work of two scores x0, x1 of the PREVIOUS tile (already
+// relative to the reference maximum, in log2 units):   p = exp2(x);  rowsum += p;  w = pack_bf16(p0, p1)
+// Written out as instructions so that the five VALU ops sit exactly in this MFMA's shadow (hipcc otherwise clusters
 // them away from the MFMAs).  v_exp results are consumed two instructions later (trans -> VALU use needs one).
-template <int R, bool FIRST>
-__device__ __forceinline__ void qk_mfma_b(int& tok, f32x16& s, u32x4 kf, int& apin, float x0, float x1, float c,
-                                          float mn, float& sum0, float& sum1, unsigned& w) {
+#define SVI_B_OPS                                                                                   \
+    "v_exp_f32 %[t0], %[x0]\n\tv_exp_f32 %[t1], %[x1]\n\t"                                          \
+    "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"                            \
+    "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
+// the same when Q was NOT pre-multiplied by softmax_scale*log2(e) (MULC): x is in raw score units, p = exp2(x * c)
+#define SVI_B_OPS_MULC                                                                              \
+    "v_mul_f32 %[t0], %[x0], %[c]\n\tv_mul_f32 %[t1], %[x1], %[c]\n\t"                              \
+    "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"                                          \
+    "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"                            \
+    "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
+template <int R, bool FIRST, bool MULC>
+__device__ __forceinline__ void qk_mfma_b(int& tok, f32x16& s, u32x4 kf, int& apin, const f32x16& cneg, float x0, float x1,
+                                          float c, float& sum0, float& sum1, unsigned& w) {
     float t0, t1;
-    if constexpr (FIRST)
-        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], 0\n\t"
-            "v_fma_f32 %[t0], %[x0], %[c], %[mn]\n\tv_fma_f32 %[t1], %[x1], %[c], %[mn]\n\t"
-            "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"
-            "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"
-            "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
+    if constexpr (FIRST && MULC)
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[cn]\n\t" SVI_B_OPS_MULC
             : [s] "=&v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-            : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [mn] "v"(mn), [q0] "n"(R), [q1] "n"(R + 3));
-    else
-        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t"
-            "v_fma_f32 %[t0], %[x0], %[c], %[mn]\n\tv_fma_f32 %[t1], %[x1], %[c], %[mn]\n\t"
-            "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"
-            "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"
-            "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
+            : [kf] "v"(kf), [cn] "v"(cneg), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [q0] "n"(R), [q1] "n"(R + 3));
+    else if constexpr (FIRST)
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[cn]\n\t" SVI_B_OPS
+            : [s] "=&v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
+            : [kf] "v"(kf), [cn] "v"(cneg), [x0] "v"(x0), [x1] "v"(x1), [q0] "n"(R), [q1] "n"(R + 3));
+    else if constexpr (MULC)
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t" SVI_B_OPS_MULC
             : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-            : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [mn] "v"(mn), [q0] "n"(R), [q1] "n"(R + 3));
+            : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [q0] "n"(R), [q1] "n"(R + 3));
+    else
+        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t" SVI_B_OPS
+            : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
+            : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [q0] "n"(R), [q1] "n"(R + 3));
 }
 // One PV MFMA:  a[R:R+15] += V^T-fragment x P-fragment
 template <int R>
@@ -334,17 +349,22 @@ __device__ __forceinline__ void pv_mfma_a(int& tok, u32x4 vf, u32x4 p, int& apin
         : [vf] "v"(vf), [p] "v"(p), [y0] "v"(y0), [y1] "v"(y1), [z0] "v"(z0), [z1] "v"(z1), [o0] "n"(R), [o1] "n"(R + 15));
 }
 // ... or followed by the "B" work of two scores of the previous tile (see qk_mfma_b)
-template <int R>
-__device__ __forceinline__ void pv_mfma_b(int& tok, u32x4 vf, u32x4 p, int& apin, float x0, float x1, float c, float mn,
-                                          float& sum0, float& sum1, unsigned& w) {
+template <int R, bool MULC>
+__device__ __forceinline__ void pv_mfma_b(int& tok, u32x4 vf, u32x4 p, int& apin, float x0, float x1, float c, float& sum0,
+                                          float& sum1, unsigned& w) {
     float t0, t1;
-    asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t"
-        "v_fma_f32 %[t0], %[x0], %[c], %[mn]\n\tv_fma_f32 %[t1], %[x1], %[c], %[mn]\n\t"
-        "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"
-        "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"
-        "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
-        : [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-        : [vf] "v"(vf), [p] "v"(p), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [mn] "v"(mn), [o0] "n"(R), [o1] "n"(R + 15));
+    if constexpr (MULC)
+        asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t" SVI_B_OPS_MULC
+            : [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
+            : [vf] "v"(vf), [p] "v"(p), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [o0] "n"(R), [o1] "n"(R + 15));
+    else
+        asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t" SVI_B_OPS
+            : [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
+            : [vf] "v"(vf), [p] "v"(p), [x0] "v"(x0), [x1] "v"(x1), [o0] "n"(R), [o1] "n"(R + 15));
+}
+template <int R>
+__device__ __forceinline__ void a_set(int& tok, float v) {                // a[R] = v
+    asm("v_accvgpr_write_b32 a[%c2], %1" : "+v"(tok) : "v"(v), "n"(R));
 }
 template <int R>
 __device__ __forceinline__ void o_zero(int& tok) {
@@ -375,10 +395,14 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, t);
 }
 typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_t;
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"     // LDS addresses are 32-bit; the host pass sees 64-bit pointers
 
 // ABL: timing-only ablation mask for tools/attn_ab.py (results are WRONG when non-zero): 1 = no B fillers, 2 = no A
 // fillers, 4 = fragment reads only at the start of each phase, 8 = no LDS-DMA staging and no barrier in the tile loop.
-template <int TAG, int ABL = 0>
+// MULC = false: the caller's Q already carries softmax_scale*log2(e) (the DiT's RMSNorm+RoPE kernel emits it that way, one
+// rounding) and scale_log2e is unused.  MULC = true (the public seam): Q is used as given and the factor is applied to the
+// fp32 scores inside B (one more VALU per score); all reference / threshold arithmetic is then in raw score units.
+template <int TAG, int ABL = 0, bool MULC = false>
 __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restrict__ Q, int ldq,
                                                             const bf16* __restrict__ K, int ldk,
                                                             const bf16* __restrict__ VT, int ldvt,
@@ -401,10 +425,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         static_for<0, 8>([&](auto kc) {
             constexpr int kk = decltype(kc)::value;
             bf16x8 v = ld_bf16x8(qp + kk * 16);
-            if (qr >= Lq) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
-            }
+            for (int e = 0; e < 8; ++e) v[e] = (qr < Lq) ? v[e] : (bf16)0.f;
             q_put<SVI_QREG0 + (g * 8 + kk) * 4>(v);
         });
     });
@@ -447,9 +469,16 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     };
 
     // ---- per-row-group softmax state ---------------------------------------------------------------------
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    float mneg[2] = {0.f, 0.f};                  // -m(t) * scale_log2e of the tile whose B phase is pending
-    float alpha[2] = {1.f, 1.f};                 // exp2((m(t-1) - m(t)) * scale_log2e) of that tile
+    const float cs = MULC ? scale_log2e : 1.0f;   // score units -> log2 units
+    // All softmax state is in score units (log2 units when Q carries softmax_scale*log2 e).  M = reference maximum the exponentials are
+    // taken against; it only moves at a rescale event.
+    float m_ref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    float alpha[2] = {1.f, 1.f};                 // exp2(M_old - M_new) of the last rescale event, 1 otherwise
+    f32x16 cneg[2];                              // -M broadcast: the C operand every score chain starts from
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cneg[g][r] = 0.f;
     u32x4 pw[2][2][2];                           // P(t-1) as MFMA B operands: [g][tt][sb], 8 bf16 each
     const int krow = perm23(l31);
     // Absolute LDS byte addresses of this lane's fragments in stage 0: the swizzle XOR makes the 8 k-steps (K) and the
@@ -487,11 +516,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     constexpr int pg = pi & 1, pj = pi >> 1;         // pj 0..11: 0..7 -> tb 0 word pj; 8..11 -> tb 1 word pj-8
                     constexpr int tb = pj >> 3, w = pj & 7, r0 = 2 * w;
                     unsigned wd;
-                    qk_mfma_b<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0>(tok, sn[g][tt], kf[f & 3], kaddr[f3 & 7], so[pg][tb][r0],
-                                                                     so[pg][tb][r0 + 1], scale_log2e, mneg[pg], ps[pg][0], ps[pg][1], wd);
+                    qk_mfma_b<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, MULC>(tok, sn[g][tt], kf[f & 3], kaddr[f3 & 7], cneg[g], so[pg][tb][r0],
+                                                                           so[pg][tb][r0 + 1], scale_log2e, ps[pg][0], ps[pg][1], wd);
                     pw[pg][tb][w >> 2][w & 3] = wd;
                 } else {
-                    qk_mfma<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0>(tok, sn[g][tt], kf[f & 3], kaddr[f3 & 7]);
+                    qk_mfma<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0>(tok, sn[g][tt], kf[f & 3], kaddr[f3 & 7], cneg[g]);
                 }
                 if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
                     kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ks + ((f + 3) >> 3) * 32 * 256);
@@ -502,14 +531,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     // phase 2 of tile t: O += V(t-1)·P(t-1) from V stage vst, with A(t) (row max of sn) on the even MFMAs and the last 8 B
     // pairs of tile t-1 on the odd MFMAs of fragments 0..7.  Leaves the candidate maxima in m_cand and returns whether some
     // row's maximum outgrew the reference by more than SVI_RESCALE_THR.  WITH_PV is false only for tile 0.
-    float m_cand[2];
+    float m_rel[2];                              // row maximum of the tile relative to M (what A computes)
     auto phase2 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], int vst, int key_base, auto masked_tag, auto with_pv) -> bool {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr bool WITH_PV = decltype(with_pv)::value;
         constexpr bool WITH_B = WITH_PV && !(ABL & 1);
         const int vs = vst * VT_BYTES;
         // MFMA result (the last QK^T MFMAs) -> VALU read, and VALU-written P -> MFMA operand: wait states by hand
-        asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
+        if constexpr (!(ABL & 64)) asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
         if (MASKED) {
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -527,11 +556,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             vf[1] = *(lds_u32x4_t)(vaddr[0] + vs + 32 * 128);
             vf[2] = *(lds_u32x4_t)(vaddr[0] + vs + 64 * 128);
         }
-        auto finish = [&](int g) {               // running max of group g complete: candidate reference, growth test
+        auto finish = [&](int g) {               // running max of group g complete: growth test against the reference
             const float mx = vmax3(ma[g], mb[g], mb[g]);
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            m_cand[g] = vmax3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), m_run[g]);
-            need = need || ((m_cand[g] - m_run[g]) * scale_log2e > SVI_RESCALE_THR);
+            m_rel[g] = vmax3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+            need = need || (m_rel[g] * cs > ((ABL & 128) ? 1e30f : SVI_RESCALE_THR));
         };
         // fragment f = (tt*2 + sb)*4 + d feeds MFMAs (f, g=0), (f, g=1); MFMA (f, 0) carries step f&7 of group f>>3's max
         static_for<0, 16>([&](auto fc) {
@@ -539,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             constexpr int tt = f >> 3, sb = (f >> 2) & 1, d = f & 3, f3 = (f + 3) & 15;
             constexpr int ga = f >> 3, r = 2 * (f & 7);
             if constexpr (WITH_PV) {
-                if constexpr (ABL & 2)
+                if constexpr ((ABL & 2) || (ABL & 32))
                     pv_mfma<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], vaddr[f3 >> 2]);
                 else
                     pv_mfma_a<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], vaddr[f3 >> 2], ma[ga], mb[ga],
@@ -550,8 +579,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 if constexpr (WITH_B && f < 8) {
                     constexpr int pg = f & 1, w = 4 + (f >> 1), r0 = 2 * w;      // tb = 1, words 4..7
                     unsigned wd;
-                    pv_mfma_b<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vf[f & 3], pw[1][tt][sb], vaddr[f3 >> 2], so[pg][1][r0], so[pg][1][r0 + 1],
-                                                            scale_log2e, mneg[pg], ps[pg][0], ps[pg][1], wd);
+                    pv_mfma_b<SVI_OREG0 + (1 * 4 + d) * 16, MULC>(tok, vf[f & 3], pw[1][tt][sb], vaddr[f3 >> 2], so[pg][1][r0],
+                                                                  so[pg][1][r0 + 1], scale_log2e, ps[pg][0], ps[pg][1], wd);
                     pw[pg][1][w >> 2][w & 3] = wd;
                 } else {
                     pv_mfma<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vf[f & 3], pw[1][tt][sb], vaddr[f3 >> 2]);
@@ -564,28 +593,35 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 ma[ga] = vmax3(ma[ga], sn[ga][0][r], sn[ga][0][r + 1]);
                 mb[ga] = vmax3(mb[ga], sn[ga][1][r], sn[ga][1][r + 1]);
             }
-            if constexpr ((f & 7) == 7 && !(ABL & 2)) finish(ga);
+            if constexpr ((f & 7) == 7 && !(ABL & 2) && !(ABL & 16)) finish(ga);
         });
         return need;
     };
-    // adopt the candidate maxima as the new reference: alpha rescales everything accumulated against the old one
-    auto commit = [&]() {
+    // Move the reference maximum of both row groups by delta[g] >= 0 (first tile: any sign): the -M tuples, the scores of
+    // the tile whose exponentials are still pending (sn, computed against the old reference) and alpha for O and l.
+    auto commit = [&](f32x16 (&sn)[2][2], const float (&delta)[2]) {
+        static_for<0, 2>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            m_ref[g] += delta[g];
+            alpha[g] = __builtin_amdgcn_exp2f(-delta[g] * cs);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            alpha[g] = __builtin_amdgcn_exp2f((m_run[g] - m_cand[g]) * scale_log2e);
-            m_run[g] = m_cand[g];
-            mneg[g] = -m_cand[g] * scale_log2e;
-        }
+            for (int r = 0; r < 16; ++r) cneg[g][r] = -m_ref[g];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sn[g][tt][r] -= delta[g];
+        });
     };
     // Deferred rescale (cdna_hip_programming.md T13): the reference maximum only moves when some row of the wave outgrew
-    // it by more than SVI_RESCALE_THR (in log2 units), so P stays <= 2^THR and the 128-register O rescale — and the
-    // barrier skew it causes when only one wave of the workgroup takes it — all but disappears.  The result is the same
-    // softmax: numerator and denominator carry the same reference.
-    auto rescale = [&](bool need) {
+    // it by more than SVI_RESCALE_THR (log2 units), so P stays <= 2^THR and the 128-register O rescale — and the barrier
+    // skew it causes when only one wave of the workgroup takes it — all but disappears.  The result is the same softmax:
+    // numerator and denominator carry the same reference.  Rows that did not grow keep theirs (delta = 0, alpha = 1).
+    auto rescale = [&](f32x16 (&sn)[2][2], bool need) {
         alpha[0] = alpha[1] = 1.0f;
         if (__any(need)) {
-            commit();
+            const float delta[2] = {fmaxf(m_rel[0], 0.f), fmaxf(m_rel[1], 0.f)};
             asm("s_nop 15" : "+v"(tok));        // MFMA result -> v_accvgpr_read wait states
+            commit(sn, delta);
             static_for<0, 2>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 static_for<0, 16>([&](auto rc) { o_scale4<SVI_OREG0 + g * 64 + 4 * decltype(rc)::value>(tok, alpha[g]); });
@@ -602,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         }
         phase1(sn, so, par, std::true_type{});
         const bool need = phase2(sn, so, par ^ 1, t * KB, masked_tag, std::true_type{});
-        rescale(need);
+        rescale(sn, need);
         if constexpr (!(STEADY && (ABL & 8))) __syncthreads();
     };
 
@@ -614,7 +650,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     stage_v(0, 0);
     phase1(sA, sB, 0, std::false_type{});
     (void)phase2(sA, sB, 1, 0, std::true_type{}, std::false_type{});
-    commit();                                                          // first reference; alpha = exp2(-inf) = 0, O and l are 0
+    {
+        const float d0[2] = {m_rel[0], m_rel[1]};                      // first reference = the row maxima of tile 0 (any sign)
+        commit(sA, d0);
+        alpha[0] = alpha[1] = 1.0f;                                    // O and l are still 0
+    }
     __syncthreads();
 
     // ---- tiles 1 .. 2*npairs-1: odd tiles write sB / consume sA, even tiles the reverse; the last two are masked ----
@@ -639,8 +679,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf(sB[g][tt][r], scale_log2e, mneg[g]));
-                    const float p1 = __builtin_amdgcn_exp2f(fmaf(sB[g][tt][r + 1], scale_log2e, mneg[g]));
+                    const float p0 = __builtin_amdgcn_exp2f(sB[g][tt][r] * cs);
+                    const float p1 = __builtin_amdgcn_exp2f(sB[g][tt][r + 1] * cs);
                     ps[g] += p0 + p1;
                     pw[g][tt][r >> 3][(r & 7) >> 1] = pack_bf16x2(p0, p1);
                 }
@@ -681,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
 }
 
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt, bf16* O,
-                            int ldo, int Lq, int Lk, int num_heads, hipStream_t st) {
+                            int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st) {
     SVI_REQUIRE(Lq > 0 && Lk > 0 && num_heads > 0, "attention: bad sizes Lq=%d Lk=%d heads=%d", Lq, Lk, num_heads);
     SVI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: leading dims must be multiples of 8");
     SVI_REQUIRE(ldvt >= ((Lk + 7) / 8) * 8, "attention: V^T leading dim %d < keys rounded up to 8", ldvt);
@@ -704,8 +744,9 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
             const char* ab = getenv("SVI_FLASH_ABL");              // timing-only ablations, see the kernel's ABL parameter
             const int abl = ab ? atoi(ab) : 0;
             typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float);
-            kern_t kern = Lq == Lk ? flash_fwd2_kernel<0, 0> : flash_fwd2_kernel<1, 0>;
-            switch (abl) {
+            kern_t kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false> : flash_fwd2_kernel<1, 0, false>)
+                                      : (Lq == Lk ? flash_fwd2_kernel<0, 0, true> : flash_fwd2_kernel<1, 0, true>);
+            switch (q_prescaled ? abl : 0) {
                 case 1: kern = flash_fwd2_kernel<0, 1>; break;
                 case 2: kern = flash_fwd2_kernel<0, 2>; break;
                 case 3: kern = flash_fwd2_kernel<0, 3>; break;
@@ -713,6 +754,10 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
                 case 7: kern = flash_fwd2_kernel<0, 7>; break;
                 case 8: kern = flash_fwd2_kernel<0, 8>; break;
                 case 15: kern = flash_fwd2_kernel<0, 15>; break;
+                case 16: kern = flash_fwd2_kernel<0, 16>; break;
+                case 32: kern = flash_fwd2_kernel<0, 32>; break;
+                case 64: kern = flash_fwd2_kernel<0, 64>; break;
+                case 128: kern = flash_fwd2_kernel<0, 128>; break;
                 default: break;
             }
             SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -723,10 +768,11 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         }
     }
     dim3 grid((Lq + QB - 1) / QB, num_heads), block(256);
+    const float v1_scale = q_prescaled ? 1.0f : scale_log2e;
     if (Lq == Lk)
-        hipLaunchKernelGGL(flash_fwd_kernel<0>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
+        hipLaunchKernelGGL(flash_fwd_kernel<0>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, v1_scale);
     else
-        hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
+        hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, v1_scale);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }

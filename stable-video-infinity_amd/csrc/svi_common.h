@@ -116,8 +116,10 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
 
 // Q [Lq, ldq], K [Lk, ldk] token-major with head hd at column hd*128; VT [(n*128), ldvt] = V transposed
 // (row = channel, col = key; columns >= Lk up to the next multiple of 8 must be readable and finite).
+// q_prescaled != 0: Q already carries softmax_scale * log2(e) = 1.4426950408889634 / sqrt(128)  (SVI_QK_SCALE_LOG2E).
+#define SVI_QK_SCALE_LOG2E 0.12751743f
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt,
-                            bf16* O, int ldo, int Lq, int Lk, int num_heads, hipStream_t st);
+                            bf16* O, int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st);
 
 svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int rows, int dim, float eps,
                              const bf16* w, const bf16* b, const float* shift, const float* scale1p,
@@ -127,8 +129,9 @@ struct SviRope {                // device tables of (cos,sin) pairs, fp32
     int npf, nph, npw;          // complex pairs per head owned by the frame / height / width axis
     int f, h, w;
 };
+// out_scale multiplies the result before its single final rounding (the DiT folds the attention scale into q there)
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
-                                   const SviRope* rope, hipStream_t st);
+                                   const SviRope* rope, float out_scale, hipStream_t st);
 svi_status svi_launch_transpose(const bf16* in, int ldi, bf16* out, int ldo, int rows, int cols, hipStream_t st);
 svi_status svi_launch_cfg_step(bf16* lat, const bf16* cond, const bf16* uncond, int64_t n, float s, float dsigma,
                                hipStream_t st);

@@ -313,23 +313,23 @@ static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, con
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, w.QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, w.VT, w.ldvt, L, D, D, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.sa.norm_q, c.eps, &h->rope, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK + D, 2 * D, L, D, b.sa.norm_k, c.eps, &h->rope, st)); }
-    { SviProfScope _p(PROF_FLASH_SELF, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.QK + D, 2 * D, w.VT, w.ldvt, w.Hb, D, L, L, H, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.sa.norm_q, c.eps, &h->rope, SVI_QK_SCALE_LOG2E, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK + D, 2 * D, L, D, b.sa.norm_k, c.eps, &h->rope, 1.0f, st)); }
+    { SviProfScope _p(PROF_FLASH_SELF, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.QK + D, 2 * D, w.VT, w.ldvt, w.Hb, D, L, L, H, 1, st)); }
     { SviProfScope _p(PROF_GEMM_O, st); SVI_TRY(linear(w.Hb, D, b.sa.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D)); }
     // --- cross attention: x += o(attn(rms(q(norm3 x)), rms(k ctx), v ctx) [+ image branch])   dit:370,266-303
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, b.norm3_w, b.norm3_b, nullptr, nullptr, st)); }
     { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.ca.norm_q, c.eps, nullptr, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.ca.norm_q, c.eps, nullptr, SVI_QK_SCALE_LOG2E, st)); }
     { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(ctx_txt, D, b.ca.k, w.CK, D, Lc, D, D, SVI_EPI_BIAS, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, 1.0f, st)); }
     { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, w.CVT, w.ldcvt, Lc, D, D, st)); }
-    { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.CK, D, w.CVT, w.ldcvt, w.Hb, D, L, Lc, H, st)); }
+    { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.CK, D, w.CVT, w.ldcvt, w.Hb, D, L, Lc, H, 1, st)); }
     if (img) {
         SVI_TRY(linear(CTX, D, b.ca.k_img, w.CKi, D, img, D, D, SVI_EPI_BIAS, st));
-        SVI_TRY(svi_launch_rmsnorm_rope(w.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, st));
+        SVI_TRY(svi_launch_rmsnorm_rope(w.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, 1.0f, st));
         SVI_TRY(linear_transposed(CTX, D, b.ca.v_img, w.CVTi, w.ldcvti, img, D, D, st));
-        SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.CKi, D, w.CVTi, w.ldcvti, w.A2, D, L, img, H, st));
+        SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.CKi, D, w.CVTi, w.ldcvti, w.A2, D, L, img, H, 1, st));
         SVI_TRY(svi_launch_add_bf16(w.Hb, w.A2, (int64_t)L * D, st));
     }
     { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D)); }

@@ -108,7 +108,7 @@ svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int row
 template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x, int ld, int rows, int dim,
                                                            const bf16* __restrict__ weight, float eps, int use_rope,
-                                                           SviRope r) {
+                                                           SviRope r, float out_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -154,12 +154,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
                     else if (pi < r.npf + r.nph) cs = r.tab_h[ph * r.nph + (pi - r.npf)];
                     else cs = r.tab_w[pw * r.npw + (pi - r.npf - r.nph)];
                     const float a = y[2 * p], bq = y[2 * p + 1];
-                    o[2 * p] = (bf16)(a * cs.x - bq * cs.y);
-                    o[2 * p + 1] = (bf16)(a * cs.y + bq * cs.x);
+                    o[2 * p] = (bf16)((a * cs.x - bq * cs.y) * out_scale);
+                    o[2 * p + 1] = (bf16)((a * cs.y + bq * cs.x) * out_scale);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16)y[j];
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)(y[j] * out_scale);
             }
             st_bf16x8(xr + col, o);
         }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
 }
 
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
-                                   const SviRope* rope, hipStream_t st) {
+                                   const SviRope* rope, float out_scale, hipStream_t st) {
     SVI_REQUIRE(dim % 8 == 0 && ld % 8 == 0, "rmsnorm: dim/ld must be multiples of 8");
     SVI_REQUIRE(dim <= 8192, "rmsnorm: dim %d > 8192 unsupported", dim);
     if (rows <= 0) return SVI_OK;
@@ -181,11 +181,11 @@ svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf1
     const int nchunk = dim / 8;
     const int use = rope ? 1 : 0;
     if (nchunk <= 64 * 3)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r, out_scale);
     else if (nchunk <= 64 * 10)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<10>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<10>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r, out_scale);
     else
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<16>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<16>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r, out_scale);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }

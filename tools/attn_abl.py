@@ -1,6 +1,7 @@
 """Timing-only ablations of flash_fwd2_kernel at the C2 self-attention shape (results are wrong for ABL != 0).
     python tools/attn_abl.py [rounds]
-ABL bits: 1 no B fillers (exp/sum/pack), 2 no A fillers (row max), 4 fragment reads only at phase start, 8 no staging/barrier."""
+ABL bits: 1 no B fillers (exp/sum/pack), 2 no A fillers (row max), 4 fragment reads only at phase start, 8 no staging/barrier,
+16 no finish/decision (max3 kept), 32 no max3 (finish kept), 64 no s_nop 15 at phase 2 start."""
 import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd"))
@@ -12,12 +13,16 @@ g = torch.Generator(device=dev).manual_seed(0)
 sq = sk = 32760; n = 12
 q, k, v = [(torch.randn((1, sq, n * 128), generator=g, device=dev)).to(torch.bfloat16) for _ in range(3)]
 os.environ["SVI_FLASH_KERNEL"] = "2"
-variants = ["v1", "0", "1", "2", "3", "4", "7", "8", "15"]
+os.environ["SVI_FLASH_ASSUME_PRESCALED"] = "1"
+variants = ["mulc", "0", "1", "2", "3", "16", "8", "15"]
 times = {a: [] for a in variants}
 def run(a):
     if a == "v1":
         os.environ["SVI_FLASH_KERNEL"] = "1"
+    elif a == "mulc":
+        os.environ.pop("SVI_FLASH_ASSUME_PRESCALED", None); os.environ["SVI_FLASH_KERNEL"] = "2"; os.environ["SVI_FLASH_ABL"] = "0"
     else:
+        os.environ["SVI_FLASH_ASSUME_PRESCALED"] = "1"
         os.environ["SVI_FLASH_KERNEL"] = "2"; os.environ["SVI_FLASH_ABL"] = a
     return svi_hip.flash_attention(q, k, v, n)
 for a in variants:
