@@ -333,6 +333,22 @@ __device__ __forceinline__ void qk_mfma_b(int& tok, f32x16& s, u32x4 kf, int& ap
             : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
             : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [q0] "n"(R), [q1] "n"(R + 3));
 }
+// A QK^T MFMA (never the first of its chain) with one LDS-DMA piece issued in its shadow: 1 KiB of a K / V^T tile,
+// global -> LDS at byte address m0v, source = descriptor rs + lane offset vo + tile offset so.  The load is invisible to
+// hipcc (no vmcnt bookkeeping on its side): the tile loop counts them by hand (8 per tile, s_waitcnt vmcnt(4) at the end).
+template <int R>
+__device__ __forceinline__ void qk_mfma_dma(int& tok, f32x16& s, u32x4 kf, int& apin, u32x4 rs, int vo, int so, int m0v) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t"
+                 "s_mov_b32 m0, %[m]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds"
+                 : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin)
+                 : [kf] "v"(kf), [m] "s"(m0v), [vo] "v"(vo), [rs] "s"(rs), [so] "s"(so), [q0] "n"(R), [q1] "n"(R + 3));
+}
+// end of a tile: everything but the newest `N` LDS-DMA pieces of this wave has landed, then the workgroup barrier that
+// makes the landed tiles visible to all waves and protects the stages the next tile overwrites.
+template <int N>
+__device__ __forceinline__ void tile_barrier(int& tok) {
+    asm volatile("s_waitcnt vmcnt(%c1)\n\ts_barrier" : "+v"(tok) : "n"(N) : "memory");
+}
 // One PV MFMA:  a[R:R+15] += V^T-fragment x P-fragment
 template <int R>
 __device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) {
@@ -408,9 +424,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                                                             const bf16* __restrict__ VT, int ldvt,
                                                             bf16* __restrict__ O, int ldo, int Lq, int Lk,
                                                             float scale_log2e) {
+    // LDS: K stages 0..3 at 0/16/32/48 KiB (tile t lives in stage t & 3), V^T stages 0..1 at 64/80 KiB (tile t in t & 1)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const Kst = smem;                       // 2 stages x 16 KiB
-    char* const Vst = smem + 2 * KT_BYTES;        // 2 stages x 16 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -435,15 +450,27 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     static_for<0, 128>([&](auto rc) { o_zero<SVI_OREG0 + decltype(rc)::value>(tok); });
     asm volatile("s_nop 4" : "+v"(tok));        // v_accvgpr_write -> MFMA operand wait states
 
-    // ---- LDS-DMA assignment: a tile is 16 pieces of 1 KiB; wave w moves pieces w, w+4, w+8, w+12 ------------
+    // ---- LDS-DMA: a tile is 16 pieces of 1 KiB; wave w moves pieces w, w+4, w+8, w+12 -----------------------------
     // buffer_load ... lds: the descriptor bounds every access, so key rows past the end of K read as zeros and need no
     // clamping; V^T key columns past Lk read the row's pad / the next row (finite by contract) and are multiplied by P = 0.
     const int ntiles = (Lk + KB - 1) / KB;
     const int npairs = (ntiles + 1) >> 1;
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16*>(K), 0, (int)(((size_t)(Lk - 1) * ldk + (size_t)(head + 1) * DH) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16*>(VT), 0, (int)(((size_t)((head + 1) * DH - 1) * ldvt + (size_t)ldvt) * 2), 0x00020000);
+    const int last = 2 * npairs - 1;             // tiles 0 .. last; a tile index >= ntiles is fully masked
+    const int lds0 = (int)(size_t)(lptr_t)smem;  // 0: all LDS of this kernel is the dynamic region (stage XOR below relies on it)
+    constexpr int VST0 = 4 * KT_BYTES;
+    u32x4 k_rs, v_rs;
+    {
+        const unsigned long long kb = (unsigned long long)K, vb = (unsigned long long)VT;
+        k_rs[0] = (unsigned)kb; k_rs[1] = (unsigned)(kb >> 32) & 0xffffu;
+        k_rs[2] = (unsigned)(((size_t)(Lk - 1) * ldk + (size_t)(head + 1) * DH) * 2); k_rs[3] = 0x00020000u;
+        v_rs[0] = (unsigned)vb; v_rs[1] = (unsigned)(vb >> 32) & 0xffffu;
+        v_rs[2] = (unsigned)(((size_t)((head + 1) * DH - 1) * ldvt + (size_t)ldvt) * 2); v_rs[3] = 0x00020000u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            k_rs[i] = __builtin_amdgcn_readfirstlane(k_rs[i]);
+            v_rs[i] = __builtin_amdgcn_readfirstlane(v_rs[i]);
+        }
+    }
     int koff[4], voff[4];                          // byte offsets of this lane's source chunk inside tile 0
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -453,25 +480,26 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         const int vr_ = 8 * pc + (lane >> 3);                  // V^T tile: 8 rows of 128 B per piece
         voff[j] = ((head * DH + vr_) * ldvt + (((lane & 7) ^ ((vr_ >> 1) & 7)) << 3)) * 2;
     }
-    auto stage_k = [&](int t, int st) {             // K tile t -> K stage st
-        char* dst = Kst + st * KT_BYTES;
-        const int soff = t * KB * ldk * 2;
+    const int piece0 = lds0 + wave * 1024;         // LDS address of this wave's piece j of a stage: piece0 + stage + 4096 j
+    // scalar byte offset of tile t inside K: t * KB * ldk * 2; inside V^T: t * KB * 2
+    // prologue-only staging through the compiler's own builtin (it waits for these with vmcnt(0) at the __syncthreads)
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(K), 0, (int)k_rs[2], 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(VT), 0, (int)v_rs[2], 0x00020000);
+    auto stage_k = [&](int t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(dst + (wave + 4 * j) * 1024), 16, koff[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(smem + (t & 3) * KT_BYTES + (wave + 4 * j) * 1024), 16, koff[j], t * KB * ldk * 2, 0, 0);
     };
-    auto stage_v = [&](int t, int st) {             // V^T tile t -> V stage st
-        char* dst = Vst + st * VT_BYTES;
-        const int soff = t * KB * 2;
+    auto stage_v = [&](int t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(dst + (wave + 4 * j) * 1024), 16, voff[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(smem + VST0 + (t & 1) * VT_BYTES + (wave + 4 * j) * 1024), 16, voff[j], t * KB * 2, 0, 0);
     };
 
     // ---- per-row-group softmax state ---------------------------------------------------------------------
     const float cs = MULC ? scale_log2e : 1.0f;   // score units -> log2 units
-    // All softmax state is in score units (log2 units when Q carries softmax_scale*log2 e).  M = reference maximum the exponentials are
-    // taken against; it only moves at a rescale event.
+    // All softmax state is in score units (log2 units when Q carries softmax_scale*log2 e).  M = reference maximum the
+    // exponentials are taken against; it only moves at a rescale event.
     float m_ref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
     float alpha[2] = {1.f, 1.f};                 // exp2(M_old - M_new) of the last rescale event, 1 otherwise
     f32x16 cneg[2];                              // -M broadcast: the C operand every score chain starts from
@@ -481,64 +509,78 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         for (int r = 0; r < 16; ++r) cneg[g][r] = 0.f;
     u32x4 pw[2][2][2];                           // P(t-1) as MFMA B operands: [g][tt][sb], 8 bf16 each
     const int krow = perm23(l31);
-    // Absolute LDS byte addresses of this lane's fragments in stage 0: the swizzle XOR makes the 8 k-steps (K) and the
-    // 4 (tt, sb) key blocks (V^T) non-additive; tt / d (+32 rows) and the stage fold into the instruction's immediate.
-    const int lds0 = (int)(size_t)(lptr_t)smem;
+    // LDS byte addresses of this lane's fragments in K stage 0 / V stage 0: the swizzle XOR makes the 8 k-steps (K) and
+    // the 4 (tt, sb) key blocks (V^T) non-additive; tt / d (+32 rows) and the stage fold into the instruction's immediate.
+    // K stages: odd tiles read stage 1 or 3, even tiles 2 or 0.  kaddr carries a 0 / 32 KiB base that flips once per tile
+    // pair (inside the odd tile, after its own K reads): odd tiles read base + 16 KiB, even tiles the flipped base + 0.
     int kaddr[8], vaddr[4];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) kaddr[kk] = lds0 + k_off(krow, 2 * kk + hi);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) vaddr[c] = lds0 + 2 * KT_BYTES + v_off(l31, 2 * c + hi);
-
-    // The 32 score pairs of a tile (per row group g: tb in {0,1}, word w in 0..7 = scores 2w, 2w+1 of s[g][tb]) become
-    // the 32 packed P words pw[g][tb][w >> 2][w & 3].  B work (exp / row-sum / pack) of tile t-1 is spread over the MFMA
-    // statements of tile t: 24 pairs ride on phase 1 (3 of every 4 MFMAs: all of tb = 0, then tb = 1 words 0..3), the last
-    // 8 (tb = 1, words 4..7, first needed by PV fragment 12) on the odd MFMAs of the first half of phase 2.
+    for (int c = 0; c < 4; ++c) vaddr[c] = lds0 + VST0 + v_off(l31, 2 * c + hi);
+    f32x16 sA[2][2], sB[2][2];                   // score tiles: even tiles live in sA, odd tiles in sB
+    u32x4 kf[4], vf[4];                          // fragment rings; kf[0..2] / vf[0..2] are filled one phase ahead
     float ps[2][2];
-    // phase 1 of tile t: S(t) -> sn from K stage kst.  Fragment f = tt*8 + kk feeds MFMAs (f, g=0), (f, g=1); fragment f+3
-    // is read behind MFMA (f, 0).  WITH_B is false only for tile 0.
-    auto phase1 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], int kst, auto with_b) {
+    float ma[2], mb[2];                          // per-lane running maxima of the tile in phase 2 (two chains per row group)
+
+    // phase 1 of tile t: S(t) -> sn from K stage KS (immediate; kaddr holds the pair's bit 15).  Fragment f = tt*8 + kk feeds
+    // MFMAs (f, g=0), (f, g=1); kf[0..2] were read in the previous phase, fragment f+3 is read behind MFMA (f, 0), and the
+    // last three statements read the first V^T fragments of phase 2 instead.  24 B pairs of tile t-1 ride on 3 of every 4
+    // MFMAs, the fourth carries an LDS-DMA piece: V(t) -> V stage VD, then K(t+3) -> K stage (t+3) & 3.
+    auto phase1 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], auto ks_c, auto vs_c, auto vd_c, int t, auto with_b) {
         constexpr bool WITH_B = decltype(with_b)::value && !(ABL & 1);
-        const int ks = kst * KT_BYTES;
+        constexpr int ks = decltype(ks_c)::value * KT_BYTES, vs = decltype(vs_c)::value * VT_BYTES;
+        constexpr int vd = VST0 + decltype(vd_c)::value * VT_BYTES;
+        const int kd = ((t + 3) & 3) * KT_BYTES;
+        const int so_k = (t + 3) * KB * ldk * 2, so_v = t * KB * 2;
         ps[0][0] = ps[0][1] = ps[1][0] = ps[1][1] = 0.f;
-        u32x4 kf[4];
-        kf[0] = *(lds_u32x4_t)(kaddr[0] + ks);
-        kf[1] = *(lds_u32x4_t)(kaddr[1] + ks);
-        kf[2] = *(lds_u32x4_t)(kaddr[2] + ks);
         static_for<0, 16>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int tt = f >> 3, kk = f & 7, f3 = (f + 3) & 15;
             static_for<0, 2>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 constexpr int k = 2 * f + g;                         // MFMA statement index in the phase
-                if constexpr (WITH_B && (k & 3) != 3) {
+                // the register whose next use must stay behind this MFMA: the address of the fragment read that follows
+                int& pin = *((f + 3 < 16) ? &kaddr[f3 & 7] : &vaddr[0]);
+                if constexpr ((k & 3) == 3) {
+                    constexpr int j = (k >> 2) & 3;
+                    if constexpr (ABL & 8)
+                        qk_mfma<SVI_QREG0 + (g * 8 + kk) * 4, false>(tok, sn[g][tt], kf[f & 3], pin, cneg[g]);
+                    else if constexpr (k < 16)
+                        qk_mfma_dma<SVI_QREG0 + (g * 8 + kk) * 4>(tok, sn[g][tt], kf[f & 3], pin, v_rs, voff[j], so_v, piece0 + vd + 4096 * j);
+                    else
+                        qk_mfma_dma<SVI_QREG0 + (g * 8 + kk) * 4>(tok, sn[g][tt], kf[f & 3], pin, k_rs, koff[j], so_k, piece0 + kd + 4096 * j);
+                } else if constexpr (WITH_B) {
                     constexpr int pi = k - (k >> 2);                 // pair 0..23: (w, g') fastest g'
                     constexpr int pg = pi & 1, pj = pi >> 1;         // pj 0..11: 0..7 -> tb 0 word pj; 8..11 -> tb 1 word pj-8
                     constexpr int tb = pj >> 3, w = pj & 7, r0 = 2 * w;
                     unsigned wd;
-                    qk_mfma_b<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, MULC>(tok, sn[g][tt], kf[f & 3], kaddr[f3 & 7], cneg[g], so[pg][tb][r0],
+                    qk_mfma_b<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, MULC>(tok, sn[g][tt], kf[f & 3], pin, cneg[g], so[pg][tb][r0],
                                                                            so[pg][tb][r0 + 1], scale_log2e, ps[pg][0], ps[pg][1], wd);
                     pw[pg][tb][w >> 2][w & 3] = wd;
                 } else {
-                    qk_mfma<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0>(tok, sn[g][tt], kf[f & 3], kaddr[f3 & 7], cneg[g]);
+                    qk_mfma<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0>(tok, sn[g][tt], kf[f & 3], pin, cneg[g]);
                 }
                 if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
                     kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ks + ((f + 3) >> 3) * 32 * 256);
                 if constexpr (g == 0 && f + 3 < 16 && (ABL & 4)) kf[(f + 3) & 3] = kf[f & 3];
+                if constexpr (g == 0 && f + 3 >= 16)                 // f = 13, 14, 15: V^T fragments 0, 1, 2 of phase 2
+                    vf[f >= 13 ? f - 13 : 0] = *(lds_u32x4_t)(vaddr[0] + vs + (f >= 13 ? f - 13 : 0) * 32 * 128);
             });
         });
     };
-    // phase 2 of tile t: O += V(t-1)·P(t-1) from V stage vst, with A(t) (row max of sn) on the even MFMAs and the last 8 B
-    // pairs of tile t-1 on the odd MFMAs of fragments 0..7.  Leaves the candidate maxima in m_cand and returns whether some
-    // row's maximum outgrew the reference by more than SVI_RESCALE_THR.  WITH_PV is false only for tile 0.
-    float m_rel[2];                              // row maximum of the tile relative to M (what A computes)
-    auto phase2 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], int vst, int key_base, auto masked_tag, auto with_pv) -> bool {
+    // phase 2 of tile t: O += V(t-1)·P(t-1) from V stage VS; A(t) (per-lane running maxima of sn) on the even MFMAs, the
+    // last 8 B pairs of tile t-1 on the odd MFMAs of fragments 0..7; the last three even statements read the first K
+    // fragments of tile t+1 (K stage KN) unless this is the last tile.
+    auto phase2 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], auto vs_c, auto kn_c, int key_base, auto masked_tag, auto with_pv,
+                      auto with_next) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr bool WITH_PV = decltype(with_pv)::value;
         constexpr bool WITH_B = WITH_PV && !(ABL & 1);
-        const int vs = vst * VT_BYTES;
+        constexpr bool WITH_NEXT = decltype(with_next)::value;
+        constexpr int vs = decltype(vs_c)::value * VT_BYTES, kn = decltype(kn_c)::value * KT_BYTES;
         // MFMA result (the last QK^T MFMAs) -> VALU read, and VALU-written P -> MFMA operand: wait states by hand
-        if constexpr (!(ABL & 64)) asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
+        asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
         if (MASKED) {
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -548,57 +590,54 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     for (int r = 0; r < 16; ++r)
                         if (key_base + 8 * hi + 32 * tt + 16 * (r >> 3) + (r & 7) >= Lk) sn[g][tt][r] = -INFINITY;
         }
-        u32x4 vf[4];
-        float ma[2] = {-INFINITY, -INFINITY}, mb[2] = {-INFINITY, -INFINITY};
-        bool need = false;
-        if constexpr (WITH_PV) {
-            vf[0] = *(lds_u32x4_t)(vaddr[0] + vs);
-            vf[1] = *(lds_u32x4_t)(vaddr[0] + vs + 32 * 128);
-            vf[2] = *(lds_u32x4_t)(vaddr[0] + vs + 64 * 128);
-        }
-        auto finish = [&](int g) {               // running max of group g complete: growth test against the reference
-            const float mx = vmax3(ma[g], mb[g], mb[g]);
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            m_rel[g] = vmax3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
-            need = need || (m_rel[g] * cs > ((ABL & 128) ? 1e30f : SVI_RESCALE_THR));
-        };
+        ma[0] = ma[1] = mb[0] = mb[1] = -INFINITY;
         // fragment f = (tt*2 + sb)*4 + d feeds MFMAs (f, g=0), (f, g=1); MFMA (f, 0) carries step f&7 of group f>>3's max
         static_for<0, 16>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int tt = f >> 3, sb = (f >> 2) & 1, d = f & 3, f3 = (f + 3) & 15;
             constexpr int ga = f >> 3, r = 2 * (f & 7);
             if constexpr (WITH_PV) {
+                constexpr int nf = f >= 13 ? f - 13 : 0;            // index of the next tile's K fragment read behind this MFMA
+                int& pin = *((f + 3 < 16) ? &vaddr[f3 >> 2] : &kaddr[nf]);
                 if constexpr ((ABL & 2) || (ABL & 32))
-                    pv_mfma<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], vaddr[f3 >> 2]);
+                    pv_mfma<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], pin);
                 else
-                    pv_mfma_a<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], vaddr[f3 >> 2], ma[ga], mb[ga],
+                    pv_mfma_a<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], pin, ma[ga], mb[ga],
                                                             sn[ga][0][r], sn[ga][0][r + 1], sn[ga][1][r], sn[ga][1][r + 1]);
                 if constexpr (f + 3 < 16 && !(ABL & 4))
                     vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
                 if constexpr (f + 3 < 16 && (ABL & 4)) vf[(f + 3) & 3] = vf[f & 3];
+                if constexpr (f + 3 >= 16 && WITH_NEXT)              // f = 13, 14, 15: K fragments 0, 1, 2 of tile t+1
+                    kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
                 if constexpr (WITH_B && f < 8) {
                     constexpr int pg = f & 1, w = 4 + (f >> 1), r0 = 2 * w;      // tb = 1, words 4..7
                     unsigned wd;
-                    pv_mfma_b<SVI_OREG0 + (1 * 4 + d) * 16, MULC>(tok, vf[f & 3], pw[1][tt][sb], vaddr[f3 >> 2], so[pg][1][r0],
+                    pv_mfma_b<SVI_OREG0 + (1 * 4 + d) * 16, MULC>(tok, vf[f & 3], pw[1][tt][sb], pin, so[pg][1][r0],
                                                                   so[pg][1][r0 + 1], scale_log2e, ps[pg][0], ps[pg][1], wd);
                     pw[pg][1][w >> 2][w & 3] = wd;
                 } else {
-                    pv_mfma<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vf[f & 3], pw[1][tt][sb], vaddr[f3 >> 2]);
+                    pv_mfma<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vf[f & 3], pw[1][tt][sb], pin);
                 }
                 if constexpr (WITH_B && f == 7) {                    // all 32 pairs of tile t-1 are done: fold the row sums
                     l_run[0] = l_run[0] * alpha[0] + (ps[0][0] + ps[0][1]);
                     l_run[1] = l_run[1] * alpha[1] + (ps[1][0] + ps[1][1]);
+                    alpha[0] = alpha[1] = 1.0f;
                 }
             } else {
                 ma[ga] = vmax3(ma[ga], sn[ga][0][r], sn[ga][0][r + 1]);
                 mb[ga] = vmax3(mb[ga], sn[ga][1][r], sn[ga][1][r + 1]);
+                if constexpr (f + 3 >= 16 && WITH_NEXT) kf[f >= 13 ? f - 13 : 0] = *(lds_u32x4_t)(kaddr[f >= 13 ? f - 13 : 0] + kn);
             }
-            if constexpr ((f & 7) == 7 && !(ABL & 2) && !(ABL & 16)) finish(ga);
         });
-        return need;
     };
-    // Move the reference maximum of both row groups by delta[g] >= 0 (first tile: any sign): the -M tuples, the scores of
-    // the tile whose exponentials are still pending (sn, computed against the old reference) and alpha for O and l.
+    // does some row of this wave exceed its reference by more than the threshold?  (per-lane maxima are enough to decide)
+    auto outgrown = [&]() -> bool {
+        if constexpr ((ABL & 2) || (ABL & 16)) return false;
+        const float mx = vmax3(ma[0], mb[0], vmax3(ma[1], mb[1], mb[1]));
+        return __any(mx * cs > ((ABL & 128) ? 1e30f : SVI_RESCALE_THR));
+    };
+    // Move the reference maximum of both row groups by delta[g] (first tile: any sign, later >= 0): the -M tuples, the scores
+    // of the tile whose exponentials are still pending (sn, computed against the old reference) and alpha for O and l.
     auto commit = [&](f32x16 (&sn)[2][2], const float (&delta)[2]) {
         static_for<0, 2>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -612,67 +651,97 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 for (int r = 0; r < 16; ++r) sn[g][tt][r] -= delta[g];
         });
     };
+    auto row_max = [&](int g) -> float {            // row maximum of the tile (relative to the reference): both lane halves
+        const float mx = vmax3(ma[g], mb[g], mb[g]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        return vmax3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+    };
     // Deferred rescale (cdna_hip_programming.md T13): the reference maximum only moves when some row of the wave outgrew
     // it by more than SVI_RESCALE_THR (log2 units), so P stays <= 2^THR and the 128-register O rescale — and the barrier
     // skew it causes when only one wave of the workgroup takes it — all but disappears.  The result is the same softmax:
     // numerator and denominator carry the same reference.  Rows that did not grow keep theirs (delta = 0, alpha = 1).
-    auto rescale = [&](f32x16 (&sn)[2][2], bool need) {
-        alpha[0] = alpha[1] = 1.0f;
-        if (__any(need)) {
-            const float delta[2] = {fmaxf(m_rel[0], 0.f), fmaxf(m_rel[1], 0.f)};
-            asm("s_nop 15" : "+v"(tok));        // MFMA result -> v_accvgpr_read wait states
-            commit(sn, delta);
-            static_for<0, 2>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                static_for<0, 16>([&](auto rc) { o_scale4<SVI_OREG0 + g * 64 + 4 * decltype(rc)::value>(tok, alpha[g]); });
-            });
-            asm("s_nop 4" : "+v"(tok));         // v_accvgpr_write -> MFMA SrcC wait states
-        }
+    // This code sits OUTSIDE the steady-state loop so that the -M tuples are loop invariants there.
+    auto rescale = [&](f32x16 (&sn)[2][2]) {
+        const float delta[2] = {fmaxf(row_max(0), 0.f), fmaxf(row_max(1), 0.f)};
+        asm("s_nop 15" : "+v"(tok));            // MFMA result -> v_accvgpr_read wait states
+        commit(sn, delta);
+        static_for<0, 2>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            static_for<0, 16>([&](auto rc) { o_scale4<SVI_OREG0 + g * 64 + 4 * decltype(rc)::value>(tok, alpha[g]); });
+        });
+        asm("s_nop 4" : "+v"(tok));             // v_accvgpr_write -> MFMA SrcC wait states
     };
-    // one tile t >= 1: loads K(t+1), V(t); phase 1 (S(t) | B(t-1)); phase 2 (PV(t-1) | A(t)); rescale; barrier
-    auto tile = [&](int t, int par, f32x16 (&sn)[2][2], f32x16 (&so)[2][2], auto masked_tag) {
-        constexpr bool STEADY = !decltype(masked_tag)::value;
-        if constexpr (!(STEADY && (ABL & 8))) {
-            stage_k(t + 1, par ^ 1);
-            stage_v(t, par);
-        }
-        phase1(sn, so, par, std::true_type{});
-        const bool need = phase2(sn, so, par ^ 1, t * KB, masked_tag, std::true_type{});
-        rescale(sn, need);
-        if constexpr (!(STEADY && (ABL & 8))) __syncthreads();
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    // one tile t >= 1; returns whether the reference must move before tile t+1.  Odd tiles: K at base + 16 KiB, read V stage
+    // 0, write V stage 1, S(t) in sB; then the base flips and the next (even) tile's first fragments come from base + 0.
+    // Even tiles: K at base + 0, read V stage 1, write V stage 0, S(t) in sA; the next (odd) tile reads base + 16 KiB.
+    auto tile_odd = [&](int t, auto masked_tag, auto with_next) -> bool {
+        phase1(sB, sA, I1{}, I0{}, I1{}, t, std::true_type{});
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) kaddr[kk] ^= 2 * KT_BYTES;      // this tile's K reads are done: move to the other half
+        phase2(sB, sA, I0{}, I0{}, t * KB, masked_tag, std::true_type{}, with_next);
+        const bool need = outgrown();
+        tile_barrier<4>(tok);
+        return need;
+    };
+    auto tile_even = [&](int t, auto masked_tag, auto with_next) -> bool {
+        phase1(sA, sB, I0{}, I1{}, I0{}, t, std::true_type{});
+        phase2(sA, sB, I1{}, I1{}, t * KB, masked_tag, std::true_type{}, with_next);
+        const bool need = outgrown();
+        tile_barrier<4>(tok);
+        return need;
     };
 
-    // ---- prologue: tile 0 (no B, no PV) ---------------------------------------------------------------------------
-    f32x16 sA[2][2], sB[2][2];
-    stage_k(0, 0);
-    __syncthreads();
-    stage_k(1, 1);
-    stage_v(0, 0);
-    phase1(sA, sB, 0, std::false_type{});
-    (void)phase2(sA, sB, 1, 0, std::true_type{}, std::false_type{});
-    {
-        const float d0[2] = {m_rel[0], m_rel[1]};                      // first reference = the row maxima of tile 0 (any sign)
+    // ---- prologue: K(0..3) and V(0) staged; tile 0 has no B and no PV ------------------------------------------------
+    stage_k(0); stage_k(1); stage_k(2); stage_k(3); stage_v(0);
+    __syncthreads();                                                   // (hipcc waits vmcnt(0) for its own LDS-DMA here)
+    kf[0] = *(lds_u32x4_t)(kaddr[0]);
+    kf[1] = *(lds_u32x4_t)(kaddr[1]);
+    kf[2] = *(lds_u32x4_t)(kaddr[2]);
+    {   // S(0) -> sA from K stage 0: plain statements, no DMA, no B; then the fragments of tile 1 (K stage 1)
+        static_for<0, 16>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int tt = f >> 3, kk = f & 7, f3 = (f + 3) & 15;
+            qk_mfma<SVI_QREG0 + kk * 4, kk == 0>(tok, sA[0][tt], kf[f & 3], kaddr[f3 & 7], cneg[0]);
+            if constexpr (f + 3 < 16) kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ((f + 3) >> 3) * 32 * 256);
+            qk_mfma<SVI_QREG0 + (8 + kk) * 4, kk == 0>(tok, sA[1][tt], kf[f & 3], kaddr[f3 & 7], cneg[1]);
+        });
+        phase2(sA, sB, I0{}, I1{}, 0, std::true_type{}, std::false_type{}, std::true_type{});
+        const float d0[2] = {row_max(0), row_max(1)};                  // first reference = the row maxima of tile 0 (any sign)
         commit(sA, d0);
         alpha[0] = alpha[1] = 1.0f;                                    // O and l are still 0
     }
-    __syncthreads();
+    __syncthreads();                                                   // K stage 0 may be overwritten from tile 1 on
 
-    // ---- tiles 1 .. 2*npairs-1: odd tiles write sB / consume sA, even tiles the reverse; the last two are masked ----
-    const int last = 2 * npairs - 1;
+    // ---- tiles 1 .. last.  Steady state = pairs (odd, even) with no rescale code inside the loop; a tile that reports an
+    // outgrown reference leaves the loop, the reference moves (rescale), and the pair is finished outside. -------------
     int t = 1;
-    for (; last - t >= 4; t += 2) {
-        tile(t, 1, sB, sA, std::false_type{});
-        tile(t + 1, 0, sA, sB, std::false_type{});
-    }
-    if (last - t == 2) {
-        tile(t, 1, sB, sA, std::false_type{});
-        tile(t + 1, 0, sA, sB, std::true_type{});
+    for (;;) {
+        int ev = 0;
+        for (; last - t >= 4; t += 2) {
+            if (tile_odd(t, std::false_type{}, std::true_type{})) { ev = 1; break; }
+            if (tile_even(t + 1, std::false_type{}, std::true_type{})) { ev = 2; break; }
+        }
+        if (ev == 0) break;
+        if (ev == 1) {
+            rescale(sB);
+            if (tile_even(t + 1, std::false_type{}, std::true_type{})) rescale(sA);
+        } else {
+            rescale(sA);
+        }
         t += 2;
     }
-    tile(t, 1, sB, sA, std::true_type{});                              // t == last (odd): S(last) in sB
+    if (last - t == 2) {
+        if (tile_odd(t, std::false_type{}, std::true_type{})) rescale(sB);
+        if (tile_even(t + 1, std::true_type{}, std::true_type{})) rescale(sA);
+        t += 2;
+    }
+    if (tile_odd(t, std::true_type{}, std::false_type{})) rescale(sB);     // t == last (odd): S(last) in sB
     // ---- drain: B(last), then O += V(last)·P(last) ------------------------------------------------------------------
     {
-        float ps[2] = {0.f, 0.f};
+        float psd[2] = {0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -681,10 +750,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 for (int r = 0; r < 16; r += 2) {
                     const float p0 = __builtin_amdgcn_exp2f(sB[g][tt][r] * cs);
                     const float p1 = __builtin_amdgcn_exp2f(sB[g][tt][r + 1] * cs);
-                    ps[g] += p0 + p1;
+                    psd[g] += p0 + p1;
                     pw[g][tt][r >> 3][(r & 7) >> 1] = pack_bf16x2(p0, p1);
                 }
-            l_run[g] = l_run[g] * alpha[g] + ps[g];
+            l_run[g] = l_run[g] * alpha[g] + psd[g];
         }
         asm("s_nop 1" : "+v"(tok), "+v"(pw[0][0][0]), "+v"(pw[0][0][1]), "+v"(pw[0][1][0]), "+v"(pw[0][1][1]));
         asm("s_nop 1" : "+v"(tok), "+v"(pw[1][0][0]), "+v"(pw[1][0][1]), "+v"(pw[1][1][0]), "+v"(pw[1][1][1]));
@@ -760,9 +829,10 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
                 case 128: kern = flash_fwd2_kernel<0, 128>; break;
                 default: break;
             }
-            SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
+            SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
             dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
-            hipLaunchKernelGGL(kern, grid2, block2, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
+            hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
             SVI_LAUNCH_CHECK();
             return SVI_OK;
         }

@@ -16,9 +16,10 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "stable-video-infinity_amd", "csrc", "svi_attention.hip")
 tmp = tempfile.mkdtemp(prefix="audit_flash2_")
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c", SRC, "-o", os.path.join(tmp, "a.o"), "-save-temps=obj"]
+OUT = os.path.join(tmp, "svi_attention-hip-amdgcn-amd-amdhsa-gfx950.s")
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only", "-S", SRC, "-o", OUT]
 subprocess.run(cmd, check=True, cwd=tmp, capture_output=True)
-asm = open(os.path.join(tmp, "svi_attention-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+asm = open(OUT).read().splitlines()
 bad = 0
 i = 0
 while i < len(asm):
