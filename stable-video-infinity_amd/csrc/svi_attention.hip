@@ -298,85 +298,103 @@ __device__ __forceinline__ void qk_mfma(int& tok, f32x16& s, u32x4 kf, int& apin
         asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]"
             : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin) : [kf] "v"(kf), [q0] "n"(R), [q1] "n"(R + 3));
 }
-// The same MFMA followed, in ONE statement, by the softmax "B" work of two scores x0, x1 of the PREVIOUS tile (already
-// relative to the reference maximum, in log2 units):   p = exp2(x);  rowsum += p;  w = pack_bf16(p0, p1)
-// Written out as instructions so that the five VALU ops sit exactly in this MFMA's shadow (hipcc otherwise clusters
-// them away from the MFMAs).  v_exp results are consumed two instructions later (trans -> VALU use needs one).
-#define SVI_B_OPS                                                                                   \
-    "v_exp_f32 %[t0], %[x0]\n\tv_exp_f32 %[t1], %[x1]\n\t"                                          \
-    "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"                            \
-    "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
-// the same when Q was NOT pre-multiplied by softmax_scale*log2(e) (MULC): x is in raw score units, p = exp2(x * c)
-#define SVI_B_OPS_MULC                                                                              \
-    "v_mul_f32 %[t0], %[x0], %[c]\n\tv_mul_f32 %[t1], %[x1], %[c]\n\t"                              \
-    "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"                                          \
-    "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\t"                            \
-    "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]"
-template <int R, bool FIRST, bool MULC>
-__device__ __forceinline__ void qk_mfma_b(int& tok, f32x16& s, u32x4 kf, int& apin, const f32x16& cneg, float x0, float x1,
-                                          float c, float& sum0, float& sum1, unsigned& w) {
-    float t0, t1;
-    if constexpr (FIRST && MULC)
-        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[cn]\n\t" SVI_B_OPS_MULC
-            : [s] "=&v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-            : [kf] "v"(kf), [cn] "v"(cneg), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [q0] "n"(R), [q1] "n"(R + 3));
-    else if constexpr (FIRST)
-        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[cn]\n\t" SVI_B_OPS
-            : [s] "=&v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-            : [kf] "v"(kf), [cn] "v"(cneg), [x0] "v"(x0), [x1] "v"(x1), [q0] "n"(R), [q1] "n"(R + 3));
-    else if constexpr (MULC)
-        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t" SVI_B_OPS_MULC
-            : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-            : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [q0] "n"(R), [q1] "n"(R + 3));
-    else
-        asm("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t" SVI_B_OPS
-            : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-            : [kf] "v"(kf), [x0] "v"(x0), [x1] "v"(x1), [q0] "n"(R), [q1] "n"(R + 3));
+// ---- MFMA statements with fillers --------------------------------------------------------------------------------------
+// One wave per SIMD issues one instruction at a time: measured on this part (tools/probe/mfma_issue_probe.hip) FIVE plain VALU
+// instructions (or three v_exp) hide in the 32-cycle shadow of a v_mfma_f32_32x32x16_bf16, every instruction beyond that
+// costs ~5 cycles.  So the softmax work is cut into single-score pieces and written INTO the MFMA statements:
+//   B, first score of a pair   (EA):  t0 = exp2(x0)            | MFMA |  sum0 += t0
+//   B, second score of a pair  (EB):  t1 = exp2(x1)            | MFMA |  sum1 += t1 ; w = pack_bf16(t0, t1)
+//   B, a whole pair            (E2):  t0 = exp2(x0), t1 = ..   | MFMA |  both sums ; w
+//   A, two scores of the current tile (PV statements only):             m = max3(m, y0, y1)
+//   one LDS-DMA piece (s_mov m0 / buffer_load ... lds)
+// The v_exp sits in front of the MFMA so that its (transcendental) result is not consumed by the very next instruction.
+// x is already relative to the reference maximum, in log2 units; with MULC it is in raw score units and a v_mul by
+// softmax_scale*log2(e) comes first.
+#define SVI_QKF "v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[cn]\n\t"
+#define SVI_QKN "v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t"
+#define SVI_PVM "v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t"
+#define SVI_EXP0 "v_exp_f32 %[t0], %[x0]\n\t"
+#define SVI_EXP1 "v_exp_f32 %[t1], %[x1]\n\t"
+#define SVI_MEXP0 "v_mul_f32 %[t0], %[x0], %[c]\n\tv_exp_f32 %[t0], %[t0]\n\t"
+#define SVI_MEXP1 "v_mul_f32 %[t1], %[x1], %[c]\n\tv_exp_f32 %[t1], %[t1]\n\t"
+#define SVI_ADD0 "v_add_f32 %[a0], %[a0], %[t0]\n\t"
+#define SVI_ADD1 "v_add_f32 %[a1], %[a1], %[t1]\n\t"
+#define SVI_CVT "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]\n\t"
+#define SVI_MAX3 "v_max3_f32 %[m], %[m], %[y0], %[y1]\n\t"
+#define SVI_DMA "s_mov_b32 m0, %[m0v]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
+#define SVI_END "; end"
+
+#define SVI_QK_OUT(sc) [s] sc(s), [tok] "+v"(tok), [ap] "+v"(apin)
+#define SVI_QK_IN [kf] "v"(kf), [q0] "n"(R), [q1] "n"(R + 3)
+#define SVI_DMA_IN [m0v] "s"(m0v), [vo] "v"(vo), [rs] "s"(rs), [so] "s"(so)
+
+// what an MFMA statement carries besides the MFMA
+enum { SVI_F_NONE = 0, SVI_F_EA = 1, SVI_F_EB = 2, SVI_F_E2 = 3 };
+struct SviDma { u32x4 rs; int vo, so, m0v; };
+
+// QK^T statement.  FILL: SVI_F_*;  DMA: one LDS-DMA piece behind it;  FIRST: first MFMA of its score chain (C = -M tuple)
+template <int R, bool FIRST, int FILL, bool DMA, bool MULC>
+__device__ __forceinline__ void qk_stmt(int& tok, f32x16& s, u32x4 kf, int& apin, const f32x16& cneg, float x0, float x1, float c,
+                                        float& t0, float& sum0, float& sum1, unsigned& w, const SviDma& d) {
+    const u32x4 rs = d.rs;
+    const int vo = d.vo, so = d.so, m0v = d.m0v;
+    float t1;
+    static_assert(!(FIRST && (DMA || FILL == SVI_F_E2)), "first statements of a chain carry at most one score");
+    if constexpr (FILL == SVI_F_NONE && !DMA) {
+        if constexpr (FIRST) asm(SVI_QKF SVI_END : SVI_QK_OUT("=&v") : SVI_QK_IN, [cn] "v"(cneg));
+        else asm(SVI_QKN SVI_END : SVI_QK_OUT("+v") : SVI_QK_IN);
+    } else if constexpr (FILL == SVI_F_NONE && DMA) {
+        asm volatile(SVI_QKN SVI_DMA SVI_END : SVI_QK_OUT("+v") : SVI_QK_IN, SVI_DMA_IN);
+    } else if constexpr (FILL == SVI_F_EA && !DMA) {
+        if constexpr (FIRST && MULC) asm(SVI_MEXP0 SVI_QKF SVI_ADD0 SVI_END : SVI_QK_OUT("=&v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [cn] "v"(cneg), [x0] "v"(x0), [c] "s"(c));
+        else if constexpr (FIRST) asm(SVI_EXP0 SVI_QKF SVI_ADD0 SVI_END : SVI_QK_OUT("=&v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [cn] "v"(cneg), [x0] "v"(x0));
+        else if constexpr (MULC) asm(SVI_MEXP0 SVI_QKN SVI_ADD0 SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0), [c] "s"(c));
+        else asm(SVI_EXP0 SVI_QKN SVI_ADD0 SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0));
+    } else if constexpr (FILL == SVI_F_EA && DMA) {
+        if constexpr (MULC) asm volatile(SVI_MEXP0 SVI_QKN SVI_ADD0 SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0), [c] "s"(c), SVI_DMA_IN);
+        else asm volatile(SVI_EXP0 SVI_QKN SVI_ADD0 SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0), SVI_DMA_IN);
+    } else if constexpr (FILL == SVI_F_EB && !DMA) {
+        if constexpr (FIRST && MULC) asm(SVI_MEXP1 SVI_QKF SVI_ADD1 SVI_CVT SVI_END : SVI_QK_OUT("=&v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [cn] "v"(cneg), [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c));
+        else if constexpr (FIRST) asm(SVI_EXP1 SVI_QKF SVI_ADD1 SVI_CVT SVI_END : SVI_QK_OUT("=&v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [cn] "v"(cneg), [x1] "v"(x1), [t0] "v"(t0));
+        else if constexpr (MULC) asm(SVI_MEXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c));
+        else asm(SVI_EXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0));
+    } else if constexpr (FILL == SVI_F_EB && DMA) {
+        if constexpr (MULC) asm volatile(SVI_MEXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c), SVI_DMA_IN);
+        else asm volatile(SVI_EXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), SVI_DMA_IN);
+    } else {   // E2, never FIRST, never DMA
+        float u0;
+        if constexpr (MULC) asm("v_mul_f32 %[u0], %[x0], %[c]\n\tv_exp_f32 %[u0], %[u0]\n\t" SVI_MEXP1 SVI_QKN "v_add_f32 %[a0], %[a0], %[u0]\n\t" SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[u0], %[t1]\n\t" SVI_END
+                                : SVI_QK_OUT("+v"), [u0] "=&v"(u0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c));
+        else asm("v_exp_f32 %[u0], %[x0]\n\t" SVI_EXP1 SVI_QKN "v_add_f32 %[a0], %[a0], %[u0]\n\t" SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[u0], %[t1]\n\t" SVI_END
+                 : SVI_QK_OUT("+v"), [u0] "=&v"(u0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x0] "v"(x0), [x1] "v"(x1));
+    }
 }
-// A QK^T MFMA (never the first of its chain) with one LDS-DMA piece issued in its shadow: 1 KiB of a K / V^T tile,
-// global -> LDS at byte address m0v, source = descriptor rs + lane offset vo + tile offset so.  The load is invisible to
-// hipcc (no vmcnt bookkeeping on its side): the tile loop counts them by hand (8 per tile, s_waitcnt vmcnt(4) at the end).
-template <int R>
-__device__ __forceinline__ void qk_mfma_dma(int& tok, f32x16& s, u32x4 kf, int& apin, u32x4 rs, int vo, int so, int m0v) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %[s], %[kf], a[%c[q0]:%c[q1]], %[s]\n\t"
-                 "s_mov_b32 m0, %[m]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds"
-                 : [s] "+v"(s), [tok] "+v"(tok), [ap] "+v"(apin)
-                 : [kf] "v"(kf), [m] "s"(m0v), [vo] "v"(vo), [rs] "s"(rs), [so] "s"(so), [q0] "n"(R), [q1] "n"(R + 3));
-}
-// end of a tile: everything but the newest `N` LDS-DMA pieces of this wave has landed, then the workgroup barrier that
-// makes the landed tiles visible to all waves and protects the stages the next tile overwrites.
-template <int N>
-__device__ __forceinline__ void tile_barrier(int& tok) {
-    asm volatile("s_waitcnt vmcnt(%c1)\n\ts_barrier" : "+v"(tok) : "n"(N) : "memory");
-}
-// One PV MFMA:  a[R:R+15] += V^T-fragment x P-fragment
-template <int R>
-__device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) {
-    asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]"
-        : [tok] "+v"(tok), [ap] "+v"(apin) : [vf] "v"(vf), [p] "v"(p), [o0] "n"(R), [o1] "n"(R + 15));
-}
-// ... followed by the softmax "A" work of four scores of the CURRENT tile: two running v_max3 chains
-template <int R>
-__device__ __forceinline__ void pv_mfma_a(int& tok, u32x4 vf, u32x4 p, int& apin, float& ma, float& mb, float y0, float y1,
-                                          float z0, float z1) {
-    asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t"
-        "v_max3_f32 %[ma], %[ma], %[y0], %[y1]\n\tv_max3_f32 %[mb], %[mb], %[z0], %[z1]"
-        : [tok] "+v"(tok), [ap] "+v"(apin), [ma] "+v"(ma), [mb] "+v"(mb)
-        : [vf] "v"(vf), [p] "v"(p), [y0] "v"(y0), [y1] "v"(y1), [z0] "v"(z0), [z1] "v"(z1), [o0] "n"(R), [o1] "n"(R + 15));
-}
-// ... or followed by the "B" work of two scores of the previous tile (see qk_mfma_b)
-template <int R, bool MULC>
-__device__ __forceinline__ void pv_mfma_b(int& tok, u32x4 vf, u32x4 p, int& apin, float x0, float x1, float c, float& sum0,
-                                          float& sum1, unsigned& w) {
-    float t0, t1;
-    if constexpr (MULC)
-        asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t" SVI_B_OPS_MULC
-            : [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-            : [vf] "v"(vf), [p] "v"(p), [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), [o0] "n"(R), [o1] "n"(R + 15));
-    else
-        asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]\n\t" SVI_B_OPS
-            : [tok] "+v"(tok), [ap] "+v"(apin), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
-            : [vf] "v"(vf), [p] "v"(p), [x0] "v"(x0), [x1] "v"(x1), [o0] "n"(R), [o1] "n"(R + 15));
+
+#define SVI_PV_OUT [tok] "+v"(tok), [ap] "+v"(apin)
+#define SVI_PV_IN [vf] "v"(vf), [p] "v"(p), [o0] "n"(R), [o1] "n"(R + 15)
+#define SVI_MAX_IN [y0] "v"(y0), [y1] "v"(y1)
+// PV statement: a[R:R+15] += V^T-fragment x P-fragment.  AMAX: one v_max3 of the A work; FILL: SVI_F_NONE / EA / EB; DMA.
+template <int R, bool AMAX, int FILL, bool DMA, bool MULC>
+__device__ __forceinline__ void pv_stmt(int& tok, u32x4 vf, u32x4 p, int& apin, float& m, float y0, float y1, float x0, float x1, float c,
+                                        float& t0, float& sum0, float& sum1, unsigned& w, const SviDma& d) {
+    const u32x4 rs = d.rs;
+    const int vo = d.vo, so = d.so, m0v = d.m0v;
+    float t1;
+    static_assert(FILL != SVI_F_E2 && !(DMA && FILL != SVI_F_NONE), "unsupported PV statement");
+    if constexpr (!AMAX) {
+        static_assert(FILL == SVI_F_NONE && !DMA, "plain PV statement");
+        asm(SVI_PVM SVI_END : SVI_PV_OUT : SVI_PV_IN);
+    } else if constexpr (DMA) {
+        asm volatile(SVI_PVM SVI_MAX3 SVI_DMA SVI_END : SVI_PV_OUT, [m] "+v"(m) : SVI_PV_IN, SVI_MAX_IN, SVI_DMA_IN);
+    } else if constexpr (FILL == SVI_F_NONE) {
+        asm(SVI_PVM SVI_MAX3 SVI_END : SVI_PV_OUT, [m] "+v"(m) : SVI_PV_IN, SVI_MAX_IN);
+    } else if constexpr (FILL == SVI_F_EA) {
+        if constexpr (MULC) asm(SVI_MEXP0 SVI_PVM SVI_ADD0 SVI_MAX3 SVI_END : SVI_PV_OUT, [m] "+v"(m), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_PV_IN, SVI_MAX_IN, [x0] "v"(x0), [c] "s"(c));
+        else asm(SVI_EXP0 SVI_PVM SVI_ADD0 SVI_MAX3 SVI_END : SVI_PV_OUT, [m] "+v"(m), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_PV_IN, SVI_MAX_IN, [x0] "v"(x0));
+    } else {
+        if constexpr (MULC) asm(SVI_MEXP1 SVI_PVM SVI_ADD1 SVI_CVT SVI_MAX3 SVI_END : SVI_PV_OUT, [m] "+v"(m), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_PV_IN, SVI_MAX_IN, [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c));
+        else asm(SVI_EXP1 SVI_PVM SVI_ADD1 SVI_CVT SVI_MAX3 SVI_END : SVI_PV_OUT, [m] "+v"(m), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_PV_IN, SVI_MAX_IN, [x1] "v"(x1), [t0] "v"(t0));
+    }
 }
 template <int R>
 __device__ __forceinline__ void a_set(int& tok, float v) {                // a[R] = v
@@ -413,6 +431,18 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_t;
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"     // LDS addresses are 32-bit; the host pass sees 64-bit pointers
 
+// end of a tile: everything but the newest `N` LDS-DMA pieces of this wave has landed, then the workgroup barrier that
+// makes the landed tiles visible to all waves and protects the stages the next tile overwrites.
+template <int N>
+__device__ __forceinline__ void tile_barrier(int& tok) {
+    asm volatile("s_waitcnt vmcnt(%c1)\n\ts_barrier" : "+v"(tok) : "n"(N) : "memory");
+}
+// One PV MFMA:  a[R:R+15] += V^T-fragment x P-fragment
+template <int R>
+__device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) {
+    asm("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]"
+        : [tok] "+v"(tok), [ap] "+v"(apin) : [vf] "v"(vf), [p] "v"(p), [o0] "n"(R), [o1] "n"(R + 15));
+}
 // ABL: timing-only ablation mask for tools/attn_ab.py (results are WRONG when non-zero): 1 = no B fillers, 2 = no A
 // fillers, 4 = fragment reads only at the start of each phase, 8 = no LDS-DMA staging and no barrier in the tile loop.
 // MULC = false: the caller's Q already carries softmax_scale*log2(e) (the DiT's RMSNorm+RoPE kernel emits it that way, one
@@ -471,15 +501,16 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             v_rs[i] = __builtin_amdgcn_readfirstlane(v_rs[i]);
         }
     }
-    int koff[4], voff[4];                          // byte offsets of this lane's source chunk inside tile 0
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pc = wave + 4 * j;
-        const int kr_ = 4 * pc + (lane >> 4);                  // K tile: 4 rows of 256 B per piece
-        koff[j] = (kr_ * ldk + head * DH + (((lane & 15) ^ (kr_ & 15)) << 3)) * 2;
-        const int vr_ = 8 * pc + (lane >> 3);                  // V^T tile: 8 rows of 128 B per piece
-        voff[j] = ((head * DH + vr_) * ldvt + (((lane & 7) ^ ((vr_ >> 1) & 7)) << 3)) * 2;
+    // byte offset of this lane's source chunk of piece 0 inside tile 0; piece j = wave + 4 j lies 16 j key rows (K) / 32 j
+    // channel rows (V^T) further on, and its swizzle is the same (16 j = 0 mod 16, 32 j / 2 = 0 mod 8): a scalar offset.
+    int koff0, voff0;
+    {
+        const int kr_ = 4 * wave + (lane >> 4);                // K tile: 4 rows of 256 B per piece
+        koff0 = (kr_ * ldk + head * DH + (((lane & 15) ^ (kr_ & 15)) << 3)) * 2;
+        const int vr_ = 8 * wave + (lane >> 3);                // V^T tile: 8 rows of 128 B per piece
+        voff0 = ((head * DH + vr_) * ldvt + (((lane & 7) ^ ((vr_ >> 1) & 7)) << 3)) * 2;
     }
+    const int kstep = 16 * ldk * 2, vstep = 32 * ldvt * 2;   // piece j -> j + 1
     const int piece0 = lds0 + wave * 1024;         // LDS address of this wave's piece j of a stage: piece0 + stage + 4096 j
     // scalar byte offset of tile t inside K: t * KB * ldk * 2; inside V^T: t * KB * 2
     // prologue-only staging through the compiler's own builtin (it waits for these with vmcnt(0) at the __syncthreads)
@@ -488,12 +519,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     auto stage_k = [&](int t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(smem + (t & 3) * KT_BYTES + (wave + 4 * j) * 1024), 16, koff[j], t * KB * ldk * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(smem + (t & 3) * KT_BYTES + (wave + 4 * j) * 1024), 16, koff0, t * KB * ldk * 2 + j * kstep, 0, 0);
     };
     auto stage_v = [&](int t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(smem + VST0 + (t & 1) * VT_BYTES + (wave + 4 * j) * 1024), 16, voff[j], t * KB * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(smem + VST0 + (t & 1) * VT_BYTES + (wave + 4 * j) * 1024), 16, voff0, t * KB * 2 + j * vstep, 0, 0);
     };
 
     // ---- per-row-group softmax state ---------------------------------------------------------------------
@@ -523,44 +554,43 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     float ps[2][2];
     float ma[2], mb[2];                          // per-lane running maxima of the tile in phase 2 (two chains per row group)
 
-    // phase 1 of tile t: S(t) -> sn from K stage KS (immediate; kaddr holds the pair's bit 15).  Fragment f = tt*8 + kk feeds
-    // MFMAs (f, g=0), (f, g=1); kf[0..2] were read in the previous phase, fragment f+3 is read behind MFMA (f, 0), and the
-    // last three statements read the first V^T fragments of phase 2 instead.  24 B pairs of tile t-1 ride on 3 of every 4
-    // MFMAs, the fourth carries an LDS-DMA piece: V(t) -> V stage VD, then K(t+3) -> K stage (t+3) & 3.
+    // ---- B bookkeeping.  The 64 scores of a lane in a tile (per row group g: tb in {0,1}, 16 scores each) form 32 pairs
+    // p = 0..31:  g = p & 1, tb = p >> 4, word w = (p >> 1) & 7  ->  scores 2w, 2w+1 of s[g][tb]  ->  pw[g][tb][w >> 2][w & 3].
+    // Pairs 0..19 of tile t-1 ride on phase 1 of tile t, pairs 20..31 (tb = 1, w = 2..7) on the first 24 statements of
+    // phase 2, in the order the PV fragments need them (words w = 4..7 of tb = 1 are first read by PV statement 24).
+    float tcar = 0.f;                            // exp2 of the first score of a pair, carried from its EA to its EB statement
+    const SviDma no_dma = {k_rs, 0, 0, 0};
+    // phase 1 of tile t: S(t) -> sn from K stage KS (immediate; kaddr holds the pair's 0 / 32 KiB base).  Fragment f = tt*8 + kk
+    // feeds statements k = 2f (g=0), 2f+1 (g=1); kf[0..2] were read in the previous phase, fragment f+3 is read behind
+    // statement 2f, and the last three even statements read the first V^T fragments of phase 2 instead.
+    // Statements k % 4 == 3 carry a whole pair (0..7), the other 24 one score each (pairs 8..19, EA then EB);
+    // statements 4, 12, 20, 28 also issue the four LDS-DMA pieces of V(t) -> V stage VD.
     auto phase1 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], auto ks_c, auto vs_c, auto vd_c, int t, auto with_b) {
         constexpr bool WITH_B = decltype(with_b)::value && !(ABL & 1);
         constexpr int ks = decltype(ks_c)::value * KT_BYTES, vs = decltype(vs_c)::value * VT_BYTES;
         constexpr int vd = VST0 + decltype(vd_c)::value * VT_BYTES;
-        const int kd = ((t + 3) & 3) * KT_BYTES;
-        const int so_k = (t + 3) * KB * ldk * 2, so_v = t * KB * 2;
+        const int so_v = t * KB * 2;
         ps[0][0] = ps[0][1] = ps[1][0] = ps[1][1] = 0.f;
         static_for<0, 16>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int tt = f >> 3, kk = f & 7, f3 = (f + 3) & 15;
             static_for<0, 2>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                constexpr int k = 2 * f + g;                         // MFMA statement index in the phase
+                constexpr int k = 2 * f + g;
                 // the register whose next use must stay behind this MFMA: the address of the fragment read that follows
                 int& pin = *((f + 3 < 16) ? &kaddr[f3 & 7] : &vaddr[0]);
-                if constexpr ((k & 3) == 3) {
-                    constexpr int j = (k >> 2) & 3;
-                    if constexpr (ABL & 8)
-                        qk_mfma<SVI_QREG0 + (g * 8 + kk) * 4, false>(tok, sn[g][tt], kf[f & 3], pin, cneg[g]);
-                    else if constexpr (k < 16)
-                        qk_mfma_dma<SVI_QREG0 + (g * 8 + kk) * 4>(tok, sn[g][tt], kf[f & 3], pin, v_rs, voff[j], so_v, piece0 + vd + 4096 * j);
-                    else
-                        qk_mfma_dma<SVI_QREG0 + (g * 8 + kk) * 4>(tok, sn[g][tt], kf[f & 3], pin, k_rs, koff[j], so_k, piece0 + kd + 4096 * j);
-                } else if constexpr (WITH_B) {
-                    constexpr int pi = k - (k >> 2);                 // pair 0..23: (w, g') fastest g'
-                    constexpr int pg = pi & 1, pj = pi >> 1;         // pj 0..11: 0..7 -> tb 0 word pj; 8..11 -> tb 1 word pj-8
-                    constexpr int tb = pj >> 3, w = pj & 7, r0 = 2 * w;
-                    unsigned wd;
-                    qk_mfma_b<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, MULC>(tok, sn[g][tt], kf[f & 3], pin, cneg[g], so[pg][tb][r0],
-                                                                           so[pg][tb][r0 + 1], scale_log2e, ps[pg][0], ps[pg][1], wd);
-                    pw[pg][tb][w >> 2][w & 3] = wd;
-                } else {
-                    qk_mfma<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0>(tok, sn[g][tt], kf[f & 3], pin, cneg[g]);
-                }
+                constexpr bool dma = ((k & 7) == 4) && !(ABL & 8);
+                constexpr bool whole = (k & 3) == 3;
+                constexpr int si = k - ((k + 1) >> 2);              // index among the 24 single-score statements
+                constexpr int pi = whole ? (k >> 2) : 8 + (si >> 1); // pair handled (or started / finished) here
+                constexpr int pg = pi & 1, tb = pi >> 4, w = (pi >> 1) & 7, r0 = 2 * w;
+                constexpr int fill = !WITH_B ? SVI_F_NONE : whole ? SVI_F_E2 : (si & 1) ? SVI_F_EB : SVI_F_EA;
+                const SviDma d = {v_rs, voff0, so_v + ((k >> 3) & 3) * vstep, piece0 + vd + 4096 * ((k >> 3) & 3)};
+                unsigned wd = 0;
+                qk_stmt<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], pin, cneg[g], so[pg][tb][r0],
+                                                                                so[pg][tb][r0 + 1], scale_log2e, tcar, ps[pg][0], ps[pg][1], wd,
+                                                                                dma ? d : no_dma);
+                if constexpr (fill == SVI_F_E2 || fill == SVI_F_EB) pw[pg][tb][w >> 2][w & 3] = wd;
                 if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
                     kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ks + ((f + 3) >> 3) * 32 * 256);
                 if constexpr (g == 0 && f + 3 < 16 && (ABL & 4)) kf[(f + 3) & 3] = kf[f & 3];
@@ -569,19 +599,22 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             });
         });
     };
-    // phase 2 of tile t: O += V(t-1)·P(t-1) from V stage VS; A(t) (per-lane running maxima of sn) on the even MFMAs, the
-    // last 8 B pairs of tile t-1 on the odd MFMAs of fragments 0..7; the last three even statements read the first K
-    // fragments of tile t+1 (K stage KN) unless this is the last tile.
-    auto phase2 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], auto vs_c, auto kn_c, int key_base, auto masked_tag, auto with_pv,
+    // phase 2 of tile t: O += V(t-1)·P(t-1) from V stage VS.  Fragment f = (tt*2 + sb)*4 + d feeds statements j = 2f, 2f+1.
+    // Every statement carries one v_max3 of A(t) (row group j >> 4, 2 of its 32 scores, two alternating chains ma / mb);
+    // statements 0..23 one score of pairs 20..31 of tile t-1; statements 24, 26, 28, 30 the LDS-DMA pieces of
+    // K(t+3) -> K stage (t+3) & 3; the last three even statements read the first K fragments of tile t+1 (K stage KN).
+    auto phase2 = [&](f32x16 (&sn)[2][2], f32x16 (&so)[2][2], auto vs_c, auto kn_c, int t, auto masked_tag, auto with_pv,
                       auto with_next) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr bool WITH_PV = decltype(with_pv)::value;
         constexpr bool WITH_B = WITH_PV && !(ABL & 1);
         constexpr bool WITH_NEXT = decltype(with_next)::value;
         constexpr int vs = decltype(vs_c)::value * VT_BYTES, kn = decltype(kn_c)::value * KT_BYTES;
+        const int kd = ((t + 3) & 3) * KT_BYTES, so_k = (t + 3) * KB * ldk * 2;
         // MFMA result (the last QK^T MFMAs) -> VALU read, and VALU-written P -> MFMA operand: wait states by hand
         asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
         if (MASKED) {
+            const int key_base = t * KB;
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -591,43 +624,42 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                         if (key_base + 8 * hi + 32 * tt + 16 * (r >> 3) + (r & 7) >= Lk) sn[g][tt][r] = -INFINITY;
         }
         ma[0] = ma[1] = mb[0] = mb[1] = -INFINITY;
-        // fragment f = (tt*2 + sb)*4 + d feeds MFMAs (f, g=0), (f, g=1); MFMA (f, 0) carries step f&7 of group f>>3's max
         static_for<0, 16>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
-            constexpr int tt = f >> 3, sb = (f >> 2) & 1, d = f & 3, f3 = (f + 3) & 15;
-            constexpr int ga = f >> 3, r = 2 * (f & 7);
-            if constexpr (WITH_PV) {
-                constexpr int nf = f >= 13 ? f - 13 : 0;            // index of the next tile's K fragment read behind this MFMA
-                int& pin = *((f + 3 < 16) ? &vaddr[f3 >> 2] : &kaddr[nf]);
-                if constexpr ((ABL & 2) || (ABL & 32))
-                    pv_mfma<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], pin);
-                else
-                    pv_mfma_a<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vf[f & 3], pw[0][tt][sb], pin, ma[ga], mb[ga],
-                                                            sn[ga][0][r], sn[ga][0][r + 1], sn[ga][1][r], sn[ga][1][r + 1]);
-                if constexpr (f + 3 < 16 && !(ABL & 4))
-                    vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
-                if constexpr (f + 3 < 16 && (ABL & 4)) vf[(f + 3) & 3] = vf[f & 3];
-                if constexpr (f + 3 >= 16 && WITH_NEXT)              // f = 13, 14, 15: K fragments 0, 1, 2 of tile t+1
-                    kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
-                if constexpr (WITH_B && f < 8) {
-                    constexpr int pg = f & 1, w = 4 + (f >> 1), r0 = 2 * w;      // tb = 1, words 4..7
-                    unsigned wd;
-                    pv_mfma_b<SVI_OREG0 + (1 * 4 + d) * 16, MULC>(tok, vf[f & 3], pw[1][tt][sb], pin, so[pg][1][r0],
-                                                                  so[pg][1][r0 + 1], scale_log2e, ps[pg][0], ps[pg][1], wd);
-                    pw[pg][1][w >> 2][w & 3] = wd;
+            constexpr int tt = f >> 3, sb = (f >> 2) & 1, d4 = f & 3, f3 = (f + 3) & 15;
+            constexpr int nf = f >= 13 ? f - 13 : 0;                // index of the next tile's K fragment read behind statement 2f
+            static_for<0, 2>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int j = 2 * f + g;
+                constexpr int ga = j >> 4, ia = j & 15, ta = ia >> 3, ra = 2 * (ia & 7);     // A: scores ra, ra+1 of sn[ga][ta]
+                float& mch = (ia & 1) ? mb[ga] : ma[ga];
+                if constexpr (WITH_PV) {
+                    int& pin = *((f + 3 < 16) ? &vaddr[f3 >> 2] : &kaddr[nf]);
+                    constexpr bool dma = (j >= 24) && !(j & 1) && !(ABL & 8);
+                    constexpr int pi = 20 + (j >> 1);                // pairs 20..31 on statements 0..23
+                    constexpr int pg = pi & 1, w = (pi >> 1) & 7, r0 = 2 * w;          // tb = 1
+                    constexpr int fill = (!WITH_B || j >= 24) ? SVI_F_NONE : (j & 1) ? SVI_F_EB : SVI_F_EA;
+                    constexpr bool amax = !((ABL & 2) || (ABL & 32));
+                    const SviDma d = {k_rs, koff0, so_k + ((j >> 1) & 3) * kstep, piece0 + kd + 4096 * ((j >> 1) & 3)};
+                    unsigned wd = 0;
+                    pv_stmt<SVI_OREG0 + (g * 4 + d4) * 16, amax, amax ? fill : SVI_F_NONE, amax && dma, MULC>(
+                        tok, vf[f & 3], pw[g][tt][sb], pin, mch, sn[ga][ta][ra], sn[ga][ta][ra + 1], so[pg][1][r0], so[pg][1][r0 + 1],
+                        scale_log2e, tcar, ps[pg][0], ps[pg][1], wd, dma ? d : no_dma);
+                    if constexpr (amax && fill == SVI_F_EB) pw[pg][1][w >> 2][w & 3] = wd;
+                    if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
+                        vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
+                    if constexpr (g == 0 && f + 3 < 16 && (ABL & 4)) vf[(f + 3) & 3] = vf[f & 3];
+                    if constexpr (g == 0 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
+                    if constexpr (WITH_B && j == 23) {               // all 32 pairs of tile t-1 are done: fold the row sums
+                        l_run[0] = l_run[0] * alpha[0] + (ps[0][0] + ps[0][1]);
+                        l_run[1] = l_run[1] * alpha[1] + (ps[1][0] + ps[1][1]);
+                        alpha[0] = alpha[1] = 1.0f;
+                    }
                 } else {
-                    pv_mfma<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vf[f & 3], pw[1][tt][sb], pin);
+                    mch = vmax3(mch, sn[ga][ta][ra], sn[ga][ta][ra + 1]);
+                    if constexpr (g == 0 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
                 }
-                if constexpr (WITH_B && f == 7) {                    // all 32 pairs of tile t-1 are done: fold the row sums
-                    l_run[0] = l_run[0] * alpha[0] + (ps[0][0] + ps[0][1]);
-                    l_run[1] = l_run[1] * alpha[1] + (ps[1][0] + ps[1][1]);
-                    alpha[0] = alpha[1] = 1.0f;
-                }
-            } else {
-                ma[ga] = vmax3(ma[ga], sn[ga][0][r], sn[ga][0][r + 1]);
-                mb[ga] = vmax3(mb[ga], sn[ga][1][r], sn[ga][1][r + 1]);
-                if constexpr (f + 3 >= 16 && WITH_NEXT) kf[f >= 13 ? f - 13 : 0] = *(lds_u32x4_t)(kaddr[f >= 13 ? f - 13 : 0] + kn);
-            }
+            });
         });
     };
     // does some row of this wave exceed its reference by more than the threshold?  (per-lane maxima are enough to decide)
@@ -681,14 +713,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         phase1(sB, sA, I1{}, I0{}, I1{}, t, std::true_type{});
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) kaddr[kk] ^= 2 * KT_BYTES;      // this tile's K reads are done: move to the other half
-        phase2(sB, sA, I0{}, I0{}, t * KB, masked_tag, std::true_type{}, with_next);
+        phase2(sB, sA, I0{}, I0{}, t, masked_tag, std::true_type{}, with_next);
         const bool need = outgrown();
         tile_barrier<4>(tok);
         return need;
     };
     auto tile_even = [&](int t, auto masked_tag, auto with_next) -> bool {
         phase1(sA, sB, I0{}, I1{}, I0{}, t, std::true_type{});
-        phase2(sA, sB, I1{}, I1{}, t * KB, masked_tag, std::true_type{}, with_next);
+        phase2(sA, sB, I1{}, I1{}, t, masked_tag, std::true_type{}, with_next);
         const bool need = outgrown();
         tile_barrier<4>(tok);
         return need;
