@@ -219,8 +219,18 @@ def main() -> None:
         per_launch_ms = fl["ms"] / fl["count"]
         alg = 4.0 * L * L * 1536
         ach = alg / (per_launch_ms * 1e-3) / 1e12
-        roof = {"kernel": "flash_fwd_kernel (self-attention)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        # HBM bytes per launch of the same kernel from PMC counters: collected in separate rocprofv3 --pmc passes
+        # (tools/profile_round.sh -> profiles/*_flash_pmc.json, corrected as MI355X_MICROARCH.md prescribes); not measurable live
+        traffic = None
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_flash_pmc.json")))
+            if pm and args.workload == "c2":
+                traffic = json.load(open(pm[-1])).get("hbm_bytes")
+        except Exception:
+            traffic = None
+        roof = {"kernel": "flash_fwd2_kernel (self-attention)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4)}
     line = {
         "metric": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step" if args.workload == "c2" else "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",

@@ -1,0 +1,38 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root):  tools/profile_round.sh <tag>
+#   1. rocprofv3 --kernel-trace --stats of the default-shaped bench (2 steps) -> gpurun_out/<tag>_kernel_stats.md
+#   2. separate rocprofv3 --pmc passes of the dominant kernel alone (tools/kernel_probe.py attn)
+#      -> gpurun_out/<tag>_flash_pmc.txt and gpurun_out/<tag>_flash_pmc.json (per-launch HBM bytes, corrected as
+#      MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE is in KiB and reads half of a wide coalesced stream on gfx950 -> x2)
+# --pmc is never combined with tracing options.
+set -u
+TAG=${1:-r1}
+R=$PWD
+export TMPDIR=/tmp
+mkdir -p $R/gpurun_out/prof_$TAG
+cd /tmp
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae"
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o trace -- $CMD > $R/gpurun_out/prof_$TAG/run.log 2>&1
+DB=$(find $R/gpurun_out/prof_$TAG -name "*_results.db" | head -1)
+python $R/tools/rocpd_summary.py "$DB" $R/gpurun_out/${TAG}_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae" > /dev/null
+grep '"metric"' $R/gpurun_out/prof_$TAG/run.log | tail -1 > $R/gpurun_out/${TAG}_bench_under_rocprof.json
+rm -f "$DB"        # the database is large; the summary is what gets committed
+cd $R
+tools/pmc_collect.sh attn gpurun_out/pmc_$TAG > gpurun_out/pmc_$TAG.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_$TAG flash > gpurun_out/${TAG}_flash_pmc.txt
+python - <<PY
+import json, re
+vals = {}
+for line in open("gpurun_out/${TAG}_flash_pmc.txt"):
+    m = re.match(r"\s+(\S+)\s+per-dispatch\s+([0-9.]+)", line)
+    if m: vals[m.group(1)] = float(m.group(2))
+fetch_kib, write_kib = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
+out = {"kernel": "flash_fwd2_kernel (self-attention, L=32760, 12 heads)", "counters_per_launch": vals,
+       "fetch_bytes": None if fetch_kib is None else fetch_kib * 1024 * 2, "write_bytes": None if write_kib is None else write_kib * 1024,
+       "note": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section: wide coalesced reads are tallied at half); separate --pmc passes, tools/pmc_collect.sh"}
+if out["fetch_bytes"] is not None and out["write_bytes"] is not None:
+    out["hbm_bytes"] = out["fetch_bytes"] + out["write_bytes"]
+json.dump(out, open("gpurun_out/${TAG}_flash_pmc.json", "w"), indent=1)
+print(json.dumps(out)[:600])
+PY
+rm -rf gpurun_out/pmc_$TAG/pass*/  # raw CSVs are large; the summary is kept
