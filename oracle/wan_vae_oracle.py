@@ -177,3 +177,33 @@ def vae_encode(sd: Dict[str, Tensor], video: Tensor) -> Tensor:
     mean = torch.tensor(LATENT_MEAN, dtype=mu.dtype).reshape(1, Z_DIM, 1, 1, 1)
     inv_std = (1.0 / torch.tensor(LATENT_STD)).to(mu.dtype).reshape(1, Z_DIM, 1, 1, 1)
     return (mu - mean) * inv_std
+
+
+# ---- I2V conditioning assembly (pipelines/svi_video.py:313-350), the tensor half of encode_images_adaptive ------------------
+def image_condition(sd: Dict[str, Tensor], first_frames: Tensor, random_ref_frame, num_frames: int, ref_pad_cfg: bool = False,
+                    ref_pad_num: int = 0) -> Tensor:
+    """first_frames [n,3,H,W] in [-1,1] -> y [1,20,T',H/8,W/8] fp32 = cat(mask, vae_encode([motion frames | padding])).
+    Parity note: no golden vector pins this function (the reference method needs the whole pipeline object); it restates
+    svi_video.py line by line: mask :319-327, conditioned frames :329-335, padding :337-347, encode + concat :349-351."""
+    n, _, H, W = first_frames.shape
+    msk = torch.ones(1, num_frames, H // 8, W // 8)
+    if ref_pad_cfg:
+        msk[:, n:] = 0                                                               # :321
+    else:
+        msk[:, 1:] = 0                                                               # :323
+    msk = torch.concat([torch.repeat_interleave(msk[:, 0:1], repeats=4, dim=1), msk[:, 1:]], dim=1)   # :324
+    msk = msk.view(1, msk.shape[1] // 4, 4, H // 8, W // 8).transpose(1, 2)[0]       # :325-326
+    cond = first_frames.permute(1, 0, 2, 3)                                           # :333 / :335
+    remaining = num_frames - n
+    if ref_pad_num == 0:
+        pad = torch.zeros(3, remaining, H, W)                                         # :338
+    elif ref_pad_num == -1:
+        pad = random_ref_frame.reshape(3, 1, H, W).repeat(1, remaining, 1, 1)         # :347
+    else:
+        parts = [random_ref_frame.reshape(3, 1, H, W)] * ref_pad_num                  # :342-343
+        if remaining > ref_pad_num:
+            parts += [torch.zeros(3, 1, H, W)] * (remaining - ref_pad_num)            # :344-345
+        pad = torch.cat(parts, dim=1)
+    video = torch.concat([cond, pad], dim=1)                                          # :348
+    y = vae_encode(sd, video.unsqueeze(0))[0]                                         # :349
+    return torch.concat([msk, y]).unsqueeze(0)                                        # :350-351

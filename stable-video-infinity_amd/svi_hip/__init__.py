@@ -10,6 +10,7 @@ from .ops import cfg_step_, flash_attention, layernorm_modulate, linear, rmsnorm
 from .pipeline import DenoiseLoop, generate_noise, install
 from .scheduler import FlowMatchScheduler
 from .vae import WanVideoVAE
+from .conditioning import condition_mask, condition_video, image_condition
 
 __all__ = ["WanDiT", "model_fn_wan_video", "flash_attention", "layernorm_modulate", "rmsnorm_rope_", "linear",
-           "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "WanVideoVAE", "_lib"]
+           "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "WanVideoVAE", "condition_mask", "condition_video", "image_condition", "_lib"]

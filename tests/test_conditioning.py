@@ -1,0 +1,63 @@
+"""I2V conditioning assembly (pipelines/svi_video.py:313-350): host logic on CPU, HIP VAE path on GPU."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import wan_vae_oracle as wvo
+
+
+def test_mask_layout_matches_reference_lines():
+    from svi_hip.conditioning import condition_mask
+    m = condition_mask(9, 16, 24, num_condition_frames=1, device="cpu")
+    assert m.shape == (4, 3, 2, 3)
+    # first latent frame = the first video frame repeated 4x -> all four channels one; everything else zero
+    assert torch.all(m[:, 0] == 1) and torch.all(m[:, 1:] == 0)
+    m = condition_mask(9, 16, 24, num_condition_frames=3, ref_pad_cfg=True, device="cpu")
+    # video frames 0,1,2 conditioned: latent frame 0 (4 copies of frame 0) all ones; latent frame 1 = video frames 1..4 -> channels 0,1
+    assert torch.all(m[:, 0] == 1)
+    assert torch.all(m[0, 1] == 1) and torch.all(m[1, 1] == 1) and torch.all(m[2:, 1] == 0) and torch.all(m[:, 2] == 0)
+
+
+@pytest.mark.parametrize("ref_pad_num", [0, 2, -1])
+def test_condition_video_padding_rules(ref_pad_num):
+    from svi_hip.conditioning import condition_video
+    ff = torch.from_numpy(synth.randn(1, 2, 3, 8, 8))
+    ref = torch.from_numpy(synth.randn(2, 3, 8, 8))
+    v = condition_video(ff, ref, 9, ref_pad_num)
+    assert v.shape == (3, 9, 8, 8)
+    assert torch.equal(v[:, :2], ff.permute(1, 0, 2, 3))
+    if ref_pad_num == 0:
+        assert torch.all(v[:, 2:] == 0)
+    elif ref_pad_num == -1:
+        assert all(torch.equal(v[:, i], ref) for i in range(2, 9))
+    else:
+        assert torch.equal(v[:, 2], ref) and torch.equal(v[:, 3], ref) and torch.all(v[:, 4:] == 0)
+
+
+def test_oracle_shapes_and_mask():
+    sd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()}
+    ff = torch.from_numpy(np.tanh(synth.randn(3, 1, 3, 16, 16)))
+    with torch.no_grad():
+        y = wvo.image_condition(sd, ff, None, 5)
+    assert y.shape == (1, 20, 2, 2, 2)
+    assert torch.all(y[0, :4, 0] == 1) and torch.all(y[0, :4, 1] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cond,ref_pad_cfg,ref_pad_num", [(1, False, 0), (2, True, 1), (1, False, -1)])
+def test_image_condition_matches_oracle(n_cond, ref_pad_cfg, ref_pad_num):
+    import svi_hip
+    from gpu_util import errs, report
+    sd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()}
+    v = svi_hip.WanVideoVAE.from_state_dict(sd)
+    ff = torch.from_numpy(np.tanh(synth.randn(700 + n_cond, n_cond, 3, 24, 32)))
+    ref = torch.from_numpy(np.tanh(synth.randn(710, 3, 24, 32)))
+    with torch.no_grad():
+        want = wvo.image_condition(sd, ff, ref, 9, ref_pad_cfg, ref_pad_num)
+    got = svi_hip.image_condition(v, ff.cuda(), ref.cuda(), 9, ref_pad_cfg, ref_pad_num, out_dtype=torch.float32)
+    r, mx, _ = errs(got, want)
+    report("image_condition", n_cond=n_cond, ref_pad_num=ref_pad_num, rel_l2=r, max_abs=mx)
+    assert got.shape == want.shape == (1, 20, 3, 3, 4)
+    assert torch.equal(got[0, :4].cpu(), want[0, :4])          # mask: exact
+    assert r < 2e-5 and mx < 2e-4, (r, mx)
