@@ -321,11 +321,13 @@ __device__ __forceinline__ void qk_mfma(int& tok, f32x16& s, u32x4 kf, int& apin
 #define SVI_ADD1 "v_add_f32 %[a1], %[a1], %[t1]\n\t"
 #define SVI_CVT "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]\n\t"
 #define SVI_MAX3 "v_max3_f32 %[m], %[m], %[y0], %[y1]\n\t"
-#define SVI_DMA "s_mov_b32 m0, %[m0v]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
+#define SVI_DMA_M0 "s_mov_b32 m0, %[m0v]\n\t"        /* in front of the MFMA: the MFMA is the wait state m0 needs */
+#define SVI_DMA "buffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
 #define SVI_END "; end"
 
 #define SVI_QK_OUT(sc) [s] sc(s), [tok] "+v"(tok), [ap] "+v"(apin)
-#define SVI_QK_IN [kf] "v"(kf), [q0] "n"(R), [q1] "n"(R + 3)
+// kf2: the NEXT fragment, listed only so that hipcc waits for both reads with one s_waitcnt (a wait is an issue slot too)
+#define SVI_QK_IN [kf] "v"(kf), [kf2] "v"(kf2), [q0] "n"(R), [q1] "n"(R + 3)
 #define SVI_DMA_IN [m0v] "s"(m0v), [vo] "v"(vo), [rs] "s"(rs), [so] "s"(so)
 
 // what an MFMA statement carries besides the MFMA
@@ -334,7 +336,7 @@ struct SviDma { u32x4 rs; int vo, so, m0v; };
 
 // QK^T statement.  FILL: SVI_F_*;  DMA: one LDS-DMA piece behind it;  FIRST: first MFMA of its score chain (C = -M tuple)
 template <int R, bool FIRST, int FILL, bool DMA, bool MULC>
-__device__ __forceinline__ void qk_stmt(int& tok, f32x16& s, u32x4 kf, int& apin, const f32x16& cneg, float x0, float x1, float c,
+__device__ __forceinline__ void qk_stmt(int& tok, f32x16& s, u32x4 kf, u32x4 kf2, int& apin, const f32x16& cneg, float x0, float x1, float c,
                                         float& t0, float& sum0, float& sum1, unsigned& w, const SviDma& d) {
     const u32x4 rs = d.rs;
     const int vo = d.vo, so = d.so, m0v = d.m0v;
@@ -344,23 +346,23 @@ __device__ __forceinline__ void qk_stmt(int& tok, f32x16& s, u32x4 kf, int& apin
         if constexpr (FIRST) asm(SVI_QKF SVI_END : SVI_QK_OUT("=&v") : SVI_QK_IN, [cn] "v"(cneg));
         else asm(SVI_QKN SVI_END : SVI_QK_OUT("+v") : SVI_QK_IN);
     } else if constexpr (FILL == SVI_F_NONE && DMA) {
-        asm volatile(SVI_QKN SVI_DMA SVI_END : SVI_QK_OUT("+v") : SVI_QK_IN, SVI_DMA_IN);
+        asm volatile(SVI_DMA_M0 SVI_QKN SVI_DMA SVI_END : SVI_QK_OUT("+v") : SVI_QK_IN, SVI_DMA_IN);
     } else if constexpr (FILL == SVI_F_EA && !DMA) {
         if constexpr (FIRST && MULC) asm(SVI_MEXP0 SVI_QKF SVI_ADD0 SVI_END : SVI_QK_OUT("=&v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [cn] "v"(cneg), [x0] "v"(x0), [c] "s"(c));
         else if constexpr (FIRST) asm(SVI_EXP0 SVI_QKF SVI_ADD0 SVI_END : SVI_QK_OUT("=&v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [cn] "v"(cneg), [x0] "v"(x0));
         else if constexpr (MULC) asm(SVI_MEXP0 SVI_QKN SVI_ADD0 SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0), [c] "s"(c));
         else asm(SVI_EXP0 SVI_QKN SVI_ADD0 SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0));
     } else if constexpr (FILL == SVI_F_EA && DMA) {
-        if constexpr (MULC) asm volatile(SVI_MEXP0 SVI_QKN SVI_ADD0 SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0), [c] "s"(c), SVI_DMA_IN);
-        else asm volatile(SVI_EXP0 SVI_QKN SVI_ADD0 SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0), SVI_DMA_IN);
+        if constexpr (MULC) asm volatile(SVI_DMA_M0 SVI_MEXP0 SVI_QKN SVI_ADD0 SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0), [c] "s"(c), SVI_DMA_IN);
+        else asm volatile(SVI_DMA_M0 SVI_EXP0 SVI_QKN SVI_ADD0 SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_QK_IN, [x0] "v"(x0), SVI_DMA_IN);
     } else if constexpr (FILL == SVI_F_EB && !DMA) {
         if constexpr (FIRST && MULC) asm(SVI_MEXP1 SVI_QKF SVI_ADD1 SVI_CVT SVI_END : SVI_QK_OUT("=&v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [cn] "v"(cneg), [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c));
         else if constexpr (FIRST) asm(SVI_EXP1 SVI_QKF SVI_ADD1 SVI_CVT SVI_END : SVI_QK_OUT("=&v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [cn] "v"(cneg), [x1] "v"(x1), [t0] "v"(t0));
         else if constexpr (MULC) asm(SVI_MEXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c));
         else asm(SVI_EXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0));
     } else if constexpr (FILL == SVI_F_EB && DMA) {
-        if constexpr (MULC) asm volatile(SVI_MEXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c), SVI_DMA_IN);
-        else asm volatile(SVI_EXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), SVI_DMA_IN);
+        if constexpr (MULC) asm volatile(SVI_DMA_M0 SVI_MEXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c), SVI_DMA_IN);
+        else asm volatile(SVI_DMA_M0 SVI_EXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), SVI_DMA_IN);
     } else {   // E2, never FIRST, never DMA
         float u0;
         if constexpr (MULC) asm("v_mul_f32 %[u0], %[x0], %[c]\n\tv_exp_f32 %[u0], %[u0]\n\t" SVI_MEXP1 SVI_QKN "v_add_f32 %[a0], %[a0], %[u0]\n\t" SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[u0], %[t1]\n\t" SVI_END
@@ -371,11 +373,11 @@ __device__ __forceinline__ void qk_stmt(int& tok, f32x16& s, u32x4 kf, int& apin
 }
 
 #define SVI_PV_OUT [tok] "+v"(tok), [ap] "+v"(apin)
-#define SVI_PV_IN [vf] "v"(vf), [p] "v"(p), [o0] "n"(R), [o1] "n"(R + 15)
+#define SVI_PV_IN [vf] "v"(vf), [vf2] "v"(vf2), [p] "v"(p), [o0] "n"(R), [o1] "n"(R + 15)
 #define SVI_MAX_IN [y0] "v"(y0), [y1] "v"(y1)
 // PV statement: a[R:R+15] += V^T-fragment x P-fragment.  AMAX: one v_max3 of the A work; FILL: SVI_F_NONE / EA / EB; DMA.
 template <int R, bool AMAX, int FILL, bool DMA, bool MULC>
-__device__ __forceinline__ void pv_stmt(int& tok, u32x4 vf, u32x4 p, int& apin, float& m, float y0, float y1, float x0, float x1, float c,
+__device__ __forceinline__ void pv_stmt(int& tok, u32x4 vf, u32x4 vf2, u32x4 p, int& apin, float& m, float y0, float y1, float x0, float x1, float c,
                                         float& t0, float& sum0, float& sum1, unsigned& w, const SviDma& d) {
     const u32x4 rs = d.rs;
     const int vo = d.vo, so = d.so, m0v = d.m0v;
@@ -385,7 +387,7 @@ __device__ __forceinline__ void pv_stmt(int& tok, u32x4 vf, u32x4 p, int& apin, 
         static_assert(FILL == SVI_F_NONE && !DMA, "plain PV statement");
         asm(SVI_PVM SVI_END : SVI_PV_OUT : SVI_PV_IN);
     } else if constexpr (DMA) {
-        asm volatile(SVI_PVM SVI_MAX3 SVI_DMA SVI_END : SVI_PV_OUT, [m] "+v"(m) : SVI_PV_IN, SVI_MAX_IN, SVI_DMA_IN);
+        asm volatile(SVI_DMA_M0 SVI_PVM SVI_MAX3 SVI_DMA SVI_END : SVI_PV_OUT, [m] "+v"(m) : SVI_PV_IN, SVI_MAX_IN, SVI_DMA_IN);
     } else if constexpr (FILL == SVI_F_NONE) {
         asm(SVI_PVM SVI_MAX3 SVI_END : SVI_PV_OUT, [m] "+v"(m) : SVI_PV_IN, SVI_MAX_IN);
     } else if constexpr (FILL == SVI_F_EA) {
@@ -587,13 +589,13 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 constexpr int fill = !WITH_B ? SVI_F_NONE : whole ? SVI_F_E2 : (si & 1) ? SVI_F_EB : SVI_F_EA;
                 const SviDma d = {v_rs, voff0, so_v + ((k >> 3) & 3) * vstep, piece0 + vd + 4096 * ((k >> 3) & 3)};
                 unsigned wd = 0;
-                qk_stmt<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], pin, cneg[g], so[pg][tb][r0],
+                // even fragments wait for themselves and their successor at once (none to wait for behind fragment 15)
+                qk_stmt<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin, cneg[g], so[pg][tb][r0],
                                                                                 so[pg][tb][r0 + 1], scale_log2e, tcar, ps[pg][0], ps[pg][1], wd,
                                                                                 dma ? d : no_dma);
                 if constexpr (fill == SVI_F_E2 || fill == SVI_F_EB) pw[pg][tb][w >> 2][w & 3] = wd;
                 if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
                     kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ks + ((f + 3) >> 3) * 32 * 256);
-                if constexpr (g == 0 && f + 3 < 16 && (ABL & 4)) kf[(f + 3) & 3] = kf[f & 3];
                 if constexpr (g == 0 && f + 3 >= 16)                 // f = 13, 14, 15: V^T fragments 0, 1, 2 of phase 2
                     vf[f >= 13 ? f - 13 : 0] = *(lds_u32x4_t)(vaddr[0] + vs + (f >= 13 ? f - 13 : 0) * 32 * 128);
             });
@@ -643,12 +645,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     const SviDma d = {k_rs, koff0, so_k + ((j >> 1) & 3) * kstep, piece0 + kd + 4096 * ((j >> 1) & 3)};
                     unsigned wd = 0;
                     pv_stmt<SVI_OREG0 + (g * 4 + d4) * 16, amax, amax ? fill : SVI_F_NONE, amax && dma, MULC>(
-                        tok, vf[f & 3], pw[g][tt][sb], pin, mch, sn[ga][ta][ra], sn[ga][ta][ra + 1], so[pg][1][r0], so[pg][1][r0 + 1],
+                        tok, vf[f & 3], vf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pw[g][tt][sb], pin, mch, sn[ga][ta][ra], sn[ga][ta][ra + 1], so[pg][1][r0], so[pg][1][r0 + 1],
                         scale_log2e, tcar, ps[pg][0], ps[pg][1], wd, dma ? d : no_dma);
                     if constexpr (amax && fill == SVI_F_EB) pw[pg][1][w >> 2][w & 3] = wd;
                     if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
                         vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
-                    if constexpr (g == 0 && f + 3 < 16 && (ABL & 4)) vf[(f + 3) & 3] = vf[f & 3];
                     if constexpr (g == 0 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
                     if constexpr (WITH_B && j == 23) {               // all 32 pairs of tile t-1 are done: fold the row sums
                         l_run[0] = l_run[0] * alpha[0] + (ps[0][0] + ps[0][1]);
@@ -715,14 +716,16 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         for (int kk = 0; kk < 8; ++kk) kaddr[kk] ^= 2 * KT_BYTES;      // this tile's K reads are done: move to the other half
         phase2(sB, sA, I0{}, I0{}, t, masked_tag, std::true_type{}, with_next);
         const bool need = outgrown();
-        tile_barrier<4>(tok);
+        if constexpr (!(ABL & 256)) tile_barrier<4>(tok);
+        if constexpr ((ABL & 256) && !(ABL & 512)) asm volatile("s_waitcnt vmcnt(4)" : "+v"(tok) :: "memory");
         return need;
     };
     auto tile_even = [&](int t, auto masked_tag, auto with_next) -> bool {
         phase1(sA, sB, I0{}, I1{}, I0{}, t, std::true_type{});
         phase2(sA, sB, I1{}, I1{}, t, masked_tag, std::true_type{}, with_next);
         const bool need = outgrown();
-        tile_barrier<4>(tok);
+        if constexpr (!(ABL & 256)) tile_barrier<4>(tok);
+        if constexpr ((ABL & 256) && !(ABL & 512)) asm volatile("s_waitcnt vmcnt(4)" : "+v"(tok) :: "memory");
         return need;
     };
 
@@ -859,6 +862,8 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
                 case 32: kern = flash_fwd2_kernel<0, 32>; break;
                 case 64: kern = flash_fwd2_kernel<0, 64>; break;
                 case 128: kern = flash_fwd2_kernel<0, 128>; break;
+                case 256: kern = flash_fwd2_kernel<0, 256>; break;
+                case 768: kern = flash_fwd2_kernel<0, 768>; break;
                 default: break;
             }
             const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages

@@ -1,6 +1,6 @@
 """Timing-only ablations of flash_fwd2_kernel at the C2 self-attention shape (results are wrong for ABL != 0).
     python tools/attn_abl.py [rounds]
-ABL bits: 1 no B fillers (exp/sum/pack), 2 no A fillers (row max), 4 fragment reads only at phase start, 8 no staging/barrier,
+ABL bits: 1 no B fillers (exp/sum/pack), 2 no A fillers (row max), 4 fragment reads only at phase start, 8 no staging/barrier, 256 no workgroup barrier (vmcnt wait kept), 768 neither barrier nor vmcnt wait,
 16 no finish/decision (max3 kept), 32 no max3 (finish kept), 64 no s_nop 15 at phase 2 start."""
 import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ sq = sk = 32760; n = 12
 q, k, v = [(torch.randn((1, sq, n * 128), generator=g, device=dev)).to(torch.bfloat16) for _ in range(3)]
 os.environ["SVI_FLASH_KERNEL"] = "2"
 os.environ["SVI_FLASH_ASSUME_PRESCALED"] = "1"
-variants = ["0", "mulc", "1", "2", "3", "8", "15", "0"]
+variants = ["0", "4", "8", "15", "0"]
 times = {a: [] for a in variants}
 variants_run = list(variants)
 q_scaled = (q.float() * (1.4426950408889634 / 128 ** 0.5)).to(torch.bfloat16)   # what the DiT's RMSNorm+RoPE kernel hands over
