@@ -22,6 +22,7 @@
 // Workgroup ids are remapped so that the 8 XCDs each own a contiguous band of tiles (per-XCD L2 keeps
 // the shared A row-panel hot; cdna_hip_programming.md T1, bijective form).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "svi_common.h"
 
@@ -218,6 +219,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 // instruction covers 8 whole 128-byte rows, so the permutation stays inside full cache lines.
 //
 // Epilogue as in the 128^2 kernel, the staged C tile is [256][264] bf16 (132 KiB, the LDS is otherwise idle).
+// Tried and dropped (bit-identical, measured on MI355X, tools/gemm_ab.py):  BK = 32 with four LDS stages and counted
+// vmcnt (3 tiles in flight): -5 % (twice the barriers, DMA latency was not the limiter);  a persistent kernel that defers
+// the epilogue of tile i into the K loop of tile i+1 (64 packed-bf16 registers, permlane-paired 16-byte stores): -5..-13 %
+// (register spills, and the row-scattered stores compete with the LDS-DMA for the address path).  What is left on the
+// table is the epilogue: 15 us per tile at K = 1536 against a 52 us main loop (760 vs 1100 TFLOP/s at K = 8960).
 // Tile order: 8 XCD bands (bijective), inside a band groups of 8 row panels walk the column panels, so the 32
 // tiles an XCD runs at once are ~8 row panels x 4 column panels: 12 operand panels for 32 tiles in its L2.
 // =================================================================================================
@@ -230,82 +236,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    const int nwg = tiles_m * tiles_n;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-    const int GM = 8;
-    const int group = swz / (GM * tiles_n);
-    const int first_m = group * GM;
-    const int gm = min(GM, tiles_m - first_m);
-    const int in_group = swz - group * GM * tiles_n;
-    const int tile_n = in_group / gm;
-    const int tile_m = first_m + (in_group - tile_n * gm);
-    const int m0 = tile_m * TM, n0 = tile_n * TN;
-
-    // ---- LDS-DMA assignment: operand tile = 32 pieces of 1 KiB (8 rows); wave w issues pieces w, w+8, w+16, w+24
-    unsigned a_off[4], w_off[4];         // element offsets of this lane's source chunk at k = 0
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (j * 8 + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 8;
-        w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 8;
-    }
-    const int nk = g.K / BK;
-    auto stage = [&](int kt, int buf) {
-        char* As = smem + buf * 2 * T_STAGE;
-        char* Ws = As + T_STAGE;
-        const bf16* ak = g.A + kt * BK;
-        const bf16* wk = g.W + kt * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(ak + a_off[j]), (lptr_t)(As + (j * 8 + wave) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(wk + w_off[j]), (lptr_t)(Ws + (j * 8 + wave) * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][4];                       // [ni][mi]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const char* As = smem + cur * 2 * T_STAGE;
-        const char* Ws = As + T_STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 xa[4], wb[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xa[i] = *reinterpret_cast<const bf16x8*>(As + lds_tile_off(wm * 128 + i * 32 + l31, 2 * kk + hi));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                wb[i] = *reinterpret_cast<const bf16x8*>(Ws + lds_tile_off(wn * 64 + i * 32 + l31, 2 * kk + hi));
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
-        }
-        __syncthreads();                    // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
-    }
-
+// Shared epilogue of the 256^2 kernels: y = bf16(acc + bias) staged through LDS as a [256][C2_LD] bf16 tile, read back row-
+// contiguously (512 B per row), activation / gate / residual applied, 16-byte coalesced stores.  All LDS reads of the main
+// loop must be complete (barrier) before this is called.
+__device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* smem, int m0, int n0, int tid,
+                                                 int wm, int wn, int l31, int hi) {
     // ---- epilogue part 1: y = bf16(acc + bias) -> LDS [256 m][C2_LD] bf16 ---------------------------
     bf16* Cs = reinterpret_cast<bf16*>(smem);
 #pragma unroll
@@ -382,6 +317,143 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g,
     }
 }
 
+typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_t;
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"     // LDS addresses are 32-bit; the host pass sees 64-bit pointers
+template <class F> __device__ __forceinline__ void static_for4(F&& f) {
+    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
+}
+template <class F> __device__ __forceinline__ void static_for8(F&& f) {
+    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
+    f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
+}
+template <class F> __device__ __forceinline__ void static_for16(F&& f) {
+    static_for8(f);
+    f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});
+    f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{}); f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{});
+}
+// acc += W-fragment x X-fragment as an asm statement: `tok` chains all of them in program order, `apin` (the LDS address of the
+// fragment read placed behind this MFMA) keeps that read from being hoisted above it.
+__device__ __forceinline__ void gemm_mfma(int& tok, f32x16& acc, u32x4 w, u32x4 x, int& apin) {
+    asm("v_mfma_f32_32x32x16_bf16 %[c], %[w], %[x], %[c]" : [c] "+v"(acc), [tok] "+v"(tok), [ap] "+v"(apin) : [w] "v"(w), [x] "v"(x));
+}
+
+template <bool use_compiler_loop>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    const int GM = 8;
+    const int group = swz / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = swz - group * GM * tiles_n;
+    const int tile_n = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n * gm);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+    // ---- LDS-DMA assignment: operand tile = 32 pieces of 1 KiB (8 rows); wave w issues pieces w, w+8, w+16, w+24
+    unsigned a_off[4], w_off[4];         // element offsets of this lane's source chunk at k = 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 8;
+        w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 8;
+    }
+    const int nk = g.K / BK;
+    auto stage = [&](int kt, int buf) {
+        char* As = smem + buf * 2 * T_STAGE;
+        char* Ws = As + T_STAGE;
+        const bf16* ak = g.A + kt * BK;
+        const bf16* wk = g.W + kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ak + a_off[j]), (lptr_t)(As + (j * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wk + w_off[j]), (lptr_t)(Ws + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][4];                       // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Fragment addresses (LDS byte offsets inside a stage): the swizzle XOR makes the 4 k-steps non-additive, the 32-row
+    // sub-tiles (+4096 B) fold into the immediate.
+    int a_addr[4], w_addr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
+        w_addr[kk] = lds0 + T_STAGE + lds_tile_off(wn * 64 + l31, 2 * kk + hi);
+    }
+    int tok = 0;
+    u32x4 xa[2][4], wb[2][2];               // fragment sets: k-step kk lives in set kk & 1, read one k-step ahead
+    auto read_frags = [&](int kk, int set, int stage_off) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[set][i] = *(lds_u32x4_t)(a_addr[kk] + stage_off + i * 32 * 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wb[set][i] = *(lds_u32x4_t)(w_addr[kk] + stage_off + i * 32 * 128);
+    };
+    stage(0, 0);
+    __syncthreads();
+    read_frags(0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const int so = cur * 2 * T_STAGE;
+        if constexpr (use_compiler_loop) {
+            // reference form: hipcc schedules (it serialises read -> wait -> 8 MFMAs per k-step; kept for A/B timing)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk) read_frags(kk, 0, so);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[0][ni]), __builtin_bit_cast(bf16x8, xa[0][mi]), acc[ni][mi], 0, 0, 0);
+            }
+        } else {
+            // pinned form: the 6 fragment reads of k-step kk+1 are issued behind the first MFMAs of k-step kk (each read is
+            // tied, through its address register, behind one MFMA statement), so LDS latency runs under the MFMAs instead of
+            // in front of them — the two waves of a SIMD run in lockstep (same barrier) and do not cover for each other.
+            static_for4([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;
+                constexpr int cs = kk & 1, ns = cs ^ 1;
+                static_for8([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ni = i >> 2, mi = i & 3;
+                    int& pin = (i < 4) ? a_addr[(kk + 1) & 3] : w_addr[(kk + 1) & 3];
+                    gemm_mfma(tok, acc[ni][mi], wb[cs][ni], xa[cs][mi], pin);
+                    if constexpr (kk < 3) {
+                        if constexpr (i < 4) xa[ns][i] = *(lds_u32x4_t)(a_addr[kk + 1] + so + i * 32 * 128);
+                        else if constexpr (i < 6) wb[ns][i - 4] = *(lds_u32x4_t)(w_addr[kk + 1] + so + (i - 4) * 32 * 128);
+                    }
+                });
+            });
+        }
+        __syncthreads();                    // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
+        if (kt + 1 < nk) read_frags(0, 0, (cur ^ 1) * 2 * T_STAGE);
+    }
+    asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
+    asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+
+    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
+}
+
+
+
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     SVI_REQUIRE(g.M >= 0 && g.N >= 0 && g.K > 0, "gemm: bad sizes M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0 || g.N == 0) return SVI_OK;
@@ -399,17 +471,22 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     {
         const long t256 = (long)((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN);
         const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
-        const char* force = getenv("SVI_GEMM_KERNEL");      // "128" / "256": A/B switch for tools/kernel_probe.py
+        const char* force = getenv("SVI_GEMM_KERNEL");      // "128" / "256" / "256c": A/B switch for tools/gemm_ab.py ("256c" = compiler-scheduled main loop)
         const bool want256 = force ? (force[0] == '2') : (t256 >= 128);
         if (want256 && g.K % BK == 0 && fits32) {
             static bool attr256 = false;
             if (!attr256) {
-                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel),
+                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
+                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
                 attr256 = true;
             }
             const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
-            hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn);
+            if (force && force[0] == '2' && force[3] == 'c')
+                hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn);
+            else
+                hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn);
             SVI_LAUNCH_CHECK();
             return SVI_OK;
         }

@@ -26,6 +26,7 @@ def rnd(*shape, scale=1.0):
     return (torch.randn(shape, generator=g, device=dev) * scale).to(torch.bfloat16)
 
 
+KINDS = ("256c", "256")          # add "128" to include the small-tile kernel
 SHAPES = {
     # name: (M, N, K, epilogue, bias_along_m)
     "qkv   [L,D]x[D,D]": (Ltok, D, D, L.EPI_BIAS, 0),
@@ -35,6 +36,10 @@ SHAPES = {
     "ffn2  gate+res": (Ltok, D, F, L.EPI_BIAS_GATE_RES, 0),
     "ragged 1000x520x192": (1000, 520, 192, L.EPI_BIAS_GELU_TANH, 0),
 }
+if len(sys.argv) > 2 and sys.argv[2] == "calib":       # calibration shapes against cdna_hip_programming.md's 256^2 numbers
+    SHAPES = {"8192^3": (8192, 8192, 8192, L.EPI_BIAS, 0), "4096^3": (4096, 4096, 4096, L.EPI_BIAS, 0),
+              "ffn2 M=8192": (8192, D, F, L.EPI_BIAS, 0), "ffn2 full, bias only": (Ltok, D, F, L.EPI_BIAS, 0),
+              "N=6144 K=8960": (Ltok, 6144, F, L.EPI_BIAS, 0)}
 for name, (M, N, K, epi, bam) in SHAPES.items():
     x = rnd(M, K); w = rnd(N, K, scale=K ** -0.5); b = rnd(M if bam else N)
     ldc = (N + 7) // 8 * 8
@@ -48,16 +53,16 @@ for name, (M, N, K, epi, bam) in SHAPES.items():
                                   gate.data_ptr() if epi == L.EPI_BIAS_GATE_RES else None,
                                   res.data_ptr() if epi == L.EPI_BIAS_GATE_RES else None, ldc, st))
 
-    for kind in ("128", "256"):
+    for kind in KINDS:
         outs[kind] = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev)
         run(kind, outs[kind])
     torch.cuda.synchronize()
-    a, c = outs["128"][:, :N].float(), outs["256"][:, :N].float()
-    nbad = int((a != c).sum())
-    maxd = float((a - c).abs().max())
-    times = {"128": [], "256": []}
+    a = outs[KINDS[0]][:, :N].float()
+    nbad = max(int((a != outs[k][:, :N].float()).sum()) for k in KINDS[1:])
+    maxd = max(float((a - outs[k][:, :N].float()).abs().max()) for k in KINDS[1:])
+    times = {k: [] for k in KINDS}
     for _ in range(rounds):
-        for kind in ("128", "256"):
+        for kind in KINDS:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
@@ -66,7 +71,7 @@ for name, (M, N, K, epi, bam) in SHAPES.items():
             times[kind].append(e0.elapsed_time(e1) / 3)
     fl = 2.0 * M * N * K
     msg = f"{name:22s} M={M} N={N} K={K}  mismatching={nbad} maxdiff={maxd:.3g}"
-    for kind in ("128", "256"):
+    for kind in KINDS:
         med, mn = statistics.median(times[kind]), min(times[kind])
         msg += f" | k{kind}: med {med*1e3:.0f} us {fl/med/1e9:.0f} TF, best {fl/mn/1e9:.0f} TF"
     print(msg, flush=True)
