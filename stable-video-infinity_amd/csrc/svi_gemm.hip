@@ -241,6 +241,22 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // loop must be complete (barrier) before this is called.
 __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* smem, int m0, int n0, int tid,
                                                  int wm, int wn, int l31, int hi) {
+    // gate·y + residual: the 16 residual chunks this thread will need are requested NOW (64 registers, the accumulators
+    // are about to die) so that their latency runs under the LDS round trip; the column block (and so the gate values)
+    // is the same for all 16 chunks of a thread.
+    u32x4 resv[16];
+    float gatev[8];
+    const int ecc = tid & 31, en = n0 + ecc * 8;
+    const bool efull = en + 8 <= g.N;
+    if (g.epi == SVI_EPI_BIAS_GATE_RES) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = m0 + ((tid + 512 * it) >> 5);
+            if (m < g.M && efull) resv[it] = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + en);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gatev[e] = (g.gate && en + e < g.N) ? g.gate[en + e] : 0.f;
+    }
     // ---- epilogue part 1: y = bf16(acc + bias) -> LDS [256 m][C2_LD] bf16 ---------------------------
     bf16* Cs = reinterpret_cast<bf16*>(smem);
 #pragma unroll
@@ -267,7 +283,7 @@ __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&
     __syncthreads();
 
     // ---- epilogue part 2: row-contiguous read-back (512 B per row), activation / gate / residual, coalesced store
-#pragma unroll 4
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int id = tid + 512 * it;
         const int ml = id >> 5, cc = id & 31;
@@ -291,7 +307,7 @@ __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&
             const bf16* rp = g.res + (size_t)m * g.ldres + n;
             float rv[8];
             if (full) {
-                bf16x8 t = ld_bf16x8(rp);
+                const bf16x8 t = __builtin_bit_cast(bf16x8, resv[it]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) rv[e] = (float)t[e];
             } else {
@@ -301,7 +317,7 @@ __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float t = y[e];
-                if (g.gate) t = rbf(((n + e < g.N) ? g.gate[n + e] : 0.f) * t);
+                if (g.gate) t = rbf(gatev[e] * t);
                 y[e] = rv[e] + t;
             }
         }
