@@ -354,7 +354,7 @@ __device__ __forceinline__ void gemm_mfma(int& tok, f32x16& acc, u32x4 w, u32x4 
 }
 
 template <bool use_compiler_loop>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lds0 = (int)(size_t)(lptr_t)smem;
     const int tid = threadIdx.x;
@@ -367,7 +367,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g,
     const int orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
     const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-    const int GM = 8;
     const int group = swz / (GM * tiles_n);
     const int first_m = group * GM;
     const int gm = min(GM, tiles_m - first_m);
@@ -499,10 +498,12 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
                 attr256 = true;
             }
             const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
+            const char* gme = getenv("SVI_GEMM_GM");               // row panels per tile group (A/B aid)
+            const int gm_rows = gme ? atoi(gme) : 2;       // measured (tools/gemm_gm.py): 2 beats 8 by 13 % on ffn1, 3 % on ffn2, flat on N = 1536
             if (force && force[0] == '2' && force[3] == 'c')
-                hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn);
+                hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
             else
-                hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn);
+                hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
             SVI_LAUNCH_CHECK();
             return SVI_OK;
         }
