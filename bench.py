@@ -164,6 +164,9 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # as DenoiseLoop.sample() does for a clip: the prompt embeddings are loop constants, their projection and the per-block
+    # cross-attention K / V^T are computed in the first forward that sees them (inside the warm-up here, inside step 0 of a clip)
+    dit.context_cache(True)
     for i in range(args.warmup):
         one_step(i)
     sync()

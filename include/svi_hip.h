@@ -97,6 +97,14 @@ svi_status svi_dit_forward(svi_dit* h, const void* x, const float* timestep, con
                            void* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc,
                            svi_stream stream);
 
+/* Hoists what depends only on the prompt out of the step loop (SURVEY §8 a2 / f N2): with the cache enabled
+ * svi_dit_forward projects a context (text_embedding / img_emb, pipelines/svi_video.py:94-99) and computes every block's
+ * cross-attention K / V^T (models/wan_video_dit.py:272-274) ONCE per distinct (context pointer, clip_feature pointer, Lc)
+ * and reuses them; results are bit-identical to the uncached path.  The caller promises that the contents behind a cached
+ * pointer do not change while the cache is on; svi_dit_context_cache(h, 0), or binding a weight, drops all entries
+ * (4 entries, least recently used first). */
+svi_status svi_dit_context_cache(svi_dit* h, int32_t enable);
+
 /* DiTBlock.forward(x, context, t_mod, freqs) for block `layer` (models/wan_video_dit.py:354-374).
  *   x_inout bf16 [L, dim] (L = f*h*w, updated in place); context bf16 [Lc(+257), dim] ALREADY
  *   projected by text_embedding/img_emb; t_mod bf16 [6, dim]; freqs implied by the (f,h,w) grid. */

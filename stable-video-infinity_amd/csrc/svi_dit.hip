@@ -51,6 +51,21 @@ struct Workspace {
 
 }  // namespace
 
+// A projected context (text_embedding / img_emb output) and the cross-attention K / V^T of every block derived from it.
+// These depend only on (prompt embedding, CLIP feature, weights): the reference recomputes them in every one of the 100
+// forwards of a clip ("hoistable"); with svi_dit_context_cache(h, 1) they are computed once per distinct
+// context pointer and reused until svi_dit_context_cache(h, 0) / a re-bind invalidates them.
+struct CtxEntry {
+    const void* key_ctx = nullptr;
+    const void* key_clip = nullptr;
+    int Lc = 0;
+    char* base = nullptr;
+    bf16* CTX = nullptr;
+    std::vector<bf16*> CK, CVT, CKi, CVTi;
+    bool filled = false;
+    unsigned long long stamp = 0;
+};
+
 struct svi_dit {
     svi_dit_config cfg;
     std::vector<BlockW> blocks;
@@ -65,6 +80,10 @@ struct svi_dit {
     int rf = 0, rh = 0, rw = 0;
     float2* rope_dev = nullptr;
     SviRope rope{};
+    // context cache
+    bool ctx_cache_on = false;
+    CtxEntry ctx_entries[4];
+    unsigned long long ctx_clock = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -190,6 +209,8 @@ extern "C" svi_status svi_dit_destroy(svi_dit* h) {
     if (!h) return SVI_OK;
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->rope_dev) (void)hipFree(h->rope_dev);
+    for (auto& e : h->ctx_entries)
+        if (e.base) (void)hipFree(e.base);
     delete h;
     return SVI_OK;
 }
@@ -206,6 +227,14 @@ extern "C" svi_status svi_dit_bind_weight(svi_dit* h, const char* name, const vo
     if (!ok) { svi_set_error("shape mismatch for '%s'", name); return SVI_ERR_INVALID; }
     SVI_REQUIRE(((uintptr_t)dev_ptr % 16) == 0, "parameter '%s' is not 16-byte aligned", name);
     *it->second.ptr = reinterpret_cast<const bf16*>(dev_ptr);
+    for (auto& e : h->ctx_entries) e.filled = false;      // cached projections were made with the old weights
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_context_cache(svi_dit* h, int32_t enable) {
+    SVI_REQUIRE(h, "null handle");
+    h->ctx_cache_on = enable != 0;
+    for (auto& e : h->ctx_entries) e.filled = false;
     return SVI_OK;
 }
 
@@ -298,8 +327,10 @@ static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16
     return svi_launch_gemm(g, st);
 }
 
+struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; };
+
 static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
-                            hipStream_t st) {
+                            const CtxKV& kv, hipStream_t st) {
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
     Workspace& w = h->ws;
@@ -321,15 +352,19 @@ static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, con
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, b.norm3_w, b.norm3_b, nullptr, nullptr, st)); }
     { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
     { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.ca.norm_q, c.eps, nullptr, SVI_QK_SCALE_LOG2E, st)); }
-    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(ctx_txt, D, b.ca.k, w.CK, D, Lc, D, D, SVI_EPI_BIAS, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, 1.0f, st)); }
-    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, w.CVT, w.ldcvt, Lc, D, D, st)); }
-    { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.CK, D, w.CVT, w.ldcvt, w.Hb, D, L, Lc, H, 1, st)); }
+    if (kv.compute) {
+        { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(ctx_txt, D, b.ca.k, kv.CK, D, Lc, D, D, SVI_EPI_BIAS, st)); }
+        { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(kv.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, 1.0f, st)); }
+        { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, kv.CVT, w.ldcvt, Lc, D, D, st)); }
+    }
+    { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb, D, L, Lc, H, 1, st)); }
     if (img) {
-        SVI_TRY(linear(CTX, D, b.ca.k_img, w.CKi, D, img, D, D, SVI_EPI_BIAS, st));
-        SVI_TRY(svi_launch_rmsnorm_rope(w.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, 1.0f, st));
-        SVI_TRY(linear_transposed(CTX, D, b.ca.v_img, w.CVTi, w.ldcvti, img, D, D, st));
-        SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.CKi, D, w.CVTi, w.ldcvti, w.A2, D, L, img, H, 1, st));
+        if (kv.compute) {
+            SVI_TRY(linear(CTX, D, b.ca.k_img, kv.CKi, D, img, D, D, SVI_EPI_BIAS, st));
+            SVI_TRY(svi_launch_rmsnorm_rope(kv.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, 1.0f, st));
+            SVI_TRY(linear_transposed(CTX, D, b.ca.v_img, kv.CVTi, w.ldcvti, img, D, D, st));
+        }
+        SVI_TRY(svi_launch_flash(w.QK, 2 * D, kv.CKi, D, kv.CVTi, w.ldcvti, w.A2, D, L, img, H, 1, st));
         SVI_TRY(svi_launch_add_bf16(w.Hb, w.A2, (int64_t)L * D, st));
     }
     { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D)); }
@@ -384,14 +419,51 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
         SVI_TRY(mod_one(h->blocks[l].modulation, w.tmod, w.modf + (size_t)l * 6 * D, D, 6, (1 << 1) | (1 << 4), 6, st));
     SVI_TRY(mod_one(h->head_mod, w.t, w.headf, D, 2, 1 << 1, 1, st));
     // --- text (and CLIP image) context                                svi_video.py:94-99
-    SVI_TRY(linear(context, c.text_dim, h->text0, w.CTXH, D, Lc, D, c.text_dim, SVI_EPI_BIAS_GELU_TANH, st));
-    SVI_TRY(linear(w.CTXH, D, h->text2, w.CTX + (size_t)img * D, D, Lc, D, D, SVI_EPI_BIAS, st));
-    if (img) {
+    CtxEntry* ce = nullptr;
+    bool ctx_compute = true;
+    if (h->ctx_cache_on) {
+        CtxEntry* lru = &h->ctx_entries[0];
+        for (auto& e : h->ctx_entries) {
+            if (e.filled && e.key_ctx == (const void*)context && e.key_clip == (const void*)clip && e.Lc == Lc) { ce = &e; break; }
+            if (e.stamp < lru->stamp) lru = &e;
+        }
+        if (ce) ctx_compute = false;
+        else {
+            ce = lru;
+            const size_t Dd = c.dim, Lctx = (size_t)Lc + img, nl = c.num_layers;
+            const size_t per_layer = al(Lctx * Dd * 2) + al(Dd * w.ldcvt * 2) + (img ? al((size_t)264 * Dd * 2) + al(Dd * 264 * 2) : 0);
+            const size_t need = al(Lctx * Dd * 2) + nl * per_layer;
+            if (!ce->base || ce->Lc != Lc || ce->CK.size() != nl) {
+                if (ce->base) { SVI_CHECK_HIP(hipFree(ce->base)); ce->base = nullptr; }
+                hipError_t e2 = hipMalloc((void**)&ce->base, need);
+                if (e2 != hipSuccess) { svi_set_error("hipMalloc(%zu B context cache) failed: %s", need, hipGetErrorString(e2)); return SVI_ERR_OOM; }
+                SVI_CHECK_HIP(hipMemsetAsync(ce->base, 0, need, st));      // V^T pad columns must read as zeros
+                size_t off = 0;
+                auto take = [&](size_t bytes) { bf16* p = reinterpret_cast<bf16*>(ce->base + off); off += al(bytes); return p; };
+                ce->CTX = take(Lctx * Dd * 2);
+                ce->CK.assign(nl, nullptr); ce->CVT.assign(nl, nullptr); ce->CKi.assign(nl, nullptr); ce->CVTi.assign(nl, nullptr);
+                for (size_t l = 0; l < nl; ++l) {
+                    ce->CK[l] = take(Lctx * Dd * 2); ce->CVT[l] = take(Dd * w.ldcvt * 2);
+                    if (img) { ce->CKi[l] = take((size_t)264 * Dd * 2); ce->CVTi[l] = take(Dd * 264 * 2); }
+                }
+            }
+            ce->key_ctx = context; ce->key_clip = clip; ce->Lc = Lc; ce->filled = true;
+        }
+        ce->stamp = ++h->ctx_clock;
+    }
+    bf16* CTXp = ce ? ce->CTX : w.CTX;
+    if (ctx_compute) {
+        SVI_TRY(linear(context, c.text_dim, h->text0, w.CTXH, D, Lc, D, c.text_dim, SVI_EPI_BIAS_GELU_TANH, st));
+        SVI_TRY(linear(w.CTXH, D, h->text2, CTXp + (size_t)img * D, D, Lc, D, D, SVI_EPI_BIAS, st));
+        if (img) {
+            SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
+            SVI_TRY(svi_launch_ln_mod(clip, 1280, w.IMG0, 1280, 257, 1280, 1e-5f, h->img_ln0_w, h->img_ln0_b, nullptr, nullptr, st));
+            SVI_TRY(linear(w.IMG0, 1280, h->img1, w.IMG1, 1280, 257, 1280, 1280, SVI_EPI_BIAS_GELU_ERF, st));
+            SVI_TRY(linear(w.IMG1, 1280, h->img3, w.Hb, D, 257, D, 1280, SVI_EPI_BIAS, st));
+            SVI_TRY(svi_launch_ln_mod(w.Hb, D, CTXp, D, 257, D, 1e-5f, h->img_ln4_w, h->img_ln4_b, nullptr, nullptr, st));
+        }
+    } else if (img) {
         SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
-        SVI_TRY(svi_launch_ln_mod(clip, 1280, w.IMG0, 1280, 257, 1280, 1e-5f, h->img_ln0_w, h->img_ln0_b, nullptr, nullptr, st));
-        SVI_TRY(linear(w.IMG0, 1280, h->img1, w.IMG1, 1280, 257, 1280, 1280, SVI_EPI_BIAS_GELU_ERF, st));
-        SVI_TRY(linear(w.IMG1, 1280, h->img3, w.Hb, D, 257, D, 1280, SVI_EPI_BIAS, st));
-        SVI_TRY(svi_launch_ln_mod(w.Hb, D, w.CTX, D, 257, D, 1e-5f, h->img_ln4_w, h->img_ln4_b, nullptr, nullptr, st));
     }
     // --- patchify                                                     svi_video.py:101, dit:473-477
     {
@@ -404,8 +476,10 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
         if (addc) SVI_TRY(svi_launch_add_bf16(w.X, addc, (int64_t)L * D, st));
     }
     // --- blocks
-    for (int l = 0; l < c.num_layers; ++l)
-        SVI_TRY(run_block(h, l, w.X, w.CTX, w.modf + (size_t)l * 6 * D, L, Lc, st));
+    for (int l = 0; l < c.num_layers; ++l) {
+        CtxKV kv{ce ? ce->CK[l] : w.CK, ce ? ce->CVT[l] : w.CVT, ce ? ce->CKi[l] : w.CKi, ce ? ce->CVTi[l] : w.CVTi, ctx_compute};
+        SVI_TRY(run_block(h, l, w.X, CTXp, w.modf + (size_t)l * 6 * D, L, Lc, kv, st));
+    }
     // --- head + unpatchify                                            dit:401-404,479-484
     {
         const int ho = c.out_dim * c.patch_t * c.patch_h * c.patch_w;
@@ -457,5 +531,6 @@ extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_i
     SVI_TRY(ensure_rope(h, f, hh, ww));
     float* modf = h->ws.modf + (size_t)layer * 6 * D;
     SVI_TRY(mod_one(h->blocks[layer].modulation, reinterpret_cast<const bf16*>(t_mod), modf, D, 6, (1 << 1) | (1 << 4), 6, st));
-    return run_block(h, layer, reinterpret_cast<bf16*>(x_inout), reinterpret_cast<const bf16*>(context), modf, L, Lc, st);
+    CtxKV kv{h->ws.CK, h->ws.CVT, h->ws.CKi, h->ws.CVTi, true};
+    return run_block(h, layer, reinterpret_cast<bf16*>(x_inout), reinterpret_cast<const bf16*>(context), modf, L, Lc, kv, st);
 }

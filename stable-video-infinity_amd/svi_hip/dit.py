@@ -65,6 +65,11 @@ class WanDiT:
     def rebind(self) -> None:
         self.bind(dict(self._params))
 
+    def context_cache(self, enable: bool) -> None:
+        """Reuse the projected context and the cross-attention K / V^T of every block across forwards that are handed the
+        same context tensor (same storage, unchanged contents); see svi_dit_context_cache in include/svi_hip.h."""
+        L.check(L.lib().svi_dit_context_cache(self._h, 1 if enable else 0), "svi_dit_context_cache")
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

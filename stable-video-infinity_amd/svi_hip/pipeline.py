@@ -54,8 +54,17 @@ class DenoiseLoop:
         self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
         latents = latents.to(torch.bfloat16).contiguous().clone()
         ts_dev = self.scheduler.timesteps.to(device=latents.device, dtype=torch.float32)
-        for i, t in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
-            self.step(latents, ts_dev[i:i + 1], self.scheduler.step_delta(t), ctx_pos, ctx_neg, cfg_scale, **cond)
+        # the prompt embeddings are constants of the loop: project them (and every block's cross-attention K / V) once
+        ctx_pos = ctx_pos.to(torch.bfloat16).contiguous()
+        ctx_neg = None if ctx_neg is None else ctx_neg.to(torch.bfloat16).contiguous()
+        if "clip_feature" in cond and cond["clip_feature"] is not None:
+            cond["clip_feature"] = cond["clip_feature"].to(torch.bfloat16).contiguous()
+        self.dit.context_cache(True)
+        try:
+            for i, t in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
+                self.step(latents, ts_dev[i:i + 1], self.scheduler.step_delta(t), ctx_pos, ctx_neg, cfg_scale, **cond)
+        finally:
+            self.dit.context_cache(False)
         return latents
 
 
@@ -70,6 +79,15 @@ def _hip_model_fn(dit_module, x, timestep, context, clip_feature=None, y=None, t
     hip = _INSTALLED.get(id(dit_module))
     if hip is None:
         raise RuntimeError("this WanModel was not passed through svi_hip.install(); refusing to fall back to PyTorch")
+    # prompt embeddings are constant across the steps of a clip: keep the context cache on while the tensor the pipeline
+    # hands us is the same storage with the same version counter (any in-place write or new tensor drops the cache)
+    key = (context.data_ptr(), context._version, tuple(context.shape), None if clip_feature is None else (clip_feature.data_ptr(), clip_feature._version))
+    seen = getattr(hip, "_ctx_keys", None)
+    if seen is None or (key not in seen and len(seen) >= 4) or any(k[0] == key[0] and k != key for k in seen):
+        hip.context_cache(False)
+        hip.context_cache(True)
+        seen = hip._ctx_keys = set()
+    seen.add(key)
     return model_fn_wan_video(hip, x, timestep, context, clip_feature=clip_feature, y=y, tea_cache=tea_cache,
                               add_condition=add_condition, use_unified_sequence_parallel=use_unified_sequence_parallel)
 

@@ -129,3 +129,24 @@ def test_c1_scale_forward_vs_oracle(hip):
     r32 = errs(got, want32)[0]
     report("dit_forward_c1grid", vs_oracle_bf16=r, vs_oracle_fp32=r32, max_abs=mx)
     assert r < 1e-2 and r32 < 2e-2, (r, r32)
+
+
+@pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
+def test_context_cache_is_bit_identical(hip, name):
+    """svi_dit_context_cache: projected context + per-block cross K/V computed once per context pointer, same bits."""
+    c, grid, nt, nv, ts, seed = CASES[name]
+    m, _ = build(hip, c, seed)
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    xd, cd = dev(x), dev(ctx)
+    kwd = {k: dev(v) for k, v in kw.items()}
+    ref = m.forward(xd, torch.tensor([ts]), cd, **kwd)
+    ctx2 = dev(torch.from_numpy(synth.randn(seed + 77, *ctx.shape)))
+    ref2 = m.forward(xd, torch.tensor([ts]), ctx2, **kwd)
+    m.context_cache(True)
+    a1 = m.forward(xd, torch.tensor([ts]), cd, **kwd)          # fills entry 1
+    b1 = m.forward(xd, torch.tensor([ts]), ctx2, **kwd)        # fills entry 2
+    a2 = m.forward(xd, torch.tensor([ts * 0.5]), cd, **kwd)    # reuses entry 1 at another timestep
+    a3 = m.forward(xd, torch.tensor([ts]), cd, **kwd)          # reuses entry 1
+    m.context_cache(False)
+    want_half = m.forward(xd, torch.tensor([ts * 0.5]), cd, **kwd)
+    assert torch.equal(a1, ref) and torch.equal(a3, ref) and torch.equal(b1, ref2) and torch.equal(a2, want_half)
