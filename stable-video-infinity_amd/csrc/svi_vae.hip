@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 #include <math.h>
+#include <stdlib.h>
 
 #include "svi_common.h"
 
@@ -34,6 +35,7 @@ namespace {
 struct ConvP {
     const float* in; int Ti, Hi, Wi, Cin, ld_in;     // stored input dims; ld_in = floats between pixels
     const float* w; int ld_w;                        // packed [tap][Cout][ld_w] (ld_w >= Cin)
+    const bf16* w3; int ld_w3; long plane_w3;        // the same weights as three bf16 planes (hi | mid | lo), [plane][tap][Cout][ld_w3]
     const float* bias;
     float* out; int To, Ho, Wo, Cout, ld_out;
     int kt, kh, kw, st, sh, sw, pt, ph, pw;
@@ -167,10 +169,212 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     }
 }
 
+
+// =================================================================================================
+// fp32 convolution on the bf16 matrix cores: every fp32 operand is split EXACTLY-ish into three bf16 terms
+//   x = hi + mid + lo   (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); 3 x 8 = 24 mantissa bits)
+// and a product is evaluated as the six partial products of weight >= 2^-16 relative
+//   a·w ~= ah·wh + ah·wm + am·wh + ah·wl + al·wh + am·wm     (dropped: 2^-24 relative and below)
+// all accumulated in the MFMA's fp32 accumulator.  Six v_mfma_f32_32x32x16_bf16 (16 channels, 32 cycles each) replace eight
+// v_mfma_f32_32x32x2_f32 (2 channels, 64 cycles each): 2.7x less matrix-pipe time at fp32-class accuracy (the parity tests
+// hold the same 2e-5 / 2e-4 bounds as for the exact-fp32 kernel).  The reference runs the VAE in fp32 on purpose
+// (pipelines/svi_video.py:386-387); this keeps that contract.
+//
+// Tile: 256 output pixels x 96 output channels per 512-thread workgroup (wave w owns pixels 32w..32w+31 x 3 channel tiles),
+// K loop over taps x 32-channel chunks, LDS double buffer = 2 x (3 planes x [256][32] bf16 + 3 planes x [96][32] bf16) = 132 KiB.
+// Activations are split on the fly while they are staged (registers -> LDS), weights were split once at bind time.
+// The weight fragment is the MFMA A operand, the activation fragment the B operand, so a lane's accumulator holds 4
+// consecutive output channels of ONE pixel: 16-byte channels-last stores.
+// LDS rows are 64 B (32 bf16); 16-byte chunk c of row r sits at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128).
+// =================================================================================================
+#define X3_PIX 256
+#define X3_CO 96
+#define X3_A_PLANE (X3_PIX * 64)                 // 16 KiB
+#define X3_W_PLANE (X3_CO * 64)                  // 6 KiB
+#define X3_STAGE (3 * X3_A_PLANE + 3 * X3_W_PLANE)
+__device__ __forceinline__ int x3_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// split 4 fp32 into three bf16x4 terms
+__device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16 hh = (bf16)x[e];
+        const float r1 = x[e] - (float)hh;
+        const bf16 mm = (bf16)r1;
+        const float r2 = r1 - (float)mm;
+        h[e] = hh; m[e] = mm; l[e] = (bf16)r2;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long HoWo = (long)p.Ho * p.Wo;
+    const long P_total = (long)p.To * HoWo;
+    const long p0 = (long)p.t_begin * HoWo + (long)blockIdx.x * X3_PIX;
+    const int co0 = blockIdx.y * X3_CO;
+    const int Hv = p.ups ? 2 * p.Hi : p.Hi, Wv = p.ups ? 2 * p.Wi : p.Wi;
+
+    // ---- staging assignment: activations 256 rows x 8 float4 (4 per thread); weights 3 planes x 96 rows x 4 chunks (16 B)
+    const int a_c4 = tid & 7;                        // which float4 (4 channels) of the 32-channel chunk
+    int a_t[4], a_y[4], a_x[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long pp = p0 + (tid >> 3) + 64 * j;
+        a_ok[j] = pp < P_total;
+        const long q = a_ok[j] ? pp : 0;
+        a_t[j] = (int)(q / HoWo);
+        const int rem = (int)(q - (long)a_t[j] * HoWo);
+        a_y[j] = rem / p.Wo;
+        a_x[j] = rem - a_y[j] * p.Wo;
+    }
+    const int nchunk = (p.Cin + 31) >> 5;
+    const int ntaps = p.kt * p.kh * p.kw;
+    const int nk = ntaps * nchunk;
+    f32x4 ra[4];
+    u32x4 rw[3];                                     // up to 3 of the 1152 weight chunks: id = tid + 512 i
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const u32x4 zero4u = {0u, 0u, 0u, 0u};
+
+    auto load_tile = [&](int kidx) {
+        const int tap = kidx / nchunk, cc = kidx - tap * nchunk;
+        const int ta = tap / (p.kh * p.kw), tb = (tap / p.kw) % p.kh, tc = tap % p.kw;
+        const int c = cc * 32 + a_c4 * 4;
+        const bool cin = c < p.Cin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ti = a_t[j] * p.st + ta - p.pt;
+            int yi = a_y[j] * p.sh + tb - p.ph, xi = a_x[j] * p.sw + tc - p.pw;
+            bool ok = a_ok[j] && cin && ti >= 0 && ti < p.Ti && yi >= 0 && yi < Hv && xi >= 0 && xi < Wv;
+            if (p.zero_frame0 && ti == 0) ok = false;
+            if (p.ups) { yi >>= 1; xi >>= 1; }
+            ra[j] = ok ? *reinterpret_cast<const f32x4*>(p.in + (((long)ti * p.Hi + yi) * p.Wi + xi) * p.ld_in + c) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int id = tid + 512 * i;            // (plane, row, chunk): 3 x 96 x 4
+            const int pl = id / 384, rem = id - pl * 384, row = rem >> 2, ch = rem & 3;
+            const int co = co0 + row, cw = cc * 32 + ch * 8;
+            const bool ok = id < 1152 && co < p.Cout && cw < p.ld_w3;
+            rw[i] = ok ? *reinterpret_cast<const u32x4*>(p.w3 + pl * p.plane_w3 + ((long)tap * p.Cout + co) * p.ld_w3 + cw) : zero4u;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* As = smem + buf * X3_STAGE;
+        char* Ws = As + 3 * X3_A_PLANE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 h, m, l;
+            split3(ra[j], h, m, l);
+            const int off = x3_off((tid >> 3) + 64 * j, a_c4 >> 1) + (a_c4 & 1) * 8;
+            *reinterpret_cast<bf16x4*>(As + off) = h;
+            *reinterpret_cast<bf16x4*>(As + X3_A_PLANE + off) = m;
+            *reinterpret_cast<bf16x4*>(As + 2 * X3_A_PLANE + off) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int id = tid + 512 * i;
+            if (id < 1152) {
+                const int pl = id / 384, rem = id - pl * 384, row = rem >> 2, ch = rem & 3;
+                *reinterpret_cast<u32x4*>(Ws + pl * X3_W_PLANE + x3_off(row, ch)) = rw[i];
+            }
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {
+        const int cur = k & 1;
+        if (k + 1 < nk) load_tile(k + 1);
+        const char* As = smem + cur * X3_STAGE;
+        const char* Ws = As + 3 * X3_A_PLANE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                a[pl] = *reinterpret_cast<const bf16x8*>(As + pl * X3_A_PLANE + x3_off(32 * wave + l31, 2 * ks + hi));
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                bf16x8 w[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    w[pl] = *reinterpret_cast<const bf16x8*>(Ws + pl * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
+                // smallest terms first
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[1], acc[n], 0, 0, 0);   // wm am
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], a[0], acc[n], 0, 0, 0);   // wl ah
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[2], acc[n], 0, 0, 0);   // wh al
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[0], acc[n], 0, 0, 0);   // wm ah
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[1], acc[n], 0, 0, 0);   // wh am
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[0], acc[n], 0, 0, 0);   // wh ah
+            }
+        }
+        if (k + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds pixel pp = p0 + 32 wave + l31, channels co0 + 32 n + 8 rg + 4 hi + 0..3 in acc[n][4 rg + e]
+    const long pp = p0 + 32 * wave + l31;
+    if (pp >= P_total) return;
+    long po;
+    int out_c_shift = 0;
+    if (p.out_mode == 0) po = pp + (long)p.t_out_off * HoWo;
+    else po = -1;
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int co = co0 + 32 * n + 8 * rg + 4 * hi;
+            if (co >= p.Cout) continue;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[n][4 * rg + e] + (p.bias ? p.bias[co + e] : 0.f);
+            if (p.out_mode == 0) {
+                if (p.res) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + po * p.ld_res + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                *reinterpret_cast<f32x4*>(p.out + po * p.ld_out + co) = v;
+            } else {
+                // upsample3d time_conv (vae:153-156): output channel halves become two consecutive frames
+                const int half = p.Cout >> 1;
+                const int t = (int)(pp / HoWo);
+                const long sp = pp - (long)t * HoWo;
+                const int j = co >= half ? 1 : 0;
+                const long pq = (long)(1 + 2 * (t - 1) + j) * HoWo + sp;
+                *reinterpret_cast<f32x4*>(p.out + pq * p.ld_out + (co - j * half)) = v;
+            }
+        }
+    (void)out_c_shift;
+}
+
 svi_status launch_conv(const ConvP& p, hipStream_t st) {
     SVI_REQUIRE(p.Cin % 4 == 0 && p.ld_in % 4 == 0 && p.ld_w % 4 == 0, "conv: Cin/ld must be multiples of 4 (Cin=%d)", p.Cin);
     const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
     if (pixels <= 0) return SVI_OK;
+    static const bool no_x3 = getenv("SVI_VAE_EXACT_FP32") != nullptr;     // A/B aid: force the exact-fp32 MFMA kernel
+    if (p.w3 && !no_x3 && p.Cout >= 64 && p.Cout % 4 == 0 && p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) &&
+        (p.out_mode == 0 || (p.Cout / 2) % 4 == 0)) {
+        static bool attr3 = false;
+        if (!attr3) {
+            SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3_STAGE));
+            attr3 = true;
+        }
+        dim3 grid3((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block3(512);
+        hipLaunchKernelGGL(conv_igemm_x3_kernel, grid3, block3, 2 * X3_STAGE, st, p);
+        SVI_LAUNCH_CHECK();
+        return SVI_OK;
+    }
     const int NT = p.Cout > 32 ? 3 : 1;
     dim3 grid((unsigned)((pixels + 127) / 128), (unsigned)((p.Cout + 32 * NT - 1) / (32 * NT))), block(256);
     static bool attr = false;
@@ -302,6 +506,22 @@ __global__ void video_out_kernel(const float* __restrict__ in, int ld, float* __
     v[i] = fminf(fmaxf(in[sp * ld + c], -1.f), 1.f);
 }
 // weights [Cout, Cin, kt, kh, kw] -> [tap][Cout][ldw] (ldw = Cin rounded up to 4, zero padded)
+// weights [Cout, Cin, taps] -> three bf16 planes [plane][tap][Cout][ldw3] with w = hi + mid + lo (ldw3 = Cin rounded up to 32)
+__global__ void pack_weight_x3_kernel(const float* __restrict__ w, bf16* __restrict__ out, int Cout, int Cin, int taps, int ldw3) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)taps * Cout * ldw3;
+    if (i >= n) return;
+    const int ci = (int)(i % ldw3);
+    const int co = (int)((i / ldw3) % Cout);
+    const int tap = (int)(i / ((long)ldw3 * Cout));
+    const float x = ci < Cin ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+    const bf16 h = (bf16)x;
+    const float r1 = x - (float)h;
+    const bf16 m = (bf16)r1;
+    out[i] = h;
+    out[n + i] = m;
+    out[2 * n + i] = (bf16)(r1 - (float)m);
+}
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int taps, int ldw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n = (long)taps * Cout * ldw;
@@ -322,7 +542,8 @@ struct ConvW {               // one conv layer: user weight (borrowed) + packed 
     const float* w_user = nullptr;
     const float* b_user = nullptr;
     float* packed = nullptr;
-    int Cout = 0, Cin = 0, kt = 1, kh = 1, kw = 1, ldw = 0;
+    bf16* packed3 = nullptr;          // three bf16 planes of the packed weights (see conv_igemm_x3_kernel)
+    int Cout = 0, Cin = 0, kt = 1, kh = 1, kw = 1, ldw = 0, ldw3 = 0;
 };
 struct Tens { float* p = nullptr; int T = 0, H = 0, W = 0, C = 0; long elems() const { return (long)T * H * W * C; } };
 
@@ -447,6 +668,7 @@ svi_status conv_layer(svi_vae* h, const std::string& name, const Tens& in, Tens*
     NEED(*out);
     if (h->dry) return SVI_OK;
     p.in = in.p; p.w = c.packed; p.ld_w = c.ldw; p.bias = c.b_user; p.out = out->p;
+    p.w3 = c.packed3; p.ld_w3 = c.ldw3; p.plane_w3 = (long)c.kt * c.kh * c.kw * c.Cout * c.ldw3;
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.Cout = c.Cout; p.ld_out = out->C;
     p.res = res ? res->p : nullptr; p.ld_res = res ? res->C : 0;
     SviProfScope _p(PROF_VAE_CONV, st);
@@ -541,6 +763,7 @@ svi_status upsample_block(svi_vae* h, const std::string& p, Tens* x, bool tempor
             ConvP q{};
             q.in = x->p; q.Ti = x->T; q.Hi = x->H; q.Wi = x->W; q.Cin = c.Cin; q.ld_in = x->C;
             q.w = c.packed; q.ld_w = c.ldw; q.bias = c.b_user;
+            q.w3 = c.packed3; q.ld_w3 = c.ldw3; q.plane_w3 = (long)c.kt * c.kh * c.kw * c.Cout * c.ldw3;
             q.out = up.p; q.To = x->T; q.Ho = x->H; q.Wo = x->W; q.Cout = c.Cout; q.ld_out = up.C;
             q.kt = 3; q.kh = q.kw = 1; q.st = q.sh = q.sw = 1; q.pt = 2;
             q.zero_frame0 = 1; q.t_begin = 1; q.out_mode = 1;
@@ -572,6 +795,7 @@ svi_status downsample_block(svi_vae* h, const std::string& p, Tens* x, bool temp
             ConvP q{};
             q.in = x->p; q.Ti = x->T; q.Hi = x->H; q.Wi = x->W; q.Cin = c.Cin; q.ld_in = x->C;
             q.w = c.packed; q.ld_w = c.ldw; q.bias = c.b_user;
+            q.w3 = c.packed3; q.ld_w3 = c.ldw3; q.plane_w3 = (long)c.kt * c.kh * c.kw * c.Cout * c.ldw3;
             q.out = dn.p; q.To = To; q.Ho = x->H; q.Wo = x->W; q.Cout = c.Cout; q.ld_out = dn.C;
             q.kt = 3; q.kh = q.kw = 1; q.st = 2; q.sh = q.sw = 1; q.pt = 0;
             q.t_out_off = 1;
@@ -691,8 +915,10 @@ extern "C" svi_status svi_vae_create(svi_vae** out) {
 
 extern "C" svi_status svi_vae_destroy(svi_vae* h) {
     if (!h) return SVI_OK;
-    for (auto& kv : h->convs)
+    for (auto& kv : h->convs) {
         if (kv.second.packed) (void)hipFree(kv.second.packed);
+        if (kv.second.packed3) (void)hipFree(kv.second.packed3);
+    }
     if (h->pool) (void)hipFree(h->pool);
     if (h->consts) (void)hipFree(h->consts);
     if (h->attn_scratch) (void)hipFree(h->attn_scratch);
@@ -737,6 +963,15 @@ extern "C" svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const vo
         if (e != hipSuccess) { svi_set_error("hipMalloc(packed VAE weight) failed: %s", hipGetErrorString(e)); return SVI_ERR_OOM; }
     }
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, cw.w_user, cw.packed, cw.Cout, cw.Cin, taps, cw.ldw);
+    if (cw.Cout >= 64) {               // layers wide enough for conv_igemm_x3_kernel also get the three-term bf16 form
+        cw.ldw3 = (cw.Cin + 31) / 32 * 32;
+        const size_t n3 = (size_t)taps * cw.Cout * cw.ldw3;
+        if (!cw.packed3) {
+            hipError_t e3 = hipMalloc((void**)&cw.packed3, 3 * n3 * 2);
+            if (e3 != hipSuccess) { svi_set_error("hipMalloc(split VAE weight) failed: %s", hipGetErrorString(e3)); return SVI_ERR_OOM; }
+        }
+        hipLaunchKernelGGL(pack_weight_x3_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, 0, cw.w_user, cw.packed3, cw.Cout, cw.Cin, taps, cw.ldw3);
+    }
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
