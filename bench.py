@@ -42,6 +42,8 @@ import torch  # noqa: E402
 WORKLOADS = {
     # name: (latent T, H, W), context tokens, steps per clip
     "c2": dict(lat=(21, 60, 104), lc=512, steps_per_clip=50, desc="Wan2.1-T2V-1.3B 81f@832x480 50-step CFG5 single clip per GPU"),
+    "c4": dict(lat=(21, 60, 104), lc=512, steps_per_clip=50, model="WAN_14B_I2V",
+               desc="Wan2.1-I2V-14B 81f@832x480 50-step CFG5 single clip per GPU (SVI's own base model; DiT only, y/clip_feature synthetic)"),
     "c1": dict(lat=(5, 32, 32), lc=512, steps_per_clip=10, desc="Wan2.1-T2V-1.3B 17f@256x256 10-step CFG5 (reference CPU-runnable case)"),
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
@@ -139,8 +141,9 @@ def main() -> None:
 
     wl = WORKLOADS[args.workload]
     T, H, W = wl["lat"]
-    cfg = dict(synth.WAN_1_3B)
-    dit = svi_hip.WanDiT(eps=1e-6, num_heads=12, **cfg)
+    cfg = dict(getattr(synth, wl.get("model", "WAN_1_3B")))
+    D, F, NL, heads = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"], cfg["dim"] // 128
+    dit = svi_hip.WanDiT(eps=1e-6, num_heads=heads, **cfg)
     dit.bind(device_weights(cfg, 0, dev))
     loop = svi_hip.DenoiseLoop(dit)
     spc = wl["steps_per_clip"]
@@ -154,10 +157,16 @@ def main() -> None:
     ctx_pos[:, 64:] = 0
     ctx_neg[:, 32:] = 0
     ts_dev = loop.scheduler.timesteps.to(dev, torch.float32)
+    cond = {}
+    if cfg["has_image_input"]:      # I2V: y = mask(4) | VAE latent(16) as encode_images_adaptive builds it, CLIP tokens of the first frame
+        yy = torch.randn((1, 20, T, H, W), generator=gen, device=dev)
+        yy[:, :4] = 0
+        yy[:, :4, 0] = 1
+        cond = dict(y=yy.to(torch.bfloat16), clip_feature=torch.randn((1, 257, 1280), generator=gen, device=dev).to(torch.bfloat16))
 
     def one_step(i: int) -> None:
         j = i % spc
-        loop.step(lat, ts_dev[j:j + 1], loop.scheduler.step_delta(loop.scheduler.timesteps[j]), ctx_pos, ctx_neg, 5.0)
+        loop.step(lat, ts_dev[j:j + 1], loop.scheduler.step_delta(loop.scheduler.timesteps[j]), ctx_pos, ctx_neg, 5.0, **cond)
 
     def sync() -> None:
         if dist is not None:
@@ -215,12 +224,14 @@ def main() -> None:
     frames = float(T)
     value = world * frames / clip_s
     L = (T // 1) * (H // 2) * (W // 2)
-    flops_forward = 30 * (12 * L * 1536 ** 2 + 4 * L * L * 1536 + 4 * wl["lc"] * 1536 ** 2 + 4 * L * wl["lc"] * 1536 + 4 * L * 1536 * 8960)
+    lc = wl["lc"]
+    flops_forward = NL * (12 * L * D ** 2 + 4 * L * L * D + 4 * lc * D ** 2 + 4 * L * lc * D + 4 * L * D * F
+                          + (4 * 257 * D ** 2 + 4 * L * 257 * D if cfg["has_image_input"] else 0))
     fl = prof.get("flash_self", {"count": 0, "ms": 0.0})
     roof = None
     if fl["count"]:
         per_launch_ms = fl["ms"] / fl["count"]
-        alg = 4.0 * L * L * 1536
+        alg = 4.0 * L * L * D
         ach = alg / (per_launch_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel from PMC counters: collected in separate rocprofv3 --pmc passes
         # (tools/profile_round.sh -> profiles/*_flash_pmc.json, corrected as MI355X_MICROARCH.md prescribes); not measurable live
@@ -236,11 +247,12 @@ def main() -> None:
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4)}
     line = {
-        "metric": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step" if args.workload == "c2" else "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",
+        "metric": {"c2": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step", "c1": "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",
+                   "c4": "denoised latent frames/sec, Wan2.1-I2V-14B 81f@832x480 50-step"}[args.workload],
         "value": round(value, 5), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
-        "config": {"workload": wl["desc"], "step": "1 scheduler step = cond+uncond DiT forward (30 blocks) + CFG + Euler",
+        "config": {"workload": wl["desc"], "step": f"1 scheduler step = cond+uncond DiT forward ({NL} blocks) + CFG + Euler",
                    "steps_per_clip": spc, "tokens": L, "clips_per_gpu": 1, "parallelism": f"clip-per-rank x{world}",
                    "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
                    "value_includes_vae_decode": vae_ms is not None,

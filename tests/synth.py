@@ -95,6 +95,10 @@ WAN_1_3B = dict(dim=1536, in_dim=16, ffn_dim=8960, out_dim=16, text_dim=4096, fr
                 patch_size=(1, 2, 2), num_layers=30, has_image_input=False)
 
 
+WAN_14B_I2V = dict(dim=5120, in_dim=36, ffn_dim=13824, out_dim=16, text_dim=4096, freq_dim=256,
+                   patch_size=(1, 2, 2), num_layers=40, has_image_input=True)      # wan_video_dit.py:699-712
+
+
 def num_heads_of(cfg: dict) -> int:
     return cfg["dim"] // 128          # the 3-D RoPE split needs head_dim == 128
 
