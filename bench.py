@@ -117,6 +117,8 @@ def main() -> None:
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--cfg-pair", action="store_true", help="SURVEY 8e-2: ranks (2p,2p+1) split the cond/uncond forwards of clip p "
+                    "(one 4.2 MB all-gather per step); needs an even --gpus. Default is one clip per rank.")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -145,12 +147,17 @@ def main() -> None:
     D, F, NL, heads = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"], cfg["dim"] // 128
     dit = svi_hip.WanDiT(eps=1e-6, num_heads=heads, **cfg)
     dit.bind(device_weights(cfg, 0, dev))
-    loop = svi_hip.DenoiseLoop(dit)
+    pair, units = None, world
+    if args.cfg_pair:
+        assert dist is not None and world % 2 == 0, "--cfg-pair needs an even number of ranks"
+        from svi_hip.parallel import CfgPair
+        pair, pair_idx, units = CfgPair.split_world()
+    loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair)
     spc = wl["steps_per_clip"]
     loop.scheduler.set_timesteps(spc, shift=5.0)
 
     # clip `rank` of the rolling window: seed = chunk_idx * 42 (test_svi.py:425), noise from the CPU generator
-    lat = svi_hip.generate_noise((1, 16, T, H, W), seed=rank * 42, device="cpu", dtype=torch.float32).to(dev, torch.bfloat16)
+    lat = svi_hip.generate_noise((1, 16, T, H, W), seed=(rank // 2 if args.cfg_pair else rank) * 42, device="cpu", dtype=torch.float32).to(dev, torch.bfloat16)
     gen = torch.Generator(device=dev).manual_seed(1234)
     ctx_pos = torch.randn((1, wl["lc"], 4096), generator=gen, device=dev).to(torch.bfloat16)
     ctx_neg = torch.randn((1, wl["lc"], 4096), generator=gen, device=dev).to(torch.bfloat16)
@@ -222,7 +229,7 @@ def main() -> None:
     clip_s_dit = spc * ms_per_step / 1000.0
     clip_s = clip_s_dit + (vae_ms or 0.0) / 1000.0
     frames = float(T)
-    value = world * frames / clip_s
+    value = units * frames / clip_s
     L = (T // 1) * (H // 2) * (W // 2)
     lc = wl["lc"]
     flops_forward = NL * (12 * L * D ** 2 + 4 * L * L * D + 4 * lc * D ** 2 + 4 * L * lc * D + 4 * L * D * F
@@ -253,10 +260,11 @@ def main() -> None:
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
         "config": {"workload": wl["desc"], "step": f"1 scheduler step = cond+uncond DiT forward ({NL} blocks) + CFG + Euler",
-                   "steps_per_clip": spc, "tokens": L, "clips_per_gpu": 1, "parallelism": f"clip-per-rank x{world}",
+                   "steps_per_clip": spc, "tokens": L, "clips_per_gpu": 0.5 if pair else 1,
+                   "parallelism": f"cfg-pair x{units} clips" if pair else f"clip-per-rank x{world}",
                    "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
                    "value_includes_vae_decode": vae_ms is not None,
-                   "dit_only_value": round(world * frames / clip_s_dit, 5),
+                   "dit_only_value": round(units * frames / clip_s_dit, 5),
                    "dit_tflops": round(2 * flops_forward / (ms_per_step * 1e-3) / 1e12, 1),
                    "outputs_finite": finite},
         "roofline": roof,

@@ -16,6 +16,12 @@ per-clip (every ~40 s) event.
 For I2V (image-conditioned) streams clip k+1 needs clip k's decoded frames, which is sequential by definition;
 those shard over *samples* with the same code (`units` are then whole samples).
 
+Second axis, for the latency of ONE clip: the cond and uncond forwards of a step are independent
+(pipelines/svi_video.py:401-408), so a pair of ranks runs one each and exchanges `noise_pred` ([1,16,21,h,w] bf16 =
+4.2 MB per step, one 2-rank all-gather over a single xGMI link, ~30 us against a ~250 ms forward); both ranks then apply
+CFG + Euler redundantly, so both hold bit-identical latents and the result equals the serial order (`CfgPair`).  The two
+axes compose: world = pairs x 2, clips round-robin over pairs (`CfgPair.split_world`).
+
 Backends: "nccl" (= RCCL on ROCm) on GPUs; "gloo" on CPU for the world_size-2 tests of the sharding/stitching logic.
 """
 from __future__ import annotations
@@ -81,6 +87,46 @@ class ClipParallel:
         conditioning would be built from.  Same collective shape as all_gather_clips, 1/21 of the bytes."""
         tails = {k: v[..., -num_motion_latents:, :, :].contiguous() for k, v in local.items()}
         return self.all_gather_clips(tails, num_clips)
+
+
+class CfgPair:
+    """Two ranks share one clip: role 0 computes the conditional forward, role 1 the unconditional one.
+
+    `step()` has the contract of DenoiseLoop.step (svi_hip/pipeline.py) and takes the two device functions it needs as
+    arguments, so the exchange logic is the same object on GPUs (RCCL) and in the CPU gloo tests."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("CfgPair needs an initialised process group")
+        self.group = group
+        if dist.get_world_size(group) != 2:
+            raise RuntimeError(f"a CFG pair is exactly 2 ranks, got {dist.get_world_size(group)}")
+        self.role = dist.get_rank(group)
+
+    @staticmethod
+    def split_world() -> "tuple[CfgPair, int, int]":
+        """world = P pairs x 2 ranks: ranks (2p, 2p+1) form pair p.  Returns (pair, pair_index, num_pairs); clips are
+        then sharded over pairs with shard_units(num_clips, pair_index, num_pairs).  Collective: every rank must call."""
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if world % 2:
+            raise RuntimeError(f"CFG pairing needs an even world size, got {world}")
+        mine = None
+        for p in range(world // 2):                       # new_group is collective over the whole world
+            g = dist.new_group(ranks=[2 * p, 2 * p + 1])
+            if rank // 2 == p:
+                mine = g
+        return CfgPair(mine), rank // 2, world // 2
+
+    def step(self, forward: Callable[..., torch.Tensor], cfg_step: Callable[..., None], latents: torch.Tensor,
+             timestep: torch.Tensor, dsigma: float, ctx_pos: torch.Tensor, ctx_neg: torch.Tensor, cfg_scale: float,
+             **cond) -> torch.Tensor:
+        """One scheduler step in place on `latents`.  forward(latents, timestep, context, **cond) -> noise_pred;
+        cfg_step(latents, cond_pred, uncond_pred, cfg_scale, dsigma) applies u + s(c - u) and the Euler update."""
+        mine = forward(latents, timestep, ctx_pos if self.role == 0 else ctx_neg, **cond).contiguous()
+        both = [torch.empty_like(mine), torch.empty_like(mine)]
+        dist.all_gather(both, mine, group=self.group)
+        cfg_step(latents, both[0], both[1], cfg_scale, dsigma)
+        return latents
 
 
 def stitch_window(clips: Sequence[Sequence], num_motion_frames: int) -> list:

@@ -28,14 +28,19 @@ def generate_noise(shape, seed=None, device="cpu", dtype=torch.float16):
 class DenoiseLoop:
     """50 x { cond forward, uncond forward, CFG combine, Euler step } with latents resident in HBM."""
 
-    def __init__(self, dit: WanDiT, scheduler: Optional[FlowMatchScheduler] = None):
+    def __init__(self, dit: WanDiT, scheduler: Optional[FlowMatchScheduler] = None, cfg_pair=None):
+        """`cfg_pair`: an svi_hip.parallel.CfgPair — this rank then runs only its half of every CFG pair of forwards."""
         self.dit = dit
+        self.cfg_pair = cfg_pair
         self.scheduler = scheduler or FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
         self._cond = self._uncond = None
 
     def step(self, latents: torch.Tensor, timestep: torch.Tensor, dsigma: float, ctx_pos: torch.Tensor,
              ctx_neg: Optional[torch.Tensor], cfg_scale: float, **cond) -> torch.Tensor:
         """One scheduler step, in place on `latents` (bf16 [B,16,T,H,W])."""
+        if self.cfg_pair is not None and cfg_scale != 1.0:
+            return self.cfg_pair.step(lambda x, t, c, **kw: self.dit.forward(x, t, c, **kw), ops.cfg_step_, latents, timestep,
+                                      dsigma, ctx_pos, ctx_neg, cfg_scale, **cond)
         if self._cond is None or self._cond.shape != latents.shape:
             self._cond = torch.empty_like(latents)
             self._uncond = torch.empty_like(latents)

@@ -72,6 +72,72 @@ def test_two_ranks_reproduce_single_rank_window(num_clips):
     assert sorted(seen) == list(range(num_clips))
 
 
+def _toy_forward(x, t, ctx, **kw):
+    """Stand-in for the DiT forward: any deterministic function of (latents, timestep, context)."""
+    return (torch.tanh(x.float() * 0.7 + ctx.float().mean() + t.float() * 1e-3) * 0.9).to(torch.bfloat16)
+
+
+def _ref_cfg_step(lat, c, u, s, dsigma):
+    """svi_video.py:410 + flow_match.py:53-64 with the reference's bf16 rounding points."""
+    v = (u + s * (c - u))
+    lat.copy_(lat + v * dsigma)
+
+
+def _serial_cfg_clip(seed, steps=4):
+    g = torch.Generator("cpu").manual_seed(seed)
+    lat = torch.randn((1, 16, 3, 4, 4), generator=g).to(torch.bfloat16)
+    cp, cn = torch.randn((1, 8, 16), generator=g).to(torch.bfloat16), torch.randn((1, 8, 16), generator=g).to(torch.bfloat16)
+    return lat, cp, cn
+
+
+def _cfg_worker(rank, world, port, num_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pair, pidx, npairs = parallel.CfgPair.split_world()
+        out = {}
+        for k in parallel.shard_units(num_clips, pidx, npairs):
+            lat, cp, cn = _serial_cfg_clip(parallel.clip_seed(k))
+            for i in range(4):
+                pair.step(_toy_forward, _ref_cfg_step, lat, torch.tensor([900.0 - 100 * i]), -0.1, cp, cn, 5.0)
+            out[k] = lat.float()
+        q.put((rank, pair.role, pidx, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,num_clips", [(2, 1), (4, 3)])
+def test_cfg_pair_matches_serial_order(world, num_clips):
+    """cond on one rank, uncond on the other, one all-gather per step: both ranks of a pair end with the latents the
+    serial loop produces, bit for bit; with 4 ranks the pairs additionally shard the clips."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cfg_worker, args=(r, world, port, num_clips, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    serial = {}
+    for k in range(num_clips):
+        lat, cp, cn = _serial_cfg_clip(parallel.clip_seed(k))
+        for i in range(4):
+            t = torch.tensor([900.0 - 100 * i])
+            _ref_cfg_step(lat, _toy_forward(lat, t, cp), _toy_forward(lat, t, cn), 5.0, -0.1)
+        serial[k] = lat.float()
+    covered = set()
+    for rank, role, pidx, out in res:
+        assert role == rank % 2 and pidx == rank // 2
+        assert sorted(out) == [k for k in range(num_clips) if k % (world // 2) == pidx]
+        for k, v in out.items():
+            assert torch.equal(v, serial[k])
+            covered.add(k)
+    assert covered == set(range(num_clips))
+
+
 def test_single_process_paths():
     par = parallel.ClipParallel()
     assert (par.rank, par.world) == (0, 1) and par.my_clips(3) == [0, 1, 2]
