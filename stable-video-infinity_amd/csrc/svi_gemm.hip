@@ -468,6 +468,162 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g,
 }
 
 
+// -------------------------------------------------------------------------------------------------
+// 256^2 kernel, main loop v3 ("256p").  Same tile, LDS image, operand swizzle and epilogue as above; what changes is WHERE the
+// per-tile barrier sits and WHEN the LDS-DMA of the next tile is issued.  In the kernel above every K tile begins with the 8
+// DMA instructions of the next tile issued back to back (≈60 cycles of issue each, nothing else can be issued by the wave
+// meanwhile — and its SIMD partner is doing the same thing) and with the first fragment reads of the tile exposed behind the
+// barrier.  Here the barrier sits between k-steps 2 and 3 of a tile: all four fragment sets of tile t are in registers by
+// then (k-step 3's set was read under k-step 2's MFMAs), so behind the barrier the wave still owns 8 MFMAs of tile t that
+// need no LDS, and under them it (a) reads k-step 0 of tile t+1 — already landed, the barrier's vmcnt(0) waited for it — and
+// (b) starts issuing the DMA of tile t+2 into the buffer tile t just vacated, one instruction every SPREAD MFMAs.  A tile's
+// DMA therefore has a whole K tile of MFMAs (≈1 us) to land with only two LDS stages, and no fragment read is exposed.
+// MFMA statements are `asm volatile` so the DMA builtins keep their place between them.
+// Measured (tools/gemm_ab.py, bit-identical to v2): 8192^3 1054 -> 1196 TFLOP/s, ffn2 1091 -> 1193, qkv 780 -> 810-840,
+// ffn1 829 -> 850; SPREAD 1 and 2 are within noise of each other, 0 (all DMA up front) is 1-2 % behind, 4 (DMA over the whole
+// tile: the last piece lands late) loses 7 %.  Tried on top and dropped: SIMD partners one phase apart ("ping-pong": waves 0-3
+// compute a 32-wide half-tile while 4-7 read fragments and issue DMA, four-stage half-tile ring) ran at the same 1200 TFLOP/s,
+// and tools/power_probe.py shows why: with random operands this kernel already holds the package at its 1400 W limit (sclk
+// 1.80 GHz; all-zero operands: 1000 W, 2.39 GHz, 1428 TFLOP/s), so a schedule that raises pipe utilisation is paid back in clock.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gemm_mfma_v(int& tok, f32x16& acc, u32x4 w, u32x4 x, int& apin) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %[c], %[w], %[x], %[c]" : [c] "+v"(acc), [tok] "+v"(tok), [ap] "+v"(apin) : [w] "v"(w), [x] "v"(x));
+}
+
+template <int SPREAD>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    const int group = swz / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = swz - group * GM * tiles_n;
+    const int tile_n = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n * gm);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+    unsigned a_off[4], w_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 8;
+        w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 8;
+    }
+    const int nk = g.K / BK;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_addr[4], w_addr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
+        w_addr[kk] = lds0 + T_STAGE + lds_tile_off(wn * 64 + l31, 2 * kk + hi);
+    }
+    int tok = 0;
+    u32x4 xa[2][4], wb[2][2];
+
+    // one k-step: 8 MFMAs on fragment set KK & 1; behind them (READ) the 6 fragment reads of k-step (KK+1)&3 from the stage at
+    // byte offset `rso`, and (DMA) pieces of the tile `dk` K-elements in, into the stage at byte offset `dso`: the MFMA with
+    // running index G0+i (0..31 over the 4 k-steps that follow a barrier) is followed by piece (G0+i)/SPREAD when due.
+#define SVI_KSTEP(KK, G0, READ, DMA, rso, dk, dso)                                                                              \
+    static_for8([&](auto ic) {                                                                                                  \
+        constexpr int i = decltype(ic)::value;                                                                                  \
+        constexpr int ni = i >> 2, mi = i & 3, cs = (KK) & 1, ns = cs ^ 1, kn = ((KK) + 1) & 3, gi = (G0) + i;                   \
+        int& pin = (i < 4) ? a_addr[kn] : w_addr[kn];                                                                           \
+        if constexpr ((DMA) && SPREAD == 0 && gi == 0) {                                                                        \
+            {                                                                                                                   \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                 \
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.A + dk + a_off[j]), (lptr_t)(smem + dso + (j * 8 + wave) * 1024), 16, 0, 0);            \
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.W + dk + w_off[j]), (lptr_t)(smem + dso + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);  \
+                }                                                                                                               \
+            }                                                                                                                   \
+        }                                                                                                                       \
+        gemm_mfma_v(tok, acc[ni][mi], wb[cs][ni], xa[cs][mi], pin);                                                             \
+        if constexpr (READ) {                                                                                                   \
+            if constexpr (i < 4) xa[ns][i] = *(lds_u32x4_t)(a_addr[kn] + (rso) + i * 32 * 128);                                 \
+            else if constexpr (i < 6) wb[ns][i - 4] = *(lds_u32x4_t)(w_addr[kn] + (rso) + (i - 4) * 32 * 128);                  \
+        }                                                                                                                       \
+        if constexpr ((DMA) && SPREAD > 0 && (gi % (SPREAD > 0 ? SPREAD : 1)) == (SPREAD > 0 ? SPREAD : 1) - 1 && gi / (SPREAD > 0 ? SPREAD : 1) < 8) {    \
+            constexpr int pc = gi / (SPREAD > 0 ? SPREAD : 1), j = pc >> 1;                                                     \
+            {                                                                                                                   \
+                if constexpr ((pc & 1) == 0)                                                                                    \
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.A + dk + a_off[j]), (lptr_t)(smem + dso + (j * 8 + wave) * 1024), 16, 0, 0);            \
+                else                                                                                                            \
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.W + dk + w_off[j]), (lptr_t)(smem + dso + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);  \
+            }                                                                                                                   \
+        }                                                                                                                       \
+    })
+
+    // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-steps 0..2 computed
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.A + a_off[j]), (lptr_t)(smem + (j * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.W + w_off[j]), (lptr_t)(smem + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.A + BK + a_off[j]), (lptr_t)(smem + 2 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.W + BK + w_off[j]), (lptr_t)(smem + 3 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[0][i] = *(lds_u32x4_t)(a_addr[0] + i * 32 * 128);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wb[0][i] = *(lds_u32x4_t)(w_addr[0] + i * 32 * 128);
+    SVI_KSTEP(0, 8, true, false, 0, -1, 0);
+    SVI_KSTEP(1, 16, true, false, 0, -1, 0);
+    SVI_KSTEP(2, 24, true, false, 0, -1, 0);
+
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        const int nso = ((kt + 1) & 1) * 2 * T_STAGE;          // stage of tile kt+1 (read)
+        const int dso = (kt & 1) * 2 * T_STAGE;                // stage tile kt vacates (DMA target of tile kt+2)
+        const int dk = (kt + 2) * BK;
+        __syncthreads();                                       // vmcnt(0): tile kt+1 landed; lgkmcnt(0) + barrier: tile kt fully read by all waves
+        SVI_KSTEP(3, 0, true, true, nso, dk, dso);
+        SVI_KSTEP(0, 8, true, true, nso, dk, dso);
+        SVI_KSTEP(1, 16, true, true, nso, dk, dso);
+        SVI_KSTEP(2, 24, true, true, nso, dk, dso);
+    }
+    if (kt + 1 < nk) {                                         // last tile: nothing left to fetch
+        const int nso = ((kt + 1) & 1) * 2 * T_STAGE;
+        __syncthreads();
+        SVI_KSTEP(3, 0, true, false, nso, -1, 0);
+        SVI_KSTEP(0, 8, true, false, nso, -1, 0);
+        SVI_KSTEP(1, 16, true, false, nso, -1, 0);
+        SVI_KSTEP(2, 24, true, false, nso, -1, 0);
+    }
+    SVI_KSTEP(3, 0, false, false, 0, -1, 0);
+#undef SVI_KSTEP
+    asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
+    asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    __syncthreads();                                           // every wave is done with the operand stages: the C tile may overwrite them
+    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
+}
+
+
 
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     SVI_REQUIRE(g.M >= 0 && g.N >= 0 && g.K > 0, "gemm: bad sizes M=%d N=%d K=%d", g.M, g.N, g.K);
@@ -495,6 +651,8 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
                 SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
+                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
+                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
                 attr256 = true;
             }
             const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
@@ -502,8 +660,12 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             const int gm_rows = gme ? atoi(gme) : 2;       // measured (tools/gemm_gm.py): 2 beats 8 by 13 % on ffn1, 3 % on ffn2, flat on N = 1536
             if (force && force[0] == '2' && force[3] == 'c')
                 hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
-            else
+            else if (force && force[0] == '2' && force[3] == '\0')       // "256": the v2 main loop (barrier at the tile boundary), kept for A/B
                 hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
+            else if (force && force[0] == '2' && force[3] == 'p' && force[4] == '2')
+                hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<2>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
+            else                                                          // default: v3 main loop, one DMA instruction behind each of the first 8 MFMAs
+                hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
             SVI_LAUNCH_CHECK();
             return SVI_OK;
         }

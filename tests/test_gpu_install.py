@@ -1,0 +1,150 @@
+"""-m gpu: the drop-in boundary.  `svi_hip.install(pipe)` is exercised against a stand-in for the reference's
+pipeline module: a module object holding a `model_fn_wan_video` global, a pipeline class defined in it, and a sampler
+that — like pipelines/svi_video.py:401-408 — looks `model_fn_wan_video` up through the module globals at call time and
+passes `self.dit` (an nn.Module whose state_dict() has the reference's keys) plus keyword inputs.  The reference itself
+cannot be imported on the GPU box, so the stand-in reproduces its *interface* (attribute names install() reads, state-dict
+keys, call form), not its arithmetic; the arithmetic is checked against the committed golden vectors of the real reference.
+"""
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import synth
+from gpu_util import dev, errs, report
+from test_oracle_dit import CASES, inputs
+
+pytestmark = pytest.mark.gpu
+
+
+class _Node(nn.Module):
+    """Container that indexes like nn.ModuleList / nn.Sequential (`blocks[0]`, `text_embedding[0]`, len(blocks))."""
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
+
+
+def module_from_state_dict(sd, device, dtype):
+    root = _Node()
+    for k, v in sd.items():
+        parts, m = k.split("."), root
+        for p in parts[:-1]:
+            if p not in m._modules:
+                m.add_module(p, _Node())
+            m = m._modules[p]
+        m.register_parameter(parts[-1], nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).to(device=device, dtype=dtype), requires_grad=False))
+    return root
+
+
+def wan_model_double(c, seed):
+    """nn.Module with the reference WanModel's state-dict keys and the attributes WanDiT.from_module reads
+    (models/wan_video_dit.py:407-470: dim, freq_dim, has_image_input, patch_embedding Conv3d, blocks[i].{ffn_dim,num_heads,norm1.eps})."""
+    sd = synth.dit_state_dict(seed, **c)
+    m = module_from_state_dict(sd, "cuda", torch.bfloat16)
+    m.dim, m.freq_dim, m.has_image_input = c["dim"], c["freq_dim"], c["has_image_input"]
+    m.patch_embedding.in_channels, m.patch_embedding.kernel_size = c["in_dim"], tuple(c["patch_size"])
+    m.text_embedding[0].in_features = c["text_dim"]
+    m.head.head.out_features = sd["head.head.weight"].shape[0]
+    for i in range(len(m.blocks)):
+        b = m.blocks[i]
+        b.ffn_dim, b.num_heads, b.norm1 = c["ffn_dim"], synth.num_heads_of(c), types.SimpleNamespace(eps=1e-6)
+    return m, sd
+
+
+SAMPLER_SRC = '''
+def model_fn_wan_video(dit, x, timestep, context, clip_feature=None, y=None, **kwargs):
+    raise AssertionError("the PyTorch model_fn was called: install() did not take effect")
+
+
+class SVIVideoPipeline:
+    def __init__(self, dit, vae):
+        self.dit, self.vae = dit, vae
+
+    def one_cfg_step(self, latents, timestep, prompt_emb_posi, prompt_emb_nega, image_emb, cfg_scale):
+        # call form of the reference sampler: module-global lookup, dit passed positionally, embeddings as keyword dicts
+        posi = model_fn_wan_video(self.dit, latents, timestep=timestep, **prompt_emb_posi, **image_emb)
+        nega = model_fn_wan_video(self.dit, latents, timestep=timestep, **prompt_emb_nega, **image_emb)
+        return nega + cfg_scale * (posi - nega), posi, nega
+'''
+
+
+@pytest.fixture()
+def pipeline_module():
+    name = "svi_video_double"
+    mod = types.ModuleType(name)
+    sys.modules[name] = mod
+    exec(compile(SAMPLER_SRC, name + ".py", "exec"), mod.__dict__)
+    mod.SVIVideoPipeline.__module__ = name
+    yield mod
+    del sys.modules[name]
+
+
+@pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
+def test_install_swaps_model_fn_and_matches_golden(golden, pipeline_module, name):
+    import svi_hip
+    c, grid, nt, nv, ts, seed = CASES[name]
+    g = golden(f"dit_{name}.npz")
+    dit, sd = wan_model_double(c, seed)
+    pipe = pipeline_module.SVIVideoPipeline(dit, None)
+    with pytest.raises(AssertionError):                      # before install(): the module's own function is what runs
+        pipeline_module.model_fn_wan_video(dit, None, None, None)
+    svi_hip.install(pipe, vae=False)
+    assert pipeline_module.model_fn_wan_video is not pipeline_module._svi_hip_original_model_fn
+    assert sorted(dit.state_dict()) == sorted(sd)            # pipe.dit is untouched: loaders / LoRA merge still see every key
+
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    lat, t = dev(x), torch.tensor([ts], device="cuda")
+    ctx_p = dev(ctx)
+    ctx_n = dev(-np.asarray(ctx))                            # any other prompt (a permutation of the tokens would not do: attention is permutation-invariant)
+    img = {k: dev(v) for k, v in kw.items()}
+    guided, posi, nega = pipe.one_cfg_step(lat, t, {"context": ctx_p}, {"context": ctx_n}, img, 5.0)
+    r16, _, _ = errs(posi, g["out_bf16"])
+    r32, _, _ = errs(posi, g["out_fp32"])
+    report("install_model_fn", case=name, vs_ref_bf16=r16, vs_ref_fp32=r32)
+    assert posi.shape == g["out_fp32"].shape and r16 < 2e-2
+    assert not torch.equal(posi, nega) and torch.isfinite(guided.float()).all()
+    # same call again (next step of the clip, same prompt tensors): served with the cached context projections, identical bits
+    _, posi2, nega2 = pipe.one_cfg_step(lat, t, {"context": ctx_p}, {"context": ctx_n}, img, 5.0)
+    assert torch.equal(posi, posi2) and torch.equal(nega, nega2)
+    # an in-place edit of the prompt embedding must not be served from the cache
+    ctx_p.mul_(0.5)
+    _, posi3, _ = pipe.one_cfg_step(lat, t, {"context": ctx_p}, {"context": ctx_n}, img, 5.0)
+    assert not torch.equal(posi, posi3)
+    direct = svi_hip.WanDiT.from_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    assert torch.equal(posi3, direct.forward(lat, t, ctx_p, **img))
+
+
+def test_install_refuses_cpu_or_fp32_dit(pipeline_module):
+    import svi_hip
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    dit, _ = wan_model_double(c, seed)
+    with pytest.raises(RuntimeError):
+        svi_hip.install(pipeline_module.SVIVideoPipeline(dit.float(), None), vae=False)
+    other, _ = wan_model_double(c, seed)
+    with pytest.raises(RuntimeError):                        # a WanModel that never went through install(): no silent PyTorch fallback
+        svi_hip.pipeline._hip_model_fn(other, None, None, torch.zeros(1, device="cuda"))
+
+
+def test_install_rebinds_vae_methods(golden, pipeline_module):
+    import svi_hip
+    g = golden("vae.npz")
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    dit, _ = wan_model_double(c, seed)
+    vsd = synth.vae_state_dict(500)                          # the weights the golden vectors were generated with (tests/gen_golden.py)
+    vae = module_from_state_dict(vsd, "cuda", torch.float32)
+    pipe = pipeline_module.SVIVideoPipeline(dit, vae)
+    svi_hip.install(pipe)
+    z = torch.from_numpy(synth.randn(501, 1, 16, 3, 4, 6))[0].cuda()
+    out = pipe.vae.decode([z], device="cuda")[0]             # signature of models/wan_video_vae.py:777
+    r, mx, _ = errs(out, g["decode_3f"])
+    assert r < 2e-5 and mx < 2e-4, (r, mx)
+    vid = torch.from_numpy(np.tanh(synth.randn(503, 3, 9, 32, 48))).cuda()
+    lat = pipe.vae.encode([vid], device="cuda")[0]           # models/wan_video_vae.py:759
+    r, mx, _ = errs(lat, g["encode_9f"])
+    assert r < 2e-5 and mx < 2e-4, (r, mx)
