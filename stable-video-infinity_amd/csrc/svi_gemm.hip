@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "svi_common.h"
+#include <cstdio>
 
 #define BM 128
 #define BN 128
@@ -239,90 +240,163 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Shared epilogue of the 256^2 kernels: y = bf16(acc + bias) staged through LDS as a [256][C2_LD] bf16 tile, read back row-
 // contiguously (512 B per row), activation / gate / residual applied, 16-byte coalesced stores.  All LDS reads of the main
 // loop must be complete (barrier) before this is called.
-__device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* smem, int m0, int n0, int tid,
-                                                 int wm, int wn, int l31, int hi) {
+//
+// Where its time went (epilogue ablations, tools/gemm_stagger.py; ffn1 = 17.5 tiles per CU): of 1042 us, 384 us were epilogue
+// — and none of that was the global stores.  175 us were 128 dependent 2-byte bias loads per thread (one memory round trip each),
+// 209 us the read-back loop: one `switch (epi)` chain, four bounds tests and an `s_waitcnt lgkmcnt(0)` per 16-byte chunk, sixteen
+// times per thread.  Now: the epilogue kind is a template parameter (one uniform branch per tile), bias values come in as eight
+// 8-byte vectors up front, and an interior tile (all but the last row panel) takes a path without bounds tests in which the
+// LDS reads of four chunks are in flight together.
+// abl (timing ablations, results wrong): 1 = no epilogue at all, 2 = no global stores, 3 = stop after the LDS staging writes.
+template <int EPI>
+__device__ __forceinline__ void gemm256_apply(float (&y)[8], const u32x4& res, const float (&gatev)[8], bool has_gate) {
+    if constexpr (EPI == SVI_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = gelu_tanh_f(y[e]);
+    } else if constexpr (EPI == SVI_EPI_BIAS_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = gelu_erf_f(y[e]);
+    } else if constexpr (EPI == SVI_EPI_BIAS_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+    } else if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
+        const bf16x8 t = __builtin_bit_cast(bf16x8, res);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = y[e];
+            if (has_gate) v = rbf(gatev[e] * v);
+            y[e] = (float)t[e] + v;
+        }
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* smem, int m0, int n0, int tid,
+                                                   int wm, int wn, int l31, int hi, int abl) {
+    const bool interior = (m0 + TM <= g.M) && (n0 + TN <= g.N);
     // gate·y + residual: the 16 residual chunks this thread will need are requested NOW (64 registers, the accumulators
     // are about to die) so that their latency runs under the LDS round trip; the column block (and so the gate values)
     // is the same for all 16 chunks of a thread.
     u32x4 resv[16];
     float gatev[8];
-    const int ecc = tid & 31, en = n0 + ecc * 8;
+    const int ecc = tid & 31, er = tid >> 5, en = n0 + ecc * 8;
     const bool efull = en + 8 <= g.N;
-    if (g.epi == SVI_EPI_BIAS_GATE_RES) {
+    if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
+        if (interior) {
+            const bf16* rp = g.res + (size_t)(m0 + er) * g.ldres + en;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int m = m0 + ((tid + 512 * it) >> 5);
-            if (m < g.M && efull) resv[it] = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + en);
+            for (int it = 0; it < 16; ++it) resv[it] = *reinterpret_cast<const u32x4*>(rp + (size_t)(16 * it) * g.ldres);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int m = m0 + er + 16 * it;
+                if (m < g.M && efull) resv[it] = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + en);
+            }
+        }
+        if (g.gate && efull && (((uintptr_t)g.gate & 15) == 0)) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(g.gate + en), g1 = *reinterpret_cast<const f32x4*>(g.gate + en + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gatev[e] = g0[e]; gatev[4 + e] = g1[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gatev[e] = (g.gate && en + e < g.N) ? g.gate[en + e] : 0.f;
+        }
+    }
+    // ---- part 1: y = bf16(acc + bias) -> LDS [256 m][C2_LD] bf16 ---------------------------------------------------------
+    u32x2 bnp[2][4];
+    float bmv[4];
+    const bool bias_n = g.bias && !g.bias_along_m, bias_m = g.bias && g.bias_along_m;
+    const bool bias_vec = bias_n && (n0 + TN <= g.N) && (((uintptr_t)g.bias & 7) == 0);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int n = n0 + wn * 64 + ni * 32 + 8 * rg + 4 * hi;
+            if (bias_vec) {
+                bnp[ni][rg] = *reinterpret_cast<const u32x2*>(g.bias + n);
+            } else {
+                unsigned short h4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h4[e] = (bias_n && n + e < g.N) ? reinterpret_cast<const unsigned short*>(g.bias)[n + e] : (unsigned short)0;
+                bnp[ni][rg][0] = (unsigned)h4[0] | ((unsigned)h4[1] << 16);
+                bnp[ni][rg][1] = (unsigned)h4[2] | ((unsigned)h4[3] << 16);
+            }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) gatev[e] = (g.gate && en + e < g.N) ? g.gate[en + e] : 0.f;
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 128 + mi * 32 + l31;
+        bmv[mi] = (bias_m && m < g.M) ? (float)g.bias[m] : 0.f;
     }
-    // ---- epilogue part 1: y = bf16(acc + bias) -> LDS [256 m][C2_LD] bf16 ---------------------------
     bf16* Cs = reinterpret_cast<bf16*>(smem);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int ml = wm * 128 + mi * 32 + l31;
-            float bm = 0.f;
-            if (g.bias && g.bias_along_m) bm = (m0 + ml < g.M) ? (float)g.bias[m0 + ml] : 0.f;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int nl = wn * 64 + ni * 32 + 8 * rg + 4 * hi;
+                const unsigned b01 = bnp[ni][rg][0], b23 = bnp[ni][rg][1];
+                const float bv[4] = {__builtin_bit_cast(float, b01 << 16) + bmv[mi], __builtin_bit_cast(float, b01 & 0xffff0000u) + bmv[mi],
+                                     __builtin_bit_cast(float, b23 << 16) + bmv[mi], __builtin_bit_cast(float, b23 & 0xffff0000u) + bmv[mi]};
                 bf16x4 pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float bv = bm;
-                    if (g.bias && !g.bias_along_m) bv = (n0 + nl + e < g.N) ? (float)g.bias[n0 + nl + e] : 0.f;
-                    pk[e] = (bf16)(acc[ni][mi][rg * 4 + e] + bv);
-                }
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[ni][mi][rg * 4 + e] + bv[e]);
                 *reinterpret_cast<bf16x4*>(Cs + ml * C2_LD + nl) = pk;
             }
         }
     }
     __syncthreads();
+    if (abl == 3) return;
 
-    // ---- epilogue part 2: row-contiguous read-back (512 B per row), activation / gate / residual, coalesced store
+    // ---- part 2: row-contiguous read-back (512 B per row), activation / gate / residual, coalesced store ---------------------
+    const bool has_gate = g.gate != nullptr;
+    if (interior) {
+        const bf16* lp = Cs + er * C2_LD + ecc * 8;
+        bf16* cp = g.C + (size_t)(m0 + er) * g.ldc + en;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            u32x4 yv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yv[j] = *reinterpret_cast<const u32x4*>(lp + (16 * (4 * b + j)) * C2_LD);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int it = 4 * b + j;
+                const bf16x8 t = __builtin_bit_cast(bf16x8, yv[j]);
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (float)t[e];
+                gemm256_apply<EPI>(y, resv[it], gatev, has_gate);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
+                if (abl == 2) { if (y[0] == 123.456f && y[7] == 1.f) cp[0] = o[3]; }
+                else st_bf16x8(cp + (size_t)(16 * it) * g.ldc, o);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-        const int id = tid + 512 * it;
-        const int ml = id >> 5, cc = id & 31;
-        const int m = m0 + ml, n = n0 + cc * 8;
+        const int ml = er + 16 * it;
+        const int m = m0 + ml, n = en;
         if (m >= g.M || n >= g.N) continue;
-        bf16x8 yv = *reinterpret_cast<const bf16x8*>(Cs + ml * C2_LD + cc * 8);
+        const bf16x8 yv = *reinterpret_cast<const bf16x8*>(Cs + ml * C2_LD + ecc * 8);
         float y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = (float)yv[e];
-        const bool full = (n + 8 <= g.N);
-        if (g.epi == SVI_EPI_BIAS_GELU_TANH) {
+        u32x4 rvv = resv[it];
+        if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
+            if (!efull) {
+                bf16x8 t;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = gelu_tanh_f(y[e]);
-        } else if (g.epi == SVI_EPI_BIAS_GELU_ERF) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = gelu_erf_f(y[e]);
-        } else if (g.epi == SVI_EPI_BIAS_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
-        } else if (g.epi == SVI_EPI_BIAS_GATE_RES) {
-            const bf16* rp = g.res + (size_t)m * g.ldres + n;
-            float rv[8];
-            if (full) {
-                const bf16x8 t = __builtin_bit_cast(bf16x8, resv[it]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] = (float)t[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] = (n + e < g.N) ? (float)rp[e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = y[e];
-                if (g.gate) t = rbf(gatev[e] * t);
-                y[e] = rv[e] + t;
+                for (int e = 0; e < 8; ++e) t[e] = (n + e < g.N) ? g.res[(size_t)m * g.ldres + n + e] : (bf16)0.f;
+                rvv = __builtin_bit_cast(u32x4, t);
             }
         }
+        gemm256_apply<EPI>(y, rvv, gatev, has_gate);
         bf16* cp = g.C + (size_t)m * g.ldc + n;
-        if (full) {
+        if (efull) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
@@ -330,6 +404,21 @@ __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&
         } else {
             for (int e = 0; e < 8 && n + e < g.N; ++e) cp[e] = (bf16)y[e];
         }
+    }
+}
+
+__device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* smem, int m0, int n0, int tid,
+                                                 int wm, int wn, int l31, int hi, int abl = 0) {
+    if (abl == 1) {
+        if (acc[0][0][0] == 123.456f) g.C[0] = (bf16)acc[1][3][5];      // keep the accumulators alive
+        return;
+    }
+    switch (g.epi) {        // uniform: one scalar branch per tile
+        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        default:                     gemm256_epilogue_t<SVI_EPI_BIAS>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
     }
 }
 
@@ -491,8 +580,15 @@ __device__ __forceinline__ void gemm_mfma_v(int& tok, f32x16& acc, u32x4 w, u32x
 }
 
 template <int SPREAD>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM, int stag_phases, int stag_sleeps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // De-phasing (see svi_launch_gemm): the workgroups of the first round (one per CU) start `phase * stag_sleeps` sleeps late,
+    // phase = CU-in-XCD index mod stag_phases, so that for the rest of the launch the CUs' epilogues (a 128 KiB store burst
+    // each, 32 MiB per round when they all coincide) are spread over the tile period instead of hitting HBM together.
+    if (stag_sleeps > 0 && (int)blockIdx.x < 256) {
+        const int ph = ((int)blockIdx.x >> 3) % stag_phases;
+        for (int i = 0; i < ph * stag_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int lds0 = (int)(size_t)(lptr_t)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -620,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g
     asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
     asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
     __syncthreads();                                           // every wave is done with the operand stages: the C tile may overwrite them
-    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
+    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, stag_phases < 0 ? -stag_phases : 0);
 }
 
 
@@ -649,23 +745,21 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             if (!attr256) {
                 SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
-                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
                 SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
-                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
                 attr256 = true;
             }
             const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
             const char* gme = getenv("SVI_GEMM_GM");               // row panels per tile group (A/B aid)
             const int gm_rows = gme ? atoi(gme) : 2;       // measured (tools/gemm_gm.py): 2 beats 8 by 13 % on ffn1, 3 % on ffn2, flat on N = 1536
-            if (force && force[0] == '2' && force[3] == 'c')
-                hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
-            else if (force && force[0] == '2' && force[3] == '\0')       // "256": the v2 main loop (barrier at the tile boundary), kept for A/B
+            if (force && force[0] == '2' && force[3] == '\0')       // "256": the v2 main loop (barrier at the tile boundary), kept for A/B
                 hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
-            else if (force && force[0] == '2' && force[3] == 'p' && force[4] == '2')
-                hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<2>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
-            else                                                          // default: v3 main loop, one DMA instruction behind each of the first 8 MFMAs
-                hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
+            else {
+                int sp = 0, ss = 0;                                       // SVI_GEMM_STAGGER="phases,sleeps" (A/B aid; sleeps of ~4.4 us)
+                if (const char* sg = getenv("SVI_GEMM_STAGGER")) sscanf(sg, "%d,%d", &sp, &ss);
+                if (sp >= 0 && sp < 2) ss = 0;      // negative `phases` = epilogue timing ablation code
+                // default: v3 main loop, one DMA instruction behind each of the first 8 MFMAs
+                hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, sp, ss);
+            }
             SVI_LAUNCH_CHECK();
             return SVI_OK;
         }
