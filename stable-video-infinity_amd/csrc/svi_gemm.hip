@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 // Tried and dropped (bit-identical, measured on MI355X, tools/gemm_ab.py):  BK = 32 with four LDS stages and counted
 // vmcnt (3 tiles in flight): -5 % (twice the barriers, DMA latency was not the limiter);  a persistent kernel that defers
 // the epilogue of tile i into the K loop of tile i+1 (64 packed-bf16 registers, permlane-paired 16-byte stores): -5..-13 %
-// (register spills, and the row-scattered stores compete with the LDS-DMA for the address path).  What is left on the
-// table is the epilogue: 15 us per tile at K = 1536 against a 52 us main loop (760 vs 1100 TFLOP/s at K = 8960).
+// (register spills, and the row-scattered stores compete with the LDS-DMA for the address path).  The epilogue itself was the
+// real loss (see gemm256_epilogue_t): after its rewrite it costs 2-9 us per tile, mostly the 128 KiB of stores.
 // Tile order: 8 XCD bands (bijective), inside a band groups of 8 row panels walk the column panels, so the 32
 // tiles an XCD runs at once are ~8 row panels x 4 column panels: 12 operand panels for 32 tiles in its L2.
 // =================================================================================================
@@ -580,15 +580,8 @@ __device__ __forceinline__ void gemm_mfma_v(int& tok, f32x16& acc, u32x4 w, u32x
 }
 
 template <int SPREAD>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM, int stag_phases, int stag_sleeps) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM, int abl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // De-phasing (see svi_launch_gemm): the workgroups of the first round (one per CU) start `phase * stag_sleeps` sleeps late,
-    // phase = CU-in-XCD index mod stag_phases, so that for the rest of the launch the CUs' epilogues (a 128 KiB store burst
-    // each, 32 MiB per round when they all coincide) are spread over the tile period instead of hitting HBM together.
-    if (stag_sleeps > 0 && (int)blockIdx.x < 256) {
-        const int ph = ((int)blockIdx.x >> 3) % stag_phases;
-        for (int i = 0; i < ph * stag_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int lds0 = (int)(size_t)(lptr_t)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -716,7 +709,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g
     asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
     asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
     __syncthreads();                                           // every wave is done with the operand stages: the C tile may overwrite them
-    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, stag_phases < 0 ? -stag_phases : 0);
+    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl);
 }
 
 
@@ -754,11 +747,11 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             if (force && force[0] == '2' && force[3] == '\0')       // "256": the v2 main loop (barrier at the tile boundary), kept for A/B
                 hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
             else {
-                int sp = 0, ss = 0;                                       // SVI_GEMM_STAGGER="phases,sleeps" (A/B aid; sleeps of ~4.4 us)
-                if (const char* sg = getenv("SVI_GEMM_STAGGER")) sscanf(sg, "%d,%d", &sp, &ss);
-                if (sp >= 0 && sp < 2) ss = 0;      // negative `phases` = epilogue timing ablation code
-                // default: v3 main loop, one DMA instruction behind each of the first 8 MFMAs
-                hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, sp, ss);
+                const char* ab = getenv("SVI_GEMM_EPI_ABL");              // epilogue timing ablations (tools/gemm_epi_abl.py); results wrong when set
+                const int abl = ab ? atoi(ab) : 0;
+                // Tried and dropped: starting the first round's workgroups out of phase (s_sleep by CU index) so that the CUs' store
+                // bursts do not coincide: no gain on ffn1 (17.5 rounds), a loss wherever the tile count is a whole number of rounds.
+                hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);
             }
             SVI_LAUNCH_CHECK();
             return SVI_OK;

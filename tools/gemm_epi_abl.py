@@ -1,4 +1,5 @@
-"""Sweep SVI_GEMM_STAGGER (phases, sleeps) on the C2 GEMM shapes.   python tools/gemm_stagger.py"""
+"""Epilogue timing ablations of the 256^2 GEMM on the C2 shapes (SVI_GEMM_EPI_ABL: 0 full, 1 no epilogue, 2 no global stores,
+3 stop after the LDS staging writes; results are wrong for != 0).   python tools/gemm_epi_abl.py"""
 import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd"))
@@ -10,7 +11,7 @@ lib = L.lib(); st = L.current_stream()
 rnd = lambda *s, scale=1.0: (torch.randn(s, generator=g, device=dev) * scale).to(torch.bfloat16)
 SHAPES = {"ffn1 gelu": (Ltok, F, D, L.EPI_BIAS_GELU_TANH), "ffn2 gate+res": (Ltok, D, F, L.EPI_BIAS_GATE_RES),
           "qkv": (Ltok, D, D, L.EPI_BIAS), "attn_o gate+res": (Ltok, D, D, L.EPI_BIAS_GATE_RES)}
-SETS = ["0,0", "-1,0", "-2,0", "-3,0"]
+SETS = ["0", "1", "2", "3"]
 for name, (M, N, K, epi) in SHAPES.items():
     x = rnd(M, K); w = rnd(N, K, scale=K ** -0.5); b = rnd(N); gate = torch.randn(N, generator=g, device=dev); res = rnd(M, N)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
@@ -20,7 +21,7 @@ for name, (M, N, K, epi) in SHAPES.items():
     times = {s: [] for s in SETS}
     for _ in range(5):
         for sset in SETS:
-            os.environ["SVI_GEMM_STAGGER"] = sset
+            os.environ["SVI_GEMM_EPI_ABL"] = sset
             run(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
