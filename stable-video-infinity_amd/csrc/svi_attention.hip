@@ -317,9 +317,21 @@ __device__ __forceinline__ void qk_mfma(int& tok, f32x16& s, u32x4 kf, int& apin
 #define SVI_EXP1 "v_exp_f32 %[t1], %[x1]\n\t"
 #define SVI_MEXP0 "v_mul_f32 %[t0], %[x0], %[c]\n\tv_exp_f32 %[t0], %[t0]\n\t"
 #define SVI_MEXP1 "v_mul_f32 %[t1], %[x1], %[c]\n\tv_exp_f32 %[t1], %[t1]\n\t"
+#ifndef SVI_FLASH_SUM_DOT2     /* default: fp32 row sums of the unrounded p, one v_add per score */
 #define SVI_ADD0 "v_add_f32 %[a0], %[a0], %[t0]\n\t"
 #define SVI_ADD1 "v_add_f32 %[a1], %[a1], %[t1]\n\t"
-#define SVI_CVT "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]\n\t"
+#define SVI_DOT ""
+#define SVI_ADDU0 "v_add_f32 %[a0], %[a0], %[u0]\n\t"
+#else
+/* -DSVI_FLASH_SUM_DOT2 (tools/build_variant.py): row sum += lo + hi of the PACKED pair with one v_dot2c_f32_bf16 against bf16 (1, 1),
+   i.e. exp, exp, pack, dot instead of exp, exp, add, add, pack.  Measured on one box, same process order: 5.52 ms vs 5.09 ms per
+   launch — the dot instruction costs far more than the two adds it replaces.  Kept only as a recorded negative result. */
+#define SVI_ADD0 ""
+#define SVI_ADD1 ""
+#define SVI_DOT "v_dot2c_f32_bf16 %[a1], 0x3f803f80, %[w]\n\t"
+#define SVI_ADDU0 ""
+#endif
+#define SVI_CVT "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]\n\t" SVI_DOT
 #define SVI_MAX3 "v_max3_f32 %[m], %[m], %[y0], %[y1]\n\t"
 #define SVI_DMA_M0 "s_mov_b32 m0, %[m0v]\n\t"        /* in front of the MFMA: the MFMA is the wait state m0 needs */
 #define SVI_DMA "buffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
@@ -365,9 +377,9 @@ __device__ __forceinline__ void qk_stmt(int& tok, f32x16& s, u32x4 kf, u32x4 kf2
         else asm volatile(SVI_DMA_M0 SVI_EXP1 SVI_QKN SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_QK_OUT("+v"), [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x1] "v"(x1), [t0] "v"(t0), SVI_DMA_IN);
     } else {   // E2, never FIRST, never DMA
         float u0;
-        if constexpr (MULC) asm("v_mul_f32 %[u0], %[x0], %[c]\n\tv_exp_f32 %[u0], %[u0]\n\t" SVI_MEXP1 SVI_QKN "v_add_f32 %[a0], %[a0], %[u0]\n\t" SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[u0], %[t1]\n\t" SVI_END
+        if constexpr (MULC) asm("v_mul_f32 %[u0], %[x0], %[c]\n\tv_exp_f32 %[u0], %[u0]\n\t" SVI_MEXP1 SVI_QKN SVI_ADDU0 SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[u0], %[t1]\n\t" SVI_DOT SVI_END
                                 : SVI_QK_OUT("+v"), [u0] "=&v"(u0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c));
-        else asm("v_exp_f32 %[u0], %[x0]\n\t" SVI_EXP1 SVI_QKN "v_add_f32 %[a0], %[a0], %[u0]\n\t" SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[u0], %[t1]\n\t" SVI_END
+        else asm("v_exp_f32 %[u0], %[x0]\n\t" SVI_EXP1 SVI_QKN SVI_ADDU0 SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[u0], %[t1]\n\t" SVI_DOT SVI_END
                  : SVI_QK_OUT("+v"), [u0] "=&v"(u0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x0] "v"(x0), [x1] "v"(x1));
     }
 }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvi_hip.so")
+LIB_PATH = os.environ.get("SVI_HIP_LIB") or os.path.join(_HERE, "libsvi_hip.so")   # SVI_HIP_LIB: A/B a variant build (tools/build_variant.py)
 
 SVI_OK = 0
 SVI_BF16, SVI_F32 = 0, 1

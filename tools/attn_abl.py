@@ -14,7 +14,7 @@ sq = sk = 32760; n = 12
 q, k, v = [(torch.randn((1, sq, n * 128), generator=g, device=dev)).to(torch.bfloat16) for _ in range(3)]
 os.environ["SVI_FLASH_KERNEL"] = "2"
 os.environ["SVI_FLASH_ASSUME_PRESCALED"] = "1"
-variants = ["0", "4", "8", "15", "0"]
+variants = (os.environ.get("ATTN_ABL_SET") or "0,4,8,15,0").split(",")
 times = {a: [] for a in variants}
 variants_run = list(variants)
 q_scaled = (q.float() * (1.4426950408889634 / 128 ** 0.5)).to(torch.bfloat16)   # what the DiT's RMSNorm+RoPE kernel hands over
