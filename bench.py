@@ -259,7 +259,7 @@ def main() -> None:
         "value": round(value, 5), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
-        "config": {"workload": wl["desc"], "step": f"1 scheduler step = cond+uncond DiT forward ({NL} blocks) + CFG + Euler",
+        "config": {"workload": wl["desc"], "step": f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
                    "steps_per_clip": spc, "tokens": L, "clips_per_gpu": 0.5 if pair else 1,
                    "parallelism": f"cfg-pair x{units} clips" if pair else f"clip-per-rank x{world}",
                    "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),

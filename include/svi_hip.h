@@ -97,6 +97,15 @@ svi_status svi_dit_forward(svi_dit* h, const void* x, const float* timestep, con
                            void* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc,
                            svi_stream stream);
 
+/* The two forwards of one classifier-free-guidance step — model_fn_wan_video(dit, latents, timestep, **prompt_emb_posi, ...) and
+ * the same call with prompt_emb_nega (pipelines/svi_video.py:401-408) — in one call.  They share latents and timestep, so the
+ * timestep embedding, patchify and block 0's self-attention (everything that precedes the first use of the prompt) are
+ * computed once.  out_cond / out_uncond are bit-identical to two svi_dit_forward calls with the respective context. */
+svi_status svi_dit_forward_cfg_pair(svi_dit* h, const void* x, const float* timestep, const void* context_cond,
+                                    const void* context_uncond, const void* clip_feature, const void* y,
+                                    const void* add_condition, void* out_cond, void* out_uncond, int32_t B, int32_t T,
+                                    int32_t H, int32_t W, int32_t Lc, svi_stream stream);
+
 /* Hoists what depends only on the prompt out of the step loop (SURVEY §8 a2 / f N2): with the cache enabled
  * svi_dit_forward projects a context (text_embedding / img_emb, pipelines/svi_video.py:94-99) and computes every block's
  * cross-attention K / V^T (models/wan_video_dit.py:272-274) ONCE per distinct (context pointer, clip_feature pointer, Lc)

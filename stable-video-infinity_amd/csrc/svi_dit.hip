@@ -43,7 +43,7 @@ struct Workspace {
     int L = 0, Lc = 0;
     char* base = nullptr;
     size_t bytes = 0;
-    bf16 *X, *Hb, *QK, *VT, *Fb, *CTX, *CTXH, *CK, *CVT, *CKi, *CVTi, *A2, *PATCH, *HO, *IMG0, *IMG1;
+    bf16 *X, *X2, *Hb, *QK, *VT, *Fb, *CTX, *CTXH, *CK, *CVT, *CKi, *CVTi, *A2, *PATCH, *HO, *IMG0, *IMG1;
     bf16 *e, *h1, *t, *st, *tmod;
     float *modf, *headf;
     int ldvt = 0, ldcvt = 0, ldcvti = 264, kpatch = 0;
@@ -263,7 +263,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc) {
     const size_t ho_ld = (ho + 7) / 8 * 8;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-    const size_t oX = take((size_t)L * D * 2), oH = take((size_t)L * D * 2), oQK = take((size_t)L * 2 * D * 2);
+    const size_t oX = take((size_t)L * D * 2), oX2 = take((size_t)L * D * 2), oH = take((size_t)L * D * 2), oQK = take((size_t)L * 2 * D * 2);
     const size_t oVT = take(D * ldvt * 2), oF = take((size_t)L * F * 2);
     const size_t oCTX = take(Lctx * D * 2), oCTXH = take((size_t)Lc * D * 2), oCK = take(Lctx * D * 2);
     const size_t oCVT = take(D * ldcvt * 2), oCKi = take((size_t)264 * D * 2), oCVTi = take(D * 264 * 2);
@@ -278,7 +278,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc) {
     SVI_CHECK_HIP(hipMemset(w.base, 0, off));           // V^T pad columns must read as zeros
     w.bytes = off; w.L = L; w.Lc = Lc; w.ldvt = ldvt; w.ldcvt = ldcvt; w.kpatch = kpatch;
     auto P = [&](size_t o) { return reinterpret_cast<bf16*>(w.base + o); };
-    w.X = P(oX); w.Hb = P(oH); w.QK = P(oQK); w.VT = P(oVT); w.Fb = P(oF); w.CTX = P(oCTX); w.CTXH = P(oCTXH);
+    w.X = P(oX); w.X2 = P(oX2); w.Hb = P(oH); w.QK = P(oQK); w.VT = P(oVT); w.Fb = P(oF); w.CTX = P(oCTX); w.CTXH = P(oCTXH);
     w.CK = P(oCK); w.CVT = P(oCVT); w.CKi = P(oCKi); w.CVTi = P(oCVTi); w.A2 = P(oA2); w.PATCH = P(oP); w.HO = P(oHO);
     w.IMG0 = P(oI0); w.IMG1 = P(oI1); w.e = P(oe); w.h1 = P(oh1); w.t = P(ot); w.st = P(ost); w.tmod = P(otm);
     w.modf = reinterpret_cast<float*>(w.base + omodf);
@@ -329,16 +329,13 @@ static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16
 
 struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; };
 
-static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
-                            const CtxKV& kv, hipStream_t st) {
+// The self-attention third of a block: reads and updates X, depends on (x, t) only — not on the prompt.
+static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* modf, int L, hipStream_t st) {
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
     Workspace& w = h->ws;
-    const int D = c.dim, F = c.ffn_dim, H = c.num_heads;
-    const int img = c.has_image_input ? 257 : 0;
-    const bf16* ctx_txt = CTX + (size_t)img * D;
-    const float *sh_a = modf, *sc_a = modf + D, *g_a = modf + 2 * D, *sh_m = modf + 3 * D, *sc_m = modf + 4 * D,
-                *g_m = modf + 5 * D;
+    const int D = c.dim, H = c.num_heads;
+    const float *sh_a = modf, *sc_a = modf + D, *g_a = modf + 2 * D;
     // --- self attention: x += gate_msa * o(attn(rope(rms(q)), rope(rms(k)), v))     dit:358,369,226-242
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_a, sc_a, st)); }
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
@@ -348,6 +345,19 @@ static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, con
     { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK + D, 2 * D, L, D, b.sa.norm_k, c.eps, &h->rope, 1.0f, st)); }
     { SviProfScope _p(PROF_FLASH_SELF, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.QK + D, 2 * D, w.VT, w.ldvt, w.Hb, D, L, L, H, 1, st)); }
     { SviProfScope _p(PROF_GEMM_O, st); SVI_TRY(linear(w.Hb, D, b.sa.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D)); }
+    return SVI_OK;
+}
+
+// Cross-attention and MLP thirds of a block.
+static svi_status run_block_rest(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
+                                 const CtxKV& kv, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const BlockW& b = h->blocks[layer];
+    Workspace& w = h->ws;
+    const int D = c.dim, F = c.ffn_dim, H = c.num_heads;
+    const int img = c.has_image_input ? 257 : 0;
+    const bf16* ctx_txt = CTX + (size_t)img * D;
+    const float *sh_m = modf + 3 * D, *sc_m = modf + 4 * D, *g_m = modf + 5 * D;
     // --- cross attention: x += o(attn(rms(q(norm3 x)), rms(k ctx), v ctx) [+ image branch])   dit:370,266-303
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, b.norm3_w, b.norm3_b, nullptr, nullptr, st)); }
     { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
@@ -375,6 +385,12 @@ static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, con
     return SVI_OK;
 }
 
+static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
+                            const CtxKV& kv, hipStream_t st) {
+    SVI_TRY(run_block_self(h, layer, X, modf, L, st));
+    return run_block_rest(h, layer, X, CTX, modf, L, Lc, kv, st);
+}
+
 // modf[i][c] = bf16(modulation[i][c] + t_mod[i][c]); rows in scale_mask store bf16(1 + that)
 // (DiTBlock.forward models/wan_video_dit.py:356-357, modulate :150-151, Head.forward :402)
 __global__ void mod_prepare_one_kernel(const bf16* __restrict__ modulation, const bf16* __restrict__ tmod,
@@ -397,17 +413,15 @@ static svi_status mod_one(const bf16* modulation, const bf16* tmod, float* modf,
     return SVI_OK;
 }
 
-static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, const bf16* context, const bf16* clip,
-                              const bf16* y, const bf16* addc, bf16* out, int T, int H, int W, int Lc, hipStream_t st) {
+// ---- stages of one forward (svi_video.py:74-137).  forward_one() runs them in the reference's order; forward_pair() shares
+// the stages that do not depend on the prompt between the conditional and the unconditional forward of a CFG step.
+struct CtxUse { CtxEntry* ce; bf16* CTXp; bool compute; };
+
+// timestep embedding -> t, t_mod, per-block modulation rows                     svi_video.py:92-93
+static svi_status stage_time(svi_dit* h, const float* timestep, hipStream_t st) {
     const svi_dit_config& c = h->cfg;
     const int D = c.dim;
-    const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
-    const int L = f * hh * ww;
-    SVI_TRY(ensure_workspace(h, L, Lc));
-    SVI_TRY(ensure_rope(h, f, hh, ww));
     Workspace& w = h->ws;
-    const int img = c.has_image_input ? 257 : 0;
-    // --- timestep embedding -> t, t_mod                              svi_video.py:92-93
     hipLaunchKernelGGL(sinusoid_kernel, dim3((c.freq_dim / 2 + 63) / 64), dim3(64), 0, st, timestep, w.e, c.freq_dim);
     SVI_LAUNCH_CHECK();
     SVI_TRY(linear(w.e, c.freq_dim, h->time0, w.h1, D, 1, D, c.freq_dim, SVI_EPI_BIAS_SILU, st));
@@ -418,7 +432,15 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
     for (int l = 0; l < c.num_layers; ++l)
         SVI_TRY(mod_one(h->blocks[l].modulation, w.tmod, w.modf + (size_t)l * 6 * D, D, 6, (1 << 1) | (1 << 4), 6, st));
     SVI_TRY(mod_one(h->head_mod, w.t, w.headf, D, 2, 1 << 1, 1, st));
-    // --- text (and CLIP image) context                                svi_video.py:94-99
+    return SVI_OK;
+}
+
+// text (and CLIP image) context: projected here or taken from the context cache      svi_video.py:94-99
+static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* clip, const bf16* y, int Lc, CtxUse* use, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const int D = c.dim;
+    Workspace& w = h->ws;
+    const int img = c.has_image_input ? 257 : 0;
     CtxEntry* ce = nullptr;
     bool ctx_compute = true;
     if (h->ctx_cache_on) {
@@ -465,31 +487,91 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
     } else if (img) {
         SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
     }
-    // --- patchify                                                     svi_video.py:101, dit:473-477
-    {
-        const int64_t n = (int64_t)L * w.kpatch;
-        hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, w.PATCH, 16,
-                           c.in_dim - 16, T, H, W, c.patch_t, c.patch_h, c.patch_w, w.kpatch, L);
-        SVI_LAUNCH_CHECK();
-        Lin pe{h->patch_w, h->patch_b};
-        SVI_TRY(linear(w.PATCH, w.kpatch, pe, w.X, D, L, D, w.kpatch, SVI_EPI_BIAS, st));
-        if (addc) SVI_TRY(svi_launch_add_bf16(w.X, addc, (int64_t)L * D, st));
-    }
-    // --- blocks
-    for (int l = 0; l < c.num_layers; ++l) {
-        CtxKV kv{ce ? ce->CK[l] : w.CK, ce ? ce->CVT[l] : w.CVT, ce ? ce->CKi[l] : w.CKi, ce ? ce->CVTi[l] : w.CVTi, ctx_compute};
-        SVI_TRY(run_block(h, l, w.X, CTXp, w.modf + (size_t)l * 6 * D, L, Lc, kv, st));
-    }
-    // --- head + unpatchify                                            dit:401-404,479-484
-    {
-        const int ho = c.out_dim * c.patch_t * c.patch_h * c.patch_w;
-        const int ho_ld = (ho + 7) / 8 * 8;
-        SVI_TRY(svi_launch_ln_mod(w.X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, w.headf, w.headf + D, st));
-        SVI_TRY(linear(w.Hb, D, h->head, w.HO, ho_ld, L, ho, D, SVI_EPI_BIAS, st));
-        const int64_t n = (int64_t)c.out_dim * T * H * W;
-        hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.HO, out, c.out_dim, T,
-                           H, W, c.patch_t, c.patch_h, c.patch_w, ho_ld);
-        SVI_LAUNCH_CHECK();
+    use->ce = ce; use->CTXp = CTXp; use->compute = ctx_compute;
+    return SVI_OK;
+}
+
+// patchify -> X                                                                svi_video.py:101, dit:473-477
+static svi_status stage_embed(svi_dit* h, const bf16* x, const bf16* y, const bf16* addc, int T, int H, int W, int L, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    Workspace& w = h->ws;
+    const int64_t n = (int64_t)L * w.kpatch;
+    hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, w.PATCH, 16,
+                       c.in_dim - 16, T, H, W, c.patch_t, c.patch_h, c.patch_w, w.kpatch, L);
+    SVI_LAUNCH_CHECK();
+    Lin pe{h->patch_w, h->patch_b};
+    SVI_TRY(linear(w.PATCH, w.kpatch, pe, w.X, c.dim, L, c.dim, w.kpatch, SVI_EPI_BIAS, st));
+    if (addc) SVI_TRY(svi_launch_add_bf16(w.X, addc, (int64_t)L * c.dim, st));
+    return SVI_OK;
+}
+
+static CtxKV kv_of(svi_dit* h, const CtxUse& u, int l) {
+    Workspace& w = h->ws;
+    return CtxKV{u.ce ? u.ce->CK[l] : w.CK, u.ce ? u.ce->CVT[l] : w.CVT, u.ce ? u.ce->CKi[l] : w.CKi, u.ce ? u.ce->CVTi[l] : w.CVTi, u.compute};
+}
+
+// head + unpatchify                                                            dit:401-404,479-484
+static svi_status stage_head(svi_dit* h, bf16* out, int T, int H, int W, int L, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    Workspace& w = h->ws;
+    const int D = c.dim;
+    const int ho = c.out_dim * c.patch_t * c.patch_h * c.patch_w;
+    const int ho_ld = (ho + 7) / 8 * 8;
+    SVI_TRY(svi_launch_ln_mod(w.X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, w.headf, w.headf + D, st));
+    SVI_TRY(linear(w.Hb, D, h->head, w.HO, ho_ld, L, ho, D, SVI_EPI_BIAS, st));
+    const int64_t n = (int64_t)c.out_dim * T * H * W;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.HO, out, c.out_dim, T,
+                       H, W, c.patch_t, c.patch_h, c.patch_w, ho_ld);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, const bf16* context, const bf16* clip,
+                              const bf16* y, const bf16* addc, bf16* out, int T, int H, int W, int Lc, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const int D = c.dim;
+    const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
+    const int L = f * hh * ww;
+    SVI_TRY(ensure_workspace(h, L, Lc));
+    SVI_TRY(ensure_rope(h, f, hh, ww));
+    Workspace& w = h->ws;
+    SVI_TRY(stage_time(h, timestep, st));
+    CtxUse cu{};
+    SVI_TRY(stage_context(h, context, clip, y, Lc, &cu, st));
+    SVI_TRY(stage_embed(h, x, y, addc, T, H, W, L, st));
+    for (int l = 0; l < c.num_layers; ++l)
+        SVI_TRY(run_block(h, l, w.X, cu.CTXp, w.modf + (size_t)l * 6 * D, L, Lc, kv_of(h, cu, l), st));
+    return stage_head(h, out, T, H, W, L, st);
+}
+
+// The two forwards of a classifier-free-guidance step (svi_video.py:401-408) see the same latents and timestep and differ only
+// in the prompt embedding, which first enters in block 0's cross-attention.  Everything before that — timestep embedding and
+// the 31 modulation rows, patchify + patch embedding, and block 0's self-attention third (LN, q/k/v, RMSNorm+RoPE, flash, o) —
+// is computed once and its X snapshot restored for the second forward: 1/60 of a step's self-attention work, results bit-
+// identical to two svi_dit_forward calls (same kernels on the same operands; tests/test_gpu_dit.py).
+static svi_status forward_pair(svi_dit* h, const bf16* x, const float* timestep, const bf16* ctx_a, const bf16* ctx_b, const bf16* clip,
+                               const bf16* y, const bf16* addc, bf16* out_a, bf16* out_b, int T, int H, int W, int Lc, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const int D = c.dim;
+    const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
+    const int L = f * hh * ww;
+    SVI_TRY(ensure_workspace(h, L, Lc));
+    SVI_TRY(ensure_rope(h, f, hh, ww));
+    Workspace& w = h->ws;
+    SVI_TRY(stage_time(h, timestep, st));
+    SVI_TRY(stage_embed(h, x, y, addc, T, H, W, L, st));
+    SVI_TRY(run_block_self(h, 0, w.X, w.modf, L, st));
+    SVI_CHECK_HIP(hipMemcpyAsync(w.X2, w.X, (size_t)L * D * 2, hipMemcpyDeviceToDevice, st));
+    const bf16* ctxs[2] = {ctx_a, ctx_b};
+    bf16* outs[2] = {out_a, out_b};
+    for (int k = 0; k < 2; ++k) {
+        if (k) SVI_CHECK_HIP(hipMemcpyAsync(w.X, w.X2, (size_t)L * D * 2, hipMemcpyDeviceToDevice, st));
+        CtxUse cu{};
+        SVI_TRY(stage_context(h, ctxs[k], clip, y, Lc, &cu, st));      // uses w.Hb as scratch for the CLIP branch only: X is untouched
+        SVI_TRY(run_block_rest(h, 0, w.X, cu.CTXp, w.modf, L, Lc, kv_of(h, cu, 0), st));
+        for (int l = 1; l < c.num_layers; ++l)
+            SVI_TRY(run_block(h, l, w.X, cu.CTXp, w.modf + (size_t)l * 6 * D, L, Lc, kv_of(h, cu, l), st));
+        SVI_TRY(stage_head(h, outs[k], T, H, W, L, st));
     }
     return SVI_OK;
 }
@@ -514,6 +596,33 @@ extern "C" svi_status svi_dit_forward(svi_dit* h, const void* x, const float* ti
         const bf16* ab = add_condition ? reinterpret_cast<const bf16*>(add_condition) + (size_t)b * L * c.dim : nullptr;
         bf16* ob = reinterpret_cast<bf16*>(out) + b * (size_t)c.out_dim * thw;
         SVI_TRY(forward_one(h, xb, timestep + b, cb, clb, yb, ab, ob, T, H, W, Lc, st));
+    }
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_forward_cfg_pair(svi_dit* h, const void* x, const float* timestep, const void* context_cond,
+                                               const void* context_uncond, const void* clip_feature, const void* y,
+                                               const void* add_condition, void* out_cond, void* out_uncond, int32_t B, int32_t T,
+                                               int32_t H, int32_t W, int32_t Lc, svi_stream stream) {
+    SVI_REQUIRE(h && x && timestep && context_cond && context_uncond && out_cond && out_uncond, "svi_dit_forward_cfg_pair: null argument");
+    SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward_cfg_pair: bad sizes");
+    const svi_dit_config& c = h->cfg;
+    SVI_REQUIRE(T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0,
+                "latent size %dx%dx%d is not divisible by the patch size", T, H, W);
+    SVI_TRY(svi_dit_check_bound(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t thw = (size_t)T * H * W;
+    const int L = (T / c.patch_t) * (H / c.patch_h) * (W / c.patch_w);
+    for (int b = 0; b < B; ++b) {
+        const bf16* xb = reinterpret_cast<const bf16*>(x) + b * 16 * thw;
+        const bf16* ca = reinterpret_cast<const bf16*>(context_cond) + (size_t)b * Lc * c.text_dim;
+        const bf16* cbn = reinterpret_cast<const bf16*>(context_uncond) + (size_t)b * Lc * c.text_dim;
+        const bf16* clb = clip_feature ? reinterpret_cast<const bf16*>(clip_feature) + (size_t)b * 257 * 1280 : nullptr;
+        const bf16* yb = y ? reinterpret_cast<const bf16*>(y) + b * (size_t)(c.in_dim - 16) * thw : nullptr;
+        const bf16* ab = add_condition ? reinterpret_cast<const bf16*>(add_condition) + (size_t)b * L * c.dim : nullptr;
+        bf16* oa = reinterpret_cast<bf16*>(out_cond) + b * (size_t)c.out_dim * thw;
+        bf16* ob = reinterpret_cast<bf16*>(out_uncond) + b * (size_t)c.out_dim * thw;
+        SVI_TRY(forward_pair(h, xb, timestep + b, ca, cbn, clb, yb, ab, oa, ob, T, H, W, Lc, st));
     }
     return SVI_OK;
 }

@@ -105,6 +105,38 @@ class WanDiT:
 
     __call__ = forward
 
+    def forward_cfg_pair(self, x: torch.Tensor, timestep: torch.Tensor, context_cond: torch.Tensor, context_uncond: torch.Tensor,
+                         clip_feature: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
+                         add_condition: Optional[torch.Tensor] = None, out_cond: Optional[torch.Tensor] = None,
+                         out_uncond: Optional[torch.Tensor] = None):
+        """Both forwards of a CFG step (svi_video.py:401-408) in one call: what precedes the first use of the prompt (timestep
+        embedding, patchify, block 0's self-attention) is computed once; outputs are bit-identical to two forward() calls."""
+        if not x.is_cuda:
+            raise RuntimeError("svi_hip runs on the GPU only")
+        x = x.to(torch.bfloat16).contiguous()
+        context_cond = context_cond.to(torch.bfloat16).contiguous()
+        context_uncond = context_uncond.to(torch.bfloat16).contiguous()
+        if context_cond.shape != context_uncond.shape:
+            raise ValueError("the two prompt embeddings of a CFG pair must have the same shape")
+        timestep = timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        B, _, T, H, W = x.shape
+        if timestep.numel() != B:
+            timestep = timestep.expand(B).contiguous()
+        if clip_feature is not None:
+            clip_feature = clip_feature.to(torch.bfloat16).contiguous()
+        if y is not None:
+            y = y.to(torch.bfloat16).contiguous()
+        if add_condition is not None:
+            add_condition = add_condition.to(torch.bfloat16).contiguous()
+        if out_cond is None:
+            out_cond = torch.empty((B, self.out_dim, T, H, W), dtype=torch.bfloat16, device=x.device)
+        if out_uncond is None:
+            out_uncond = torch.empty((B, self.out_dim, T, H, W), dtype=torch.bfloat16, device=x.device)
+        L.check(L.lib().svi_dit_forward_cfg_pair(self._h, L.ptr(x), L.ptr(timestep), L.ptr(context_cond), L.ptr(context_uncond),
+                                                 L.ptr(clip_feature), L.ptr(y), L.ptr(add_condition), L.ptr(out_cond), L.ptr(out_uncond),
+                                                 B, T, H, W, context_cond.shape[1], L.current_stream()), "svi_dit_forward_cfg_pair")
+        return out_cond, out_uncond
+
     def block_forward(self, layer: int, x: torch.Tensor, context: torch.Tensor, t_mod: torch.Tensor,
                       grid: Tuple[int, int, int]) -> torch.Tensor:
         """x [1, L, dim] (not modified; a copy is updated and returned), context [1, Lc(+257), dim] already

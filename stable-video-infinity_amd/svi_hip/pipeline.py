@@ -44,11 +44,15 @@ class DenoiseLoop:
         if self._cond is None or self._cond.shape != latents.shape:
             self._cond = torch.empty_like(latents)
             self._uncond = torch.empty_like(latents)
-        self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
         if cfg_scale != 1.0:
-            self.dit.forward(latents, timestep, ctx_neg, out=self._uncond, **cond)
+            if ctx_neg.shape == ctx_pos.shape:      # one call: the prompt-independent head of the forward is shared, results unchanged
+                self.dit.forward_cfg_pair(latents, timestep, ctx_pos, ctx_neg, out_cond=self._cond, out_uncond=self._uncond, **cond)
+            else:
+                self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
+                self.dit.forward(latents, timestep, ctx_neg, out=self._uncond, **cond)
             ops.cfg_step_(latents, self._cond, self._uncond, cfg_scale, dsigma)
         else:
+            self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
             ops.cfg_step_(latents, self._cond, None, 1.0, dsigma)
         return latents
 

@@ -150,3 +150,26 @@ def test_context_cache_is_bit_identical(hip, name):
     m.context_cache(False)
     want_half = m.forward(xd, torch.tensor([ts * 0.5]), cd, **kwd)
     assert torch.equal(a1, ref) and torch.equal(a3, ref) and torch.equal(b1, ref2) and torch.equal(a2, want_half)
+
+
+@pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
+@pytest.mark.parametrize("cache", [False, True])
+def test_cfg_pair_is_bit_identical_to_two_forwards(hip, name, cache):
+    """svi_dit_forward_cfg_pair shares the prompt-independent head of the forward (time embedding, patchify, block 0's
+    self-attention) between the cond and uncond forwards of a step: same bits as two svi_dit_forward calls."""
+    c, grid, nt, nv, ts, seed = CASES[name]
+    m, _ = build(hip, c, seed)
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    kw = {k: dev(v) for k, v in kw.items()}
+    cp, cn = dev(ctx), dev(-np.asarray(ctx))
+    t = torch.tensor([ts])
+    a = m.forward(dev(x), t, cp, **kw).clone()
+    b = m.forward(dev(x), t, cn, **kw).clone()
+    m.context_cache(cache)
+    try:
+        for _ in range(2):                         # second round is served from the context cache when it is on
+            pa, pb = m.forward_cfg_pair(dev(x), t, cp, cn, **kw)
+            assert torch.equal(pa, a) and torch.equal(pb, b)
+    finally:
+        m.context_cache(False)
+    assert not torch.equal(a, b)
