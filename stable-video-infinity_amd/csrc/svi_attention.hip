@@ -325,7 +325,10 @@ __device__ __forceinline__ void qk_mfma(int& tok, f32x16& s, u32x4 kf, int& apin
 #else
 /* -DSVI_FLASH_SUM_DOT2 (tools/build_variant.py): row sum += lo + hi of the PACKED pair with one v_dot2c_f32_bf16 against bf16 (1, 1),
    i.e. exp, exp, pack, dot instead of exp, exp, add, add, pack.  Measured on one box, same process order: 5.52 ms vs 5.09 ms per
-   launch — the dot instruction costs far more than the two adds it replaces.  Kept only as a recorded negative result. */
+   launch — the dot instruction costs far more than the two adds it replaces.  Kept only as a recorded negative result.
+   The same holds for v_pk_add_f32 (pairs of exponentials in aligned register pairs, one packed add per pair, added one
+   statement late): correct, no register copies, and 5.53 ms vs 5.01 ms.  On this part a VOP3P instruction in an MFMA shadow
+   costs more than two plain VOP2 adds; the softmax stays on v_add / v_max3 / v_cvt_pk. */
 #define SVI_ADD0 ""
 #define SVI_ADD1 ""
 #define SVI_DOT "v_dot2c_f32_bf16 %[a1], 0x3f803f80, %[w]\n\t"
