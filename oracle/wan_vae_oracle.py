@@ -183,8 +183,10 @@ def vae_encode(sd: Dict[str, Tensor], video: Tensor) -> Tensor:
 def image_condition(sd: Dict[str, Tensor], first_frames: Tensor, random_ref_frame, num_frames: int, ref_pad_cfg: bool = False,
                     ref_pad_num: int = 0) -> Tensor:
     """first_frames [n,3,H,W] in [-1,1] -> y [1,20,T',H/8,W/8] fp32 = cat(mask, vae_encode([motion frames | padding])).
-    Parity note: no golden vector pins this function (the reference method needs the whole pipeline object); it restates
-    svi_video.py line by line: mask :319-327, conditioned frames :329-335, padding :337-347, encode + concat :349-351."""
+    Pinned: tests/golden/image_condition.npz holds y as returned by the reference's own encode_images_adaptive (compiled out
+    of pipelines/svi_video.py by tests/gen_golden.py, run on a stand-in pipeline object with the seeded reference VAE);
+    tests/test_conditioning.py checks this restatement against it.  Line map: mask :319-327, conditioned frames :329-335,
+    padding :337-347, encode + concat :349-351."""
     n, _, H, W = first_frames.shape
     msk = torch.ones(1, num_frames, H // 8, W // 8)
     if ref_pad_cfg:

@@ -157,6 +157,58 @@ def gen_vae(vae_mod):
     np.savez(os.path.join(OUT, "vae.npz"), **out)
 
 
+def _reference_method(rel_path, class_name, func_name, namespace):
+    """Compile ONE method of a reference class out of its source file (the pipeline modules cannot be imported whole here:
+    transformers/ftfy/imageio...) and return it as a plain function.  The reference code is executed, not copied."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, rel_path)).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == class_name:
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name == func_name:
+                    mod = ast.Module(body=[fn], type_ignores=[])
+                    exec(compile(mod, os.path.join(REF, rel_path), "exec"), namespace)
+                    return namespace[func_name]
+    raise KeyError((rel_path, class_name, func_name))
+
+
+def gen_image_condition(vae_mod):
+    """SVIVideoPipeline.encode_images_adaptive (pipelines/svi_video.py:291-364) run on a stand-in `self` that carries the
+    reference VAE (seeded weights), BasePipeline.preprocess_image and a CLIP stub: pins row a22 (y = mask | VAE latent)."""
+    from PIL import Image
+    ns = {"torch": torch, "np": np}
+    encode_images_adaptive = _reference_method("diffsynth/pipelines/svi_video.py", "SVIVideoPipeline", "encode_images_adaptive", ns)
+    preprocess_image = _reference_method("diffsynth/pipelines/base.py", "BasePipeline", "preprocess_image", ns)
+    v = vae_mod.WanVideoVAE()
+    v.load_state_dict({k: t(a) for k, a in synth.vae_state_dict(500).items()}, strict=True)
+
+    class Clip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def encode_image(self, images):
+            return torch.zeros(1, 257, 1280)
+
+    class Self:
+        torch_dtype = torch.bfloat16
+        device = "cpu"
+
+    me = Self()
+    me.vae, me.image_encoder = v, Clip()
+    me.preprocess_image = lambda image, use_aug=False: preprocess_image(me, image, use_aug)
+    H, W, T = 32, 48, 9
+    out = {}
+    with torch.no_grad():
+        for i, (name, n, cfg, pad) in enumerate(synth.IMAGE_CONDITION_CASES):
+            frames = [Image.fromarray(a) for a in synth.condition_frames(600 + i, n, H, W)]
+            ref = Image.fromarray(synth.condition_frames(650 + i, 1, H, W)[0])
+            r = encode_images_adaptive(me, frames, ref, T, H, W, use_first_aug=False, ref_pad_cfg=cfg, ref_pad_num=pad)
+            assert r["y"].dtype == torch.bfloat16 and tuple(r["y"].shape) == (1, 20, 3, 4, 6)
+            out[name] = r["y"].float().numpy()
+    np.savez(os.path.join(OUT, "image_condition.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -167,6 +219,7 @@ def main():
     dit_case(dit_mod, "tiny_i2v", synth.TINY_DIT_I2V, (2, 4, 4), 16, 10, 92.5926, 200)
     gen_denoise(dit_mod, fm)
     gen_vae(vae_mod)
+    gen_image_condition(vae_mod)
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

@@ -186,3 +186,18 @@ def text_context(seed: int, tokens: int, text_dim: int, valid: int) -> np.ndarra
     c = randn(seed, 1, tokens, text_dim)
     c[:, valid:] = 0
     return c
+
+
+def condition_frames(seed: int, n: int, height: int, width: int) -> np.ndarray:
+    """uint8 RGB frames [n, height, width, 3] (what the clip loop hands to encode_images_adaptive as PIL images)."""
+    return np.random.RandomState(seed).randint(0, 256, size=(n, height, width, 3)).astype(np.uint8)
+
+
+def frames_to_tensor(frames_u8: np.ndarray) -> np.ndarray:
+    """BasePipeline.preprocess_image (pipelines/base.py:44-45) per frame: float32(x) * (2 / 255) - 1, [n, 3, H, W]."""
+    return (frames_u8.astype(np.float32) * (2 / 255) - 1).transpose(0, 3, 1, 2)
+
+
+# (name, number of condition frames, ref_pad_cfg, ref_pad_num): the cases of tests/golden/image_condition.npz
+IMAGE_CONDITION_CASES = [("first_only_zero_pad", 1, False, 0), ("first_only_ref_everywhere", 1, False, -1),
+                         ("two_motion_frames_ref_pad2_cfg", 2, True, 2), ("five_motion_frames_zero_pad", 5, False, 0)]

@@ -44,6 +44,45 @@ def test_oracle_shapes_and_mask():
     assert torch.all(y[0, :4, 0] == 1) and torch.all(y[0, :4, 1] == 0)
 
 
+def _golden_case(i):
+    """Inputs of case i of tests/golden/image_condition.npz (tests/gen_golden.py::gen_image_condition ran the reference's
+    own encode_images_adaptive on these frames): uint8 frames -> preprocess_image's float32 arithmetic."""
+    name, n, cfg, pad = synth.IMAGE_CONDITION_CASES[i]
+    ff = torch.from_numpy(synth.frames_to_tensor(synth.condition_frames(600 + i, n, 32, 48)))
+    ref = torch.from_numpy(synth.frames_to_tensor(synth.condition_frames(650 + i, 1, 32, 48)))[0]
+    return name, n, cfg, pad, ff, ref
+
+
+@pytest.mark.parametrize("i", range(len(synth.IMAGE_CONDITION_CASES)))
+def test_oracle_image_condition_is_pinned_to_reference(golden, i):
+    """Row a22 pinned: the oracle's restatement against y as returned by SVIVideoPipeline.encode_images_adaptive (bf16)."""
+    name, n, cfg, pad, ff, ref = _golden_case(i)
+    sd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()}
+    with torch.no_grad():
+        y = wvo.image_condition(sd, ff, ref, 9, cfg, pad)
+    want = torch.from_numpy(golden("image_condition.npz")[name])
+    assert y.shape == want.shape
+    assert torch.equal(y[0, :4], want[0, :4])                                   # mask: exact
+    got = y.to(torch.bfloat16).float()                                          # the reference returns y in the DiT dtype
+    # same fp32 arithmetic up to summation order: after the bf16 cast at most a few values sit on a rounding boundary
+    diff = (got - want).abs()
+    assert float(diff.max()) <= 2 ** -7 * float(want.abs().max()) and float((diff > 0).float().mean()) < 0.01, (float(diff.max()), float((diff > 0).float().mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(synth.IMAGE_CONDITION_CASES)))
+def test_image_condition_matches_reference_golden(golden, i):
+    import svi_hip
+    name, n, cfg, pad, ff, ref = _golden_case(i)
+    sd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()}
+    v = svi_hip.WanVideoVAE.from_state_dict(sd)
+    got = svi_hip.image_condition(v, ff.cuda(), ref.cuda(), 9, cfg, pad).float().cpu()      # bf16, as the reference returns it
+    want = torch.from_numpy(golden("image_condition.npz")[name])
+    assert got.shape == want.shape and torch.equal(got[0, :4], want[0, :4])
+    diff = (got - want).abs()
+    assert float(diff.max()) <= 2 ** -7 * float(want.abs().max()) and float((diff > 0).float().mean()) < 0.01, (float(diff.max()), float((diff > 0).float().mean()))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_cond,ref_pad_cfg,ref_pad_num", [(1, False, 0), (2, True, 1), (1, False, -1)])
 def test_image_condition_matches_oracle(n_cond, ref_pad_cfg, ref_pad_num):
