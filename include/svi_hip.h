@@ -97,6 +97,17 @@ svi_status svi_dit_forward(svi_dit* h, const void* x, const float* timestep, con
                            void* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc,
                            svi_stream stream);
 
+/* TeaCache support (pipelines/svi_video.py:23-72 class TeaCache, :117-131 its use inside model_fn_wan_video).
+ * svi_dit_time_mod: t_mod bf16 [B, 6, dim], the tensor TeaCache.check() compares between steps (host logic decides).
+ * svi_dit_forward_tea: svi_dit_forward with tea_mode 0 = plain; 1 = run the blocks and write
+ *   residual bf16 [B, L, dim] = bf16(x_after_blocks - x_before_blocks)          (TeaCache.store, :64-66);
+ *   2 = skip the blocks: x = bf16(x_patchified + residual), then the head       (TeaCache.update, :68-70). */
+svi_status svi_dit_time_mod(svi_dit* h, const float* timestep, void* t_mod_out, int32_t B, svi_stream stream);
+svi_status svi_dit_forward_tea(svi_dit* h, const void* x, const float* timestep, const void* context,
+                               const void* clip_feature, const void* y, const void* add_condition, void* out,
+                               int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc, int32_t tea_mode, void* residual,
+                               svi_stream stream);
+
 /* The two forwards of one classifier-free-guidance step — model_fn_wan_video(dit, latents, timestep, **prompt_emb_posi, ...) and
  * the same call with prompt_emb_nega (pipelines/svi_video.py:401-408) — in one call.  They share latents and timestep, so the
  * timestep embedding, patchify and block 0's self-attention (everything that precedes the first use of the prompt) are

@@ -526,8 +526,12 @@ static svi_status stage_head(svi_dit* h, bf16* out, int T, int H, int W, int L, 
     return SVI_OK;
 }
 
+// tea_mode (TeaCache, pipelines/svi_video.py:23-72,117-131): 0 = plain forward; 1 = run the blocks and leave
+// residual = bf16(x_after_blocks - x_before_blocks) in `residual` (TeaCache.store); 2 = skip the blocks, x = bf16(x + residual)
+// (TeaCache.update).  The skip decision itself is host logic on t_mod (svi_dit_time_mod + svi_hip.TeaCache).
 static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, const bf16* context, const bf16* clip,
-                              const bf16* y, const bf16* addc, bf16* out, int T, int H, int W, int Lc, hipStream_t st) {
+                              const bf16* y, const bf16* addc, bf16* out, int T, int H, int W, int Lc, hipStream_t st,
+                              int tea_mode = 0, bf16* residual = nullptr) {
     const svi_dit_config& c = h->cfg;
     const int D = c.dim;
     const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
@@ -536,11 +540,18 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
     SVI_TRY(ensure_rope(h, f, hh, ww));
     Workspace& w = h->ws;
     SVI_TRY(stage_time(h, timestep, st));
+    if (tea_mode == 2) {
+        SVI_TRY(stage_embed(h, x, y, addc, T, H, W, L, st));
+        SVI_TRY(svi_launch_add_bf16(w.X, residual, (int64_t)L * D, st));
+        return stage_head(h, out, T, H, W, L, st);
+    }
     CtxUse cu{};
     SVI_TRY(stage_context(h, context, clip, y, Lc, &cu, st));
     SVI_TRY(stage_embed(h, x, y, addc, T, H, W, L, st));
+    if (tea_mode == 1) SVI_CHECK_HIP(hipMemcpyAsync(w.X2, w.X, (size_t)L * D * 2, hipMemcpyDeviceToDevice, st));
     for (int l = 0; l < c.num_layers; ++l)
         SVI_TRY(run_block(h, l, w.X, cu.CTXp, w.modf + (size_t)l * 6 * D, L, Lc, kv_of(h, cu, l), st));
+    if (tea_mode == 1) SVI_TRY(svi_launch_sub_bf16(residual, w.X, w.X2, (int64_t)L * D, st));
     return stage_head(h, out, T, H, W, L, st);
 }
 
@@ -596,6 +607,49 @@ extern "C" svi_status svi_dit_forward(svi_dit* h, const void* x, const float* ti
         const bf16* ab = add_condition ? reinterpret_cast<const bf16*>(add_condition) + (size_t)b * L * c.dim : nullptr;
         bf16* ob = reinterpret_cast<bf16*>(out) + b * (size_t)c.out_dim * thw;
         SVI_TRY(forward_one(h, xb, timestep + b, cb, clb, yb, ab, ob, T, H, W, Lc, st));
+    }
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_forward_tea(svi_dit* h, const void* x, const float* timestep, const void* context,
+                                          const void* clip_feature, const void* y, const void* add_condition, void* out,
+                                          int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc, int32_t tea_mode, void* residual,
+                                          svi_stream stream) {
+    SVI_REQUIRE(h && x && timestep && context && out, "svi_dit_forward_tea: null argument");
+    SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward_tea: bad sizes");
+    SVI_REQUIRE(tea_mode >= 0 && tea_mode <= 2 && (tea_mode == 0 || residual), "svi_dit_forward_tea: tea_mode %d needs a residual buffer", tea_mode);
+    const svi_dit_config& c = h->cfg;
+    SVI_REQUIRE(T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0,
+                "latent size %dx%dx%d is not divisible by the patch size", T, H, W);
+    SVI_TRY(svi_dit_check_bound(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t thw = (size_t)T * H * W;
+    const int L = (T / c.patch_t) * (H / c.patch_h) * (W / c.patch_w);
+    for (int b = 0; b < B; ++b) {
+        const bf16* xb = reinterpret_cast<const bf16*>(x) + b * 16 * thw;
+        const bf16* cb = reinterpret_cast<const bf16*>(context) + (size_t)b * Lc * c.text_dim;
+        const bf16* clb = clip_feature ? reinterpret_cast<const bf16*>(clip_feature) + (size_t)b * 257 * 1280 : nullptr;
+        const bf16* yb = y ? reinterpret_cast<const bf16*>(y) + b * (size_t)(c.in_dim - 16) * thw : nullptr;
+        const bf16* ab = add_condition ? reinterpret_cast<const bf16*>(add_condition) + (size_t)b * L * c.dim : nullptr;
+        bf16* ob = reinterpret_cast<bf16*>(out) + b * (size_t)c.out_dim * thw;
+        bf16* rb = residual ? reinterpret_cast<bf16*>(residual) + (size_t)b * L * c.dim : nullptr;
+        SVI_TRY(forward_one(h, xb, timestep + b, cb, clb, yb, ab, ob, T, H, W, Lc, st, tea_mode, rb));
+    }
+    return SVI_OK;
+}
+
+// t_mod = time_projection(silu(time_embedding(sinusoidal(t)))) as bf16 [B, 6, dim] (pipelines/svi_video.py:92-93): the quantity
+// TeaCache.check compares between steps (svi_video.py:44-52).
+extern "C" svi_status svi_dit_time_mod(svi_dit* h, const float* timestep, void* t_mod_out, int32_t B, svi_stream stream) {
+    SVI_REQUIRE(h && timestep && t_mod_out && B > 0, "svi_dit_time_mod: bad argument");
+    SVI_TRY(svi_dit_check_bound(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int D = h->cfg.dim;
+    if (!h->ws.base) SVI_TRY(ensure_workspace(h, 256, 8));            // the time path only needs the small scratch rows
+    for (int b = 0; b < B; ++b) {
+        SVI_TRY(stage_time(h, timestep + b, st));
+        SVI_CHECK_HIP(hipMemcpyAsync(reinterpret_cast<bf16*>(t_mod_out) + (size_t)b * 6 * D, h->ws.tmod, (size_t)6 * D * 2,
+                                     hipMemcpyDeviceToDevice, st));
     }
     return SVI_OK;
 }

@@ -254,6 +254,22 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(bf16* __restrict__ a, con
         a[i] = (bf16)((float)a[i] + (float)b[i]);
 }
 
+// out = bf16(a - b): the TeaCache residual, hidden_states - previous_hidden_states (pipelines/svi_video.py:65)
+__global__ __launch_bounds__(256) void sub_bf16_kernel(bf16* __restrict__ out, const bf16* __restrict__ a, const bf16* __restrict__ b, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (bf16)((float)a[i] - (float)b[i]);
+}
+
+svi_status svi_launch_sub_bf16(bf16* out, const bf16* a, const bf16* b, int64_t n, hipStream_t st) {
+    if (n <= 0) return SVI_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sub_bf16_kernel, dim3(blocks), dim3(256), 0, st, out, a, b, n);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
 svi_status svi_launch_add_bf16(bf16* a, const bf16* b, int64_t n, hipStream_t st) {
     if (n <= 0) return SVI_OK;
     int blocks = (int)((n + 255) / 256);

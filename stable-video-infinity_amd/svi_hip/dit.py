@@ -81,7 +81,10 @@ class WanDiT:
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, timestep: torch.Tensor, context: torch.Tensor,
                 clip_feature: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
-                add_condition: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                add_condition: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                tea_mode: int = 0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """tea_mode / residual: TeaCache plumbing (svi_dit_forward_tea): 1 = also write residual [B, L, dim] = x_after_blocks -
+        x_before_blocks, 2 = skip the blocks and add `residual` instead."""
         if not x.is_cuda:
             raise RuntimeError("svi_hip runs on the GPU only")
         x = x.to(torch.bfloat16).contiguous()
@@ -98,9 +101,28 @@ class WanDiT:
             add_condition = add_condition.to(torch.bfloat16).contiguous()
         if out is None:
             out = torch.empty((B, self.out_dim, T, H, W), dtype=torch.bfloat16, device=x.device)
+        if tea_mode:
+            if residual is None or not residual.is_cuda or residual.dtype != torch.bfloat16 or not residual.is_contiguous() \
+                    or residual.numel() != B * self.tokens(T, H, W) * self.dim:
+                raise ValueError("tea_mode needs a contiguous CUDA bf16 residual of shape [B, L, dim]")
+            L.check(L.lib().svi_dit_forward_tea(self._h, L.ptr(x), L.ptr(timestep), L.ptr(context), L.ptr(clip_feature), L.ptr(y),
+                                                L.ptr(add_condition), L.ptr(out), B, T, H, W, context.shape[1], int(tea_mode),
+                                                L.ptr(residual), L.current_stream()), "svi_dit_forward_tea")
+            return out
         L.check(L.lib().svi_dit_forward(self._h, L.ptr(x), L.ptr(timestep), L.ptr(context), L.ptr(clip_feature), L.ptr(y),
                                         L.ptr(add_condition), L.ptr(out), B, T, H, W, context.shape[1],
                                         L.current_stream()), "svi_dit_forward")
+        return out
+
+    def tokens(self, T: int, H: int, W: int) -> int:
+        pt, ph, pw = self.patch_size
+        return (T // pt) * (H // ph) * (W // pw)
+
+    def time_mod(self, timestep: torch.Tensor) -> torch.Tensor:
+        """t_mod bf16 [B, 6, dim] = time_projection(silu(time_embedding(sinusoidal(t)))) (svi_video.py:92-93)."""
+        timestep = timestep.to(device="cuda", dtype=torch.float32).reshape(-1).contiguous()
+        out = torch.empty((timestep.numel(), 6, self.dim), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().svi_dit_time_mod(self._h, L.ptr(timestep), L.ptr(out), timestep.numel(), L.current_stream()), "svi_dit_time_mod")
         return out
 
     __call__ = forward
@@ -155,10 +177,30 @@ def model_fn_wan_video(dit: WanDiT, x: torch.Tensor, timestep: torch.Tensor, con
                        clip_feature: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
                        tea_cache=None, add_condition=None, use_unified_sequence_parallel: bool = False,
                        **kwargs) -> torch.Tensor:
-    """Same signature as pipelines/svi_video.py:74-85.  TeaCache and USP are reference options this backend does not
-    serve: asking for them is an error rather than a silent change of results."""
-    if tea_cache is not None:
-        raise NotImplementedError("TeaCache is not implemented by the HIP backend (pass tea_cache=None)")
+    """Same signature as pipelines/svi_video.py:74-85.
+
+    tea_cache: the reference's TeaCache object (svi_video.py:23-72) or svi_hip.TeaCache — both are driven through their own
+    check(dit, x, t_mod): the skip decision is theirs (host arithmetic on t_mod), the residual bookkeeping is done on the device
+    (`previous_residual` holds our [B, L, dim] buffer).  USP is a reference option this backend does not serve: asking for it is
+    an error rather than a silent change of results."""
     if use_unified_sequence_parallel:
         raise NotImplementedError("USP is not implemented by the HIP backend; clips/CFG shard over ranks instead")
-    return dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition)
+    if tea_cache is None:
+        return dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition)
+    t_mod = dit.time_mod(timestep)
+    # check() clones `x` only to form the residual later (store()); the residual is formed on the device here, so a token suffices
+    skip = tea_cache.check(dit, t_mod[:, :1, :1], t_mod)
+    B, _, T, H, W = x.shape
+    if skip:
+        res = tea_cache.previous_residual
+        if res is None:
+            raise RuntimeError("TeaCache asked to skip before any residual was stored")
+        return dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition, tea_mode=2, residual=res)
+    res = getattr(tea_cache, "_svi_residual", None)
+    if res is None or res.shape != (B, dit.tokens(T, H, W), dit.dim):
+        res = torch.empty((B, dit.tokens(T, H, W), dit.dim), dtype=torch.bfloat16, device=x.device)
+        tea_cache._svi_residual = res
+    out = dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition, tea_mode=1, residual=res)
+    tea_cache.previous_residual = res            # what TeaCache.store() would have computed (svi_video.py:64-66)
+    tea_cache.previous_hidden_states = None
+    return out

@@ -36,8 +36,18 @@ class DenoiseLoop:
         self._cond = self._uncond = None
 
     def step(self, latents: torch.Tensor, timestep: torch.Tensor, dsigma: float, ctx_pos: torch.Tensor,
-             ctx_neg: Optional[torch.Tensor], cfg_scale: float, **cond) -> torch.Tensor:
-        """One scheduler step, in place on `latents` (bf16 [B,16,T,H,W])."""
+             ctx_neg: Optional[torch.Tensor], cfg_scale: float, tea_cache_posi=None, tea_cache_nega=None, **cond) -> torch.Tensor:
+        """One scheduler step, in place on `latents` (bf16 [B,16,T,H,W]).  tea_cache_posi / _nega: one TeaCache per CFG branch
+        (svi_video.py:500-501); with them the two forwards go through model_fn_wan_video separately, as in the reference."""
+        if tea_cache_posi is not None:
+            from .dit import model_fn_wan_video
+            cpred = model_fn_wan_video(self.dit, latents, timestep, ctx_pos, tea_cache=tea_cache_posi, **cond)
+            if cfg_scale != 1.0:
+                upred = model_fn_wan_video(self.dit, latents, timestep, ctx_neg, tea_cache=tea_cache_nega, **cond)
+                ops.cfg_step_(latents, cpred, upred, cfg_scale, dsigma)
+            else:
+                ops.cfg_step_(latents, cpred, None, 1.0, dsigma)
+            return latents
         if self.cfg_pair is not None and cfg_scale != 1.0:
             return self.cfg_pair.step(lambda x, t, c, **kw: self.dit.forward(x, t, c, **kw), ops.cfg_step_, latents, timestep,
                                       dsigma, ctx_pos, ctx_neg, cfg_scale, **cond)
@@ -59,8 +69,15 @@ class DenoiseLoop:
     @torch.no_grad()
     def sample(self, latents: torch.Tensor, ctx_pos: torch.Tensor, ctx_neg: Optional[torch.Tensor],
                num_inference_steps: int = 50, cfg_scale: float = 5.0, sigma_shift: float = 5.0,
-               denoising_strength: float = 1.0, progress_bar_cmd: Callable = lambda x: x, **cond) -> torch.Tensor:
+               denoising_strength: float = 1.0, progress_bar_cmd: Callable = lambda x: x, tea_cache_l1_thresh: Optional[float] = None,
+               tea_cache_model_id: str = "", **cond) -> torch.Tensor:
+        """tea_cache_l1_thresh / tea_cache_model_id: as SVIVideoPipeline.__call__ (svi_video.py:442-443, 500-501); None = off."""
         self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
+        tea = {}
+        if tea_cache_l1_thresh is not None:
+            from .teacache import TeaCache
+            tea = dict(tea_cache_posi=TeaCache(num_inference_steps, tea_cache_l1_thresh, tea_cache_model_id),
+                       tea_cache_nega=TeaCache(num_inference_steps, tea_cache_l1_thresh, tea_cache_model_id))
         latents = latents.to(torch.bfloat16).contiguous().clone()
         ts_dev = self.scheduler.timesteps.to(device=latents.device, dtype=torch.float32)
         # the prompt embeddings are constants of the loop: project them (and every block's cross-attention K / V) once
@@ -71,7 +88,7 @@ class DenoiseLoop:
         self.dit.context_cache(True)
         try:
             for i, t in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
-                self.step(latents, ts_dev[i:i + 1], self.scheduler.step_delta(t), ctx_pos, ctx_neg, cfg_scale, **cond)
+                self.step(latents, ts_dev[i:i + 1], self.scheduler.step_delta(t), ctx_pos, ctx_neg, cfg_scale, **tea, **cond)
         finally:
             self.dit.context_cache(False)
         return latents

@@ -172,6 +172,55 @@ def _reference_method(rel_path, class_name, func_name, namespace):
     raise KeyError((rel_path, class_name, func_name))
 
 
+def _reference_toplevel(rel_path, name, namespace):
+    """Compile ONE top-level class or function of a reference source file (see _reference_method)."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, rel_path)).read())
+    for node in tree.body:
+        if isinstance(node, (ast.ClassDef, ast.FunctionDef)) and node.name == name:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF, rel_path), "exec"), namespace)
+            return namespace[name]
+    raise KeyError((rel_path, name))
+
+
+TEA_STEPS, TEA_THRESH, TEA_MODEL, TEA_TIMESTEPS = synth.TEA_STEPS, synth.TEA_THRESH, synth.TEA_MODEL, synth.TEA_TIMESTEPS
+
+
+def gen_teacache(dit_mod, fm):
+    """The reference's own TeaCache class and model_fn_wan_video (compiled out of pipelines/svi_video.py) driving the reference
+    WanModel (tiny T2V config, seeded) through an 8-step single-branch loop: which steps skip, and every step's output."""
+    ns = {"torch": torch, "np": np, "WanModel": dit_mod.WanModel, "Optional": None,
+          "sinusoidal_embedding_1d": dit_mod.sinusoidal_embedding_1d}
+    TeaCache = _reference_toplevel("diffsynth/pipelines/svi_video.py", "TeaCache", ns)
+    ns["TeaCache"] = TeaCache
+    model_fn = _reference_toplevel("diffsynth/pipelines/svi_video.py", "model_fn_wan_video", ns)
+    c, grid, nt, nv, seed = synth.TINY_DIT, (3, 4, 6), 20, 13, 100
+    m = dit_mod.WanModel(eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    m.load_state_dict({k: t(a) for k, a in synth.dit_state_dict(seed, **c).items()}, strict=True)
+    m = m.to(torch.bfloat16).eval()
+    f, h, w = grid
+    x = t(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w)).to(torch.bfloat16)
+    ctx = t(synth.text_context(seed + 2, nt, c["text_dim"], nv)).to(torch.bfloat16)
+    # Random-init time embeddings are chaotic in t (cos(t) itself turns by radians per unit step), so neighbouring rungs of a
+    # real ladder would always look "far apart"; closely spaced timesteps give the small, varied t_mod changes that make the
+    # accumulate / threshold / reset logic take both branches.
+    timesteps = torch.tensor(TEA_TIMESTEPS, dtype=torch.float32)
+    tc = TeaCache(TEA_STEPS, rel_l1_thresh=TEA_THRESH, model_id=TEA_MODEL)
+    outs, skipped, tmods = [], [], []
+    with torch.no_grad():
+        for i in range(TEA_STEPS):
+            ts = timesteps[i:i + 1]
+            before = tc.previous_residual
+            o = model_fn(m, x, timestep=ts, context=ctx, tea_cache=tc)
+            skipped.append(tc.previous_hidden_states is None and before is tc.previous_residual and i not in (0, TEA_STEPS - 1))
+            outs.append(o.float().numpy())
+            tmods.append(tc.previous_modulated_input.float().numpy())
+            x = (x.float() + 0.05 * o.float()).to(torch.bfloat16)          # any deterministic latent update keeps the loop moving
+    np.savez(os.path.join(OUT, "teacache_tiny.npz"), outs=np.stack(outs), skipped=np.array(skipped), t_mod=np.stack(tmods),
+             timesteps=timesteps.numpy())
+    print("teacache skipped:", skipped)
+
+
 def gen_image_condition(vae_mod):
     """SVIVideoPipeline.encode_images_adaptive (pipelines/svi_video.py:291-364) run on a stand-in `self` that carries the
     reference VAE (seeded weights), BasePipeline.preprocess_image and a CLIP stub: pins row a22 (y = mask | VAE latent)."""
@@ -220,6 +269,7 @@ def main():
     gen_denoise(dit_mod, fm)
     gen_vae(vae_mod)
     gen_image_condition(vae_mod)
+    gen_teacache(dit_mod, fm)
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

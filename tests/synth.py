@@ -201,3 +201,8 @@ def frames_to_tensor(frames_u8: np.ndarray) -> np.ndarray:
 # (name, number of condition frames, ref_pad_cfg, ref_pad_num): the cases of tests/golden/image_condition.npz
 IMAGE_CONDITION_CASES = [("first_only_zero_pad", 1, False, 0), ("first_only_ref_everywhere", 1, False, -1),
                          ("two_motion_frames_ref_pad2_cfg", 2, True, 2), ("five_motion_frames_zero_pad", 5, False, 0)]
+
+
+# tests/golden/teacache_tiny.npz (tests/gen_golden.py::gen_teacache): steps, threshold, model id and the timesteps used
+TEA_STEPS, TEA_THRESH, TEA_MODEL = 8, 0.01, "Wan2.1-T2V-1.3B"
+TEA_TIMESTEPS = [500.0, 500.01, 500.03, 500.035, 500.075, 500.08, 500.15, 500.155]

@@ -76,9 +76,7 @@ def test_model_fn_signature_and_refusals(hip):
     a = hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx))
     b = m.forward(dev(x), torch.tensor([ts]), dev(ctx))
     assert torch.equal(a, b)                       # deterministic: same kernels, same order
-    with pytest.raises(NotImplementedError):
-        hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx), tea_cache=object())
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):        # USP is refused loudly (TeaCache is served: tests/test_teacache.py)
         hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx), use_unified_sequence_parallel=True)
 
 
