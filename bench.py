@@ -225,6 +225,11 @@ def main() -> None:
             vae_ms = None
             vae_note = str(ex)[:120]
 
+    if dist is not None:      # the slowest rank's decode and every rank's finiteness decide, as for the step time
+        red = torch.tensor([vae_ms or 0.0, 0.0 if finite else 1.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        vae_ms = float(red[0].item()) if vae_ms is not None else None
+        finite = red[1].item() == 0.0
     ms_per_step = elapsed * 1000.0 / args.steps
     clip_s_dit = spc * ms_per_step / 1000.0
     clip_s = clip_s_dit + (vae_ms or 0.0) / 1000.0
