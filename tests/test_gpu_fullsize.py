@@ -1,0 +1,106 @@
+"""-m gpu: the hot path at BASELINE.json's full sizes (C2: Wan2.1-1.3B widths, L = 21x30x52 = 32760 tokens), where the CPU
+oracle takes hours.  Checked here: sampled rows against fp64 (the operators are row-separable: a sampled query row / output
+row needs the whole K, V / whole weight but nothing of the other rows), size-independent properties (determinism, the CFG pair
+and the context cache reproducing separate forwards bit for bit), and finiteness.  Inputs are generated on the GPU from seeds.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+L2, D, F, HEADS = 21 * 30 * 52, 1536, 8960, 12
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import svi_hip
+    return svi_hip
+
+
+def _rnd(seed, *shape, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda") * scale).to(torch.bfloat16)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+def test_self_attention_c2_sampled_rows_vs_fp64(hip):
+    """flash_fwd2 at L = 32760, 12 heads: 96 query rows spread over the sequence (first / last rows, block boundaries, the ragged
+    last block) against fp64 softmax(q k^T / sqrt(128)) v over all 32760 keys.  Bound as for the small shapes: rel-L2 <= 6e-3."""
+    q, k, v = _rnd(1, 1, L2, D), _rnd(2, 1, L2, D), _rnd(3, 1, L2, D)
+    out = hip.flash_attention(q, k, v, HEADS)
+    assert out.shape == (1, L2, D) and torch.isfinite(out.float()).all()
+    rows = torch.tensor(sorted(set([0, 1, 63, 64, 255, 256, 257, 4095, 16383, 16384, L2 - 257, L2 - 256, L2 - 2, L2 - 1] +
+                                   list(range(7, L2, L2 // 82)))), device="cuda")
+    qs = q[0, rows].double().view(len(rows), HEADS, 128).transpose(0, 1)              # [h, r, d]
+    kk = k[0].double().view(L2, HEADS, 128).permute(1, 2, 0)                           # [h, d, L]
+    vv = v[0].double().view(L2, HEADS, 128).transpose(0, 1)                           # [h, L, d]
+    p = torch.softmax(qs @ kk / 128 ** 0.5, dim=-1)
+    want = (p @ vv).transpose(0, 1).reshape(len(rows), D)
+    r = _rel(out[0, rows], want)
+    assert r < 6e-3, r
+    assert torch.equal(out, hip.flash_attention(q, k, v, HEADS))                       # deterministic
+
+
+@pytest.mark.parametrize("name,M,N,K,epi", [("qkv", L2, D, D, "bias"), ("ffn1", L2, F, D, "gelu"), ("ffn2", L2, D, F, "gate_res")])
+def test_gemm_c2_sampled_rows_vs_fp64(hip, name, M, N, K, epi):
+    """The 256^2 LDS-DMA kernel at the C2 GEMM shapes (interior tiles, the ragged last row panel M = 127 x 256 + 248, N = 35
+    column panels for ffn1): sampled output rows against fp64 with the epilogue's bf16 rounding points."""
+    from svi_hip import _lib as L
+    x, w, b = _rnd(10, M, K), _rnd(11, N, K, scale=K ** -0.5), _rnd(12, N)
+    res, gate = _rnd(13, M, N), torch.randn(N, generator=torch.Generator(device="cuda").manual_seed(14), device="cuda")
+    out = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    code = {"bias": L.EPI_BIAS, "gelu": L.EPI_BIAS_GELU_TANH, "gate_res": L.EPI_BIAS_GATE_RES}[epi]
+    L.check(L.lib().svi_gemm_bf16(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, b.data_ptr(), 0, code,
+                                  gate.data_ptr() if epi == "gate_res" else None, res.data_ptr() if epi == "gate_res" else None, N,
+                                  L.current_stream()))
+    rows = torch.tensor([0, 1, 127, 128, 255, 256, 511, 12345, 32511, 32512, M - 249, M - 248, M - 2, M - 1], device="cuda")
+    y = (x[rows].double() @ w.double().t() + b.double()).to(torch.bfloat16).double()         # nn.Linear output in bf16
+    if epi == "gelu":
+        y = torch.nn.functional.gelu(y, approximate="tanh")
+    elif epi == "gate_res":
+        y = res[rows].double() + (gate.double() * y).to(torch.bfloat16).double()
+    r = _rel(out[rows], y)
+    assert torch.isfinite(out.float()).all() and r < 4e-3, (name, r)
+
+
+def test_dit_c2_geometry_pair_cache_determinism(hip):
+    """Wan2.1-1.3B widths, 2 blocks, the full C2 latent [1,16,21,60,104]: two runs bit-equal; the CFG pair entry point and the
+    context cache reproduce two separate uncached forwards bit for bit; outputs finite."""
+    import synth
+    c = dict(synth.WAN_1_3B)
+    c["num_layers"] = 2
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sd = {}
+    for name, shape in synth.dit_param_shapes(**c).items():
+        leaf = name.rsplit(".", 1)[-1]
+        fan = 1
+        for s in shape[1:]:
+            fan *= s
+        if leaf == "modulation":
+            t = torch.randn(shape, generator=g, device="cuda") / shape[-1] ** 0.5
+        elif leaf == "weight" and len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device="cuda")
+        elif leaf == "weight":
+            t = (torch.rand(shape, generator=g, device="cuda") * 2 - 1) / fan ** 0.5
+        else:
+            t = (torch.rand(shape, generator=g, device="cuda") * 2 - 1) * 0.05
+        sd[name] = t.to(torch.bfloat16).contiguous()
+    m = hip.WanDiT(eps=1e-6, num_heads=12, **c)
+    m.bind(sd)
+    x = _rnd(20, 1, 16, 21, 60, 104)
+    cp, cn = _rnd(21, 1, 512, 4096), _rnd(22, 1, 512, 4096)
+    t = torch.tensor([991.7355])
+    a, b = m.forward(x, t, cp).clone(), m.forward(x, t, cn).clone()
+    assert torch.isfinite(a.float()).all() and not torch.equal(a, b)
+    assert torch.equal(a, m.forward(x, t, cp))
+    m.context_cache(True)
+    try:
+        for _ in range(2):
+            pa, pb = m.forward_cfg_pair(x, t, cp, cn)
+            assert torch.equal(pa, a) and torch.equal(pb, b)
+    finally:
+        m.context_cache(False)
