@@ -205,34 +205,43 @@ def main() -> None:
         elapsed = float(tmax.item())
     finite = bool(torch.isfinite(lat.float()).all().item())
 
-    # VAE decode of the finished clip (fp32, as pipelines/svi_video.py:385-389), timed once on the same stream
-    vae_ms = None
+    # VAE decode of the finished clip (fp32, as pipelines/svi_video.py:385-389), timed once on the same stream; for the I2V
+    # model also the per-clip conditioning encode y = mask | VAE.encode([motion frame | zeros]) (svi_video.py:291-350)
+    vae_ms, enc_ms = None, None
     if not args.no_vae:
-        try:
-            from svi_hip.vae import WanVideoVAE, device_vae_weights
-            vae = WanVideoVAE.from_state_dict(device_vae_weights(0, dev))
-            z = lat.float()
-            vae.decode(z, device=dev)                      # warm-up (workspace allocation)
+        from svi_hip.vae import WanVideoVAE, device_vae_weights
+        vae = WanVideoVAE.from_state_dict(device_vae_weights(0, dev))
+        z = lat.float()
+        vae.decode(z, device=dev)                      # warm-up (workspace allocation)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        vid = vae.decode(z, device=dev)
+        e1.record()
+        torch.cuda.synchronize()
+        vae_ms = e0.elapsed_time(e1)
+        finite = finite and bool(torch.isfinite(vid).all().item())
+        if cfg["has_image_input"]:
+            first = vid[:, :, :1].permute(0, 2, 1, 3, 4)[0].contiguous()          # the decoded first frame as the motion frame [1,3,H,W]
+            nf = 4 * (T - 1) + 1
+            svi_hip.image_condition(vae, first, None, nf)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            vid = vae.decode(z, device=dev)
+            ycond = svi_hip.image_condition(vae, first, None, nf)
             e1.record()
             torch.cuda.synchronize()
-            vae_ms = e0.elapsed_time(e1)
-            finite = finite and bool(torch.isfinite(vid).all().item())
-        except (ImportError, RuntimeError) as ex:          # VAE kernels not built yet -> DiT-only metric, said so below
-            vae_ms = None
-            vae_note = str(ex)[:120]
+            enc_ms = e0.elapsed_time(e1)
+            finite = finite and bool(torch.isfinite(ycond.float()).all().item())
 
     if dist is not None:      # the slowest rank's decode and every rank's finiteness decide, as for the step time
-        red = torch.tensor([vae_ms or 0.0, 0.0 if finite else 1.0], device=dev, dtype=torch.float64)
+        red = torch.tensor([vae_ms or 0.0, 0.0 if finite else 1.0, enc_ms or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         vae_ms = float(red[0].item()) if vae_ms is not None else None
+        enc_ms = float(red[2].item()) if enc_ms is not None else None
         finite = red[1].item() == 0.0
     ms_per_step = elapsed * 1000.0 / args.steps
     clip_s_dit = spc * ms_per_step / 1000.0
-    clip_s = clip_s_dit + (vae_ms or 0.0) / 1000.0
+    clip_s = clip_s_dit + ((vae_ms or 0.0) + (enc_ms or 0.0)) / 1000.0
     frames = float(T)
     value = units * frames / clip_s
     L = (T // 1) * (H // 2) * (W // 2)
@@ -268,6 +277,7 @@ def main() -> None:
                    "steps_per_clip": spc, "tokens": L, "clips_per_gpu": 0.5 if pair else 1,
                    "parallelism": f"cfg-pair x{units} clips" if pair else f"clip-per-rank x{world}",
                    "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
+                   "vae_condition_encode_ms": None if enc_ms is None else round(enc_ms, 2),
                    "value_includes_vae_decode": vae_ms is not None,
                    "dit_only_value": round(units * frames / clip_s_dit, 5),
                    "dit_tflops": round(2 * flops_forward / (ms_per_step * 1e-3) / 1e12, 1),
