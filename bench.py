@@ -119,6 +119,8 @@ def main() -> None:
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--cfg-pair", action="store_true", help="SURVEY 8e-2: ranks (2p,2p+1) split the cond/uncond forwards of clip p "
                     "(one 4.2 MB all-gather per step); needs an even --gpus. Default is one clip per rank.")
+    ap.add_argument("--seq-parallel", action="store_true", help="SURVEY 8e-3: ONE clip on all ranks (strong scaling): every forward is "
+                    "spread Ulysses-style over the ranks (heads must divide); with --cfg-pair: 2 CFG branches x N/2 sequence shards")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -147,17 +149,23 @@ def main() -> None:
     D, F, NL, heads = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"], cfg["dim"] // 128
     dit = svi_hip.WanDiT(eps=1e-6, num_heads=heads, **cfg)
     dit.bind(device_weights(cfg, 0, dev))
-    pair, units = None, world
-    if args.cfg_pair:
+    pair, units, sp_group, sp = None, world, None, False
+    if args.seq_parallel and dist is not None:
+        sp, units = True, 1
+        if args.cfg_pair:
+            from svi_hip.parallel import split_cfg_sequence
+            pair, sp_group, _ = split_cfg_sequence()
+            sp = dist.get_world_size(sp_group) > 1
+    elif args.cfg_pair:
         assert dist is not None and world % 2 == 0, "--cfg-pair needs an even number of ranks"
         from svi_hip.parallel import CfgPair
         pair, pair_idx, units = CfgPair.split_world()
-    loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair)
+    loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp)
     spc = wl["steps_per_clip"]
     loop.scheduler.set_timesteps(spc, shift=5.0)
 
     # clip `rank` of the rolling window: seed = chunk_idx * 42 (test_svi.py:425), noise from the CPU generator
-    lat = svi_hip.generate_noise((1, 16, T, H, W), seed=(rank // 2 if args.cfg_pair else rank) * 42, device="cpu", dtype=torch.float32).to(dev, torch.bfloat16)
+    lat = svi_hip.generate_noise((1, 16, T, H, W), seed=(0 if args.seq_parallel else rank // 2 if args.cfg_pair else rank) * 42, device="cpu", dtype=torch.float32).to(dev, torch.bfloat16)
     gen = torch.Generator(device=dev).manual_seed(1234)
     ctx_pos = torch.randn((1, wl["lc"], 4096), generator=gen, device=dev).to(torch.bfloat16)
     ctx_neg = torch.randn((1, wl["lc"], 4096), generator=gen, device=dev).to(torch.bfloat16)
@@ -252,7 +260,7 @@ def main() -> None:
     roof = None
     if fl["count"]:
         per_launch_ms = fl["ms"] / fl["count"]
-        alg = 4.0 * L * L * D
+        alg = 4.0 * L * L * D / (dist.get_world_size(sp_group) if sp else 1)      # a sequence-parallel rank attends with heads / S
         ach = alg / (per_launch_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel from PMC counters: collected in separate rocprofv3 --pmc passes
         # (tools/profile_round.sh -> profiles/*_flash_pmc.json, corrected as MI355X_MICROARCH.md prescribes); not measurable live
@@ -271,11 +279,12 @@ def main() -> None:
         "metric": {"c2": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step", "c1": "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",
                    "c4": "denoised latent frames/sec, Wan2.1-I2V-14B 81f@832x480 50-step"}[args.workload],
         "value": round(value, 5), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.seq_parallel else "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
         "config": {"workload": wl["desc"], "step": f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
-                   "steps_per_clip": spc, "tokens": L, "clips_per_gpu": 0.5 if pair else 1,
-                   "parallelism": f"cfg-pair x{units} clips" if pair else f"clip-per-rank x{world}",
+                   "steps_per_clip": spc, "tokens": L, "clips_per_gpu": round(units / world, 4),
+                   "parallelism": (f"one clip: {'cfg-pair x ' if pair else ''}sequence-parallel over {world} ranks" if args.seq_parallel else
+                                   f"cfg-pair x{units} clips" if pair else f"clip-per-rank x{world}"),
                    "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
                    "vae_condition_encode_ms": None if enc_ms is None else round(enc_ms, 2),
                    "value_includes_vae_decode": vae_ms is not None,

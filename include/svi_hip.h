@@ -125,6 +125,29 @@ svi_status svi_dit_forward_cfg_pair(svi_dit* h, const void* x, const float* time
  * (4 entries, least recently used first). */
 svi_status svi_dit_context_cache(svi_dit* h, int32_t enable);
 
+/* Sequence-parallel (Ulysses) pieces of one forward — SURVEY §8e axis 3; the reference's USP path: the token chunk / all_gather of
+ * pipelines/svi_video.py:119-135 and the all-to-all attention of distributed/xdit_context_parallel.py.  A rank owns token rows
+ * [row0, row0 + nrows) of the (f h w) sequence for everything row-local and trades tokens for heads around self-attention; the
+ * exchanges (RCCL all-to-all / all-gather) are the caller's, between these calls (svi_hip/sequence_parallel.py):
+ *   svi_dit_sp_begin        timestep embedding, context (cache honoured), patchify of the rank's rows
+ *   svi_dit_sp_block_qkv    block `layer`: LN + modulate, q | k (RMSNorm + RoPE at the rows' true positions, q pre-scaled by
+ *                           softmax_scale*log2e) -> qk_out bf16 [nrows, 2*dim];  V^T -> vt_out bf16 [dim, ldvt] (cols >= nrows untouched)
+ *   svi_attention_vt_fwd    attention of a head group on those layouts (after the exchange: all tokens, n = heads/P)
+ *   svi_dit_sp_block_rest   attn bf16 [nrows, dim] (after the exchange back) -> output projection + gate + residual,
+ *                           cross-attention, MLP of block `layer`
+ *   svi_dit_sp_head         head rows bf16 [nrows, svi_dit_head_ld]; all-gathered, then svi_dit_unpatchify -> [out_dim, T, H, W]
+ * With one rank (row0 = 0, nrows = L) the sequence is bit-identical to svi_dit_forward. */
+svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* timestep, const void* context, const void* clip_feature,
+                            const void* y, const void* add_condition, int32_t T, int32_t H, int32_t W, int32_t Lc,
+                            int32_t row0, int32_t nrows, svi_stream stream);
+svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* qk_out, void* vt_out, int32_t ldvt, svi_stream stream);
+svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const void* attn, svi_stream stream);
+svi_status svi_dit_sp_head(svi_dit* h, void* head_rows_out, svi_stream stream);
+svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void* out, int32_t T, int32_t H, int32_t W, svi_stream stream);
+int32_t svi_dit_head_ld(svi_dit* h);
+svi_status svi_attention_vt_fwd(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vt, int32_t ldvt, void* out,
+                                int32_t ldo, int32_t s_q, int32_t s_kv, int32_t n, int32_t q_prescaled, svi_stream stream);
+
 /* DiTBlock.forward(x, context, t_mod, freqs) for block `layer` (models/wan_video_dit.py:354-374).
  *   x_inout bf16 [L, dim] (L = f*h*w, updated in place); context bf16 [Lc(+257), dim] ALREADY
  *   projected by text_embedding/img_emb; t_mod bf16 [6, dim]; freqs implied by the (f,h,w) grid. */

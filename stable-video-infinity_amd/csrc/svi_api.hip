@@ -130,6 +130,22 @@ extern "C" svi_status svi_attention_fwd(const void* q, const void* k, const void
     return SVI_OK;
 }
 
+// Attention on the layouts the DiT keeps internally: q / k token-major with row strides, V already transposed
+// (vt [n*128, ldvt], zero beyond s_kv), q optionally pre-multiplied by softmax_scale * log2(e).  The sequence-parallel driver
+// calls it on a head group after the token <-> head exchange.
+extern "C" svi_status svi_attention_vt_fwd(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vt, int32_t ldvt,
+                                           void* out, int32_t ldo, int32_t s_q, int32_t s_kv, int32_t n, int32_t q_prescaled,
+                                           svi_stream stream) {
+    SVI_REQUIRE(q && k && vt && out, "svi_attention_vt_fwd: null argument");
+    SVI_REQUIRE(s_q > 0 && s_kv > 0 && n > 0 && ldq >= n * 128 && ldk >= n * 128 && ldo >= n * 128 && ldvt >= s_kv,
+                "svi_attention_vt_fwd: bad sizes");
+    SVI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "svi_attention_vt_fwd: strides must be multiples of 8 elements");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SviProfScope _p(PROF_FLASH_SELF, st);
+    return svi_launch_flash(reinterpret_cast<const bf16*>(q), ldq, reinterpret_cast<const bf16*>(k), ldk, reinterpret_cast<const bf16*>(vt), ldvt,
+                            reinterpret_cast<bf16*>(out), ldo, s_q, s_kv, n, q_prescaled ? 1 : 0, st);
+}
+
 extern "C" svi_status svi_layernorm_modulate(const void* x, void* out, int32_t rows, int32_t dim, float eps, const void* w,
                                              const void* b, const void* shift, const void* scale, svi_stream stream) {
     SVI_REQUIRE(x && out, "svi_layernorm_modulate: null argument");

@@ -118,6 +118,7 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
 // (row = channel, col = key; columns >= Lk up to the next multiple of 8 must be readable and finite).
 // q_prescaled != 0: Q already carries softmax_scale * log2(e) = 1.4426950408889634 / sqrt(128)  (SVI_QK_SCALE_LOG2E).
 #define SVI_QK_SCALE_LOG2E 0.12751743f
+// (svi_launch_flash: q/k token-major with row strides, V TRANSPOSED [heads*128, ldvt])
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt,
                             bf16* O, int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st);
 
@@ -128,6 +129,7 @@ struct SviRope {                // device tables of (cos,sin) pairs, fp32
     const float2* tab_f; const float2* tab_h; const float2* tab_w;
     int npf, nph, npw;          // complex pairs per head owned by the frame / height / width axis
     int f, h, w;
+    int row0;                   // token index of row 0 of the launch (sequence-parallel shards start mid-grid)
 };
 // out_scale multiplies the result before its single final rounding (the DiT folds the attention scale into q there)
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,

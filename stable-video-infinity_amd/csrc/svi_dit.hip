@@ -66,6 +66,8 @@ struct CtxEntry {
     unsigned long long stamp = 0;
 };
 
+struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; };
+
 struct svi_dit {
     svi_dit_config cfg;
     std::vector<BlockW> blocks;
@@ -84,6 +86,11 @@ struct svi_dit {
     bool ctx_cache_on = false;
     CtxEntry ctx_entries[4];
     unsigned long long ctx_clock = 0;
+    // sequence-parallel shard in flight (svi_dit_sp_begin .. svi_dit_sp_head)
+    int sp_rows = 0, sp_row0 = 0, sp_Lc = 0;
+    bool sp_active = false;
+    const bf16* sp_ctxp = nullptr;
+    std::vector<CtxKV> sp_kv;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -107,10 +114,11 @@ __global__ void silu_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
 
 // patch tokens: P[l][k], k = ((c*pt + a)*ph + b)*pw + cw ; token l = (fi*hh + hi)*ww + wi  (dit:473-477)
 __global__ void patch_gather_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y, bf16* __restrict__ P,
-                                    int Cx, int Cy, int T, int H, int W, int pt, int ph, int pw, int kp, int L) {
+                                    int Cx, int Cy, int T, int H, int W, int pt, int ph, int pw, int kp, int L, int row0) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)L * kp) return;
-    const int l = (int)(idx / kp), k = (int)(idx - (int64_t)l * kp);
+    const int lr = (int)(idx / kp), k = (int)(idx - (int64_t)lr * kp);
+    const int l = lr + row0;                         // token index in the (f h w) grid; row lr of this launch
     const int hh = H / ph, ww = W / pw;
     const int K = (Cx + Cy) * pt * ph * pw;
     if (k >= K) { P[idx] = (bf16)0.f; return; }
@@ -327,25 +335,43 @@ static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16
     return svi_launch_gemm(g, st);
 }
 
-struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; };
-
-// The self-attention third of a block: reads and updates X, depends on (x, t) only — not on the prompt.
-static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* modf, int L, hipStream_t st) {
+// The self-attention third of a block depends on (x, t) only — not on the prompt.  It is written in three pieces so that a
+// sequence-parallel shard can exchange heads for tokens around the attention (svi_dit_sp_*): (1) q | k (RMSNorm + RoPE applied,
+// q pre-scaled) and V^T of the shard's rows [row0, row0 + L), (2) attention, (3) output projection + gate + residual.
+static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* modf, int L, int row0, bf16* QK, bf16* VT, int ldvt,
+                            hipStream_t st) {
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
     Workspace& w = h->ws;
-    const int D = c.dim, H = c.num_heads;
-    const float *sh_a = modf, *sc_a = modf + D, *g_a = modf + 2 * D;
+    const int D = c.dim;
+    const float *sh_a = modf, *sc_a = modf + D;
+    SviRope rope = h->rope;
+    rope.row0 = row0;
     // --- self attention: x += gate_msa * o(attn(rope(rms(q)), rope(rms(k)), v))     dit:358,369,226-242
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_a, sc_a, st)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, w.QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, w.VT, w.ldvt, L, D, D, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.sa.norm_q, c.eps, &h->rope, SVI_QK_SCALE_LOG2E, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK + D, 2 * D, L, D, b.sa.norm_k, c.eps, &h->rope, 1.0f, st)); }
-    { SviProfScope _p(PROF_FLASH_SELF, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.QK + D, 2 * D, w.VT, w.ldvt, w.Hb, D, L, L, H, 1, st)); }
-    { SviProfScope _p(PROF_GEMM_O, st); SVI_TRY(linear(w.Hb, D, b.sa.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(QK, 2 * D, L, D, b.sa.norm_q, c.eps, &rope, SVI_QK_SCALE_LOG2E, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(QK + D, 2 * D, L, D, b.sa.norm_k, c.eps, &rope, 1.0f, st)); }
     return SVI_OK;
+}
+
+static svi_status block_attn_out(svi_dit* h, int layer, bf16* X, const bf16* attn, const float* modf, int L, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const BlockW& b = h->blocks[layer];
+    const int D = c.dim;
+    const float* g_a = modf + 2 * D;
+    { SviProfScope _p(PROF_GEMM_O, st); SVI_TRY(linear(attn, D, b.sa.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D)); }
+    return SVI_OK;
+}
+
+static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* modf, int L, hipStream_t st) {
+    Workspace& w = h->ws;
+    const int D = h->cfg.dim;
+    SVI_TRY(block_qkv(h, layer, X, modf, L, 0, w.QK, w.VT, w.ldvt, st));
+    { SviProfScope _p(PROF_FLASH_SELF, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.QK + D, 2 * D, w.VT, w.ldvt, w.Hb, D, L, L, h->cfg.num_heads, 1, st)); }
+    return block_attn_out(h, layer, X, w.Hb, modf, L, st);
 }
 
 // Cross-attention and MLP thirds of a block.
@@ -492,16 +518,17 @@ static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* cli
 }
 
 // patchify -> X                                                                svi_video.py:101, dit:473-477
-static svi_status stage_embed(svi_dit* h, const bf16* x, const bf16* y, const bf16* addc, int T, int H, int W, int L, hipStream_t st) {
+static svi_status stage_embed(svi_dit* h, const bf16* x, const bf16* y, const bf16* addc, int T, int H, int W, int L, hipStream_t st,
+                              int row0 = 0) {       // row0: first token of a sequence-parallel shard (L = its row count)
     const svi_dit_config& c = h->cfg;
     Workspace& w = h->ws;
     const int64_t n = (int64_t)L * w.kpatch;
     hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, w.PATCH, 16,
-                       c.in_dim - 16, T, H, W, c.patch_t, c.patch_h, c.patch_w, w.kpatch, L);
+                       c.in_dim - 16, T, H, W, c.patch_t, c.patch_h, c.patch_w, w.kpatch, L, row0);
     SVI_LAUNCH_CHECK();
     Lin pe{h->patch_w, h->patch_b};
     SVI_TRY(linear(w.PATCH, w.kpatch, pe, w.X, c.dim, L, c.dim, w.kpatch, SVI_EPI_BIAS, st));
-    if (addc) SVI_TRY(svi_launch_add_bf16(w.X, addc, (int64_t)L * c.dim, st));
+    if (addc) SVI_TRY(svi_launch_add_bf16(w.X, addc + (size_t)row0 * c.dim, (int64_t)L * c.dim, st));
     return SVI_OK;
 }
 
@@ -510,20 +537,28 @@ static CtxKV kv_of(svi_dit* h, const CtxUse& u, int l) {
     return CtxKV{u.ce ? u.ce->CK[l] : w.CK, u.ce ? u.ce->CVT[l] : w.CVT, u.ce ? u.ce->CKi[l] : w.CKi, u.ce ? u.ce->CVTi[l] : w.CVTi, u.compute};
 }
 
-// head + unpatchify                                                            dit:401-404,479-484
-static svi_status stage_head(svi_dit* h, bf16* out, int T, int H, int W, int L, hipStream_t st) {
+// head (dit:401-404): LN + modulation + Linear(dim -> out_dim * patch volume) on the rows in X -> HO [L, ho_ld]
+static int head_ld(const svi_dit_config& c) { return (c.out_dim * c.patch_t * c.patch_h * c.patch_w + 7) / 8 * 8; }
+static svi_status stage_head_rows(svi_dit* h, bf16* HO, int L, hipStream_t st) {
     const svi_dit_config& c = h->cfg;
     Workspace& w = h->ws;
     const int D = c.dim;
     const int ho = c.out_dim * c.patch_t * c.patch_h * c.patch_w;
-    const int ho_ld = (ho + 7) / 8 * 8;
     SVI_TRY(svi_launch_ln_mod(w.X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, w.headf, w.headf + D, st));
-    SVI_TRY(linear(w.Hb, D, h->head, w.HO, ho_ld, L, ho, D, SVI_EPI_BIAS, st));
+    return linear(w.Hb, D, h->head, HO, head_ld(c), L, ho, D, SVI_EPI_BIAS, st);
+}
+// unpatchify (dit:479-484) of all L = f*h*w head rows
+static svi_status stage_unpatchify(svi_dit* h, const bf16* HO, bf16* out, int T, int H, int W, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
     const int64_t n = (int64_t)c.out_dim * T * H * W;
-    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.HO, out, c.out_dim, T,
-                       H, W, c.patch_t, c.patch_h, c.patch_w, ho_ld);
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, HO, out, c.out_dim, T,
+                       H, W, c.patch_t, c.patch_h, c.patch_w, head_ld(c));
     SVI_LAUNCH_CHECK();
     return SVI_OK;
+}
+static svi_status stage_head(svi_dit* h, bf16* out, int T, int H, int W, int L, hipStream_t st) {
+    SVI_TRY(stage_head_rows(h, h->ws.HO, L, st));
+    return stage_unpatchify(h, h->ws.HO, out, T, H, W, st);
 }
 
 // tea_mode (TeaCache, pipelines/svi_video.py:23-72,117-131): 0 = plain forward; 1 = run the blocks and leave
@@ -680,6 +715,66 @@ extern "C" svi_status svi_dit_forward_cfg_pair(svi_dit* h, const void* x, const 
     }
     return SVI_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sequence-parallel (Ulysses) execution of one forward: SURVEY §8e axis 3, the reference's USP path
+// (pipelines/svi_video.py:119-135 chunk / all_gather, distributed/xdit_context_parallel.py usp_attn_forward).  A rank owns the
+// token rows [row0, row0 + nrows) of the (f h w) sequence for everything that is row-local (norms, projections, cross
+// attention, MLP, head) and trades tokens for heads around self-attention.  The exchange itself (RCCL all-to-all) is the
+// caller's (svi_hip/sequence_parallel.py); these entry points are the row-local pieces between the exchanges.
+// ------------------------------------------------------------------------------------------------
+extern "C" svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* timestep, const void* context,
+                                       const void* clip_feature, const void* y, const void* add_condition, int32_t T, int32_t H,
+                                       int32_t W, int32_t Lc, int32_t row0, int32_t nrows, svi_stream stream) {
+    SVI_REQUIRE(h && x && timestep && context, "svi_dit_sp_begin: null argument");
+    const svi_dit_config& c = h->cfg;
+    SVI_REQUIRE(T > 0 && H > 0 && W > 0 && Lc > 0 && T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0, "svi_dit_sp_begin: bad sizes");
+    const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w, L = f * hh * ww;
+    SVI_REQUIRE(row0 >= 0 && nrows > 0 && row0 + nrows <= L, "svi_dit_sp_begin: rows [%d, %d) outside the %d-token sequence", row0, row0 + nrows, L);
+    SVI_TRY(svi_dit_check_bound(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SVI_TRY(ensure_workspace(h, nrows, Lc));
+    SVI_TRY(ensure_rope(h, f, hh, ww));
+    SVI_TRY(stage_time(h, timestep, st));
+    CtxUse cu{};
+    SVI_TRY(stage_context(h, reinterpret_cast<const bf16*>(context), reinterpret_cast<const bf16*>(clip_feature),
+                          reinterpret_cast<const bf16*>(y), Lc, &cu, st));
+    SVI_TRY(stage_embed(h, reinterpret_cast<const bf16*>(x), reinterpret_cast<const bf16*>(y), reinterpret_cast<const bf16*>(add_condition),
+                        T, H, W, nrows, st, row0));
+    h->sp_rows = nrows; h->sp_row0 = row0; h->sp_Lc = Lc; h->sp_active = true; h->sp_ctxp = cu.CTXp;
+    h->sp_kv.clear();
+    for (int l = 0; l < c.num_layers; ++l) h->sp_kv.push_back(kv_of(h, cu, l));
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* qk_out, void* vt_out, int32_t ldvt, svi_stream stream) {
+    SVI_REQUIRE(h && h->sp_active && qk_out && vt_out, "svi_dit_sp_block_qkv: no shard in flight (svi_dit_sp_begin) or null buffer");
+    SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && ldvt >= h->sp_rows && ldvt % 8 == 0, "svi_dit_sp_block_qkv: bad layer / ldvt");
+    return block_qkv(h, layer, h->ws.X, h->ws.modf + (size_t)layer * 6 * h->cfg.dim, h->sp_rows, h->sp_row0,
+                     reinterpret_cast<bf16*>(qk_out), reinterpret_cast<bf16*>(vt_out), ldvt, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const void* attn, svi_stream stream) {
+    SVI_REQUIRE(h && h->sp_active && attn, "svi_dit_sp_block_rest: no shard in flight or null buffer");
+    SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers, "svi_dit_sp_block_rest: bad layer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float* modf = h->ws.modf + (size_t)layer * 6 * h->cfg.dim;
+    SVI_TRY(block_attn_out(h, layer, h->ws.X, reinterpret_cast<const bf16*>(attn), modf, h->sp_rows, st));
+    return run_block_rest(h, layer, h->ws.X, h->sp_ctxp, modf, h->sp_rows, h->sp_Lc, h->sp_kv[layer], st);
+}
+
+extern "C" svi_status svi_dit_sp_head(svi_dit* h, void* head_rows_out, svi_stream stream) {
+    SVI_REQUIRE(h && h->sp_active && head_rows_out, "svi_dit_sp_head: no shard in flight or null buffer");
+    h->sp_active = false;
+    return stage_head_rows(h, reinterpret_cast<bf16*>(head_rows_out), h->sp_rows, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void* out, int32_t T, int32_t H, int32_t W, svi_stream stream) {
+    SVI_REQUIRE(h && head_rows && out && T > 0 && H > 0 && W > 0, "svi_dit_unpatchify: bad argument");
+    return stage_unpatchify(h, reinterpret_cast<const bf16*>(head_rows), reinterpret_cast<bf16*>(out), T, H, W, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t svi_dit_head_ld(svi_dit* h) { return h ? head_ld(h->cfg) : 0; }
 
 extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_inout, const void* context,
                                             const void* t_mod, int32_t f, int32_t hh, int32_t ww, int32_t Lc,

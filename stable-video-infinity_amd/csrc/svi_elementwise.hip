@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
     const float rs = rsqrtf(wave_sum(ss) / (float)dim + eps);
     int pf = 0, ph = 0, pw = 0;
     if (use_rope) {
-        const int hw = r.h * r.w;
-        pf = row / hw;
-        const int rem = row - pf * hw;
+        const int hw = r.h * r.w, tok = row + r.row0;
+        pf = tok / hw;
+        const int rem = tok - pf * hw;
         ph = rem / r.w;
         pw = rem - ph * r.w;
     }
@@ -175,7 +175,7 @@ svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf1
     if (rope) {
         r = *rope;
         SVI_REQUIRE(dim % 128 == 0 && r.npf + r.nph + r.npw == 64, "rope needs head_dim 128");
-        SVI_REQUIRE(r.f * r.h * r.w == rows, "rope grid %dx%dx%d != rows %d", r.f, r.h, r.w, rows);
+        SVI_REQUIRE(r.row0 >= 0 && r.row0 + rows <= r.f * r.h * r.w, "rope grid %dx%dx%d does not cover rows [%d, %d)", r.f, r.h, r.w, r.row0, r.row0 + rows);
     }
     dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
     const int nchunk = dim / 8;

@@ -12,6 +12,7 @@ from .scheduler import FlowMatchScheduler
 from .vae import WanVideoVAE
 from .conditioning import condition_mask, condition_video, image_condition
 from .teacache import TeaCache
+from . import sequence_parallel
 
 __all__ = ["WanDiT", "model_fn_wan_video", "flash_attention", "layernorm_modulate", "rmsnorm_rope_", "linear",
            "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "WanVideoVAE", "condition_mask", "condition_video", "image_condition", "TeaCache", "_lib"]

@@ -34,6 +34,13 @@ SYMBOLS = [
     ("svi_dit_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
     ("svi_dit_check_bound", _i32, [_vp]),
     ("svi_dit_forward", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_dit_sp_begin", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_dit_sp_block_qkv", _i32, [_vp, _i32, _vp, _vp, _i32, _vp]),
+    ("svi_dit_sp_block_rest", _i32, [_vp, _i32, _vp, _vp]),
+    ("svi_dit_sp_head", _i32, [_vp, _vp, _vp]),
+    ("svi_dit_unpatchify", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("svi_dit_head_ld", _i32, [_vp]),
+    ("svi_attention_vt_fwd", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_time_mod", _i32, [_vp, _vp, _vp, _i32, _vp]),
     ("svi_dit_forward_tea", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     ("svi_dit_forward_cfg_pair", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -181,10 +181,18 @@ def model_fn_wan_video(dit: WanDiT, x: torch.Tensor, timestep: torch.Tensor, con
 
     tea_cache: the reference's TeaCache object (svi_video.py:23-72) or svi_hip.TeaCache — both are driven through their own
     check(dit, x, t_mod): the skip decision is theirs (host arithmetic on t_mod), the residual bookkeeping is done on the device
-    (`previous_residual` holds our [B, L, dim] buffer).  USP is a reference option this backend does not serve: asking for it is
-    an error rather than a silent change of results."""
+    (`previous_residual` holds our [B, L, dim] buffer).
+    use_unified_sequence_parallel: with an initialised process group of more than one rank (dit.sp_group, default: the world) the
+    forward is spread Ulysses-style over the ranks (svi_hip/sequence_parallel.py); with one rank it is the plain forward, as in
+    the reference."""
     if use_unified_sequence_parallel:
-        raise NotImplementedError("USP is not implemented by the HIP backend; clips/CFG shard over ranks instead")
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(getattr(dit, "sp_group", None)) > 1:   # svi_video.py:119-121
+            if tea_cache is not None:
+                raise NotImplementedError("TeaCache together with sequence parallelism is not served by the HIP backend")
+            from .sequence_parallel import forward_distributed
+            return forward_distributed(dit, x, timestep, context, group=getattr(dit, "sp_group", None), clip_feature=clip_feature, y=y,
+                                       add_condition=add_condition)
     if tea_cache is None:
         return dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition)
     t_mod = dit.time_mod(timestep)

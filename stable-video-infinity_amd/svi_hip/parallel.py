@@ -129,6 +129,27 @@ class CfgPair:
         return latents
 
 
+def split_cfg_sequence(world: Optional[int] = None, rank: Optional[int] = None):
+    """One clip on an even number of ranks: world = 2 (CFG branches) x S (sequence shards).  Rank r = branch * S + shard:
+    ranks [0, S) carry the conditional forward, [S, 2S) the unconditional one, each spread Ulysses-style over its S ranks;
+    ranks (s, S + s) form a CFG pair and exchange noise_pred once per step.  Returns (CfgPair, sp_group, S).  Collective."""
+    world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
+    if world % 2:
+        raise RuntimeError(f"CFG x sequence needs an even world size, got {world}")
+    S = world // 2
+    sp_mine = pair_mine = None
+    for b in range(2):
+        g = dist.new_group(ranks=list(range(b * S, (b + 1) * S)))
+        if rank // S == b:
+            sp_mine = g
+    for s_ in range(S):
+        g = dist.new_group(ranks=[s_, S + s_])
+        if rank % S == s_:
+            pair_mine = g
+    return CfgPair(pair_mine), sp_mine, S
+
+
 def stitch_window(clips: Sequence[Sequence], num_motion_frames: int) -> list:
     """The reference's stitching rule (test_svi.py:472-476): every clip but the last loses its final
     `num_motion_frames` frames (they are re-generated as the head of the next clip)."""

@@ -28,10 +28,13 @@ def generate_noise(shape, seed=None, device="cpu", dtype=torch.float16):
 class DenoiseLoop:
     """50 x { cond forward, uncond forward, CFG combine, Euler step } with latents resident in HBM."""
 
-    def __init__(self, dit: WanDiT, scheduler: Optional[FlowMatchScheduler] = None, cfg_pair=None):
-        """`cfg_pair`: an svi_hip.parallel.CfgPair — this rank then runs only its half of every CFG pair of forwards."""
+    def __init__(self, dit: WanDiT, scheduler: Optional[FlowMatchScheduler] = None, cfg_pair=None, sp_group=None, sequence_parallel: bool = False):
+        """`cfg_pair`: an svi_hip.parallel.CfgPair — this rank then runs only its half of every CFG pair of forwards.
+        `sequence_parallel` (+ `sp_group`, default: the world): every forward is spread Ulysses-style over the ranks of the group
+        (svi_hip/sequence_parallel.py); all of them hold the full latents and apply the same CFG/Euler update."""
         self.dit = dit
         self.cfg_pair = cfg_pair
+        self.sequence_parallel, self.sp_group = sequence_parallel, sp_group
         self.scheduler = scheduler or FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
         self._cond = self._uncond = None
 
@@ -48,9 +51,17 @@ class DenoiseLoop:
             else:
                 ops.cfg_step_(latents, cpred, None, 1.0, dsigma)
             return latents
+        fwd = lambda x, t, c, **kw: self.dit.forward(x, t, c, **kw)      # noqa: E731
+        if self.sequence_parallel:
+            from .sequence_parallel import forward_distributed
+            fwd = lambda x, t, c, **kw: forward_distributed(self.dit, x, t, c, group=self.sp_group, **kw)      # noqa: E731
         if self.cfg_pair is not None and cfg_scale != 1.0:
-            return self.cfg_pair.step(lambda x, t, c, **kw: self.dit.forward(x, t, c, **kw), ops.cfg_step_, latents, timestep,
-                                      dsigma, ctx_pos, ctx_neg, cfg_scale, **cond)
+            return self.cfg_pair.step(fwd, ops.cfg_step_, latents, timestep, dsigma, ctx_pos, ctx_neg, cfg_scale, **cond)
+        if self.sequence_parallel:
+            cpred = fwd(latents, timestep, ctx_pos, **cond)
+            upred = fwd(latents, timestep, ctx_neg, **cond) if cfg_scale != 1.0 else None
+            ops.cfg_step_(latents, cpred, upred, cfg_scale if upred is not None else 1.0, dsigma)
+            return latents
         if self._cond is None or self._cond.shape != latents.shape:
             self._cond = torch.empty_like(latents)
             self._uncond = torch.empty_like(latents)

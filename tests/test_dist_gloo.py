@@ -138,6 +138,79 @@ def test_cfg_pair_matches_serial_order(world, num_clips):
     assert covered == set(range(num_clips))
 
 
+def _sp_worker(rank, world, port, queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from svi_hip import sequence_parallel as sp
+        Lfull, D = 12 * world, 128 * world
+        Ls, Dp = Lfull // world, D // world
+        g = torch.Generator("cpu").manual_seed(5)
+        Q, K, V = [torch.randn((Lfull, D), generator=g).to(torch.bfloat16) for _ in range(3)]     # the global tensors, known to all
+        rows = slice(rank * Ls, (rank + 1) * Ls)
+        qk = torch.cat([Q[rows], K[rows]], dim=1)                        # what svi_dit_sp_block_qkv leaves on this rank
+        vt = torch.zeros((D, (Ls + 7) // 8 * 8), dtype=torch.bfloat16)
+        vt[:, :Ls] = V[rows].t()
+        q, k, vt_full = sp.unpack_qkv(sp.all_to_all(sp.pack_qkv(qk, vt, world)), Ls, Dp)
+        cols = slice(rank * Dp, (rank + 1) * Dp)
+        ok_qkv = torch.equal(q, Q[:, cols]) and torch.equal(k, K[:, cols]) and torch.equal(vt_full[:, :Lfull], V[:, cols].t()) \
+            and bool((vt_full[:, Lfull:] == 0).all())
+        O = (Q.float() * 0.5 + K.float()).to(torch.bfloat16)             # any [L, D] result of "attention", column block = head group
+        attn = sp.unpack_out(sp.all_to_all(sp.pack_out(O[:, cols].contiguous(), world)), Ls, Dp)
+        queue.put((rank, ok_qkv, torch.equal(attn, O[rows])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sequence_parallel_exchange_layout(world):
+    """tokens -> heads and back over a real all-to-all (gloo): after the first exchange a rank holds ALL tokens of ITS head
+    group (q, k row-major, V transposed, zero padded), after the second its OWN rows of all heads."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == list(range(world))
+    assert all(a and b for _, a, b in res), res
+
+
+def _groups_worker(rank, world, port, queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pair, sp_group, S = parallel.split_cfg_sequence()
+        a = torch.tensor([float(2 ** rank)])
+        dist.all_reduce(a, group=sp_group)                   # sum of 2^r over the members identifies the group
+        b = torch.tensor([float(2 ** rank)])
+        dist.all_reduce(b, group=pair.group)
+        queue.put((rank, pair.role, S, int(a.item()), int(b.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg_x_sequence_group_layout():
+    """world 4 = 2 CFG branches x 2 sequence shards: ranks {0,1} / {2,3} are the sequence groups, {0,2} / {1,3} the CFG pairs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_groups_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in [q.get(timeout=120) for _ in procs]}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: (0, 2, 3, 5), 1: (0, 2, 3, 10), 2: (1, 2, 12, 5), 3: (1, 2, 12, 10)}
+
+
 def test_single_process_paths():
     par = parallel.ClipParallel()
     assert (par.rank, par.world) == (0, 1) and par.my_clips(3) == [0, 1, 2]

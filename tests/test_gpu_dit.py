@@ -76,8 +76,9 @@ def test_model_fn_signature_and_refusals(hip):
     a = hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx))
     b = m.forward(dev(x), torch.tensor([ts]), dev(ctx))
     assert torch.equal(a, b)                       # deterministic: same kernels, same order
-    with pytest.raises(NotImplementedError):        # USP is refused loudly (TeaCache is served: tests/test_teacache.py)
-        hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx), use_unified_sequence_parallel=True)
+    # USP without a process group is the plain forward, as in the reference (svi_video.py:119-121); with one: tests/test_gpu_sp.py
+    c2 = hip.model_fn_wan_video(m, dev(x), torch.tensor([ts]).cuda(), dev(ctx), use_unified_sequence_parallel=True)
+    assert torch.equal(c2, b)
 
 
 def test_add_condition_and_batch(hip):

@@ -67,9 +67,7 @@ def test_gemm_c2_sampled_rows_vs_fp64(hip, name, M, N, K, epi):
     assert torch.isfinite(out.float()).all() and r < 4e-3, (name, r)
 
 
-def test_dit_c2_geometry_pair_cache_determinism(hip):
-    """Wan2.1-1.3B widths, 2 blocks, the full C2 latent [1,16,21,60,104]: two runs bit-equal; the CFG pair entry point and the
-    context cache reproduce two separate uncached forwards bit for bit; outputs finite."""
+def _wan13b_two_blocks(hip, n_handles=1):
     import synth
     c = dict(synth.WAN_1_3B)
     c["num_layers"] = 2
@@ -78,8 +76,8 @@ def test_dit_c2_geometry_pair_cache_determinism(hip):
     for name, shape in synth.dit_param_shapes(**c).items():
         leaf = name.rsplit(".", 1)[-1]
         fan = 1
-        for s in shape[1:]:
-            fan *= s
+        for s_ in shape[1:]:
+            fan *= s_
         if leaf == "modulation":
             t = torch.randn(shape, generator=g, device="cuda") / shape[-1] ** 0.5
         elif leaf == "weight" and len(shape) == 1:
@@ -89,8 +87,18 @@ def test_dit_c2_geometry_pair_cache_determinism(hip):
         else:
             t = (torch.rand(shape, generator=g, device="cuda") * 2 - 1) * 0.05
         sd[name] = t.to(torch.bfloat16).contiguous()
-    m = hip.WanDiT(eps=1e-6, num_heads=12, **c)
-    m.bind(sd)
+    out = []
+    for _ in range(n_handles):
+        m = hip.WanDiT(eps=1e-6, num_heads=12, **c)
+        m.bind(sd)
+        out.append(m)
+    return out
+
+
+def test_dit_c2_geometry_pair_cache_determinism(hip):
+    """Wan2.1-1.3B widths, 2 blocks, the full C2 latent [1,16,21,60,104]: two runs bit-equal; the CFG pair entry point and the
+    context cache reproduce two separate uncached forwards bit for bit; outputs finite."""
+    m = _wan13b_two_blocks(hip)[0]
     x = _rnd(20, 1, 16, 21, 60, 104)
     cp, cn = _rnd(21, 1, 512, 4096), _rnd(22, 1, 512, 4096)
     t = torch.tensor([991.7355])
@@ -104,3 +112,15 @@ def test_dit_c2_geometry_pair_cache_determinism(hip):
             assert torch.equal(pa, a) and torch.equal(pb, b)
     finally:
         m.context_cache(False)
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_sequence_parallel_c2_geometry(hip, P):
+    """The Ulysses schedule at C2 size: shards of 16380 / 8190 rows (ragged against every tile size), 6 / 3 heads per rank, the
+    256^2 GEMM and the long-sequence attention kernel on shard-local buffers — same bits as the single-rank forward."""
+    from svi_hip import sequence_parallel as sp
+    ms = _wan13b_two_blocks(hip, P + 1)
+    x, ctx, t = _rnd(20, 1, 16, 21, 60, 104), _rnd(21, 1, 512, 4096), torch.tensor([991.7355])
+    want = ms[-1].forward(x, t, ctx)
+    got = sp.forward_local(ms[:P], x, t, ctx)
+    assert torch.equal(got, want)

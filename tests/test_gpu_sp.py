@@ -1,0 +1,112 @@
+"""-m gpu: sequence-parallel (Ulysses) forward, SURVEY §8e axis 3.  P shards run in one process on one GPU with the all-to-all
+simulated by in-process gathers (svi_hip.sequence_parallel.forward_local): every kernel, row offset and head-group layout of the
+multi-rank path is exercised; only the transport differs (tests/test_dist_gloo.py covers that over gloo).  Expected: the same
+bits as the single-rank forward — each row / head sees the same operands in the same order."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+WIDE_T2V = dict(dim=512, in_dim=16, ffn_dim=1024, out_dim=16, text_dim=64, freq_dim=256, patch_size=(1, 2, 2), num_layers=2, has_image_input=False)
+WIDE_I2V = dict(dim=512, in_dim=36, ffn_dim=768, out_dim=16, text_dim=64, freq_dim=256, patch_size=(1, 2, 2), num_layers=2, has_image_input=True)
+
+
+def handles(hip, c, seed, n):
+    sd = {k: torch.from_numpy(v).to("cuda", torch.bfloat16).contiguous() for k, v in synth.dit_state_dict(seed, **c).items()}
+    out = []
+    for _ in range(n):
+        m = hip.WanDiT(eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+        m.bind(sd)                                       # all shards borrow the same weights
+        out.append(m)
+    return out
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("grid", [(2, 4, 6), (4, 16, 32)])     # 48 tokens (ragged tiles); 2048 tokens (the long-sequence attention kernel)
+def test_sequence_parallel_is_bit_identical_t2v(P, grid):
+    import svi_hip
+    from svi_hip import sequence_parallel as sp
+    f, h, w = grid
+    ms = handles(svi_hip, WIDE_T2V, 900, P + 1)
+    x = dev(synth.randn(901, 1, 16, f, 2 * h, 2 * w))
+    ctx = dev(synth.text_context(902, 24, 64, 17))
+    t = torch.tensor([712.5])
+    want = ms[-1].forward(x, t, ctx)
+    got = sp.forward_local(ms[:P], x, t, ctx)
+    assert got.shape == want.shape and torch.isfinite(got.float()).all()
+    assert torch.equal(got, want)
+
+
+def test_sequence_parallel_i2v_and_add_condition():
+    import svi_hip
+    from svi_hip import sequence_parallel as sp
+    f, h, w = 3, 4, 4
+    ms = handles(svi_hip, WIDE_I2V, 910, 3)
+    x = dev(synth.randn(911, 1, 16, f, 2 * h, 2 * w))
+    y = dev(synth.randn(912, 1, 20, f, 2 * h, 2 * w))
+    clip = dev(synth.randn(913, 1, 257, 1280))
+    addc = dev(0.1 * synth.randn(914, 1, f * h * w, 512))
+    ctx = dev(synth.text_context(915, 16, 64, 9))
+    t = torch.tensor([92.5926])
+    want = ms[-1].forward(x, t, ctx, clip_feature=clip, y=y, add_condition=addc)
+    got = sp.forward_local(ms[:2], x, t, ctx, clip_feature=clip, y=y, add_condition=addc)
+    assert torch.equal(got, want)
+
+
+def test_shard_refuses_bad_divisions():
+    import svi_hip
+    from svi_hip import sequence_parallel as sp
+    m = handles(svi_hip, WIDE_T2V, 900, 1)[0]
+    with pytest.raises(ValueError):
+        sp.SequenceShard(m, 0, 3)                        # 4 heads over 3 ranks
+    sh = sp.SequenceShard(m, 0, 4)
+    with pytest.raises(ValueError):                      # 2*3*5 = 30 tokens over 4 ranks
+        sh.begin(dev(synth.randn(1, 1, 16, 2, 6, 10)), torch.tensor([500.0]), dev(synth.text_context(2, 8, 64, 5)))
+
+
+def _dist_worker(rank, world, port, queue):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share the one GPU of the test box; gloo moves
+    try:                                                                # the exchanges through the host, the kernels run on the GPU
+        import svi_hip
+        torch.cuda.set_device(0)
+        m = handles(svi_hip, WIDE_T2V, 900, 1)[0]
+        x = dev(synth.randn(901, 1, 16, 2, 8, 12))
+        ctx = dev(synth.text_context(902, 24, 64, 17))
+        t = torch.tensor([712.5])
+        want = m.forward(x, t, ctx)
+        got = svi_hip.model_fn_wan_video(m, x, t, ctx, use_unified_sequence_parallel=True)     # -> forward_distributed
+        loop = svi_hip.DenoiseLoop(m, sequence_parallel=True)
+        lat = x.clone()
+        loop.step(lat, t.cuda(), -0.05, ctx, dev(synth.text_context(903, 24, 64, 11)), 5.0)
+        ref = x.clone()
+        svi_hip.DenoiseLoop(m).step(ref, t.cuda(), -0.05, ctx, dev(synth.text_context(903, 24, 64, 11)), 5.0)
+        queue.put((rank, bool(torch.equal(got, want)), bool(torch.equal(lat, ref))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_forward_distributed_across_processes(world):
+    """model_fn_wan_video(use_unified_sequence_parallel=True) and a sequence-parallel DenoiseLoop step with a real process
+    group (one process per rank, all-to-all / all-gather through torch.distributed): every rank gets the single-rank bits."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == list(range(world)) and all(a and b for _, a, b in res), res
