@@ -23,6 +23,33 @@ def _free_port():
     return p
 
 
+def _run_ranks(worker, world, *args, attempts=2):
+    """Spawn `world` processes running worker(rank, world, port, *args, queue) and collect one queue item per rank.  A rendezvous
+    can fail for reasons outside the code under test (the probed port taken in between, a slow fork): one retry on a new port."""
+    last = None
+    for _ in range(attempts):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, world, port, *args, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = [q.get(timeout=120) for _ in procs]
+            for p in procs:
+                p.join(timeout=60)
+            if all(p.exitcode == 0 for p in procs):
+                return res
+            last = RuntimeError(f"exit codes {[p.exitcode for p in procs]}")
+        except Exception as ex:          # queue.Empty: a rank died or hung
+            last = ex
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
+    raise last
+
+
 def _clip(k):
     """Stand-in for a denoised clip that depends only on k — like seed = k*42 does (test_svi.py:425)."""
     g = torch.Generator("cpu").manual_seed(parallel.clip_seed(k))
@@ -48,16 +75,7 @@ def _worker(rank, world, port, num_clips, q):
 
 @pytest.mark.parametrize("num_clips", [2, 5])
 def test_two_ranks_reproduce_single_rank_window(num_clips):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, num_clips, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_worker, 2, num_clips)
     serial = [_clip(k).float() for k in range(num_clips)]
     seen = []
     for rank, mine, window, tails in res:
@@ -111,16 +129,7 @@ def _cfg_worker(rank, world, port, num_clips, q):
 def test_cfg_pair_matches_serial_order(world, num_clips):
     """cond on one rank, uncond on the other, one all-gather per step: both ranks of a pair end with the latents the
     serial loop produces, bit for bit; with 4 ranks the pairs additionally shard the clips."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_cfg_worker, args=(r, world, port, num_clips, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_cfg_worker, world, num_clips)
     serial = {}
     for k in range(num_clips):
         lat, cp, cn = _serial_cfg_clip(parallel.clip_seed(k))
@@ -167,16 +176,7 @@ def _sp_worker(rank, world, port, queue):
 def test_sequence_parallel_exchange_layout(world):
     """tokens -> heads and back over a real all-to-all (gloo): after the first exchange a rank holds ALL tokens of ITS head
     group (q, k row-major, V transposed, zero padded), after the second its OWN rows of all heads."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_sp_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_sp_worker, world)
     assert sorted(r for r, _, _ in res) == list(range(world))
     assert all(a and b for _, a, b in res), res
 
@@ -198,16 +198,7 @@ def _groups_worker(rank, world, port, queue):
 
 def test_cfg_x_sequence_group_layout():
     """world 4 = 2 CFG branches x 2 sequence shards: ranks {0,1} / {2,3} are the sequence groups, {0,2} / {1,3} the CFG pairs."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_groups_worker, args=(r, 4, port, q)) for r in range(4)]
-    for p in procs:
-        p.start()
-    res = {r[0]: r[1:] for r in [q.get(timeout=120) for _ in procs]}
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = {r[0]: r[1:] for r in _run_ranks(_groups_worker, 4)}
     assert res == {0: (0, 2, 3, 5), 1: (0, 2, 3, 10), 2: (1, 2, 12, 5), 3: (1, 2, 12, 10)}
 
 
