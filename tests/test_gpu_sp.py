@@ -97,16 +97,6 @@ def _dist_worker(rank, world, port, queue):
 def test_forward_distributed_across_processes(world):
     """model_fn_wan_video(use_unified_sequence_parallel=True) and a sequence-parallel DenoiseLoop step with a real process
     group (one process per rank, all-to-all / all-gather through torch.distributed): every rank gets the single-rank bits."""
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    from spawn_util import run_ranks
+    res = run_ranks(_dist_worker, world, timeout=300)
     assert sorted(r for r, _, _ in res) == list(range(world)) and all(a and b for _, a, b in res), res
