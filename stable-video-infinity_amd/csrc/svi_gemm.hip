@@ -247,7 +247,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // times per thread.  Now: the epilogue kind is a template parameter (one uniform branch per tile), bias values come in as eight
 // 8-byte vectors up front, and an interior tile (all but the last row panel) takes a path without bounds tests in which the
 // LDS reads of four chunks are in flight together.
-// abl (timing ablations, results wrong): 1 = no epilogue at all, 2 = no global stores, 3 = stop after the LDS staging writes.
+// abl (timing ablations): 1 = no epilogue at all, 2 = no global stores, 3 = stop after the LDS staging writes (results wrong);
+// 4 = non-temporal stores (results unchanged).
 template <int EPI>
 __device__ __forceinline__ void gemm256_apply(float (&y)[8], const u32x4& res, const float (&gatev)[8], bool has_gate) {
     if constexpr (EPI == SVI_EPI_BIAS_GELU_TANH) {
@@ -371,6 +372,10 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
                 if (abl == 2) { if (y[0] == 123.456f && y[7] == 1.f) cp[0] = o[3]; }
+                // abl 4: non-temporal stores.  Alone the GEMM gains (attn_o 153 -> 140 us, ffn1 861 -> 841 us: the tile no longer
+                // pushes operand panels out of L2), but in the block the next kernel (LN / the next GEMM) then finds its input in
+                // HBM instead of L2 / MALL and gives the time back: step 470.3 vs 469.7 ms.  Ordinary stores stay.
+                else if (abl == 4) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(cp + (size_t)(16 * it) * g.ldc));
                 else st_bf16x8(cp + (size_t)(16 * it) * g.ldc, o);
             }
         }
