@@ -205,6 +205,14 @@ svi_status svi_vae_destroy(svi_vae* h);
 svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const void* dev_ptr, svi_dtype dtype,
                                const int64_t* shape, int32_t rank);
 svi_status svi_vae_check_bound(svi_vae* h);
+/* The 8-bit frame hand-off between the clips of a stream, on the device.
+ * svi_video_to_u8: SVIVideoPipeline.tensor2video (pipelines/svi_video.py:366-370): video f32 [3, T, H, W] in [-1, 1] ->
+ *   frames u8 [T, H, W, 3] = uint8(clip((x + 1) * 127.5, 0, 255)).
+ * svi_u8_to_video: BasePipeline.preprocess_image (pipelines/base.py:44-45): frames u8 [n, H, W, 3] -> f32 [n, 3, H, W] =
+ *   float32(x) * (2 / 255) - 1.  Both bit-identical to the reference's host arithmetic. */
+svi_status svi_video_to_u8(const float* video, uint8_t* frames, int32_t T, int32_t H, int32_t W, svi_stream stream);
+svi_status svi_u8_to_video(const uint8_t* frames, float* video, int32_t n, int32_t H, int32_t W, svi_stream stream);
+
 /* WanVideoVAE.decode -> single_decode -> VideoVAE_.decode (models/wan_video_vae.py:777-789,753-756,552-575)
  *   latents f32 [16, T, h, w]  ->  video f32 [3, 1+4(T-1), 8h, 8w], clamped to [-1,1]. */
 svi_status svi_vae_decode(svi_vae* h, const float* latents, float* video, int32_t T, int32_t hh, int32_t ww,

@@ -146,6 +146,15 @@ extern "C" svi_status svi_attention_vt_fwd(const void* q, int32_t ldq, const voi
                             reinterpret_cast<bf16*>(out), ldo, s_q, s_kv, n, q_prescaled ? 1 : 0, st);
 }
 
+extern "C" svi_status svi_video_to_u8(const float* video, uint8_t* frames, int32_t T, int32_t H, int32_t W, svi_stream stream) {
+    SVI_REQUIRE(video && frames && T > 0 && H > 0 && W > 0, "svi_video_to_u8: bad argument");
+    return svi_launch_video_to_u8(video, frames, (long)T * H * W, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" svi_status svi_u8_to_video(const uint8_t* frames, float* video, int32_t n, int32_t H, int32_t W, svi_stream stream) {
+    SVI_REQUIRE(video && frames && n > 0 && H > 0 && W > 0, "svi_u8_to_video: bad argument");
+    return svi_launch_u8_to_video(frames, video, n, (long)H * W, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" svi_status svi_layernorm_modulate(const void* x, void* out, int32_t rows, int32_t dim, float eps, const void* w,
                                              const void* b, const void* shift, const void* scale, svi_stream stream) {
     SVI_REQUIRE(x && out, "svi_layernorm_modulate: null argument");

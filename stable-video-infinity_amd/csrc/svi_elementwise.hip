@@ -278,3 +278,42 @@ svi_status svi_launch_add_bf16(bf16* a, const bf16* b, int64_t n, hipStream_t st
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Frame hand-off of the clip loop, on the device.  The reference turns the decoded video into 8-bit frames
+// (SVIVideoPipeline.tensor2video, pipelines/svi_video.py:366-370: ((x + 1) * 127.5).clip(0, 255).astype(uint8), 'C T H W -> T H W C')
+// and turns the last frames back into [-1, 1] floats for the next clip's conditioning (BasePipeline.preprocess_image,
+// pipelines/base.py:44-45: float32(x) * (2 / 255) - 1, 'H W C -> C H W').  Same fp32 arithmetic here, so the 8-bit frames and the
+// conditioning input are bit-identical to the host round trip — without leaving HBM.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void video_to_u8_kernel(const float* __restrict__ v, unsigned char* __restrict__ out, long thw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;           // over T*H*W*3 outputs
+    if (idx >= thw * 3) return;
+    const long px = idx / 3;
+    const int c = (int)(idx - px * 3);
+    float y = (v[(long)c * thw + px] + 1.0f) * 127.5f;
+    y = fminf(fmaxf(y, 0.0f), 255.0f);
+    out[idx] = (unsigned char)(int)y;                                       // astype(uint8): truncation
+}
+__global__ __launch_bounds__(256) void u8_to_video_kernel(const unsigned char* __restrict__ f, float* __restrict__ out, int n, long hw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;           // over n*3*H*W outputs, [n, 3, H, W]
+    if (idx >= (long)n * 3 * hw) return;
+    const long px = idx % hw;
+    const int c = (int)((idx / hw) % 3);
+    const long i = idx / (3 * hw);
+    out[idx] = (float)f[(i * hw + px) * 3 + c] * (float)(2.0 / 255.0) - 1.0f;
+}
+
+svi_status svi_launch_video_to_u8(const float* video, unsigned char* out, long thw, hipStream_t st) {
+    if (thw <= 0) return SVI_OK;
+    hipLaunchKernelGGL(video_to_u8_kernel, dim3((unsigned)((thw * 3 + 255) / 256)), dim3(256), 0, st, video, out, thw);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+svi_status svi_launch_u8_to_video(const unsigned char* frames, float* out, int n, long hw, hipStream_t st) {
+    if (n <= 0 || hw <= 0) return SVI_OK;
+    hipLaunchKernelGGL(u8_to_video_kernel, dim3((unsigned)(((long)n * 3 * hw + 255) / 256)), dim3(256), 0, st, frames, out, n, hw);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}

@@ -57,6 +57,8 @@ SYMBOLS = [
     ("svi_vae_destroy", _i32, [_vp]),
     ("svi_vae_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
     ("svi_vae_check_bound", _i32, [_vp]),
+    ("svi_video_to_u8", _i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    ("svi_u8_to_video", _i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_vae_decode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_vae_encode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
 ]

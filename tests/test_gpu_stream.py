@@ -1,0 +1,66 @@
+"""-m gpu: the resident clip loop of an image-conditioned stream (svi_hip.StreamLoop, test_svi.py:424-476 around __call__).
+Every stage is pinned elsewhere (DiT, scheduler, VAE, encode_images_adaptive); here: the 8-bit frame hand-off is the reference's
+host arithmetic bit for bit, and the loop composes the stages as the reference's loop does (seeds, prompt cycling, motion frames =
+the last 8-bit frames of the previous clip, stitching rule)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_u8_round_trip_matches_host_arithmetic():
+    import svi_hip
+    rs = np.random.RandomState(3)
+    v = rs.uniform(-1.3, 1.3, size=(3, 4, 10, 14)).astype(np.float32)
+    v.flat[:8] = [-1.0, 1.0, 0.0, -0.99607843, 0.00392157, 1.0000001, -1.0000001, 0.5]      # edges, exact grid points
+    want = ((np.transpose(v, (1, 2, 3, 0)) + 1) * 127.5).clip(0, 255).astype(np.uint8)       # tensor2video, svi_video.py:367-368
+    got = svi_hip.video_to_u8(torch.from_numpy(v).cuda())
+    assert got.dtype == torch.uint8 and np.array_equal(got.cpu().numpy(), want)
+    frames = rs.randint(0, 256, size=(5, 10, 14, 3)).astype(np.uint8)
+    want_f = synth.frames_to_tensor(frames)                                                   # preprocess_image, base.py:44-45
+    got_f = svi_hip.u8_to_video(torch.from_numpy(frames).cuda())
+    assert np.array_equal(got_f.cpu().numpy(), want_f)
+    # note: with the reference's truncating cast quantise(dequantise(x)) is NOT the identity (201 -> 200.99998 -> 200); the
+    # device kernels reproduce exactly that, they do not "fix" it
+    back = svi_hip.video_to_u8(got_f.permute(1, 0, 2, 3).contiguous()).cpu().numpy()
+    host = ((np.transpose(want_f, (0, 2, 3, 1)) + 1) * 127.5).clip(0, 255).astype(np.uint8)
+    assert np.array_equal(back, host)
+
+
+@pytest.mark.parametrize("n_motion", [1, 2])
+def test_stream_loop_composition(n_motion):
+    import svi_hip
+    c = synth.TINY_DIT_I2V
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(200, **c).items()}
+    dit = svi_hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    vae = svi_hip.WanVideoVAE.from_state_dict({k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()})
+    H, W, NF, STEPS, CLIPS = 32, 48, 9, 2, 3
+    img = torch.from_numpy(synth.condition_frames(31, 1, H, W))
+    ref = torch.from_numpy(synth.condition_frames(32, 1, H, W)[0])
+    prompts = [(dev(synth.text_context(40 + i, 16, c["text_dim"], 9)), dev(synth.text_context(50 + i, 16, c["text_dim"], 5))) for i in range(2)]
+    clipf = dev(synth.randn(33, 1, 257, 1280))
+    sl = svi_hip.StreamLoop(dit, vae, clip_encoder=lambda first: clipf, num_motion_frames=n_motion, num_frames=NF,
+                            num_inference_steps=STEPS, ref_pad_num=-1)
+    video = sl.run(img, ref, prompts, CLIPS)
+    assert video.dtype == torch.uint8 and tuple(video.shape) == ((NF - n_motion) * (CLIPS - 1) + NF, H, W, 3)
+    tr = sl.trace
+    assert [t["seed"] for t in tr] == [0, 42, 84]                                            # seed = chunk_idx * seed_times
+    assert torch.equal(tr[0]["motion"].cpu(), img)
+    refv = svi_hip.u8_to_video(ref[None].cuda())[0]
+    for k in range(CLIPS):
+        if k:
+            assert torch.equal(tr[k]["motion"], tr[k - 1]["frames"][-n_motion:])             # hand-off: the previous clip's last 8-bit frames
+        y = svi_hip.image_condition(vae, svi_hip.u8_to_video(tr[k]["motion"]), refv, NF, False, -1)
+        assert torch.equal(y, tr[k]["y"])
+        # the clip itself: the plain denoise loop on (seed_k, prompt_k, y_k), then decode -> 8 bit
+        lat = svi_hip.generate_noise((1, 16, 3, H // 8, W // 8), seed=42 * k, device="cpu", dtype=torch.float32).to("cuda", torch.bfloat16)
+        cp, cn = prompts[k % 2]
+        lat = svi_hip.DenoiseLoop(dit).sample(lat, cp, cn, num_inference_steps=STEPS, y=y, clip_feature=clipf)
+        assert torch.equal(lat, tr[k]["latents"])
+        assert torch.equal(svi_hip.video_to_u8(vae.decode(lat.float(), device="cuda")[0]), tr[k]["frames"])
+    stitched = torch.cat([t["frames"][:-n_motion] for t in tr[:-1]] + [tr[-1]["frames"]])
+    assert torch.equal(video, stitched)
