@@ -748,7 +748,10 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             }
             const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
             const char* gme = getenv("SVI_GEMM_GM");               // row panels per tile group (A/B aid)
-            const int gm_rows = gme ? atoi(gme) : 2;       // measured (tools/gemm_gm.py): 2 beats 8 by 13 % on ffn1, 3 % on ffn2, flat on N = 1536
+            // measured (tools/gemm_gm.py, v3 loop): N = 1536 (6 column panels): 2 is best (ffn2 1257 vs 1168-1230 TFLOP/s), flat on q/k/v;
+            // N = 8960 (35 column panels, ffn1): 5-6 give 1050 vs 1022 at 2 and 980 at 8 — a 5 x 6 block of concurrent tiles per XCD
+            // needs the fewest operand panels (HBM fetch per launch at 2: 2.2 GB against 0.13 GB of operands, profiles/r1h_gemm_ffn1_pmc.txt)
+            const int gm_rows = gme ? atoi(gme) : (tn >= 16 ? 5 : 2);
             if (force && force[0] == '2' && force[3] == '\0')       // "256": the v2 main loop (barrier at the tile boundary), kept for A/B
                 hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
             else {
