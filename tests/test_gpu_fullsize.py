@@ -67,10 +67,10 @@ def test_gemm_c2_sampled_rows_vs_fp64(hip, name, M, N, K, epi):
     assert torch.isfinite(out.float()).all() and r < 4e-3, (name, r)
 
 
-def _wan13b_two_blocks(hip, n_handles=1):
+def _wan13b_two_blocks(hip, n_handles=1, layers=2):
     import synth
     c = dict(synth.WAN_1_3B)
-    c["num_layers"] = 2
+    c["num_layers"] = layers
     g = torch.Generator(device="cuda").manual_seed(5)
     sd = {}
     for name, shape in synth.dit_param_shapes(**c).items():
@@ -124,3 +124,26 @@ def test_sequence_parallel_c2_geometry(hip, P):
     want = ms[-1].forward(x, t, ctx)
     got = sp.forward_local(ms[:P], x, t, ctx)
     assert torch.equal(got, want)
+
+
+def test_dit_c2_geometry_vs_cpu_oracle(hip):
+    """The whole forward at the full C2 geometry (Wan2.1-1.3B widths, L = 32760, one block) against the CPU oracle in fp32 on the
+    same bf16-valued weights and inputs (about a minute of host time on the GPU box): the one place where every kernel's
+    full-size code path (256^2 GEMMs, long-sequence attention, 3 KiB row kernels) meets the reference's arithmetic end to end.
+    Bound: the whole-forward fp32 bound of the small cases, rel-L2 <= 2e-2."""
+    from oracle import wan_dit_oracle as wdo
+    import synth
+    m = _wan13b_two_blocks(hip, layers=1)[0]
+    x, ctx, t = _rnd(20, 1, 16, 21, 60, 104), _rnd(21, 1, 512, 4096), torch.tensor([991.7355])
+    ctx[:, 64:] = 0                                                     # zero-padded prompt, as wan_prompter.py:107-108 leaves it
+    got = m.forward(x, t, ctx).float().cpu()
+    sd = {k: v.float().cpu() for k, v in m._params.items()}
+    c = dict(synth.WAN_1_3B)
+    cfg = wdo.DiTConfig(dim=c["dim"], in_dim=c["in_dim"], ffn_dim=c["ffn_dim"], out_dim=c["out_dim"], text_dim=c["text_dim"],
+                        freq_dim=c["freq_dim"], patch_size=c["patch_size"], num_heads=12, num_layers=1, has_image_input=False)
+    with torch.no_grad():
+        want = wdo.dit_forward(sd, cfg, x.float().cpu(), t, ctx.float().cpu())
+    r = _rel(got, want)
+    from gpu_util import report
+    report("dit_forward_c2_geometry_vs_oracle_fp32", rel_l2=r)
+    assert got.shape == want.shape and r < 2e-2, r
