@@ -147,3 +147,15 @@ def test_dit_c2_geometry_vs_cpu_oracle(hip):
     from gpu_util import report
     report("dit_forward_c2_geometry_vs_oracle_fp32", rel_l2=r)
     assert got.shape == want.shape and r < 2e-2, r
+
+
+def test_dit_720p_geometry(hip):
+    """81 frames at 1280x720 (the I2V-720P configuration's grid, 21x45x80 = 75600 tokens) at 1.3B widths, one block: finite,
+    deterministic, and the two-rank sequence-parallel schedule reproduces it bit for bit."""
+    from svi_hip import sequence_parallel as sp
+    ms = _wan13b_two_blocks(hip, 3, layers=1)
+    x, ctx, t = _rnd(30, 1, 16, 21, 90, 160), _rnd(31, 1, 512, 4096), torch.tensor([500.0])
+    a = ms[-1].forward(x, t, ctx)
+    assert a.shape == (1, 16, 21, 90, 160) and torch.isfinite(a.float()).all()
+    assert torch.equal(a, ms[-1].forward(x, t, ctx))
+    assert torch.equal(a, sp.forward_local(ms[:2], x, t, ctx))
