@@ -721,7 +721,6 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
     // one tile t >= 1; returns whether the reference must move before tile t+1.  Odd tiles: K at base + 16 KiB, read V stage
     // 0, write V stage 1, S(t) in sB; then the base flips and the next (even) tile's first fragments come from base + 0.
     // Even tiles: K at base + 0, read V stage 1, write V stage 0, S(t) in sA; the next (odd) tile reads base + 16 KiB.
