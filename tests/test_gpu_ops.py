@@ -208,3 +208,25 @@ def test_cfg_step_bit_exact(hip):
     want1 = bf16r(lat + bf16r(c * ds))
     got1 = host(hip.cfg_step_(dev(lat), dev(c), None, 1.0, ds))
     assert torch.equal(got1, want1)
+
+
+# ------------------------------------------------------------------------------------------ LoRA merge
+@pytest.mark.parametrize("out_f,in_f,r,alpha", [(1536, 1536, 128, 1.0), (8960, 1536, 64, 0.7), (200, 264, 32, 2.0)])
+def test_lora_merge_matches_reference_rounding(hip, out_f, in_f, r, alpha):
+    """models/lora.py:246-262 in the model dtype: bf16(W + bf16(alpha * bf16(up @ down))).  The dot products are formed in fp64
+    here; where fp32 accumulation order decides a bf16 rounding tie the result may differ by one ulp of the product term."""
+    w = bf16r(torch.from_numpy(synth.randn(81, out_f, in_f)) * 0.05)
+    up = bf16r(torch.from_numpy(synth.randn(82, out_f, r)) * 0.1)
+    down = bf16r(torch.from_numpy(synth.randn(83, r, in_f)) * 0.1)
+    prod = (up.double() @ down.double()).to(torch.bfloat16)
+    want = (w.to(torch.bfloat16) + (alpha * prod)).float()            # torch: bf16 * python float -> bf16, bf16 + bf16 -> bf16
+    wd = dev(w)
+    ptr = wd.data_ptr()
+    got = hip.lora.merge_lora_(wd, up, down, alpha)
+    assert got.data_ptr() == ptr                                      # in place: a bound WanDiT keeps seeing the tensor
+    r_, mx, _ = errs(got, want)
+    frac = float((host(got) != want).float().mean())
+    report("lora_merge", out_f=out_f, in_f=in_f, rank=r, rel_l2=r_, differing=frac)
+    assert r_ < 1e-3 and frac < 0.02, (r_, frac)
+    with pytest.raises(ValueError):
+        hip.lora.merge_lora_(wd, up[:, :-8], down, alpha)
