@@ -187,6 +187,32 @@ def test_flash_attention_online_softmax_rescale(hip):
     assert r < 6e-3 and mx < 0.05, (r, mx)
 
 
+@pytest.mark.parametrize("pattern", ["spikes", "ramp", "late_giant"])
+def test_flash_attention_long_sequence_rescale_paths(hip, pattern):
+    """The long-sequence kernel (Lk >= 2048) moves its reference maximum only when a row outgrows it by 2^8 and does so outside
+    its steady-state loop: drive that path hard.  spikes: single keys 30-60 logits above the rest at tile boundaries and inside
+    tiles, early and late; ramp: key norms grow along the sequence so every few tiles some row outgrows its reference;
+    late_giant: the very last key dominates every row (everything accumulated before is rescaled to ~0)."""
+    Lq, Lk, heads = 320, 4200, 2
+    D = heads * 128
+    q = bf16r(torch.from_numpy(synth.randn(91, 1, Lq, D)))
+    k = bf16r(torch.from_numpy(synth.randn(92, 1, Lk, D)))
+    v = bf16r(torch.from_numpy(synth.randn(93, 1, Lk, D)))
+    if pattern == "spikes":
+        for key, row, gain in [(0, 5, 3.0), (63, 70, 4.0), (64, 71, 4.0), (2047, 130, 3.5), (2048, 200, 5.0), (4199, 319, 4.0), (4100, 5, 5.0)]:
+            k[0, key] = q[0, row] * gain
+    elif pattern == "ramp":
+        k = bf16r(k * torch.linspace(0.2, 3.0, Lk).view(1, Lk, 1))
+    else:
+        k[0, Lk - 1] = bf16r(q[0].mean(dim=0) * 0 + 1.0) * 2.0
+        q = bf16r(q + 1.5)                                  # every row has a large positive projection on the last key
+    want = wdo.attention(q.double(), k.double(), v.double(), heads).float()
+    got = hip.flash_attention(dev(q), dev(k), dev(v), heads)
+    r, mx, _ = errs(got, want)
+    report("flash_attention_long_rescale", pattern=pattern, rel_l2=r, max_abs=mx)
+    assert torch.isfinite(got.float()).all() and r < 6e-3, (pattern, r, mx)
+
+
 def test_flash_attention_batch_and_linearity_in_v(hip):
     """Size-independent property: attention is linear in V;  attn(q,k,a*v1+v2) == a*attn(q,k,v1)+attn(q,k,v2)."""
     q = dev(synth.randn(71, 2, 200, 256)); k = dev(synth.randn(72, 2, 300, 256))
