@@ -225,6 +225,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 // the epilogue of tile i into the K loop of tile i+1 (64 packed-bf16 registers, permlane-paired 16-byte stores): -5..-13 %
 // (register spills, and the row-scattered stores compete with the LDS-DMA for the address path).  The epilogue itself was the
 // real loss (see gemm256_epilogue_t): after its rewrite it costs 2-9 us per tile, mostly the 128 KiB of stores.
+// Also tried: two independent 4-wave workgroups per CU on 128 x 256 x 32 tiles (three-stage half-tile ring, the v3 barrier
+// placement) so that one workgroup's epilogue falls under the other's main loop: bit-identical, but 840-940 TFLOP/s on every
+// shape against 970-1260 here — half-tiles double the barriers and DMA instructions per MFMA and raise the L2 -> LDS traffic by
+// half, which costs more than the hidden epilogue returns.
 // Tile order: 8 XCD bands (bijective), inside a band groups of 8 row panels walk the column panels, so the 32
 // tiles an XCD runs at once are ~8 row panels x 4 column panels: 12 operand panels for 32 tiles in its L2.
 // =================================================================================================
