@@ -134,6 +134,8 @@ struct SviRope {                // device tables of (cos,sin) pairs, fp32
 // out_scale multiplies the result before its single final rounding (the DiT folds the attention scale into q there)
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
                                    const SviRope* rope, float out_scale, hipStream_t st);
+svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf16* weight, const bf16* weight1, float eps,
+                                    const SviRope* rope, float out_scale, float out_scale1, hipStream_t st);
 svi_status svi_launch_transpose(const bf16* in, int ldi, bf16* out, int ldo, int rows, int cols, hipStream_t st);
 svi_status svi_launch_cfg_step(bf16* lat, const bf16* cond, const bf16* uncond, int64_t n, float s, float dsigma,
                                hipStream_t st);

@@ -352,8 +352,8 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(QK, 2 * D, L, D, b.sa.norm_q, c.eps, &rope, SVI_QK_SCALE_LOG2E, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(QK + D, 2 * D, L, D, b.sa.norm_k, c.eps, &rope, 1.0f, st)); }
+    // q and k in one launch (grid.y = operand): q additionally carries softmax_scale * log2(e) into its single final rounding
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope2(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st)); }
     return SVI_OK;
 }
 

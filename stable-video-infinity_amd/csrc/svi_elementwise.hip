@@ -105,15 +105,18 @@ svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int row
 // here cos/sin come from a host-built fp64->fp32 table and the 2x2 rotate runs in fp32 — the result
 // is rounded to bf16 either way (difference <= 1 bf16 ulp on rounding ties only).
 // ------------------------------------------------------------------------------------------------
+// blockIdx.y selects one of up to two [rows, dim] operands that sit side by side in a row (q | k of the DiT's QK buffer): operand
+// p starts at column p * dim and has its own weight and output scale — one launch normalises both.
 template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x, int ld, int rows, int dim,
-                                                           const bf16* __restrict__ weight, float eps, int use_rope,
-                                                           SviRope r, float out_scale) {
+                                                           const bf16* __restrict__ weight, const bf16* __restrict__ weight1, float eps, int use_rope,
+                                                           SviRope r, float out_scale, float out_scale1) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = dim >> 3;
-    bf16* xr = x + (size_t)row * ld;
+    bf16* xr = x + (size_t)row * ld + (size_t)blockIdx.y * dim;
+    if (blockIdx.y) { weight = weight1; out_scale = out_scale1; }
     float v[MAXC][8];
     float ss = 0.f;
 #pragma unroll
@@ -168,6 +171,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
 
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
                                    const SviRope* rope, float out_scale, hipStream_t st) {
+    return svi_launch_rmsnorm_rope2(x, ld, rows, dim, weight, nullptr, eps, rope, out_scale, 1.0f, st);
+}
+
+// weight1 != nullptr: a second operand at columns [dim, 2 dim) of every row gets weight1 / out_scale1 in the same launch
+svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf16* weight, const bf16* weight1, float eps,
+                                    const SviRope* rope, float out_scale, float out_scale1, hipStream_t st) {
     SVI_REQUIRE(dim % 8 == 0 && ld % 8 == 0, "rmsnorm: dim/ld must be multiples of 8");
     SVI_REQUIRE(dim <= 8192, "rmsnorm: dim %d > 8192 unsupported", dim);
     if (rows <= 0) return SVI_OK;
@@ -177,15 +186,16 @@ svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf1
         SVI_REQUIRE(dim % 128 == 0 && r.npf + r.nph + r.npw == 64, "rope needs head_dim 128");
         SVI_REQUIRE(r.row0 >= 0 && r.row0 + rows <= r.f * r.h * r.w, "rope grid %dx%dx%d does not cover rows [%d, %d)", r.f, r.h, r.w, r.row0, r.row0 + rows);
     }
-    dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+    SVI_REQUIRE(!weight1 || ld >= 2 * dim, "rmsnorm: a second operand needs ld >= 2 dim");
+    dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, weight1 ? 2 : 1), block(256);
     const int nchunk = dim / 8;
     const int use = rope ? 1 : 0;
     if (nchunk <= 64 * 3)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r, out_scale);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1);
     else if (nchunk <= 64 * 10)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<10>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r, out_scale);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<10>, grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1);
     else
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<16>, grid, block, 0, st, x, ld, rows, dim, weight, eps, use, r, out_scale);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<16>, grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
