@@ -1,0 +1,41 @@
+"""What the sequence-parallel schedule costs besides the transport, on ONE GPU: P shards run back to back with the exchange
+simulated by device copies (svi_hip.sequence_parallel.forward_local) vs the plain forward, Wan2.1-1.3B widths, C2 geometry.
+With P ranks on P GPUs the shard work runs concurrently, so  (local time / P)  is the per-rank compute + packing time that the
+all-to-all transport is added to.   python tools/sp_overhead.py [layers]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import torch
+import svi_hip, synth
+from svi_hip import sequence_parallel as sp
+from bench import device_weights
+layers = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+dev = torch.device("cuda")
+cfg = dict(synth.WAN_1_3B); cfg["num_layers"] = layers
+sd = device_weights(cfg, 0, dev)
+def handle():
+    m = svi_hip.WanDiT(eps=1e-6, num_heads=12, **cfg); m.bind(sd); return m
+g = torch.Generator(device=dev).manual_seed(1)
+x = torch.randn((1, 16, 21, 60, 104), generator=g, device=dev).to(torch.bfloat16)
+ctx = torch.randn((1, 512, 4096), generator=g, device=dev).to(torch.bfloat16)
+t = torch.tensor([500.0])
+def timeit(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+plain = handle()
+for m in (plain,): m.context_cache(True)
+base = timeit(lambda: plain.forward(x, t, ctx))
+print(f"plain forward, {layers} blocks: {base:.1f} ms")
+for P in (2, 4, 6):
+    hs = [handle() for _ in range(P)]
+    for m in hs: m.context_cache(True)
+    ms = timeit(lambda: sp.forward_local(hs, x, t, ctx))
+    per_rank = ms / P
+    bytes_a2a = 2 * (32760 // P) * 1536 // P * (P - 1) * 2 * (3 + 1) / 2     # out + back per block and rank (q,k,v out; o back), bf16
+    print(f"P={P}: all shards back to back {ms:.1f} ms -> per rank {per_rank:.1f} ms ({per_rank / (base / P) - 1:+.1%} over an ideal 1/P split); "
+          f"exchange volume per block and rank {(32760 // P) * (1536 // P) * (P - 1) * 2 * 4 / 1e6:.1f} MB")
+    del hs
