@@ -223,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     const long p0 = (long)p.t_begin * HoWo + (long)blockIdx.x * X3_PIX;
     const int co0 = blockIdx.y * X3_CO;
     const int Hv = p.ups ? 2 * p.Hi : p.Hi, Wv = p.ups ? 2 * p.Wi : p.Wi;
+    const int ups_sh = p.ups ? 1 : 0;
     const int nchunk = (p.Cin + 31) >> 5;
     const int khw = p.kh * p.kw, ntaps = p.kt * khw;
     const int nk = ntaps * nchunk;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 #define SVI_X3_LOAD_A(S, j)                                                                                                      \
     do {                                                                                                                         \
         int yi_ = by[j] + tb_, xi_ = bx[j] + tc_;                                                                                \
-        if (p.ups) { yi_ >>= 1; xi_ >>= 1; }                                                                                     \
+        yi_ >>= ups_sh; xi_ >>= ups_sh;                                                                                          \
         const unsigned off_ = (unsigned)((((bt[j] + ta_) * p.Hi + yi_) * p.Wi + xi_) * p.ld_in + c_) * 4u;                        \
         const bool ok_ = cin_ && ((a_mask[j] >> tap_) & 1u);                                                                     \
         ra[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok_ ? off_ : OOB, 0, 0));              \
@@ -315,12 +316,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     } while (0)
 #define SVI_X3_STEP(CBUF, SI, kidx, valid, SS, SBUF)                                                                             \
     do {                                                                                                                         \
-        const int tap_ = (kidx) / nchunk, cc_ = (kidx) - tap_ * nchunk;                                                          \
-        const int ta_ = tap_ / khw, tb_ = (tap_ / p.kw) % p.kh, tc_ = tap_ % p.kw;                                               \
+        /* (tap, cc) of the step being requested: running counters (no divisions in the loop), advanced after the step */        \
+        const int tap_ = it_tap, cc_ = it_cc, ta_ = it_ta, tb_ = it_tb, tc_ = it_tc;                                             \
         const int c_ = cc_ * 32 + a_c4 * 4;                                                                                      \
         const bool wvalid_ = (valid) && !SVI_X3_ABL(1);                                                                          \
         const bool cin_ = wvalid_ && c_ < p.Cin;                                                                                 \
-        const unsigned wk_ = (unsigned)(((long)tap_ * p.Cout * p.ld_w3 + cc_ * 32) * 2);                                          \
+        const unsigned wk_ = it_wk;                                                                                              \
         const char* As_c = smem + (CBUF) * X3_STAGE;                                                                             \
         const char* Ws_c = As_c + 3 * X3_A_PLANE;                                                                                \
         bf16x8 a_[3];                                                                                                            \
@@ -351,6 +352,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
             else if (s_ == 4) { SVI_X3_LOAD_W(SI, 0); SVI_X3_LOAD_W(SI, 1); }                                                    \
             else SVI_X3_LOAD_W(SI, 2);                                                                                           \
         }                                                                                                                        \
+        SVI_X3_ADVANCE();                                                                                                        \
+    } while (0)
+    // next (tap, channel chunk): channel chunks innermost, then kw, kh, kt — all uniform (scalar) arithmetic
+#define SVI_X3_ADVANCE()                                                                                                         \
+    do {                                                                                                                         \
+        it_wk += 64u;                                                                                                            \
+        if (++it_cc == nchunk) {                                                                                                 \
+            it_cc = 0; ++it_tap;                                                                                                 \
+            it_wk = (unsigned)((long)it_tap * p.Cout * p.ld_w3 * 2);                                                             \
+            if (++it_tc == p.kw) { it_tc = 0; if (++it_tb == p.kh) { it_tb = 0; ++it_ta; } }                                     \
+        }                                                                                                                        \
     } while (0)
 
     f32x16 acc[3];
@@ -360,6 +372,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
     // prologue: step 0 -> set 0 -> stage 0; step 1 -> set 1.  Steady state: pairs of steps, no branch inside a step.
+    int it_tap = 0, it_cc = 0, it_ta = 0, it_tb = 0, it_tc = 0;
+    unsigned it_wk = 0;
     {
         const int tap_ = 0, cc_ = 0, ta_ = 0, tb_ = 0, tc_ = 0;
         const int c_ = a_c4 * 4;
@@ -370,31 +384,32 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) SVI_X3_LOAD_W(0, i);
     }
+    SVI_X3_ADVANCE();
 #pragma unroll
     for (int j = 0; j < 4; ++j) SVI_X3_STAGE_A(0, 0, j);
 #pragma unroll
     for (int i = 0; i < 3; ++i) SVI_X3_STAGE_W(0, 0, i);
     {
-        const int kidx = min(1, nk - 1);
-        const int tap_ = kidx / nchunk, cc_ = kidx - tap_ * nchunk;
-        const int ta_ = tap_ / khw, tb_ = (tap_ / p.kw) % p.kh, tc_ = tap_ % p.kw;
+        const int tap_ = it_tap, cc_ = it_cc, ta_ = it_ta, tb_ = it_tb, tc_ = it_tc;
         const int c_ = cc_ * 32 + a_c4 * 4;
         const bool wvalid_ = nk > 1 && !SVI_X3_ABL(1), cin_ = wvalid_ && c_ < p.Cin;
-        const unsigned wk_ = (unsigned)(((long)tap_ * p.Cout * p.ld_w3 + cc_ * 32) * 2);
+        const unsigned wk_ = it_wk;
 #pragma unroll
         for (int j = 0; j < 4; ++j) SVI_X3_LOAD_A(1, j);
 #pragma unroll
         for (int i = 0; i < 3; ++i) SVI_X3_LOAD_W(1, i);
     }
+    SVI_X3_ADVANCE();
     __syncthreads();
     const int nkk = SVI_X3_ABL(16) ? 0 : nk;
     for (int k = 0; k < nkk; k += 2) {
-        SVI_X3_STEP(0, 0, min(k + 2, nk - 1), k + 2 < nk, 1, 1);      // compute stage 0 | stage set 1 (step k+1) -> stage 1 | load step k+2 -> set 0
+        SVI_X3_STEP(0, 0, k + 2, k + 2 < nk, 1, 1);      // compute stage 0 | stage set 1 (step k+1) -> stage 1 | load step k+2 -> set 0
         __syncthreads();
-        SVI_X3_STEP(1, 1, min(k + 3, nk - 1), k + 3 < nk, 0, 0);      // compute stage 1 | stage set 0 (step k+2) -> stage 0 | load step k+3 -> set 1
+        SVI_X3_STEP(1, 1, k + 3, k + 3 < nk, 0, 0);      // compute stage 1 | stage set 0 (step k+2) -> stage 0 | load step k+3 -> set 1
         __syncthreads();
     }
 #undef SVI_X3_STEP
+#undef SVI_X3_ADVANCE
 #undef SVI_X3_LOAD_A
 #undef SVI_X3_LOAD_W
 #undef SVI_X3_STAGE_A
