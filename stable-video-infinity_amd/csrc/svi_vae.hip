@@ -365,6 +365,89 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         }                                                                                                                        \
     } while (0)
 
+#ifndef SVI_X3_UNPINNED          /* default; -DSVI_X3_UNPINNED keeps hipcc's own order inside a slice (A/B: 1.79 vs 1.73 s per C2 decode) */
+    // The same step with every instruction's place fixed (sched_barrier between the pieces): each MFMA is followed by a piece of
+    // the staging / request work — one element of the three-way split, the three LDS stores, the address arithmetic and the
+    // buffer load — so that the vector ALU works in the MFMAs' shadows and the six MFMAs chained on one accumulator are spaced
+    // apart.  The fragments of slice s+1 are read behind the first MFMA of slice s.
+#undef SVI_X3_STEP
+#define SVI_SB() __builtin_amdgcn_sched_barrier(0)
+#define SVI_X3_SPLIT1(S, j, e)                                                                                                   \
+    do {                                                                                                                         \
+        const float x_ = ra[S][j][e];                                                                                            \
+        const bf16 hh_ = (bf16)x_;                                                                                               \
+        const float r1_ = x_ - (float)hh_;                                                                                       \
+        const bf16 mm_ = (bf16)r1_;                                                                                              \
+        const float r2_ = r1_ - (float)mm_;                                                                                      \
+        hq_[e] = hh_; mq_[e] = mm_; lq_[e] = (bf16)r2_;                                                                          \
+    } while (0)
+#define SVI_X3_STEP(CBUF, SI, kidx, valid, SS, SBUF)                                                                             \
+    do {                                                                                                                         \
+        const int tap_ = it_tap, cc_ = it_cc, ta_ = it_ta, tb_ = it_tb, tc_ = it_tc;                                             \
+        const int c_ = cc_ * 32 + a_c4 * 4;                                                                                      \
+        const bool wvalid_ = (valid) && !SVI_X3_ABL(1);                                                                          \
+        const bool cin_ = wvalid_ && c_ < p.Cin;                                                                                 \
+        const unsigned wk_ = it_wk;                                                                                              \
+        const char* As_c = smem + (CBUF) * X3_STAGE;                                                                             \
+        const char* Ws_c = As_c + 3 * X3_A_PLANE;                                                                                \
+        bf16x8 af_[2][3], wf_[2][3];                                                                                             \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                                       \
+            af_[0][pl] = *reinterpret_cast<const bf16x8*>(As_c + pl * X3_A_PLANE + x3_off(32 * wave + l31, hi));                 \
+            wf_[0][pl] = *reinterpret_cast<const bf16x8*>(Ws_c + pl * X3_W_PLANE + x3_off(l31, hi));                             \
+        }                                                                                                                        \
+        SVI_SB();                                                                                                                \
+        _Pragma("unroll") for (int s_ = 0; s_ < 6; ++s_) {                                                                       \
+            const int ks = s_ / 3, n = s_ % 3, sn = s_ + 1, ksn = sn / 3, nn = sn % 3;                                           \
+            const int wc = s_ & 1, wn = wc ^ 1;                                                                                  \
+            bf16x4 hq_, mq_, lq_;                                                                                                \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][1], af_[ks][1], acc[n], 0, 0, 0);   /* wm am */            \
+            SVI_SB();                                                                                                            \
+            if (s_ < 5) {                                                                                                        \
+                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                 \
+                    wf_[wn][pl] = *reinterpret_cast<const bf16x8*>(Ws_c + pl * X3_W_PLANE + x3_off(32 * nn + l31, 2 * ksn + hi)); \
+                if (s_ == 1) {                                                                                                   \
+                    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                             \
+                        af_[1][pl] = *reinterpret_cast<const bf16x8*>(As_c + pl * X3_A_PLANE + x3_off(32 * wave + l31, 2 + hi)); \
+                }                                                                                                                \
+            }                                                                                                                    \
+            if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 0);                                                                                \
+            SVI_SB();                                                                                                            \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][2], af_[ks][0], acc[n], 0, 0, 0);   /* wl ah */            \
+            SVI_SB();                                                                                                            \
+            if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 1);                                                                                \
+            SVI_SB();                                                                                                            \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][0], af_[ks][2], acc[n], 0, 0, 0);   /* wh al */            \
+            SVI_SB();                                                                                                            \
+            if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 2);                                                                                \
+            SVI_SB();                                                                                                            \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][1], af_[ks][0], acc[n], 0, 0, 0);   /* wm ah */            \
+            SVI_SB();                                                                                                            \
+            if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 3);                                                                                \
+            SVI_SB();                                                                                                            \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][0], af_[ks][1], acc[n], 0, 0, 0);   /* wh am */            \
+            SVI_SB();                                                                                                            \
+            if (!SVI_X3_ABL(2)) {                                                                                                \
+                if (s_ < 4) {                                                                                                    \
+                    char* As_ = smem + (SBUF) * X3_STAGE;                                                                        \
+                    const int off_ = x3_off((tid >> 3) + 64 * s_, a_c4 >> 1) + (a_c4 & 1) * 8;                                   \
+                    *reinterpret_cast<bf16x4*>(As_ + off_) = hq_;                                                                \
+                    *reinterpret_cast<bf16x4*>(As_ + X3_A_PLANE + off_) = mq_;                                                   \
+                    *reinterpret_cast<bf16x4*>(As_ + 2 * X3_A_PLANE + off_) = lq_;                                               \
+                } else if (s_ == 4) { SVI_X3_STAGE_W(SS, SBUF, 0); SVI_X3_STAGE_W(SS, SBUF, 1); }                                \
+                else SVI_X3_STAGE_W(SS, SBUF, 2);                                                                                \
+            }                                                                                                                    \
+            SVI_SB();                                                                                                            \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][0], af_[ks][0], acc[n], 0, 0, 0);   /* wh ah */            \
+            SVI_SB();                                                                                                            \
+            if (s_ < 4) SVI_X3_LOAD_A(SI, s_);                                                                                   \
+            else if (s_ == 4) { SVI_X3_LOAD_W(SI, 0); SVI_X3_LOAD_W(SI, 1); }                                                    \
+            else SVI_X3_LOAD_W(SI, 2);                                                                                           \
+            SVI_SB();                                                                                                            \
+        }                                                                                                                        \
+        SVI_X3_ADVANCE();                                                                                                        \
+    } while (0)
+#endif
+
     f32x16 acc[3];
 #pragma unroll
     for (int n = 0; n < 3; ++n)
