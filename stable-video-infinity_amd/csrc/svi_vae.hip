@@ -546,7 +546,10 @@ svi_status launch_conv(const ConvP& p, hipStream_t st) {
     if (pixels <= 0) return SVI_OK;
     static const bool no_x3 = getenv("SVI_VAE_EXACT_FP32") != nullptr;     // A/B aid: force the exact-fp32 MFMA kernel
     if (p.w3 && !no_x3 && p.Cout >= 64 && p.Cout % 4 == 0 && p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) &&
-        (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) && (((uintptr_t)p.bias | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0) {
+        (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) && (((uintptr_t)p.bias | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0 &&
+        p.kt * p.kh * p.kw <= 32 &&                                                   // tap bit mask
+        (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 4 < 0xFFFFF000L &&               // 32-bit offsets inside the buffer window
+        (long)3 * p.plane_w3 * 2 < 0xFFFFF000L) {
         static bool attr3 = false;
         if (!attr3) {
             SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3_STAGE));
