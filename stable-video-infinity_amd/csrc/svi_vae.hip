@@ -285,10 +285,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     // steps ahead) into register set SI.  A step past the end (valid = false) loads out-of-range zeros, stages zeros, adds zeros.
 #define SVI_X3_LOAD_A(S, j)                                                                                                      \
     do {                                                                                                                         \
-        int yi_ = by[j] + tb_, xi_ = bx[j] + tc_;                                                                                \
-        yi_ >>= ups_sh; xi_ >>= ups_sh;                                                                                          \
-        const unsigned off_ = (unsigned)((((bt[j] + ta_) * p.Hi + yi_) * p.Wi + xi_) * p.ld_in + c_) * 4u;                        \
-        const bool ok_ = cin_ && ((a_mask[j] >> tap_) & 1u);                                                                     \
+        /* tap_off[j]: byte offset of this pixel's input position for the tap being requested (OOB if it does not exist),      \
+           recomputed only when the tap changes (SVI_X3_ADVANCE); per step just the channel offset is added */                 \
+        const unsigned off_ = tap_off[j] + (unsigned)c_ * 4u;                                                                    \
+        const bool ok_ = cin_ & (tap_off[j] != OOB);                                                                             \
         ra[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok_ ? off_ : OOB, 0, 0));              \
     } while (0)
 #define SVI_X3_LOAD_W(S, i)                                                                                                      \
@@ -355,6 +355,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         SVI_X3_ADVANCE();                                                                                                        \
     } while (0)
     // next (tap, channel chunk): channel chunks innermost, then kw, kh, kt — all uniform (scalar) arithmetic
+#define SVI_X3_TAP_BASES()                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                              \
+        const int yi_ = (by[j] + it_tb) >> ups_sh, xi_ = (bx[j] + it_tc) >> ups_sh;                                              \
+        const unsigned o_ = (unsigned)((((bt[j] + it_ta) * p.Hi + yi_) * p.Wi + xi_) * p.ld_in) * 4u;                             \
+        tap_off[j] = ((a_mask[j] >> it_tap) & 1u) ? o_ : OOB;                                                                    \
+    }
 #define SVI_X3_ADVANCE()                                                                                                         \
     do {                                                                                                                         \
         it_wk += 64u;                                                                                                            \
@@ -362,6 +368,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
             it_cc = 0; ++it_tap;                                                                                                 \
             it_wk = (unsigned)((long)it_tap * p.Cout * p.ld_w3 * 2);                                                             \
             if (++it_tc == p.kw) { it_tc = 0; if (++it_tb == p.kh) { it_tb = 0; ++it_ta; } }                                     \
+            SVI_X3_TAP_BASES();                                                                                                  \
         }                                                                                                                        \
     } while (0)
 
@@ -457,6 +464,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     // prologue: step 0 -> set 0 -> stage 0; step 1 -> set 1.  Steady state: pairs of steps, no branch inside a step.
     int it_tap = 0, it_cc = 0, it_ta = 0, it_tb = 0, it_tc = 0;
     unsigned it_wk = 0;
+    unsigned tap_off[4];
+    SVI_X3_TAP_BASES();
     {
         const int tap_ = 0, cc_ = 0, ta_ = 0, tb_ = 0, tc_ = 0;
         const int c_ = a_c4 * 4;
@@ -493,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     }
 #undef SVI_X3_STEP
 #undef SVI_X3_ADVANCE
+#undef SVI_X3_TAP_BASES
 #undef SVI_X3_LOAD_A
 #undef SVI_X3_LOAD_W
 #undef SVI_X3_STAGE_A
