@@ -187,6 +187,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 // The weight fragment is the MFMA A operand, the activation fragment the B operand, so a lane's accumulator holds 4
 // consecutive output channels of ONE pixel: 16-byte channels-last stores.
 // LDS rows are 64 B (32 bf16); 16-byte chunk c of row r sits at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128).
+// Where it stands: 1.65e15 bf16 MFMA FLOP per C2 decode in 1.6 s = 1.03 PFLOP/s — the same power-limited regime as the GEMMs
+// (profiles/r1e_power_probe.txt).  Tried on top and dropped: splitting the layer input ONCE into three bf16 planes (a streaming
+// pre-pass) and staging them by LDS-DMA with per-lane gather addresses and zero padding by the buffer range (no staging
+// registers, no ds_write, 6 fewer VALU per MFMA): bit-identical, the convolutions ran at the same speed and the pre-pass (110 ms)
+// and the 1.5x larger operand stream made the decode 5 % slower; six accumulator chains instead of three: no change.
 // =================================================================================================
 #define X3_PIX 256
 #define X3_CO 96
