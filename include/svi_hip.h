@@ -18,7 +18,10 @@
  *   - Errors: integer status, never abort/throw across the ABI; message via svi_last_error()
  *     (thread-local).  There is NO CPU fallback: with no usable GPU every compute call fails.
  *   - Activations are bf16 (row-major, innermost dim contiguous) unless stated; accumulation fp32.
- *   - Handles are not thread-safe; one handle per device.
+ *   - Handles are not thread-safe; one handle per device.  The operator-level seams (svi_attention_fwd,
+ *     svi_layernorm_modulate, svi_rmsnorm_rope) share one process-wide scratch buffer: call them from one thread
+ *     and on one stream at a time (stream order is what protects the scratch between consecutive calls).
+ *     The event profiler (svi_prof_*) is process-wide and single-threaded as well.
  */
 #ifndef SVI_HIP_H
 #define SVI_HIP_H

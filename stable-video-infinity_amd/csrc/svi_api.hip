@@ -199,7 +199,11 @@ extern "C" svi_status svi_rmsnorm_rope(void* x, int32_t ld, int32_t rows, int32_
     char* scr = nullptr;
     svi_status s = scratch_reserve(cnt * sizeof(float2), &scr);
     if (s != SVI_OK) { free(host); return s; }
-    hipError_t e = hipMemcpy(scr, host, cnt * sizeof(float2), hipMemcpyHostToDevice);
+    // the scratch may still be read by work enqueued earlier (a previous call's table): drain the stream before rewriting it,
+    // and the device after, since `st` need not be ordered after the null stream the copy runs on (operator seam, not the hot path)
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(scr, host, cnt * sizeof(float2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     free(host);
     if (e != hipSuccess) { svi_set_error("hipMemcpy(rope table) failed: %s", hipGetErrorString(e)); return SVI_ERR_HIP; }
     SviRope r;

@@ -284,6 +284,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc) {
     hipError_t e = hipMalloc((void**)&w.base, off);
     if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B workspace) failed: %s", off, hipGetErrorString(e)); return SVI_ERR_OOM; }
     SVI_CHECK_HIP(hipMemset(w.base, 0, off));           // V^T pad columns must read as zeros
+    SVI_CHECK_HIP(hipDeviceSynchronize());              // the caller's stream need not be ordered after the null stream
     w.bytes = off; w.L = L; w.Lc = Lc; w.ldvt = ldvt; w.ldcvt = ldcvt; w.kpatch = kpatch;
     auto P = [&](size_t o) { return reinterpret_cast<bf16*>(w.base + o); };
     w.X = P(oX); w.X2 = P(oX2); w.Hb = P(oH); w.QK = P(oQK); w.VT = P(oVT); w.Fb = P(oF); w.CTX = P(oCTX); w.CTXH = P(oCTXH);
@@ -313,6 +314,7 @@ static svi_status ensure_rope(svi_dit* h, int f, int hh, int ww) {
     if (h->rope_dev) { SVI_CHECK_HIP(hipFree(h->rope_dev)); h->rope_dev = nullptr; }
     SVI_CHECK_HIP(hipMalloc((void**)&h->rope_dev, host.size() * sizeof(float2)));
     SVI_CHECK_HIP(hipMemcpy(h->rope_dev, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
+    SVI_CHECK_HIP(hipDeviceSynchronize());
     h->rf = f; h->rh = hh; h->rw = ww;
     h->rope.tab_f = h->rope_dev;
     h->rope.tab_h = h->rope_dev + (size_t)f * npf;

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 #define SVI_X3_STEP(CBUF, SI, kidx, valid, SS, SBUF)                                                                             \
     do {                                                                                                                         \
         /* (tap, cc) of the step being requested: running counters (no divisions in the loop), advanced after the step */        \
-        const int tap_ = it_tap, cc_ = it_cc, ta_ = it_ta, tb_ = it_tb, tc_ = it_tc;                                             \
+        const int cc_ = it_cc;                                             \
         const int c_ = cc_ * 32 + a_c4 * 4;                                                                                      \
         const bool wvalid_ = (valid) && !SVI_X3_ABL(1);                                                                          \
         const bool cin_ = wvalid_ && c_ < p.Cin;                                                                                 \
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     } while (0)
 #define SVI_X3_STEP(CBUF, SI, kidx, valid, SS, SBUF)                                                                             \
     do {                                                                                                                         \
-        const int tap_ = it_tap, cc_ = it_cc, ta_ = it_ta, tb_ = it_tb, tc_ = it_tc;                                             \
+        const int cc_ = it_cc;                                             \
         const int c_ = cc_ * 32 + a_c4 * 4;                                                                                      \
         const bool wvalid_ = (valid) && !SVI_X3_ABL(1);                                                                          \
         const bool cin_ = wvalid_ && c_ < p.Cin;                                                                                 \
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     unsigned tap_off[4];
     SVI_X3_TAP_BASES();
     {
-        const int tap_ = 0, cc_ = 0, ta_ = 0, tb_ = 0, tc_ = 0;
+        const int cc_ = 0;
         const int c_ = a_c4 * 4;
         const bool wvalid_ = !SVI_X3_ABL(1), cin_ = wvalid_ && c_ < p.Cin;
         const unsigned wk_ = 0;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) SVI_X3_STAGE_W(0, 0, i);
     {
-        const int tap_ = it_tap, cc_ = it_cc, ta_ = it_ta, tb_ = it_tb, tc_ = it_tc;
+        const int cc_ = it_cc;
         const int c_ = cc_ * 32 + a_c4 * 4;
         const bool wvalid_ = nk > 1 && !SVI_X3_ABL(1), cin_ = wvalid_ && c_ < p.Cin;
         const unsigned wk_ = it_wk;
@@ -765,6 +765,7 @@ struct svi_vae {
     float* attn_scratch = nullptr; size_t attn_bytes = 0;
     bool dry = false;
     long dry_max = 0;
+    bool pack_pending = false;                          // weight packing kernels enqueued on the null stream since the last call
 };
 
 namespace {
@@ -1176,6 +1177,7 @@ extern "C" svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const vo
         hipLaunchKernelGGL(pack_weight_x3_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, 0, cw.w_user, cw.packed3, cw.Cout, cw.Cin, taps, cw.ldw3);
     }
     SVI_LAUNCH_CHECK();
+    h->pack_pending = true;
     return SVI_OK;
 }
 
@@ -1186,11 +1188,16 @@ extern "C" svi_status svi_vae_check_bound(svi_vae* h) {
 
 static svi_status vae_prepare(svi_vae* h) {
     SVI_TRY(check_bound(h));
+    if (h->pack_pending) {       // packing ran on the null stream; the caller's stream need not be ordered after it
+        SVI_CHECK_HIP(hipStreamSynchronize(nullptr));
+        h->pack_pending = false;
+    }
     if (!h->consts) {
         float host[32];
         for (int i = 0; i < 16; ++i) { host[i] = kMean[i]; host[16 + i] = 1.0f / kStd[i]; }
         SVI_CHECK_HIP(hipMalloc((void**)&h->consts, sizeof(host)));
         SVI_CHECK_HIP(hipMemcpy(h->consts, host, sizeof(host), hipMemcpyHostToDevice));
+        SVI_CHECK_HIP(hipDeviceSynchronize());
     }
     return SVI_OK;
 }
