@@ -18,6 +18,45 @@ import torch
 from . import _lib as L
 
 
+def _version(t: torch.Tensor) -> int:
+    """Version counter of a tensor (bumped by every in-place write); inference tensors do not keep one."""
+    return 0 if t.is_inference() else t._version
+
+
+class PromptPins:
+    """Bookkeeping that makes the pointer-keyed context cache of the C side (svi_dit_context_cache) safe to leave on.
+
+    The C side recognises a prompt embedding by its device pointer.  Two things can make a pointer lie: the tensor is freed and
+    the allocator hands its storage to the next prompt's embedding (same shape, same address), or the tensor is written in
+    place.  So every tensor the cache may have seen is kept alive here — its storage cannot be recycled while it is pinned —
+    together with its version counter and shape; `admit` says when the C-side entries must be dropped."""
+
+    def __init__(self, capacity: int = 8):
+        self.capacity = capacity
+        self._pins: Dict[int, Tuple[torch.Tensor, int, Tuple[int, ...]]] = {}
+
+    def __len__(self) -> int:
+        return len(self._pins)
+
+    def clear(self) -> None:
+        self._pins = {}
+
+    def admit(self, tensors) -> bool:
+        """Pin the prompt-side tensors of one call.  Returns True when the cache entries made so far are no longer trustworthy
+        (a pinned tensor changed, or more prompts are in flight than are kept) — the caller then drops them; the tensors of this
+        call are pinned either way."""
+        tensors = [t for t in tensors if t is not None]
+        stale = any(p is not None and (p[1] != _version(t) or p[2] != tuple(t.shape))
+                    for t in tensors for p in [self._pins.get(t.data_ptr())])
+        fresh = {t.data_ptr() for t in tensors if t.data_ptr() not in self._pins}
+        drop = stale or len(self._pins) + len(fresh) > self.capacity
+        if drop:
+            self._pins = {}
+        for t in tensors:
+            self._pins[t.data_ptr()] = (t, _version(t), tuple(t.shape))
+        return drop
+
+
 class WanDiT:
     def __init__(self, dim: int, in_dim: int, ffn_dim: int, out_dim: int, text_dim: int, freq_dim: int, eps: float,
                  patch_size: Tuple[int, int, int], num_heads: int, num_layers: int, has_image_input: bool):
@@ -30,6 +69,8 @@ class WanDiT:
         L.check(L.lib().svi_dit_create(C.byref(cfg), C.byref(h)), "svi_dit_create")
         self._h = h
         self._params: Dict[str, torch.Tensor] = {}
+        self._ctx_cache_on = False
+        self._ctx_pins = PromptPins()
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
@@ -67,8 +108,24 @@ class WanDiT:
 
     def context_cache(self, enable: bool) -> None:
         """Reuse the projected context and the cross-attention K / V^T of every block across forwards that are handed the
-        same context tensor (same storage, unchanged contents); see svi_dit_context_cache in include/svi_hip.h."""
+        same context tensor (same storage, unchanged contents); see svi_dit_context_cache in include/svi_hip.h.  While it is on,
+        context / clip_feature must be contiguous CUDA bf16 tensors (a converted temporary would be recognised by an address the
+        allocator recycles); they are kept alive here and an in-place write to one of them drops the cache (PromptPins)."""
         L.check(L.lib().svi_dit_context_cache(self._h, 1 if enable else 0), "svi_dit_context_cache")
+        self._ctx_cache_on = bool(enable)
+        self._ctx_pins.clear()
+
+    def _prompt_args(self, *tensors):
+        """The prompt-side inputs (context(s), clip_feature) as contiguous bf16; see context_cache()."""
+        if not self._ctx_cache_on:
+            return tuple(None if t is None else t.to(torch.bfloat16).contiguous() for t in tensors)
+        for t in tensors:
+            if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous()):
+                raise ValueError("with the context cache on, context / clip_feature must be contiguous CUDA bf16 tensors that live "
+                                 "across the calls (convert once, outside the step loop)")
+        if self._ctx_pins.admit(tensors):
+            L.check(L.lib().svi_dit_context_cache(self._h, 1), "svi_dit_context_cache")      # re-enabling drops every entry
+        return tensors
 
     def __del__(self):
         try:
@@ -88,13 +145,11 @@ class WanDiT:
         if not x.is_cuda:
             raise RuntimeError("svi_hip runs on the GPU only")
         x = x.to(torch.bfloat16).contiguous()
-        context = context.to(torch.bfloat16).contiguous()
+        context, clip_feature = self._prompt_args(context, clip_feature)
         timestep = timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         B, _, T, H, W = x.shape
         if timestep.numel() != B:
             timestep = timestep.expand(B).contiguous()
-        if clip_feature is not None:
-            clip_feature = clip_feature.to(torch.bfloat16).contiguous()
         if y is not None:
             y = y.to(torch.bfloat16).contiguous()
         if add_condition is not None:
@@ -136,16 +191,13 @@ class WanDiT:
         if not x.is_cuda:
             raise RuntimeError("svi_hip runs on the GPU only")
         x = x.to(torch.bfloat16).contiguous()
-        context_cond = context_cond.to(torch.bfloat16).contiguous()
-        context_uncond = context_uncond.to(torch.bfloat16).contiguous()
         if context_cond.shape != context_uncond.shape:
             raise ValueError("the two prompt embeddings of a CFG pair must have the same shape")
+        context_cond, context_uncond, clip_feature = self._prompt_args(context_cond, context_uncond, clip_feature)
         timestep = timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         B, _, T, H, W = x.shape
         if timestep.numel() != B:
             timestep = timestep.expand(B).contiguous()
-        if clip_feature is not None:
-            clip_feature = clip_feature.to(torch.bfloat16).contiguous()
         if y is not None:
             y = y.to(torch.bfloat16).contiguous()
         if add_condition is not None:

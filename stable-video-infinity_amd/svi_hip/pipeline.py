@@ -15,7 +15,7 @@ from typing import Callable, Dict, Optional
 import torch
 
 from . import ops
-from .dit import WanDiT, model_fn_wan_video
+from .dit import WanDiT, _version, model_fn_wan_video
 from .scheduler import FlowMatchScheduler
 
 
@@ -109,6 +109,21 @@ class DenoiseLoop:
 _INSTALLED: Dict[int, WanDiT] = {}
 
 
+def _stable_bf16(hip: WanDiT, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """`t` as contiguous bf16 with a stable address: the conversion of a given tensor (same storage, version, layout) is made once
+    and both the original and the copy are kept, so neither address can come back as another prompt's."""
+    if t is None or (t.dtype == torch.bfloat16 and t.is_contiguous()):
+        return t
+    memo = hip.__dict__.setdefault("_bf16_memo", {})
+    key = (t.data_ptr(), _version(t), tuple(t.shape), tuple(t.stride()), t.dtype)
+    hit = memo.get(key)
+    if hit is None:
+        if len(memo) >= 8:
+            memo.clear()
+        hit = memo[key] = (t, t.to(torch.bfloat16).contiguous())
+    return hit[1]
+
+
 def _hip_model_fn(dit_module, x, timestep, context, clip_feature=None, y=None, tea_cache=None, add_condition=None,
                   use_unified_sequence_parallel=False, **kwargs):
     """model_fn_wan_video with the reference's exact signature; `dit_module` is the reference WanModel the
@@ -116,15 +131,12 @@ def _hip_model_fn(dit_module, x, timestep, context, clip_feature=None, y=None, t
     hip = _INSTALLED.get(id(dit_module))
     if hip is None:
         raise RuntimeError("this WanModel was not passed through svi_hip.install(); refusing to fall back to PyTorch")
-    # prompt embeddings are constant across the steps of a clip: keep the context cache on while the tensor the pipeline
-    # hands us is the same storage with the same version counter (any in-place write or new tensor drops the cache)
-    key = (context.data_ptr(), context._version, tuple(context.shape), None if clip_feature is None else (clip_feature.data_ptr(), clip_feature._version))
-    seen = getattr(hip, "_ctx_keys", None)
-    if seen is None or (key not in seen and len(seen) >= 4) or any(k[0] == key[0] and k != key for k in seen):
-        hip.context_cache(False)
+    # prompt embeddings are constant across the steps of a clip: the context cache stays on; WanDiT keeps every tensor the cache
+    # has seen alive and drops the cache on an in-place write (dit.PromptPins), so a new clip's prompt can never be taken for an
+    # old one.  Embeddings that are not bf16-contiguous are converted ONCE per tensor and the copy is what the cache sees.
+    if not hip._ctx_cache_on:
         hip.context_cache(True)
-        seen = hip._ctx_keys = set()
-    seen.add(key)
+    context, clip_feature = _stable_bf16(hip, context), _stable_bf16(hip, clip_feature)
     return model_fn_wan_video(hip, x, timestep, context, clip_feature=clip_feature, y=y, tea_cache=tea_cache,
                               add_condition=add_condition, use_unified_sequence_parallel=use_unified_sequence_parallel)
 

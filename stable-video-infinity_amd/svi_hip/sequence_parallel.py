@@ -117,8 +117,8 @@ class SequenceShard:
             raise ValueError(f"{self.L} tokens do not divide over {self.world} ranks")
         self.Ls = self.L // self.world
         self.ldvt = (self.Ls + 7) // 8 * 8
-        self._keep = [x, context.to(torch.bfloat16).contiguous(), timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(),
-                      None if clip_feature is None else clip_feature.to(torch.bfloat16).contiguous(),
+        context, clip_feature = d._prompt_args(context, clip_feature)
+        self._keep = [x, context, timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(), clip_feature,
                       None if y is None else y.to(torch.bfloat16).contiguous(),
                       None if add_condition is None else add_condition.to(torch.bfloat16).contiguous()]
         x, context, ts, clip, yy, addc = self._keep

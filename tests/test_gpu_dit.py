@@ -151,6 +151,38 @@ def test_context_cache_is_bit_identical(hip, name):
     assert torch.equal(a1, ref) and torch.equal(a3, ref) and torch.equal(b1, ref2) and torch.equal(a2, want_half)
 
 
+def test_context_cache_survives_prompt_turnover(hip):
+    """A rolling window hands the DiT a new prompt embedding per clip: the old tensor dies, the allocator may return its address
+    for the next one, or the pipeline may overwrite it in place.  The cache is keyed by pointer on the C side, so WanDiT pins what
+    the cache has seen and drops it on an in-place write: results must always be those of the uncached forward."""
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    m, _ = build(hip, c, seed)
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    xd, t = dev(x), torch.tensor([ts])
+    others = [dev(torch.from_numpy(synth.randn(seed + 200 + i, *ctx.shape))) for i in range(12)]
+    want0 = m.forward(xd, t, dev(ctx)).clone()
+    wants = [m.forward(xd, t, o).clone() for o in others]
+    m.context_cache(True)
+    try:
+        cur = dev(ctx)
+        assert torch.equal(m.forward(xd, t, cur), want0)
+        del cur                                            # clip over: the embedding is dropped by its owner ...
+        for o, w in zip(others, wants):                    # ... and fresh ones of the same shape arrive (more than the pin capacity)
+            fresh = o.clone()
+            assert torch.equal(m.forward(xd, t, fresh), w)
+            assert torch.equal(m.forward(xd, t, fresh), w)         # served from the cache
+            del fresh
+        keep = dev(ctx)
+        assert torch.equal(m.forward(xd, t, keep), want0)
+        keep.copy_(others[3])                              # in-place overwrite of a cached embedding
+        assert torch.equal(m.forward(xd, t, keep), wants[3])
+        with pytest.raises(ValueError):                    # a conversion would hand the cache a temporary
+            m.forward(xd, t, keep.float())
+    finally:
+        m.context_cache(False)
+    assert torch.equal(m.forward(xd, t, keep.float()), wants[3])
+
+
 @pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
 @pytest.mark.parametrize("cache", [False, True])
 def test_cfg_pair_is_bit_identical_to_two_forwards(hip, name, cache):
