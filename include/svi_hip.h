@@ -204,7 +204,9 @@ svi_status svi_prof_summary(char* buf, int64_t buflen);
 svi_status svi_vae_create(svi_vae** out);
 svi_status svi_vae_destroy(svi_vae* h);
 /* name = reference state-dict key ("model.decoder.conv1.weight", ...); dtype SVI_F32
- * (the pipelines run the VAE in fp32: pipelines/svi_video.py:386-387,303-309). */
+ * (the pipelines run the VAE in fp32: pipelines/svi_video.py:386-387,303-309).  Convolution weights are re-packed for the
+ * kernels at bind time by a launch on the NULL stream: the tensor must be complete with respect to that stream when it is
+ * bound; the first encode / decode after a bind waits for the packing before it enqueues on the caller's stream. */
 svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const void* dev_ptr, svi_dtype dtype,
                                const int64_t* shape, int32_t rank);
 svi_status svi_vae_check_bound(svi_vae* h);
