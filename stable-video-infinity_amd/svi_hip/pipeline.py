@@ -92,10 +92,10 @@ class DenoiseLoop:
         latents = latents.to(torch.bfloat16).contiguous().clone()
         ts_dev = self.scheduler.timesteps.to(device=latents.device, dtype=torch.float32)
         # the prompt embeddings are constants of the loop: project them (and every block's cross-attention K / V) once
-        ctx_pos = ctx_pos.to(torch.bfloat16).contiguous()
-        ctx_neg = None if ctx_neg is None else ctx_neg.to(torch.bfloat16).contiguous()
+        ctx_pos = ctx_pos.to(device=latents.device, dtype=torch.bfloat16).contiguous()
+        ctx_neg = None if ctx_neg is None else ctx_neg.to(device=latents.device, dtype=torch.bfloat16).contiguous()
         if "clip_feature" in cond and cond["clip_feature"] is not None:
-            cond["clip_feature"] = cond["clip_feature"].to(torch.bfloat16).contiguous()
+            cond["clip_feature"] = cond["clip_feature"].to(device=latents.device, dtype=torch.bfloat16).contiguous()
         self.dit.context_cache(True)
         try:
             for i, t in enumerate(progress_bar_cmd(self.scheduler.timesteps)):

@@ -43,6 +43,8 @@ class StreamLoop:
     def __init__(self, dit, vae, clip_encoder: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, num_motion_frames: int = 1,
                  num_frames: int = 81, num_inference_steps: int = 50, cfg_scale: float = 5.0, sigma_shift: float = 5.0,
                  ref_pad_cfg: bool = False, ref_pad_num: int = 0, seed_times: int = 42):
+        if num_motion_frames < 1:
+            raise ValueError("an image-conditioned stream hands at least one motion frame from clip to clip (test_svi.py:472-476)")
         self.loop = DenoiseLoop(dit)
         self.vae, self.clip_encoder = vae, clip_encoder
         self.num_motion_frames, self.num_frames = num_motion_frames, num_frames
