@@ -881,7 +881,14 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
                 default: break;
             }
             const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
-            SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+            static const void* configured[24];                     // instantiations whose LDS limit has been raised (once each)
+            static int n_configured = 0;
+            bool seen = false;
+            for (int i = 0; i < n_configured; ++i) seen = seen || configured[i] == reinterpret_cast<const void*>(kern);
+            if (!seen) {
+                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+                if (n_configured < 24) configured[n_configured++] = reinterpret_cast<const void*>(kern);
+            }
             dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
             hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
             SVI_LAUNCH_CHECK();

@@ -22,6 +22,7 @@
 // Workgroup ids are remapped so that the 8 XCDs each own a contiguous band of tiles (per-XCD L2 keeps
 // the shared A row-panel hot; cdna_hip_programming.md T1, bijective form).
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "svi_common.h"
@@ -756,7 +757,7 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             // N = 8960 (35 column panels, ffn1): 5-6 give 1050 vs 1022 at 2 and 980 at 8 — a 5 x 6 block of concurrent tiles per XCD
             // needs the fewest operand panels (HBM fetch per launch at 2: 2.2 GB against 0.13 GB of operands, profiles/r1h_gemm_ffn1_pmc.txt)
             const int gm_rows = gme ? atoi(gme) : (tn >= 16 ? 5 : 2);
-            if (force && force[0] == '2' && force[3] == '\0')       // "256": the v2 main loop (barrier at the tile boundary), kept for A/B
+            if (force && strcmp(force, "256") == 0)       // "256": the v2 main loop (barrier at the tile boundary), kept for A/B
                 hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
             else {
                 const char* ab = getenv("SVI_GEMM_EPI_ABL");              // epilogue timing ablations (tools/gemm_epi_abl.py); results wrong when set
