@@ -1,0 +1,136 @@
+"""Size-independent properties of the host logic around the hot path (hypothesis; CPU only, no compute calls).
+
+  * the two sequence-parallel exchanges (svi_hip/sequence_parallel.py; the reference's USP chunk / all-to-all / all-gather,
+    pipelines/svi_video.py:119-135, distributed/xdit_context_parallel.py) are exact re-layouts for ANY shard count, ragged sizes
+    included: tokens -> heads gives every rank all tokens of its head group, heads -> tokens is its inverse;
+  * clip sharding is a partition, stitching follows test_svi.py:472-476 for any clip lengths;
+  * FlowMatchScheduler (schedulers/flow_match.py:3-63) ladders are monotone and the 50 Euler deltas of a clip telescope to the
+    sigma the clip started from.
+"""
+import math
+
+import torch
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+from svi_hip import parallel
+from svi_hip import sequence_parallel as sp
+from svi_hip.scheduler import FlowMatchScheduler
+
+FAST = settings(max_examples=60, deadline=None)
+
+
+def _ids(L, D):
+    """[L, D] tensor whose entry (l, c) encodes its own coordinates (exact in bf16 for the sizes used: values < 256)."""
+    return (torch.arange(L)[:, None] % 16 * 16 + torch.arange(D)[None, :] % 16).to(torch.bfloat16)
+
+
+@FAST
+@given(P=st.sampled_from([1, 2, 3, 4, 6, 8]), heads_per=st.integers(1, 3), Ls=st.integers(1, 21), seed=st.integers(0, 2 ** 16))
+def test_tokens_to_heads_and_back(P, heads_per, Ls, seed):
+    Dp = 8 * heads_per                       # stands in for heads_per x 128 columns; the layout code only sees column blocks
+    D, L = P * Dp, P * Ls
+    g = torch.Generator().manual_seed(seed)
+    Q, K, V = (torch.randn((L, D), generator=g).to(torch.bfloat16) for _ in range(3))
+    ldvt = (Ls + 7) // 8 * 8
+    sends = []
+    for r in range(P):
+        rows = slice(r * Ls, (r + 1) * Ls)
+        qk = torch.cat([Q[rows], K[rows]], dim=1).contiguous()
+        vt = torch.zeros((D, ldvt), dtype=torch.bfloat16)
+        vt[:, :Ls] = V[rows].t()
+        vt[:, Ls:] = 7.0                     # whatever sits in the pad columns of a shard must not travel
+        sends.append(sp.pack_qkv(qk, vt, P))
+    recv = sp.all_to_all_local(sends)
+    outs = []
+    for j in range(P):
+        cols = slice(j * Dp, (j + 1) * Dp)
+        q, k, vt = sp.unpack_qkv(recv[j], Ls, Dp)
+        assert q.shape == (L, Dp) and torch.equal(q, Q[:, cols]) and torch.equal(k, K[:, cols])
+        assert vt.shape == (Dp, (L + 7) // 8 * 8)
+        assert torch.equal(vt[:, :L], V[:, cols].t()) and not vt[:, L:].any()      # zero pad: the kernel reads those columns
+        outs.append(sp.pack_out((q.float() + 2 * k.float()).to(torch.bfloat16).contiguous(), P))
+    back = sp.all_to_all_local(outs)
+    want = (Q.float() + 2 * K.float()).to(torch.bfloat16)
+    for r in range(P):
+        attn = sp.unpack_out(back[r], Ls, Dp)
+        assert attn.shape == (Ls, D) and torch.equal(attn, want[r * Ls:(r + 1) * Ls])
+
+
+@FAST
+@given(P=st.integers(1, 8), Ls=st.integers(1, 9), Dp=st.sampled_from([8, 16, 24]))
+def test_exchange_moves_every_element_exactly_once(P, Ls, Dp):
+    """Coordinates survive the round trip: nothing is duplicated or dropped by pack / exchange / unpack."""
+    D, L = P * Dp, P * Ls
+    X = _ids(L, D)
+    packs = []
+    for j in range(P):
+        packs.append(sp.pack_out(X[:, j * Dp:(j + 1) * Dp].contiguous(), P))
+    back = sp.all_to_all_local(packs)
+    got = torch.cat([sp.unpack_out(back[r], Ls, Dp) for r in range(P)], dim=0)
+    assert torch.equal(got, X)
+
+
+@FAST
+@given(n=st.integers(0, 200), world=st.integers(1, 16))
+def test_clip_sharding_is_a_balanced_partition(n, world):
+    shards = [parallel.shard_units(n, r, world) for r in range(world)]
+    flat = sorted(k for s in shards for k in s)
+    assert flat == list(range(n))
+    sizes = [len(s) for s in shards]
+    assert max(sizes) - min(sizes) <= 1
+    assert all(s == sorted(s) for s in shards)                      # a rank meets its clips in window order
+    assert all(k % world == r for r, s in enumerate(shards) for k in s)
+
+
+@FAST
+@given(lengths=st.lists(st.integers(1, 30), min_size=1, max_size=8), m=st.integers(0, 5))
+def test_stitching_rule(lengths, m):
+    """test_svi.py:472-476: every clip but the last loses its final `num_motion_frames` frames."""
+    clips = [[(i, f) for f in range(n)] for i, n in enumerate(lengths)]
+    out = parallel.stitch_window(clips, m)
+    want = []
+    for i, c in enumerate(clips):
+        want += c if (i == len(clips) - 1 or m == 0) else c[:-m] if m < len(c) else []
+    assert out == want
+    assert out[-lengths[-1]:] == clips[-1]                           # the last clip is whole
+    assert len(out) == sum(max(n - m, 0) for n in lengths[:-1]) + lengths[-1]
+
+
+@FAST
+@given(k=st.integers(0, 500), n=st.integers(1, 12), rep=st.integers(1, 7), first=st.booleans(), seed_times=st.sampled_from([-1, 0, 1, 42, 1000]))
+def test_prompt_and_seed_schedule(k, n, rep, first, seed_times):
+    """test_svi.py:425-438: seed = chunk_idx * seed_times (-1 = unseeded); prompt index cycles every `rep` clips."""
+    want = 0 if first else (k // rep) % n
+    assert parallel.clip_prompt_index(k, n, rep, first) == want
+    s = parallel.clip_seed(k, seed_times)
+    assert s is None if seed_times == -1 else s == k * seed_times
+
+
+@FAST
+@given(steps=st.integers(1, 120), shift=st.floats(1.0, 12.0), strength=st.floats(0.05, 1.0))
+def test_flow_match_ladder(steps, shift, strength):
+    sch = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)     # as SVIVideoPipeline builds it (svi_video.py:148)
+    sch.set_timesteps(steps, denoising_strength=strength, shift=shift)
+    sig = sch.sigmas.double()
+    assert len(sig) == steps and torch.equal(sch.timesteps, sch.sigmas * 1000)
+    assert bool((sig[1:] < sig[:-1]).all()) and sig[-1] > 0 and sig[0] <= 1.0 + 1e-6
+    assert math.isclose(float(sig[0]), shift * strength / (1 + (shift - 1) * strength), rel_tol=1e-5)
+    deltas = [sch.step_delta(t) for t in sch.timesteps]
+    assert all(d < 0 for d in deltas)
+    assert math.isclose(sum(deltas), -float(sig[0]), rel_tol=0, abs_tol=1e-5)   # the clip ends at sigma = 0
+    assert math.isclose(deltas[-1], -float(sig[-1]), abs_tol=1e-7)
+
+
+@FAST
+@given(steps=st.integers(2, 60), i=st.integers(0, 59))
+def test_nearest_timestep_lookup(steps, i):
+    """step() finds its position by nearest timestep (flow_match.py:54-55): a timestep that went through bf16 or a device round
+    trip still lands on its own step."""
+    sch = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(steps)
+    i = i % steps
+    t = sch.timesteps[i]
+    for noisy in (t, t.to(torch.bfloat16).float() if steps <= 30 else t, t + 1e-3):
+        want = float((sch.sigmas[i + 1] if i + 1 < steps else 0.0) - sch.sigmas[i])
+        assert math.isclose(sch.step_delta(noisy), want, abs_tol=1e-7)
