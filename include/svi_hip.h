@@ -72,6 +72,11 @@ int32_t svi_abi_version(void);
 /* Number of visible HIP devices (0 => every compute entry point will fail with SVI_ERR_HIP). */
 int32_t svi_device_count(void);
 
+/* A/B tooling: the library reads its environment switches (SVI_FLASH_KERNEL, SVI_GEMM_KERNEL, SVI_GEMM_GM, SVI_VAE_EXACT_FP32 —
+ * all of them select between kernels that compute the same result) once, at first use; tools that flip them inside one process
+ * call this afterwards.  Switches that change results exist only in variant builds (-DSVI_ABLATIONS), never in the product. */
+svi_status svi_switches_reload(void);
+
 /* ------------------------------------------------------------------ DiT: whole model ------ */
 /* WanModel(...) construction (weights are bound afterwards, by reference state-dict key). */
 svi_status svi_dit_create(const svi_dit_config* cfg, svi_dit** out);
@@ -226,6 +231,19 @@ svi_status svi_vae_decode(svi_vae* h, const float* latents, float* video, int32_
  *   video f32 [3, 1+4k, H, W]  ->  latents f32 [16, 1+k, H/8, W/8]  (normalised mean). */
 svi_status svi_vae_encode(svi_vae* h, const float* video, float* latents, int32_t T, int32_t H, int32_t W,
                           svi_stream stream);
+
+/* WanVideoVAE.tiled_decode / tiled_encode (models/wan_video_vae.py:643-693 / :696-744, masks :621-640): the spatial tiling the
+ * pipelines switch on with `tiled=True` (the default of SVIVideoPipeline.__call__, pipelines/svi_video.py:439).  Tiles start every
+ * tile_stride, are clipped at the far edge, and a start is dropped once the previous tile reaches the edge; each tile is read in
+ * place from the caller's tensor, run through the same graph as svi_vae_decode / _encode, multiplied by the linear-ramp mask
+ * (ramp width = (tile_size - tile_stride), in output elements) and accumulated in task order; the result is values / weight,
+ * clamped to [-1,1] for decode only AFTER the blend (tile values are not clamped, as in the reference).  `video` / `latents` serve
+ * as the accumulator.  Decode: sizes and strides in LATENT pixels; encode: in VIDEO pixels, multiples of 8 (the reference's
+ * encode() multiplies its latent-unit arguments by 8 before the call, :765-767). */
+svi_status svi_vae_tiled_decode(svi_vae* h, const float* latents, float* video, int32_t T, int32_t hh, int32_t ww,
+                                int32_t size_h, int32_t size_w, int32_t stride_h, int32_t stride_w, svi_stream stream);
+svi_status svi_vae_tiled_encode(svi_vae* h, const float* video, float* latents, int32_t T, int32_t H, int32_t W,
+                                int32_t size_h, int32_t size_w, int32_t stride_h, int32_t stride_w, svi_stream stream);
 
 #ifdef __cplusplus
 }

@@ -141,8 +141,9 @@ def encoder_layout() -> List[tuple]:
     return out
 
 
-def vae_decode(sd: Dict[str, Tensor], z: Tensor) -> Tensor:
-    """latents [B,16,T,h,w] (normalised) -> video [B,3,1+4(T-1),8h,8w] clamped to [-1,1]."""
+def vae_decode(sd: Dict[str, Tensor], z: Tensor, clamp: bool = True) -> Tensor:
+    """latents [B,16,T,h,w] (normalised) -> video [B,3,1+4(T-1),8h,8w] clamped to [-1,1] (single_decode, vae:753-756;
+    clamp=False: VideoVAE_.decode alone, which is what the tiled path blends, vae:666)."""
     mean = torch.tensor(LATENT_MEAN, dtype=z.dtype).reshape(1, Z_DIM, 1, 1, 1)
     inv_std = (1.0 / torch.tensor(LATENT_STD)).to(z.dtype).reshape(1, Z_DIM, 1, 1, 1)
     x = z / inv_std + mean
@@ -157,7 +158,7 @@ def vae_decode(sd: Dict[str, Tensor], z: Tensor) -> Tensor:
         x = residual_block(sd, p, x) if kind == "res" else upsample_block(sd, p, x, kind == "up3d")
     x = silu(channel_rms(x, sd[d + "head.0.gamma"]))
     x = causal_conv3d(x, sd[d + "head.2.weight"], sd[d + "head.2.bias"])
-    return x.clamp(-1.0, 1.0)
+    return x.clamp(-1.0, 1.0) if clamp else x
 
 
 def vae_encode(sd: Dict[str, Tensor], video: Tensor) -> Tensor:
@@ -177,6 +178,60 @@ def vae_encode(sd: Dict[str, Tensor], video: Tensor) -> Tensor:
     mean = torch.tensor(LATENT_MEAN, dtype=mu.dtype).reshape(1, Z_DIM, 1, 1, 1)
     inv_std = (1.0 / torch.tensor(LATENT_STD)).to(mu.dtype).reshape(1, Z_DIM, 1, 1, 1)
     return (mu - mean) * inv_std
+
+
+# ---- spatial tiling (WanVideoVAE.tiled_decode / tiled_encode, vae:621-744) ---------------------------------------------------
+def ramp_1d(length: int, left_bound: bool, right_bound: bool, border: int) -> Tensor:
+    """build_1d_mask (vae:621-627)."""
+    x = torch.ones(length)
+    if not left_bound:
+        x[:border] = (torch.arange(border) + 1) / border
+    if not right_bound:
+        x[-border:] = torch.flip((torch.arange(border) + 1) / border, dims=(0,))
+    return x
+
+
+def tile_tasks(H: int, W: int, size, stride) -> List[tuple]:
+    """The task list of vae:648-655: a start is dropped when the previous tile already reaches the far edge."""
+    out = []
+    for h in range(0, H, stride[0]):
+        if h - stride[0] >= 0 and h - stride[0] + size[0] >= H:
+            continue
+        for w in range(0, W, stride[1]):
+            if w - stride[1] >= 0 and w - stride[1] + size[1] >= W:
+                continue
+            out.append((h, h + size[0], w, w + size[1]))
+    return out
+
+
+def _blend(tiles_fn, src: Tensor, out_shape, size, stride, scale_to_out, border) -> Tensor:
+    _, _, _, H, W = src.shape
+    values = torch.zeros(out_shape, dtype=src.dtype)
+    weight = torch.zeros((1, 1, *out_shape[2:]), dtype=src.dtype)
+    for h, h_, w, w_ in tile_tasks(H, W, size, stride):
+        tile = tiles_fn(src[:, :, :, h:h_, w:w_])
+        th, tw = tile.shape[3:]
+        m = torch.minimum(ramp_1d(th, h == 0, h_ >= H, border[0])[:, None].expand(th, tw),
+                          ramp_1d(tw, w == 0, w_ >= W, border[1])[None, :].expand(th, tw))[None, None, None]      # build_mask :630-640
+        oh, ow = scale_to_out(h), scale_to_out(w)
+        values[:, :, :, oh:oh + th, ow:ow + tw] += tile * m                                                   # :668-676
+        weight[:, :, :, oh:oh + th, ow:ow + tw] += m                                                          # :677-685
+    return values / weight
+
+
+def tiled_decode(sd: Dict[str, Tensor], z: Tensor, tile_size, tile_stride) -> Tensor:
+    """vae:643-693; sizes in latent pixels; un-clamped tiles, one clamp after the blend (:687)."""
+    B, _, T, H, W = z.shape
+    out = _blend(lambda t: vae_decode(sd, t, clamp=False), z, (B, 3, 4 * T - 3, 8 * H, 8 * W), tile_size, tile_stride, lambda a: a * 8,
+                 ((tile_size[0] - tile_stride[0]) * 8, (tile_size[1] - tile_stride[1]) * 8))
+    return out.clamp(-1.0, 1.0)
+
+
+def tiled_encode(sd: Dict[str, Tensor], video: Tensor, tile_size, tile_stride) -> Tensor:
+    """vae:696-744; sizes in VIDEO pixels (WanVideoVAE.encode multiplies its latent-unit arguments by 8 first, :765-767)."""
+    B, _, T, H, W = video.shape
+    return _blend(lambda t: vae_encode(sd, t), video, (B, 16, (T + 3) // 4, H // 8, W // 8), tile_size, tile_stride, lambda a: a // 8,
+                  ((tile_size[0] - tile_stride[0]) // 8, (tile_size[1] - tile_stride[1]) // 8))
 
 
 # ---- I2V conditioning assembly (pipelines/svi_video.py:313-350), the tensor half of encode_images_adaptive ------------------

@@ -15,6 +15,70 @@ void svi_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* svi_last_error(void) { return g_err; }
+
+static int env_int(const char* name, int lo, int dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    char* end = nullptr;
+    const long x = strtol(v, &end, 10);
+    if (end == v || x < lo || x > (1 << 20)) { fprintf(stderr, "libsvi_hip: ignoring %s=%s (expected an integer >= %d)\n", name, v, lo); return dflt; }
+    return (int)x;
+}
+static SviSwitches parse_switches() {
+    SviSwitches s;
+    s.flash_kernel = env_int("SVI_FLASH_KERNEL", 1, 0);
+    if (s.flash_kernel > 2) s.flash_kernel = 0;
+    s.gemm_kernel = env_int("SVI_GEMM_KERNEL", 128, 0);
+    if (s.gemm_kernel != 128 && s.gemm_kernel != 256 && s.gemm_kernel != 257) s.gemm_kernel = 0;
+    s.gemm_gm = env_int("SVI_GEMM_GM", 1, 0);
+    s.vae_exact_fp32 = getenv("SVI_VAE_EXACT_FP32") != nullptr;
+#ifdef SVI_ABLATIONS
+    s.flash_abl = env_int("SVI_FLASH_ABL", 0, 0);
+    s.gemm_epi_abl = env_int("SVI_GEMM_EPI_ABL", 0, 0);
+    s.vae_abl = env_int("SVI_VAE_ABL", 0, 0);
+    s.flash_assume_prescaled = getenv("SVI_FLASH_ASSUME_PRESCALED") != nullptr;
+#endif
+    return s;
+}
+static SviSwitches& switches_storage() {
+    static SviSwitches sw = parse_switches();
+    return sw;
+}
+const SviSwitches& svi_switches() { return switches_storage(); }
+extern "C" svi_status svi_switches_reload(void) {
+    switches_storage() = parse_switches();
+    return SVI_OK;
+}
+
+int svi_current_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); svi_set_error("no usable HIP device"); return -1; }
+    return d;
+}
+
+svi_status svi_claim_device(int* handle_device) {
+    const int d = svi_current_device();
+    if (d < 0) return SVI_ERR_HIP;
+    if (*handle_device < 0) *handle_device = d;
+    if (*handle_device != d) {
+        svi_set_error("handle belongs to device %d but the current device is %d (one handle per device)", *handle_device, d);
+        return SVI_ERR_INVALID;
+    }
+    return SVI_OK;
+}
+
+svi_status svi_ensure_lds(const void* kernel, int bytes) {
+    struct Seen { int dev; const void* fn; };
+    static Seen seen[256];
+    static int n_seen = 0;
+    const int dev = svi_current_device();
+    if (dev < 0) return SVI_ERR_HIP;
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].dev == dev && seen[i].fn == kernel) return SVI_OK;
+    SVI_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (n_seen < 256) seen[n_seen++] = Seen{dev, kernel};
+    return SVI_OK;
+}
 extern "C" int32_t svi_abi_version(void) { return SVI_HIP_ABI_VERSION; }
 extern "C" int32_t svi_device_count(void) {
     int n = 0;
@@ -85,16 +149,20 @@ struct Scratch {
     char* p = nullptr;
     size_t bytes = 0;
 };
-Scratch g_scratch;
+Scratch g_scratch[16];          // one per device: the seams may be used under any current device
 
 svi_status scratch_reserve(size_t bytes, char** out) {
-    if (g_scratch.bytes < bytes) {
-        if (g_scratch.p) { SVI_CHECK_HIP(hipFree(g_scratch.p)); g_scratch.p = nullptr; g_scratch.bytes = 0; }
-        hipError_t e = hipMalloc((void**)&g_scratch.p, bytes);
+    const int dev = svi_current_device();
+    if (dev < 0) return SVI_ERR_HIP;
+    SVI_REQUIRE(dev < 16, "device index %d beyond the scratch table", dev);
+    Scratch& sc = g_scratch[dev];
+    if (sc.bytes < bytes) {
+        if (sc.p) { SVI_CHECK_HIP(hipFree(sc.p)); sc.p = nullptr; sc.bytes = 0; }
+        hipError_t e = hipMalloc((void**)&sc.p, bytes);
         if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B scratch) failed: %s", bytes, hipGetErrorString(e)); return SVI_ERR_OOM; }
-        g_scratch.bytes = bytes;
+        sc.bytes = bytes;
     }
-    *out = g_scratch.p;
+    *out = sc.p;
     return SVI_OK;
 }
 
@@ -124,8 +192,12 @@ extern "C" svi_status svi_attention_fwd(const void* q, const void* k, const void
         const bf16* vi = reinterpret_cast<const bf16*>(v) + (size_t)i * s_kv * D;
         bf16* oi = reinterpret_cast<bf16*>(out) + (size_t)i * s_q * D;
         SVI_TRY(svi_launch_transpose(vi, D, vt, ldvt, s_kv, D, st));
-        // SVI_FLASH_ASSUME_PRESCALED is a timing aid for tools/attn_abl.py only (it makes the results wrong by the scale factor)
-        SVI_TRY(svi_launch_flash(qi, D, ki, D, vt, ldvt, oi, D, s_q, s_kv, n, getenv("SVI_FLASH_ASSUME_PRESCALED") ? 1 : 0, st));
+#ifdef SVI_ABLATIONS       // timing aid of tools/attn_abl.py (results wrong by the scale factor): variant builds only
+        const int prescaled = svi_switches().flash_assume_prescaled;
+#else
+        const int prescaled = 0;
+#endif
+        SVI_TRY(svi_launch_flash(qi, D, ki, D, vt, ldvt, oi, D, s_q, s_kv, n, prescaled, st));
     }
     return SVI_OK;
 }

@@ -845,56 +845,41 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     SVI_REQUIRE(ldvt >= ((Lk + 7) / 8) * 8, "attention: V^T leading dim %d < keys rounded up to 8", ldvt);
     SVI_REQUIRE(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)VT % 16) == 0 &&
                     ((uintptr_t)O % 8) == 0, "attention: operands must be 16-byte aligned");
-    static bool attr_set = false;
     const int lds = 2 * (KT_BYTES + VT_BYTES);
-    if (!attr_set) {
-        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
-    {
-        const char* force = getenv("SVI_FLASH_KERNEL");            // "1" / "2": A/B switch for tools/attn_ab.py
-        const bool v2 = force ? force[0] == '2' : (Lk >= 2048);     // short key axes (text context) are prologue-bound: v1
-        if (v2) {
-            const char* ab = getenv("SVI_FLASH_ABL");              // timing-only ablations, see the kernel's ABL parameter
-            const int abl = ab ? atoi(ab) : 0;
-            typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float);
-            kern_t kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false> : flash_fwd2_kernel<1, 0, false>)
-                                      : (Lq == Lk ? flash_fwd2_kernel<0, 0, true> : flash_fwd2_kernel<1, 0, true>);
-            switch (q_prescaled ? abl : 0) {
-                case 1: kern = flash_fwd2_kernel<0, 1>; break;
-                case 2: kern = flash_fwd2_kernel<0, 2>; break;
-                case 3: kern = flash_fwd2_kernel<0, 3>; break;
-                case 4: kern = flash_fwd2_kernel<0, 4>; break;
-                case 7: kern = flash_fwd2_kernel<0, 7>; break;
-                case 8: kern = flash_fwd2_kernel<0, 8>; break;
-                case 15: kern = flash_fwd2_kernel<0, 15>; break;
-                case 16: kern = flash_fwd2_kernel<0, 16>; break;
-                case 32: kern = flash_fwd2_kernel<0, 32>; break;
-                case 64: kern = flash_fwd2_kernel<0, 64>; break;
-                case 128: kern = flash_fwd2_kernel<0, 128>; break;
-                case 256: kern = flash_fwd2_kernel<0, 256>; break;
-                case 768: kern = flash_fwd2_kernel<0, 768>; break;
-                default: break;
-            }
-            const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
-            static const void* configured[24];                     // instantiations whose LDS limit has been raised (once each)
-            static int n_configured = 0;
-            bool seen = false;
-            for (int i = 0; i < n_configured; ++i) seen = seen || configured[i] == reinterpret_cast<const void*>(kern);
-            if (!seen) {
-                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-                if (n_configured < 24) configured[n_configured++] = reinterpret_cast<const void*>(kern);
-            }
-            dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
-            hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
-            SVI_LAUNCH_CHECK();
-            return SVI_OK;
+    const SviSwitches& sw = svi_switches();
+    const bool v2 = sw.flash_kernel ? sw.flash_kernel == 2 : (Lk >= 2048);     // short key axes (text context) are prologue-bound: v1
+    if (v2) {
+        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float);
+        kern_t kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false> : flash_fwd2_kernel<1, 0, false>)
+                                  : (Lq == Lk ? flash_fwd2_kernel<0, 0, true> : flash_fwd2_kernel<1, 0, true>);
+#ifdef SVI_ABLATIONS       // timing-only ablations (tools/attn_ab.py; results wrong), see the kernel's ABL parameter: variant builds only
+        switch (q_prescaled ? sw.flash_abl : 0) {
+            case 1: kern = flash_fwd2_kernel<0, 1>; break;
+            case 2: kern = flash_fwd2_kernel<0, 2>; break;
+            case 3: kern = flash_fwd2_kernel<0, 3>; break;
+            case 4: kern = flash_fwd2_kernel<0, 4>; break;
+            case 7: kern = flash_fwd2_kernel<0, 7>; break;
+            case 8: kern = flash_fwd2_kernel<0, 8>; break;
+            case 15: kern = flash_fwd2_kernel<0, 15>; break;
+            case 16: kern = flash_fwd2_kernel<0, 16>; break;
+            case 32: kern = flash_fwd2_kernel<0, 32>; break;
+            case 64: kern = flash_fwd2_kernel<0, 64>; break;
+            case 128: kern = flash_fwd2_kernel<0, 128>; break;
+            case 256: kern = flash_fwd2_kernel<0, 256>; break;
+            case 768: kern = flash_fwd2_kernel<0, 768>; break;
+            default: break;
         }
+#endif
+        const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(kern), lds2));
+        dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
+        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
+        SVI_LAUNCH_CHECK();
+        return SVI_OK;
     }
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(flash_fwd_kernel<0>), lds));
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(flash_fwd_kernel<1>), lds));
     dim3 grid((Lq + QB - 1) / QB, num_heads), block(256);
     const float v1_scale = q_prescaled ? 1.0f : scale_log2e;
     if (Lq == Lk)

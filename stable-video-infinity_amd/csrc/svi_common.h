@@ -54,6 +54,30 @@ void svi_set_error(const char* fmt, ...);
         if (_s != SVI_OK) return _s;                                                          \
     } while (0)
 
+// ---- process-wide switches, read ONCE (first use) ------------------------------------------------
+// A/B aids that select between kernels computing the SAME result (bit-identical or within the stated parity bounds); they
+// never change what is computed.  Switches that make results wrong (timing ablations) exist only in variant builds made with
+// -DSVI_ABLATIONS (tools/build_variant.py) and are absent from the product library.
+struct SviSwitches {
+    int flash_kernel = 0;        // SVI_FLASH_KERNEL = 1 | 2 : force flash_fwd_kernel / flash_fwd2_kernel (0: by key count)
+    int gemm_kernel = 0;         // SVI_GEMM_KERNEL = 128 | 256 | 257 : force the 128^2 kernel / the v2 256^2 main loop / the v3 loop (0: by tile count)
+    int gemm_gm = 0;             // SVI_GEMM_GM = n >= 1 : row panels per tile group (0: per shape)
+    int vae_exact_fp32 = 0;      // SVI_VAE_EXACT_FP32 : fp32-MFMA convolution everywhere
+#ifdef SVI_ABLATIONS
+    int flash_abl = 0, gemm_epi_abl = 0, vae_abl = 0, flash_assume_prescaled = 0;
+#endif
+};
+const SviSwitches& svi_switches();
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: raise it once per (device, kernel).
+svi_status svi_ensure_lds(const void* kernel, int bytes);
+// The device current on this thread, or -1 (message set).
+int svi_current_device();
+// Handles belong to ONE device (workspace, packed weights, LDS attributes live there): the first compute call claims the device
+// current on the calling thread, later calls under another current device are refused instead of faulting.
+svi_status svi_claim_device(int* handle_device);
+#define SVI_REQUIRE_DEVICE(h) SVI_TRY(svi_claim_device(&(h)->device))
+
 // ---- device helpers ----------------------------------------------------------------------
 #ifdef __HIPCC__
 // value of a float after a round trip through bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32):

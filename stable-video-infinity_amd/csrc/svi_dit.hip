@@ -43,7 +43,7 @@ struct Workspace {
     int L = 0, Lc = 0;
     char* base = nullptr;
     size_t bytes = 0;
-    bf16 *X, *X2, *Hb, *QK, *VT, *Fb, *CTX, *CTXH, *CK, *CVT, *CKi, *CVTi, *A2, *PATCH, *HO, *IMG0, *IMG1;
+    bf16 *X, *X2, *Hb, *QK, *VT, *Fb, *CTX, *CTXH, *CK, *CVT, *CKi, *CVTi, *A2, *PATCH, *HO, *IMG0, *IMG1, *IMGD;
     bf16 *e, *h1, *t, *st, *tmod;
     float *modf, *headf;
     int ldvt = 0, ldcvt = 0, ldcvti = 264, kpatch = 0;
@@ -70,6 +70,7 @@ struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; };
 
 struct svi_dit {
     svi_dit_config cfg;
+    int device = -1;                  // claimed by the first compute call (svi_claim_device)
     std::vector<BlockW> blocks;
     const bf16 *patch_w = nullptr, *patch_b = nullptr;
     Lin text0, text2, time0, time2, timeproj, head;
@@ -277,7 +278,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc) {
     const size_t oCVT = take(D * ldcvt * 2), oCKi = take((size_t)264 * D * 2), oCVTi = take(D * 264 * 2);
     const size_t oA2 = take(img ? (size_t)L * D * 2 : 256);
     const size_t oP = take((size_t)L * kpatch * 2), oHO = take((size_t)L * ho_ld * 2);
-    const size_t oI0 = take((size_t)264 * 1280 * 2), oI1 = take((size_t)264 * 1280 * 2);
+    const size_t oI0 = take((size_t)264 * 1280 * 2), oI1 = take((size_t)264 * 1280 * 2), oID = take((size_t)264 * D * 2);
     const size_t oe = take(c.freq_dim * 2), oh1 = take(D * 2), ot = take(D * 2), ost = take(D * 2), otm = take(6 * D * 2);
     const size_t omodf = take((size_t)c.num_layers * 6 * D * 4), oheadf = take(2 * D * 4);
     if (w.base) { SVI_CHECK_HIP(hipFree(w.base)); w.base = nullptr; }
@@ -289,7 +290,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc) {
     auto P = [&](size_t o) { return reinterpret_cast<bf16*>(w.base + o); };
     w.X = P(oX); w.X2 = P(oX2); w.Hb = P(oH); w.QK = P(oQK); w.VT = P(oVT); w.Fb = P(oF); w.CTX = P(oCTX); w.CTXH = P(oCTXH);
     w.CK = P(oCK); w.CVT = P(oCVT); w.CKi = P(oCKi); w.CVTi = P(oCVTi); w.A2 = P(oA2); w.PATCH = P(oP); w.HO = P(oHO);
-    w.IMG0 = P(oI0); w.IMG1 = P(oI1); w.e = P(oe); w.h1 = P(oh1); w.t = P(ot); w.st = P(ost); w.tmod = P(otm);
+    w.IMG0 = P(oI0); w.IMG1 = P(oI1); w.IMGD = P(oID); w.e = P(oe); w.h1 = P(oh1); w.t = P(ot); w.st = P(ost); w.tmod = P(otm);
     w.modf = reinterpret_cast<float*>(w.base + omodf);
     w.headf = reinterpret_cast<float*>(w.base + oheadf);
     return SVI_OK;
@@ -509,8 +510,8 @@ static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* cli
             SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
             SVI_TRY(svi_launch_ln_mod(clip, 1280, w.IMG0, 1280, 257, 1280, 1e-5f, h->img_ln0_w, h->img_ln0_b, nullptr, nullptr, st));
             SVI_TRY(linear(w.IMG0, 1280, h->img1, w.IMG1, 1280, 257, 1280, 1280, SVI_EPI_BIAS_GELU_ERF, st));
-            SVI_TRY(linear(w.IMG1, 1280, h->img3, w.Hb, D, 257, D, 1280, SVI_EPI_BIAS, st));
-            SVI_TRY(svi_launch_ln_mod(w.Hb, D, CTXp, D, 257, D, 1e-5f, h->img_ln4_w, h->img_ln4_b, nullptr, nullptr, st));
+            SVI_TRY(linear(w.IMG1, 1280, h->img3, w.IMGD, D, 257, D, 1280, SVI_EPI_BIAS, st));      // own [264, D] rows: Hb holds only L rows (L < 257 on tiny grids / shards)
+            SVI_TRY(svi_launch_ln_mod(w.IMGD, D, CTXp, D, 257, D, 1e-5f, h->img_ln4_w, h->img_ln4_b, nullptr, nullptr, st));
         }
     } else if (img) {
         SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
@@ -628,7 +629,10 @@ extern "C" svi_status svi_dit_forward(svi_dit* h, const void* x, const float* ti
                                       const void* clip_feature, const void* y, const void* add_condition, void* out,
                                       int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc, svi_stream stream) {
     SVI_REQUIRE(h && x && timestep && context && out, "svi_dit_forward: null argument");
+    SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward: bad sizes");
+    SVI_REQUIRE(y || h->cfg.in_dim == 16, "this model takes %d extra input channels: y must be given", h->cfg.in_dim - 16);
+    SVI_REQUIRE(!h->cfg.has_image_input || clip_feature, "has_image_input model needs clip_feature");
     const svi_dit_config& c = h->cfg;
     SVI_REQUIRE(T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0,
                 "latent size %dx%dx%d is not divisible by the patch size", T, H, W);
@@ -653,7 +657,10 @@ extern "C" svi_status svi_dit_forward_tea(svi_dit* h, const void* x, const float
                                           int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc, int32_t tea_mode, void* residual,
                                           svi_stream stream) {
     SVI_REQUIRE(h && x && timestep && context && out, "svi_dit_forward_tea: null argument");
+    SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward_tea: bad sizes");
+    SVI_REQUIRE(y || h->cfg.in_dim == 16, "this model takes %d extra input channels: y must be given", h->cfg.in_dim - 16);
+    SVI_REQUIRE(!h->cfg.has_image_input || clip_feature, "has_image_input model needs clip_feature");
     SVI_REQUIRE(tea_mode >= 0 && tea_mode <= 2 && (tea_mode == 0 || residual), "svi_dit_forward_tea: tea_mode %d needs a residual buffer", tea_mode);
     const svi_dit_config& c = h->cfg;
     SVI_REQUIRE(T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0,
@@ -679,6 +686,7 @@ extern "C" svi_status svi_dit_forward_tea(svi_dit* h, const void* x, const float
 // TeaCache.check compares between steps (svi_video.py:44-52).
 extern "C" svi_status svi_dit_time_mod(svi_dit* h, const float* timestep, void* t_mod_out, int32_t B, svi_stream stream) {
     SVI_REQUIRE(h && timestep && t_mod_out && B > 0, "svi_dit_time_mod: bad argument");
+    SVI_REQUIRE_DEVICE(h);
     SVI_TRY(svi_dit_check_bound(h));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int D = h->cfg.dim;
@@ -696,7 +704,10 @@ extern "C" svi_status svi_dit_forward_cfg_pair(svi_dit* h, const void* x, const 
                                                const void* add_condition, void* out_cond, void* out_uncond, int32_t B, int32_t T,
                                                int32_t H, int32_t W, int32_t Lc, svi_stream stream) {
     SVI_REQUIRE(h && x && timestep && context_cond && context_uncond && out_cond && out_uncond, "svi_dit_forward_cfg_pair: null argument");
+    SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward_cfg_pair: bad sizes");
+    SVI_REQUIRE(y || h->cfg.in_dim == 16, "this model takes %d extra input channels: y must be given", h->cfg.in_dim - 16);
+    SVI_REQUIRE(!h->cfg.has_image_input || clip_feature, "has_image_input model needs clip_feature");
     const svi_dit_config& c = h->cfg;
     SVI_REQUIRE(T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0,
                 "latent size %dx%dx%d is not divisible by the patch size", T, H, W);
@@ -729,8 +740,11 @@ extern "C" svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* t
                                        const void* clip_feature, const void* y, const void* add_condition, int32_t T, int32_t H,
                                        int32_t W, int32_t Lc, int32_t row0, int32_t nrows, svi_stream stream) {
     SVI_REQUIRE(h && x && timestep && context, "svi_dit_sp_begin: null argument");
+    SVI_REQUIRE_DEVICE(h);
     const svi_dit_config& c = h->cfg;
     SVI_REQUIRE(T > 0 && H > 0 && W > 0 && Lc > 0 && T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0, "svi_dit_sp_begin: bad sizes");
+    SVI_REQUIRE(y || c.in_dim == 16, "this model takes %d extra input channels: y must be given", c.in_dim - 16);
+    SVI_REQUIRE(!c.has_image_input || clip_feature, "has_image_input model needs clip_feature");
     const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w, L = f * hh * ww;
     SVI_REQUIRE(row0 >= 0 && nrows > 0 && row0 + nrows <= L, "svi_dit_sp_begin: rows [%d, %d) outside the %d-token sequence", row0, row0 + nrows, L);
     SVI_TRY(svi_dit_check_bound(h));
@@ -751,6 +765,7 @@ extern "C" svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* t
 
 extern "C" svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* qk_out, void* vt_out, int32_t ldvt, svi_stream stream) {
     SVI_REQUIRE(h && h->sp_active && qk_out && vt_out, "svi_dit_sp_block_qkv: no shard in flight (svi_dit_sp_begin) or null buffer");
+    SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && ldvt >= h->sp_rows && ldvt % 8 == 0, "svi_dit_sp_block_qkv: bad layer / ldvt");
     return block_qkv(h, layer, h->ws.X, h->ws.modf + (size_t)layer * 6 * h->cfg.dim, h->sp_rows, h->sp_row0,
                      reinterpret_cast<bf16*>(qk_out), reinterpret_cast<bf16*>(vt_out), ldvt, reinterpret_cast<hipStream_t>(stream));
@@ -758,6 +773,7 @@ extern "C" svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* qk_o
 
 extern "C" svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const void* attn, svi_stream stream) {
     SVI_REQUIRE(h && h->sp_active && attn, "svi_dit_sp_block_rest: no shard in flight or null buffer");
+    SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers, "svi_dit_sp_block_rest: bad layer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float* modf = h->ws.modf + (size_t)layer * 6 * h->cfg.dim;
@@ -767,12 +783,14 @@ extern "C" svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const voi
 
 extern "C" svi_status svi_dit_sp_head(svi_dit* h, void* head_rows_out, svi_stream stream) {
     SVI_REQUIRE(h && h->sp_active && head_rows_out, "svi_dit_sp_head: no shard in flight or null buffer");
+    SVI_REQUIRE_DEVICE(h);
     h->sp_active = false;
     return stage_head_rows(h, reinterpret_cast<bf16*>(head_rows_out), h->sp_rows, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void* out, int32_t T, int32_t H, int32_t W, svi_stream stream) {
     SVI_REQUIRE(h && head_rows && out && T > 0 && H > 0 && W > 0, "svi_dit_unpatchify: bad argument");
+    SVI_REQUIRE_DEVICE(h);
     return stage_unpatchify(h, reinterpret_cast<const bf16*>(head_rows), reinterpret_cast<bf16*>(out), T, H, W, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -782,6 +800,7 @@ extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_i
                                             const void* t_mod, int32_t f, int32_t hh, int32_t ww, int32_t Lc,
                                             svi_stream stream) {
     SVI_REQUIRE(h && x_inout && context && t_mod, "svi_dit_block_forward: null argument");
+    SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers, "layer %d out of range", layer);
     SVI_REQUIRE(f > 0 && hh > 0 && ww > 0 && Lc > 0, "bad grid");
     SVI_TRY(svi_dit_check_bound(h));

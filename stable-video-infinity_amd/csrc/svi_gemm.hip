@@ -590,7 +590,13 @@ __device__ __forceinline__ void gemm_mfma_v(int& tok, f32x16& acc, u32x4 w, u32x
 }
 
 template <int SPREAD>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM, int abl) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM, int abl_arg) {
+#ifdef SVI_ABLATIONS
+    const int abl = abl_arg;          // epilogue timing ablations: variant builds only (tools/build_variant.py -DSVI_ABLATIONS)
+#else
+    constexpr int abl = 0;            // the product kernel carries no results-changing switch
+    (void)abl_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lds0 = (int)(size_t)(lptr_t)smem;
     const int tid = threadIdx.x;
@@ -741,29 +747,26 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     {
         const long t256 = (long)((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN);
         const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
-        const char* force = getenv("SVI_GEMM_KERNEL");      // "128" / "256" / "256c": A/B switch for tools/gemm_ab.py ("256c" = compiler-scheduled main loop)
-        const bool want256 = force ? (force[0] == '2') : (t256 >= 128);
+        const SviSwitches& sw = svi_switches();
+        const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 256 : (t256 >= 128);
         if (want256 && g.K % BK == 0 && fits32) {
-            static bool attr256 = false;
-            if (!attr256) {
-                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
-                SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
-                attr256 = true;
-            }
             const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
-            const char* gme = getenv("SVI_GEMM_GM");               // row panels per tile group (A/B aid)
             // measured (tools/gemm_gm.py, v3 loop): N = 1536 (6 column panels): 2 is best (ffn2 1257 vs 1168-1230 TFLOP/s), flat on q/k/v;
             // N = 8960 (35 column panels, ffn1): 5-6 give 1050 vs 1022 at 2 and 980 at 8 — a 5 x 6 block of concurrent tiles per XCD
             // needs the fewest operand panels (HBM fetch per launch at 2: 2.2 GB against 0.13 GB of operands, profiles/r1h_gemm_ffn1_pmc.txt)
-            const int gm_rows = gme ? atoi(gme) : (tn >= 16 ? 5 : 2);
-            if (force && strcmp(force, "256") == 0)       // "256": the v2 main loop (barrier at the tile boundary), kept for A/B
+            const int gm_rows = sw.gemm_gm ? sw.gemm_gm : (tn >= 16 ? 5 : 2);
+            if (sw.gemm_kernel == 256) {      // the v2 main loop (barrier at the tile boundary), kept for A/B
+                SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<false>), LDS256_BYTES));
                 hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
-            else {
-                const char* ab = getenv("SVI_GEMM_EPI_ABL");              // epilogue timing ablations (tools/gemm_epi_abl.py); results wrong when set
-                const int abl = ab ? atoi(ab) : 0;
+            } else {
                 // Tried and dropped: starting the first round's workgroups out of phase (s_sleep by CU index) so that the CUs' store
                 // bursts do not coincide: no gain on ffn1 (17.5 rounds), a loss wherever the tile count is a whole number of rounds.
+                SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<1>), LDS256_BYTES));
+#ifdef SVI_ABLATIONS          // epilogue timing ablations (tools/gemm_epi_abl.py; results wrong when set): variant builds only
+                const int abl = sw.gemm_epi_abl;
+#else
+                const int abl = 0;
+#endif
                 hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);
             }
             SVI_LAUNCH_CHECK();
@@ -771,12 +774,7 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
         }
     }
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES));
-        attr_set = true;
-    }
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel), 4 * STAGE_BYTES));
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m,
                        tiles_n);
     SVI_LAUNCH_CHECK();

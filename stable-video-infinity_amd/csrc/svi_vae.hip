@@ -22,6 +22,7 @@
 // buffered through registers, XOR-swizzled 128-byte rows (conflict-free ds_read_b128).  One ds_read_b128
 // per operand feeds 4 MFMA k-steps (lane-half hi owns k = 8q+4hi+s; A and B use the same map).
 // Algorithmic work per conv: 2 * To*Ho*Wo * Cout * Cin * kt*kh*kw FLOP.
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -212,9 +213,9 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16
     }
 }
 
-// timing ablations (tools/vae_ab.py, SVI_VAE_ABL): compiled in only with -DSVI_VAE_ABL_BUILD so that the product kernel has no
+// timing ablations (tools/vae_ab.py, SVI_VAE_ABL): compiled in only with -DSVI_ABLATIONS so that the product kernel has no
 // branches inside a K step
-#ifdef SVI_VAE_ABL_BUILD
+#ifdef SVI_ABLATIONS
 #define SVI_X3_ABL(bit) (p.abl & (bit))
 #else
 #define SVI_X3_ABL(bit) false
@@ -559,33 +560,26 @@ svi_status launch_conv(const ConvP& p, hipStream_t st) {
     SVI_REQUIRE(p.Cin % 4 == 0 && p.ld_in % 4 == 0 && p.ld_w % 4 == 0, "conv: Cin/ld must be multiples of 4 (Cin=%d)", p.Cin);
     const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
     if (pixels <= 0) return SVI_OK;
-    static const bool no_x3 = getenv("SVI_VAE_EXACT_FP32") != nullptr;     // A/B aid: force the exact-fp32 MFMA kernel
+    const bool no_x3 = svi_switches().vae_exact_fp32 != 0;                 // A/B aid: force the exact-fp32 MFMA kernel
     if (p.w3 && !no_x3 && p.Cout >= 64 && p.Cout % 4 == 0 && p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) &&
         (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) && (((uintptr_t)p.bias | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0 &&
         p.kt * p.kh * p.kw <= 32 &&                                                   // tap bit mask
         (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 4 < 0xFFFFF000L &&               // 32-bit offsets inside the buffer window
         (long)3 * p.plane_w3 * 2 < 0xFFFFF000L) {
-        static bool attr3 = false;
-        if (!attr3) {
-            SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3_STAGE));
-            attr3 = true;
-        }
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_igemm_x3_kernel), 2 * X3_STAGE));
         dim3 grid3((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block3(512);
-        static const int vae_abl = getenv("SVI_VAE_ABL") ? atoi(getenv("SVI_VAE_ABL")) : 0;
         ConvP pa = p;
-        pa.abl = vae_abl;
+#ifdef SVI_ABLATIONS
+        pa.abl = svi_switches().vae_abl;
+#endif
         hipLaunchKernelGGL(conv_igemm_x3_kernel, grid3, block3, 2 * X3_STAGE, st, pa);
         SVI_LAUNCH_CHECK();
         return SVI_OK;
     }
     const int NT = p.Cout > 32 ? 3 : 1;
     dim3 grid((unsigned)((pixels + 127) / 128), (unsigned)((p.Cout + 32 * NT - 1) / (32 * NT))), block(256);
-    static bool attr = false;
-    if (!attr) {
-        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 3 * 32 * 128)));
-        SVI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 1 * 32 * 128)));
-        attr = true;
-    }
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_igemm_kernel<3>), 2 * (128 * 128 + 3 * 32 * 128)));
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_igemm_kernel<1>), 2 * (128 * 128 + 1 * 32 * 128)));
     if (NT == 3)
         hipLaunchKernelGGL(conv_igemm_kernel<3>, grid, block, 2 * (128 * 128 + 3 * 32 * 128), st, p);
     else
@@ -708,6 +702,78 @@ __global__ void video_out_kernel(const float* __restrict__ in, int ld, float* __
     const long sp = i - (long)c * thw;
     v[i] = fminf(fmaxf(in[sp * ld + c], -1.f), 1.f);
 }
+// ---- spatial tiling (WanVideoVAE.tiled_decode / tiled_encode, vae:643-744) -------------------------------------------
+// A tile is a window [h0, h0+th) x [w0, w0+tw) of the caller's [C, T, Hf, Wf] tensor: read in place (no gathered copy), its
+// result multiplied by the reference's linear-ramp mask and accumulated into the full-size output; `weight` accumulates the mask
+// ([Hf, Wf] plane: the reference's [1,1,T,H,W] weight does not depend on t), the finalisation divides (and, for decode, clamps).
+// Every product / sum / quotient is a separately rounded fp32 operation in the reference's order (tiles in task order), so the
+// blend itself is bit-identical to the reference's CPU arithmetic given the same tile values.
+struct TileWin {
+    int Hf, Wf, h0, w0, th, tw;          // full plane, window origin and size (in elements of the tensor the window is cut from)
+    int oHf, oWf, oh0, ow0;              // the same window in the output tensor's resolution
+    int lb, rb, tb, bb;                  // is_bound: (top, bottom, left, right) = (h==0, h_>=H, w==0, w_>=W)   vae:663
+    int border_h, border_w;              // ramp widths in output elements
+};
+// build_1d_mask (vae:621-627): ones, ramp (i+1)/border on a non-bound left edge, mirrored on a non-bound right edge (the right
+// edge is written last, so it wins where the two ramps overlap)
+__device__ __forceinline__ float mask_1d(int i, int length, int left_bound, int right_bound, int border) {
+    float m = 1.f;
+    if (!left_bound && i < border) m = (float)(i + 1) / (float)border;
+    if (!right_bound && i >= length - border) m = (float)(length - i) / (float)border;
+    return m;
+}
+__global__ void latent_in_win_kernel(const float* __restrict__ z, float* __restrict__ out, int T, TileWin tw, const float* __restrict__ mean,
+                                     const float* __restrict__ inv_std) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)T * tw.th * tw.tw * 16;
+    if (i >= n) return;
+    const int c = (int)(i & 15);
+    long sp = i >> 4;
+    const int x = (int)(sp % tw.tw); sp /= tw.tw;
+    const int y = (int)(sp % tw.th);
+    const int t = (int)(sp / tw.th);
+    out[i] = z[(((long)c * T + t) * tw.Hf + tw.h0 + y) * tw.Wf + tw.w0 + x] / inv_std[c] + mean[c];
+}
+__global__ void video_in_win_kernel(const float* __restrict__ v, float* __restrict__ out, int T, TileWin tw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)T * tw.th * tw.tw * 4;
+    if (i >= n) return;
+    const int c = (int)(i & 3);
+    long sp = i >> 2;
+    const int x = (int)(sp % tw.tw); sp /= tw.tw;
+    const int y = (int)(sp % tw.th);
+    const int t = (int)(sp / tw.th);
+    out[i] = c < 3 ? v[(((long)c * T + t) * tw.Hf + tw.h0 + y) * tw.Wf + tw.w0 + x] : 0.f;
+}
+// tile result, channels-last [To, oth, otw, ld] -> values[C][To][oHf][oWf] += v * mask ; weight[oHf][oWf] += mask   (vae:668-685)
+// mode 0: decode (v = raw decoder output, NOT clamped: the reference clamps after the blend, vae:687);
+// mode 1: encode (v = (mu - mean) * inv_std, vae:542-549)
+__global__ void tile_blend_kernel(const float* __restrict__ in, int ld, float* __restrict__ values, float* __restrict__ weight, int C, int To,
+                                  int oth, int otw, TileWin tw, int mode, const float* __restrict__ mean, const float* __restrict__ inv_std) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)To * oth * otw;
+    if (i >= n) return;
+    const int x = (int)(i % otw);
+    const int y = (int)((i / otw) % oth);
+    const int t = (int)(i / ((long)otw * oth));
+    const float m = fminf(mask_1d(y, oth, tw.lb, tw.rb, tw.border_h), mask_1d(x, otw, tw.tb, tw.bb, tw.border_w));
+    const long pix = (long)(tw.oh0 + y) * tw.oWf + tw.ow0 + x;
+    const long plane = (long)tw.oHf * tw.oWf;
+    for (int c = 0; c < C; ++c) {
+        float v = in[i * ld + c];
+        if (mode == 1) v = (v - mean[c]) * inv_std[c];
+        const long o = ((long)c * To + t) * plane + pix;
+        values[o] = values[o] + v * m;
+    }
+    if (t == 0) weight[pix] = weight[pix] + m;
+}
+__global__ void tile_finalize_kernel(float* __restrict__ values, const float* __restrict__ weight, long planes, long plane, int clamp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * plane) return;
+    float v = values[i] / weight[i % plane];
+    if (clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+    values[i] = v;
+}
 // weights [Cout, Cin, kt, kh, kw] -> [tap][Cout][ldw] (ldw = Cin rounded up to 4, zero padded)
 // weights [Cout, Cin, taps] -> three bf16 planes [plane][tap][Cout][ldw3] with w = hi + mid + lo (ldw3 = Cin rounded up to 32)
 __global__ void pack_weight_x3_kernel(const float* __restrict__ w, bf16* __restrict__ out, int Cout, int Cin, int taps, int ldw3) {
@@ -753,6 +819,7 @@ struct Tens { float* p = nullptr; int T = 0, H = 0, W = 0, C = 0; long elems() c
 }  // namespace
 
 struct svi_vae {
+    int device = -1;                                    // claimed by the first call that touches the GPU (svi_claim_device)
     std::map<std::string, ConvW> convs;                 // key = layer prefix without ".weight"
     std::map<std::string, const float*> gammas;         // key = full name
     std::map<std::string, std::vector<int64_t>> gamma_shapes;
@@ -766,6 +833,9 @@ struct svi_vae {
     bool dry = false;
     long dry_max = 0;
     bool pack_pending = false;                          // weight packing kernels enqueued on the null stream since the last call
+    float* blend_w = nullptr; size_t blend_bytes = 0;   // mask accumulator of the tiled paths ([H, W] plane)
+    const TileWin* win = nullptr;                       // set while a tile of svi_vae_tiled_* runs through the graphs
+    float* blend_values = nullptr;
 };
 
 namespace {
@@ -1018,7 +1088,8 @@ svi_status decode_graph(svi_vae* h, const float* latents, float* video, int T, i
     NEED(z);
     if (!h->dry) {
         const long n = (long)T * hh * ww * 16;
-        hipLaunchKernelGGL(latent_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latents, z.p, (long)T * hh * ww, h->consts, h->consts + 16);
+        if (h->win) hipLaunchKernelGGL(latent_in_win_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latents, z.p, T, *h->win, h->consts, h->consts + 16);
+        else hipLaunchKernelGGL(latent_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latents, z.p, (long)T * hh * ww, h->consts, h->consts + 16);
         SVI_LAUNCH_CHECK();
     }
     Tens x, t2;
@@ -1042,7 +1113,9 @@ svi_status decode_graph(svi_vae* h, const float* latents, float* video, int T, i
     free_t(h, n);
     if (!h->dry) {
         const long thw = (long)rgb.T * rgb.H * rgb.W;
-        hipLaunchKernelGGL(video_out_kernel, dim3((unsigned)((thw * 3 + 255) / 256)), dim3(256), 0, st, rgb.p, rgb.C, video, thw);
+        if (h->win) hipLaunchKernelGGL(tile_blend_kernel, dim3((unsigned)((thw + 255) / 256)), dim3(256), 0, st, rgb.p, rgb.C, video, h->blend_w, 3, rgb.T,
+                                       rgb.H, rgb.W, *h->win, 0, h->consts, h->consts + 16);
+        else hipLaunchKernelGGL(video_out_kernel, dim3((unsigned)((thw * 3 + 255) / 256)), dim3(256), 0, st, rgb.p, rgb.C, video, thw);
         SVI_LAUNCH_CHECK();
     }
     free_t(h, rgb);
@@ -1055,7 +1128,8 @@ svi_status encode_graph(svi_vae* h, const float* video, float* latents, int T, i
     NEED(v);
     if (!h->dry) {
         const long thw = (long)T * H * W;
-        hipLaunchKernelGGL(video_in_kernel, dim3((unsigned)((thw * 4 + 255) / 256)), dim3(256), 0, st, video, v.p, thw);
+        if (h->win) hipLaunchKernelGGL(video_in_win_kernel, dim3((unsigned)((thw * 4 + 255) / 256)), dim3(256), 0, st, video, v.p, T, *h->win);
+        else hipLaunchKernelGGL(video_in_kernel, dim3((unsigned)((thw * 4 + 255) / 256)), dim3(256), 0, st, video, v.p, thw);
         SVI_LAUNCH_CHECK();
     }
     Tens x;
@@ -1079,7 +1153,9 @@ svi_status encode_graph(svi_vae* h, const float* video, float* latents, int T, i
     free_t(h, hd);
     if (!h->dry) {
         const long thw = (long)mu.T * mu.H * mu.W;
-        hipLaunchKernelGGL(latent_out_kernel, dim3((unsigned)((thw * 16 + 255) / 256)), dim3(256), 0, st, mu.p, mu.C, latents, thw, h->consts, h->consts + 16);
+        if (h->win) hipLaunchKernelGGL(tile_blend_kernel, dim3((unsigned)((thw + 255) / 256)), dim3(256), 0, st, mu.p, mu.C, latents, h->blend_w, 16, mu.T,
+                                       mu.H, mu.W, *h->win, 1, h->consts, h->consts + 16);
+        else hipLaunchKernelGGL(latent_out_kernel, dim3((unsigned)((thw * 16 + 255) / 256)), dim3(256), 0, st, mu.p, mu.C, latents, thw, h->consts, h->consts + 16);
         SVI_LAUNCH_CHECK();
     }
     free_t(h, mu);
@@ -1126,6 +1202,7 @@ extern "C" svi_status svi_vae_destroy(svi_vae* h) {
     if (h->pool) (void)hipFree(h->pool);
     if (h->consts) (void)hipFree(h->consts);
     if (h->attn_scratch) (void)hipFree(h->attn_scratch);
+    if (h->blend_w) (void)hipFree(h->blend_w);
     delete h;
     return SVI_OK;
 }
@@ -1135,6 +1212,7 @@ extern "C" svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const vo
     SVI_REQUIRE(h && name && dev_ptr && shape, "svi_vae_bind_weight: null argument");
     SVI_REQUIRE(dtype == SVI_F32, "VAE parameter '%s' must be fp32", name);
     SVI_REQUIRE(((uintptr_t)dev_ptr % 16) == 0, "VAE parameter '%s' is not 16-byte aligned", name);
+    SVI_REQUIRE_DEVICE(h);
     const std::string key(name);
     auto shape_ok = [&](const std::vector<int64_t>& want) {
         if ((int)want.size() != rank) return false;
@@ -1205,6 +1283,7 @@ static svi_status vae_prepare(svi_vae* h) {
 extern "C" svi_status svi_vae_decode(svi_vae* h, const float* latents, float* video, int32_t T, int32_t hh, int32_t ww,
                                      svi_stream stream) {
     SVI_REQUIRE(h && latents && video && T > 0 && hh > 0 && ww > 0, "svi_vae_decode: bad argument");
+    SVI_REQUIRE_DEVICE(h);
     SVI_TRY(vae_prepare(h));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     h->dry = true; h->dry_max = 0;
@@ -1218,6 +1297,7 @@ extern "C" svi_status svi_vae_decode(svi_vae* h, const float* latents, float* vi
 extern "C" svi_status svi_vae_encode(svi_vae* h, const float* video, float* latents, int32_t T, int32_t H, int32_t W,
                                      svi_stream stream) {
     SVI_REQUIRE(h && video && latents && T > 0 && H > 0 && W > 0, "svi_vae_encode: bad argument");
+    SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE((T - 1) % 4 == 0 && H % 8 == 0 && W % 8 == 0, "svi_vae_encode: needs T = 1+4k frames and H, W multiples of 8 (got %d, %d, %d)", T, H, W);
     SVI_TRY(vae_prepare(h));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1227,4 +1307,114 @@ extern "C" svi_status svi_vae_encode(svi_vae* h, const float* video, float* late
     SVI_TRY(ensure_pool(h, h->dry_max));
     h->slot_used.assign(h->nslots, 0);
     return encode_graph(h, video, latents, T, H, W, st);
+}
+
+// ---- tiled paths ------------------------------------------------------------------------------------------------------------
+namespace {
+// The task list of vae:648-655 / :697-704: tiles start every `stride`; a start is dropped when the previous tile already reaches
+// the far edge.
+std::vector<std::pair<int, int>> tile_starts(int full, int size, int stride) {
+    std::vector<std::pair<int, int>> t;
+    for (int a = 0; a < full; a += stride) {
+        if (a - stride >= 0 && a - stride + size >= full) continue;
+        t.push_back({a, a + size});
+    }
+    return t;
+}
+svi_status ensure_blend(svi_vae* h, size_t bytes) {
+    if (h->blend_bytes >= bytes) return SVI_OK;
+    if (h->blend_w) { SVI_CHECK_HIP(hipFree(h->blend_w)); h->blend_w = nullptr; h->blend_bytes = 0; }
+    hipError_t e = hipMalloc((void**)&h->blend_w, bytes);
+    if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B tile blend weights) failed: %s", bytes, hipGetErrorString(e)); return SVI_ERR_OOM; }
+    h->blend_bytes = bytes;
+    return SVI_OK;
+}
+}  // namespace
+
+extern "C" svi_status svi_vae_tiled_decode(svi_vae* h, const float* latents, float* video, int32_t T, int32_t hh, int32_t ww,
+                                           int32_t size_h, int32_t size_w, int32_t stride_h, int32_t stride_w, svi_stream stream) {
+    SVI_REQUIRE(h && latents && video && T > 0 && hh > 0 && ww > 0, "svi_vae_tiled_decode: bad argument");
+    SVI_REQUIRE_DEVICE(h);
+    SVI_REQUIRE(size_h > 0 && size_w > 0 && stride_h > 0 && stride_w > 0 && stride_h <= size_h && stride_w <= size_w,
+                "svi_vae_tiled_decode: tile_size / tile_stride must be positive with stride <= size");
+    SVI_TRY(vae_prepare(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int f = 8, To = 4 * T - 3, Ho = hh * f, Wo = ww * f;
+    SVI_TRY(ensure_blend(h, (size_t)Ho * Wo * 4));
+    const auto hs = tile_starts(hh, size_h, stride_h), wsv = tile_starts(ww, size_w, stride_w);
+    // the pool is sized by the largest (first) tile
+    const int mh = std::min(size_h, hh), mw = std::min(size_w, ww);
+    h->dry = true; h->dry_max = 0;
+    SVI_TRY(decode_graph(h, latents, video, T, mh, mw, st));
+    h->dry = false;
+    SVI_TRY(ensure_pool(h, h->dry_max));
+    SVI_CHECK_HIP(hipMemsetAsync(video, 0, (size_t)3 * To * Ho * Wo * 4, st));
+    SVI_CHECK_HIP(hipMemsetAsync(h->blend_w, 0, (size_t)Ho * Wo * 4, st));
+    svi_status rc = SVI_OK;
+    for (auto& a : hs) {
+        for (auto& b : wsv) {
+            TileWin w{};
+            w.Hf = hh; w.Wf = ww; w.h0 = a.first; w.w0 = b.first;
+            w.th = std::min(a.second, hh) - a.first; w.tw = std::min(b.second, ww) - b.first;
+            w.oHf = Ho; w.oWf = Wo; w.oh0 = a.first * f; w.ow0 = b.first * f;
+            w.lb = a.first == 0; w.rb = a.second >= hh; w.tb = b.first == 0; w.bb = b.second >= ww;
+            w.border_h = (size_h - stride_h) * f; w.border_w = (size_w - stride_w) * f;
+            // the reference writes a `border`-long ramp into the tile's mask: a clipped tile shorter than the ramp is an error there too
+            if ((!w.lb || !w.rb) && w.th * f < w.border_h) { svi_set_error("tile of %d rows is shorter than the %d-row blend border", w.th * f, w.border_h); return SVI_ERR_INVALID; }
+            if ((!w.tb || !w.bb) && w.tw * f < w.border_w) { svi_set_error("tile of %d columns is shorter than the %d-column blend border", w.tw * f, w.border_w); return SVI_ERR_INVALID; }
+            h->win = &w;
+            h->slot_used.assign(h->nslots, 0);
+            rc = decode_graph(h, latents, video, T, w.th, w.tw, st);
+            h->win = nullptr;
+            if (rc != SVI_OK) return rc;
+        }
+    }
+    const long plane = (long)Ho * Wo, planes = 3L * To;
+    hipLaunchKernelGGL(tile_finalize_kernel, dim3((unsigned)((planes * plane + 255) / 256)), dim3(256), 0, st, video, h->blend_w, planes, plane, 1);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_vae_tiled_encode(svi_vae* h, const float* video, float* latents, int32_t T, int32_t H, int32_t W,
+                                           int32_t size_h, int32_t size_w, int32_t stride_h, int32_t stride_w, svi_stream stream) {
+    SVI_REQUIRE(h && video && latents && T > 0 && H > 0 && W > 0, "svi_vae_tiled_encode: bad argument");
+    SVI_REQUIRE_DEVICE(h);
+    SVI_REQUIRE((T - 1) % 4 == 0 && H % 8 == 0 && W % 8 == 0, "svi_vae_tiled_encode: needs T = 1+4k frames and H, W multiples of 8 (got %d, %d, %d)", T, H, W);
+    SVI_REQUIRE(size_h > 0 && size_w > 0 && stride_h > 0 && stride_w > 0 && stride_h <= size_h && stride_w <= size_w &&
+                size_h % 8 == 0 && size_w % 8 == 0 && stride_h % 8 == 0 && stride_w % 8 == 0,
+                "svi_vae_tiled_encode: tile_size / tile_stride are in pixels, multiples of 8, stride <= size");
+    SVI_TRY(vae_prepare(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int f = 8, To = (T + 3) / 4, Ho = H / f, Wo = W / f;
+    SVI_TRY(ensure_blend(h, (size_t)Ho * Wo * 4));
+    const auto hs = tile_starts(H, size_h, stride_h), wsv = tile_starts(W, size_w, stride_w);
+    const int mh = std::min(size_h, H), mw = std::min(size_w, W);
+    h->dry = true; h->dry_max = 0;
+    SVI_TRY(encode_graph(h, video, latents, T, mh, mw, st));
+    h->dry = false;
+    SVI_TRY(ensure_pool(h, h->dry_max));
+    SVI_CHECK_HIP(hipMemsetAsync(latents, 0, (size_t)16 * To * Ho * Wo * 4, st));
+    SVI_CHECK_HIP(hipMemsetAsync(h->blend_w, 0, (size_t)Ho * Wo * 4, st));
+    svi_status rc = SVI_OK;
+    for (auto& a : hs) {
+        for (auto& b : wsv) {
+            TileWin w{};
+            w.Hf = H; w.Wf = W; w.h0 = a.first; w.w0 = b.first;
+            w.th = std::min(a.second, H) - a.first; w.tw = std::min(b.second, W) - b.first;
+            w.oHf = Ho; w.oWf = Wo; w.oh0 = a.first / f; w.ow0 = b.first / f;
+            w.lb = a.first == 0; w.rb = a.second >= H; w.tb = b.first == 0; w.bb = b.second >= W;
+            w.border_h = (size_h - stride_h) / f; w.border_w = (size_w - stride_w) / f;
+            if ((!w.lb || !w.rb) && w.th / f < w.border_h) { svi_set_error("tile of %d latent rows is shorter than the %d-row blend border", w.th / f, w.border_h); return SVI_ERR_INVALID; }
+            if ((!w.tb || !w.bb) && w.tw / f < w.border_w) { svi_set_error("tile of %d latent columns is shorter than the %d-column blend border", w.tw / f, w.border_w); return SVI_ERR_INVALID; }
+            h->win = &w;
+            h->slot_used.assign(h->nslots, 0);
+            rc = encode_graph(h, video, latents, T, w.th, w.tw, st);
+            h->win = nullptr;
+            if (rc != SVI_OK) return rc;
+        }
+    }
+    const long plane = (long)Ho * Wo, planes = 16L * To;
+    hipLaunchKernelGGL(tile_finalize_kernel, dim3((unsigned)((planes * plane + 255) / 256)), dim3(256), 0, st, latents, h->blend_w, planes, plane, 0);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
 }

@@ -29,6 +29,7 @@ SYMBOLS = [
     ("svi_last_error", C.c_char_p, []),
     ("svi_abi_version", _i32, []),
     ("svi_device_count", _i32, []),
+    ("svi_switches_reload", _i32, []),
     ("svi_dit_create", _i32, [C.POINTER(DitConfig), C.POINTER(_vp)]),
     ("svi_dit_destroy", _i32, [_vp]),
     ("svi_dit_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
@@ -61,6 +62,8 @@ SYMBOLS = [
     ("svi_u8_to_video", _i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_vae_decode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_vae_encode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("svi_vae_tiled_decode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_vae_tiled_encode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 ]
 
 _lib = None
@@ -99,6 +102,15 @@ def ptr(t) -> int:
 def current_stream() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def set_switch(name: str, value=None) -> None:
+    """A/B tooling: set (or, with None, remove) one of the library's environment switches and make the library re-read them."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    check(lib().svi_switches_reload(), "svi_switches_reload")
 
 
 def prof_enable(on: bool) -> None:

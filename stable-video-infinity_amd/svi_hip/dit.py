@@ -69,6 +69,7 @@ class WanDiT:
         L.check(L.lib().svi_dit_create(C.byref(cfg), C.byref(h)), "svi_dit_create")
         self._h = h
         self._params: Dict[str, torch.Tensor] = {}
+        self._param_versions = []
         self._ctx_cache_on = False
         self._ctx_pins = PromptPins()
 
@@ -102,9 +103,21 @@ class WanDiT:
                     f"bind {name}")
             self._params[name] = t
         L.check(lib.svi_dit_check_bound(self._h), "svi_dit_check_bound")
+        self._param_versions = [(t, _version(t)) for t in self._params.values()]
 
     def rebind(self) -> None:
+        """Re-read every parameter's address (after a LoRA merge, .to(), an offload round trip ...); drops the context cache."""
         self.bind(dict(self._params))
+
+    def weights_changed(self) -> bool:
+        """True when a bound parameter was written in place since bind() (merge_lora_, load_state_dict into the same storage):
+        the cached cross-attention K / V were projected with the old values."""
+        return any(_version(t) != v for t, v in self._param_versions)
+
+    def _refresh_if_weights_changed(self) -> None:
+        if self._ctx_cache_on and self.weights_changed():
+            self.rebind()
+            self._ctx_pins.clear()
 
     def context_cache(self, enable: bool) -> None:
         """Reuse the projected context and the cross-attention K / V^T of every block across forwards that are handed the
@@ -117,6 +130,7 @@ class WanDiT:
 
     def _prompt_args(self, *tensors):
         """The prompt-side inputs (context(s), clip_feature) as contiguous bf16; see context_cache()."""
+        self._refresh_if_weights_changed()
         if not self._ctx_cache_on:
             return tuple(None if t is None else t.to(torch.bfloat16).contiguous() for t in tensors)
         for t in tensors:
@@ -126,6 +140,31 @@ class WanDiT:
         if self._ctx_pins.admit(tensors):
             L.check(L.lib().svi_dit_context_cache(self._h, 1), "svi_dit_context_cache")      # re-enabling drops every entry
         return tensors
+
+    def check_inputs(self, x, contexts, clip_feature=None, y=None, add_condition=None) -> None:
+        """Shape contract of model_fn_wan_video's inputs.  The C side walks raw pointers with the sizes it is told, so what the
+        reference would reject with a shape error (wrong channel counts, a missing y / clip_feature, a foreign text width) is
+        rejected here instead of being read out of bounds."""
+        if x.dim() != 5 or x.shape[1] != 16:
+            raise ValueError(f"latents must be [B, 16, T, H, W] (got {tuple(x.shape)})")
+        B, _, T, H, W = x.shape
+        pt, ph, pw = self.patch_size
+        if T % pt or H % ph or W % pw:
+            raise ValueError(f"latent grid {T}x{H}x{W} is not divisible by the patch size {self.patch_size}")
+        for c in contexts:
+            if c is None or c.dim() != 3 or c.shape[0] != B or c.shape[2] != self.text_dim:
+                raise ValueError(f"context must be [B={B}, Lc, text_dim={self.text_dim}] (got {None if c is None else tuple(c.shape)})")
+        if self.in_dim > 16:
+            if y is None or tuple(y.shape) != (B, self.in_dim - 16, T, H, W):
+                raise ValueError(f"this model takes y of shape {(B, self.in_dim - 16, T, H, W)} (got {None if y is None else tuple(y.shape)})")
+        elif y is not None:
+            raise ValueError("y was given but the model has in_dim == 16")
+        if self.has_image_input:
+            if clip_feature is None or tuple(clip_feature.shape) != (B, 257, 1280):
+                raise ValueError(f"has_image_input model needs clip_feature [B={B}, 257, 1280] (got "
+                                 f"{None if clip_feature is None else tuple(clip_feature.shape)})")
+        if add_condition is not None and tuple(add_condition.shape) != (B, self.tokens(T, H, W), self.dim):
+            raise ValueError(f"add_condition must be [B, L, dim] = {(B, self.tokens(T, H, W), self.dim)} (got {tuple(add_condition.shape)})")
 
     def __del__(self):
         try:
@@ -144,6 +183,9 @@ class WanDiT:
         x_before_blocks, 2 = skip the blocks and add `residual` instead."""
         if not x.is_cuda:
             raise RuntimeError("svi_hip runs on the GPU only")
+        self.check_inputs(x, (context,), clip_feature, y, add_condition)
+        if not self.has_image_input:
+            clip_feature = None                    # the reference ignores it without an image branch (svi_video.py:96-99)
         x = x.to(torch.bfloat16).contiguous()
         context, clip_feature = self._prompt_args(context, clip_feature)
         timestep = timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
@@ -190,9 +232,12 @@ class WanDiT:
         embedding, patchify, block 0's self-attention) is computed once; outputs are bit-identical to two forward() calls."""
         if not x.is_cuda:
             raise RuntimeError("svi_hip runs on the GPU only")
-        x = x.to(torch.bfloat16).contiguous()
         if context_cond.shape != context_uncond.shape:
             raise ValueError("the two prompt embeddings of a CFG pair must have the same shape")
+        self.check_inputs(x, (context_cond, context_uncond), clip_feature, y, add_condition)
+        if not self.has_image_input:
+            clip_feature = None
+        x = x.to(torch.bfloat16).contiguous()
         context_cond, context_uncond, clip_feature = self._prompt_args(context_cond, context_uncond, clip_feature)
         timestep = timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         B, _, T, H, W = x.shape

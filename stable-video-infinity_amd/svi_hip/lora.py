@@ -7,8 +7,9 @@ reference's rounding points (the fp32 accumulation order inside the 128-long dot
 14B model that is ~400 launches of a [5120, r] x [r, 5120] product instead of ~400 CPU matrix products.
 
 Which tensors pair up (`lora_A/lora_B`, `lora_up/lora_down`, prefixes) is the reference loader's business (get_name_dict); this
-module takes the pairs.  Weights borrowed by a WanDiT stay valid (the update is in place); call `dit.rebind()` afterwards to drop
-the context cache, whose cross-attention K / V were projected with the old weights.
+module takes the pairs.  Weights borrowed by a WanDiT stay valid (the update is in place); the context cache, whose cross-attention
+K / V were projected with the old weights, is dropped: pass `dit=` to merge_state_dict_ (it calls `dit.rebind()`), and a WanDiT also
+notices in-place writes to its bound parameters by itself (version counters, WanDiT.weights_changed) before the next forward.
 """
 from __future__ import annotations
 
@@ -34,12 +35,16 @@ def merge_lora_(weight: torch.Tensor, up: torch.Tensor, down: torch.Tensor, alph
     gate = torch.full((in_f,), float(alpha), dtype=torch.float32, device=weight.device)
     L.check(L.lib().svi_gemm_bf16(L.ptr(up), r, L.ptr(down_t), r, L.ptr(weight), in_f, out_f, in_f, r, None, 0, L.EPI_BIAS_GATE_RES,
                                   L.ptr(gate), L.ptr(weight), in_f, L.current_stream()), "lora merge")
+    weight[:0].zero_()          # the kernel wrote through a raw pointer: bump the tensor's version counter (no launch for 0 elements)
     return weight
 
 
-def merge_state_dict_(state_dict: Dict[str, torch.Tensor], pairs: Dict[str, Tuple[torch.Tensor, torch.Tensor]], alpha: float = 1.0) -> int:
+def merge_state_dict_(state_dict: Dict[str, torch.Tensor], pairs: Dict[str, Tuple[torch.Tensor, torch.Tensor]], alpha: float = 1.0,
+                      dit=None) -> int:
     """Patch state_dict[name] in place for every name -> (up, down) pair; returns the number of tensors updated
-    (the reference prints it, lora.py:263)."""
+    (the reference prints it, lora.py:263).  `dit`: the WanDiT that borrows these tensors — re-bound afterwards."""
     for name, (up, down) in pairs.items():
         merge_lora_(state_dict[name], up, down, alpha)
+    if dit is not None:
+        dit.rebind()
     return len(pairs)

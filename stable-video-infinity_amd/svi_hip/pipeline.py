@@ -43,6 +43,10 @@ class DenoiseLoop:
         """One scheduler step, in place on `latents` (bf16 [B,16,T,H,W]).  tea_cache_posi / _nega: one TeaCache per CFG branch
         (svi_video.py:500-501); with them the two forwards go through model_fn_wan_video separately, as in the reference."""
         if tea_cache_posi is not None:
+            if self.cfg_pair is not None or self.sequence_parallel:
+                # model_fn_wan_video refuses TeaCache + sequence parallelism; taking the TeaCache branch here would silently run both
+                # full forwards on every rank and skip the collectives
+                raise NotImplementedError("TeaCache together with the CFG pair / sequence parallelism is not served by the HIP backend")
             from .dit import model_fn_wan_video
             cpred = model_fn_wan_video(self.dit, latents, timestep, ctx_pos, tea_cache=tea_cache_posi, **cond)
             if cfg_scale != 1.0:

@@ -107,6 +107,9 @@ class SequenceShard:
 
     def begin(self, x, timestep, context, clip_feature=None, y=None, add_condition=None):
         d = self.dit
+        d.check_inputs(x, (context,), clip_feature, y, add_condition)
+        if not d.has_image_input:
+            clip_feature = None
         x = x.to(torch.bfloat16).contiguous()
         B, _, T, H, W = x.shape
         if B != 1:

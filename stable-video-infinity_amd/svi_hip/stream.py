@@ -54,10 +54,13 @@ class StreamLoop:
 
     @torch.no_grad()
     def run(self, input_frames_u8: torch.Tensor, ref_frame_u8: torch.Tensor, prompts: Sequence[tuple], num_clips: int,
-            prompt_repeat_times: int = 1, use_first_prompt_only: bool = False, clip_feature: Optional[torch.Tensor] = None) -> torch.Tensor:
+            prompt_repeat_times: int = 1, use_first_prompt_only: bool = False, clip_feature: Optional[torch.Tensor] = None,
+            start_clip: int = 0) -> torch.Tensor:
         """input_frames_u8 [n, H, W, 3] (the input image, n = 1, or the motion frames of an earlier stream), ref_frame_u8 [H, W, 3]
         (`random_ref_frame`), prompts: list of (context_pos, context_neg) embeddings.  Returns the stitched 8-bit video
-        [frames, H, W, 3] on the GPU: every clip but the last loses its final `num_motion_frames` frames."""
+        [frames, H, W, 3] on the GPU: every clip but the last loses its final `num_motion_frames` frames.
+        `start_clip`: resume a stream at clip index k (input_frames_u8 = the motion frames clip k-1 handed over): clips
+        k .. num_clips-1 run with the seeds and prompts of their own indices."""
         from .parallel import clip_prompt_index, clip_seed
         motion = input_frames_u8.to("cuda")
         ref = u8_to_video(ref_frame_u8.to("cuda")[None])[0]
@@ -65,7 +68,7 @@ class StreamLoop:
         tlat = (self.num_frames - 1) // 4 + 1
         pieces = []
         self.trace = []
-        for k in range(num_clips):
+        for k in range(start_clip, num_clips):
             first = u8_to_video(motion)                                          # preprocess_image of every motion frame
             y = image_condition(self.vae, first, ref, self.num_frames, self.ref_pad_cfg, self.ref_pad_num)
             cf = self.clip_encoder(first[:1]) if self.clip_encoder is not None else clip_feature

@@ -7,8 +7,8 @@
     .decode(hidden_states, device, tiled=False, tile_size, tile_stride) -> Tensor[N,3,T,H,W] vae:777-789
 
 The whole clip stays resident in HBM (no temporal chunking, no feature cache: see csrc/svi_vae.hip).  `tiled=True`
-reproduces the reference's spatial tiling and linear-ramp blending (vae:621-744) with the tiles decoded by the HIP
-kernels and blended on the GPU instead of on the CPU.
+is the reference's spatial tiling and linear-ramp blending (vae:621-744) in one C call (svi_vae_tiled_decode / _encode): tiles are read
+in place, decoded by the same kernels and blended on the GPU with the reference's fp32 arithmetic and task order.
 """
 from __future__ import annotations
 
@@ -154,63 +154,28 @@ class WanVideoVAE:
         L.check(L.lib().svi_vae_encode(self._h, L.ptr(v), L.ptr(out), t, h, w, L.current_stream()), "svi_vae_encode")
         return out
 
-    # ---- tiling with linear-ramp blending: vae:621-744 ------------------------------------------------------------
-    @staticmethod
-    def _mask_1d(length, left_bound, right_bound, border, device):
-        x = torch.ones((length,), device=device)
-        if not left_bound:
-            x[:border] = (torch.arange(border, device=device) + 1) / border
-        if not right_bound:
-            x[-border:] = torch.flip((torch.arange(border, device=device) + 1) / border, dims=(0,))
-        return x
+    # ---- spatial tiling: vae:621-744 (one C call each; tiles, masks and the blend run on the device) ---------------------
+    def tiled_decode(self, hidden_states: torch.Tensor, device, tile_size, tile_stride) -> torch.Tensor:
+        """[1,16,T,h,w] -> [1,3,4T-3,8h,8w]; tile_size / tile_stride in latent pixels (vae:643-693)."""
+        z = hidden_states.to(device="cuda", dtype=torch.float32).contiguous()
+        _, c, t, h, w = z.shape
+        if c != 16:
+            raise ValueError("latents must have 16 channels")
+        out = torch.empty((1, 3, 4 * t - 3, 8 * h, 8 * w), dtype=torch.float32, device=z.device)
+        L.check(L.lib().svi_vae_tiled_decode(self._h, L.ptr(z), L.ptr(out), t, h, w, int(tile_size[0]), int(tile_size[1]),
+                                             int(tile_stride[0]), int(tile_stride[1]), L.current_stream()), "svi_vae_tiled_decode")
+        return out
 
-    def _mask(self, data, is_bound, border):
-        _, _, _, H, W = data.shape
-        hm = self._mask_1d(H, is_bound[0], is_bound[1], border[0], data.device)[:, None].expand(H, W)
-        wm = self._mask_1d(W, is_bound[2], is_bound[3], border[1], data.device)[None, :].expand(H, W)
-        return torch.minimum(hm, wm)[None, None, None]
-
-    @staticmethod
-    def _tasks(H, W, size, stride):
-        tasks = []
-        for h in range(0, H, stride[0]):
-            if h - stride[0] >= 0 and h - stride[0] + size[0] >= H:
-                continue
-            for w in range(0, W, stride[1]):
-                if w - stride[1] >= 0 and w - stride[1] + size[1] >= W:
-                    continue
-                tasks.append((h, h + size[0], w, w + size[1]))
-        return tasks
-
-    def tiled_decode(self, hidden_states, device, tile_size, tile_stride):
-        _, _, T, H, W = hidden_states.shape
-        f = self.upsampling_factor
-        dev = torch.device("cuda")
-        weight = torch.zeros((1, 1, T * 4 - 3, H * f, W * f), dtype=torch.float32, device=dev)
-        values = torch.zeros((1, 3, T * 4 - 3, H * f, W * f), dtype=torch.float32, device=dev)
-        for h, h_, w, w_ in self._tasks(H, W, tile_size, tile_stride):
-            tile = self.single_decode(hidden_states[:, :, :, h:h_, w:w_])
-            m = self._mask(tile, (h == 0, h_ >= H, w == 0, w_ >= W),
-                           ((tile_size[0] - tile_stride[0]) * f, (tile_size[1] - tile_stride[1]) * f))
-            th, tw = h * f, w * f
-            values[:, :, :, th:th + tile.shape[3], tw:tw + tile.shape[4]] += tile * m
-            weight[:, :, :, th:th + tile.shape[3], tw:tw + tile.shape[4]] += m
-        return (values / weight).clamp_(-1, 1)
-
-    def tiled_encode(self, video, device, tile_size, tile_stride):
-        _, _, T, H, W = video.shape
-        f = self.upsampling_factor
-        dev = torch.device("cuda")
-        weight = torch.zeros((1, 1, (T + 3) // 4, H // f, W // f), dtype=torch.float32, device=dev)
-        values = torch.zeros((1, 16, (T + 3) // 4, H // f, W // f), dtype=torch.float32, device=dev)
-        for h, h_, w, w_ in self._tasks(H, W, tile_size, tile_stride):
-            tile = self.single_encode(video[:, :, :, h:h_, w:w_])
-            m = self._mask(tile, (h == 0, h_ >= H, w == 0, w_ >= W),
-                           ((tile_size[0] - tile_stride[0]) // f, (tile_size[1] - tile_stride[1]) // f))
-            th, tw = h // f, w // f
-            values[:, :, :, th:th + tile.shape[3], tw:tw + tile.shape[4]] += tile * m
-            weight[:, :, :, th:th + tile.shape[3], tw:tw + tile.shape[4]] += m
-        return values / weight
+    def tiled_encode(self, video: torch.Tensor, device, tile_size, tile_stride) -> torch.Tensor:
+        """[1,3,T,H,W] -> [1,16,(T+3)//4,H/8,W/8]; tile_size / tile_stride in video pixels (vae:696-744)."""
+        v = video.to(device="cuda", dtype=torch.float32).contiguous()
+        _, c, t, h, w = v.shape
+        if c != 3:
+            raise ValueError("video must have 3 channels")
+        out = torch.empty((1, 16, (t + 3) // 4, h // 8, w // 8), dtype=torch.float32, device=v.device)
+        L.check(L.lib().svi_vae_tiled_encode(self._h, L.ptr(v), L.ptr(out), t, h, w, int(tile_size[0]), int(tile_size[1]),
+                                             int(tile_stride[0]), int(tile_stride[1]), L.current_stream()), "svi_vae_tiled_encode")
+        return out
 
     # ---- public surface: vae:759-789 ----------------------------------------------------------------------------------
     def encode(self, videos: Sequence[torch.Tensor], device=None, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
@@ -218,8 +183,11 @@ class WanVideoVAE:
         for video in videos:
             video = video.unsqueeze(0)
             if tiled:
-                hs = self.tiled_encode(video.to("cuda", torch.float32), device, (tile_size[0] * 8, tile_size[1] * 8),
-                                       (tile_stride[0] * 8, tile_stride[1] * 8))
+                # as the reference (vae:765-767): the x8 is applied to the loop's own variables, so from the second video of a
+                # batch on the tiles are 8x larger again (one tile per video in practice); kept, it is observable behaviour
+                tile_size = (tile_size[0] * 8, tile_size[1] * 8)
+                tile_stride = (tile_stride[0] * 8, tile_stride[1] * 8)
+                hs = self.tiled_encode(video, device, tile_size, tile_stride)
             else:
                 hs = self.single_encode(video, device)
             outs.append(hs.squeeze(0))
@@ -230,7 +198,7 @@ class WanVideoVAE:
         for hs in hidden_states:
             hs = hs.unsqueeze(0)
             if tiled:
-                video = self.tiled_decode(hs.to("cuda", torch.float32), device, tile_size, tile_stride)
+                video = self.tiled_decode(hs, device, tile_size, tile_stride)
             else:
                 video = self.single_decode(hs, device)
             outs.append(video.squeeze(0))

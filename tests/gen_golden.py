@@ -258,18 +258,236 @@ def gen_image_condition(vae_mod):
     np.savez(os.path.join(OUT, "image_condition.npz"), **out)
 
 
-def main():
+# ------------------------------------------------------------------------------------------------------------------
+# Fixtures at the BASELINE configurations' own sizes.  These run the reference for minutes, so
+# `python tests/gen_golden.py <name> ...` regenerates only the named fixtures (no argument: all of them).
+# ------------------------------------------------------------------------------------------------------------------
+C1_VIDEO_STRIDE = synth.C1_VIDEO_STRIDE
+
+
+def gen_c1_e2e(dit_mod, vae_mod, fm):
+    """BASELINE config 1 end to end on the reference itself: the full 30-layer Wan2.1-T2V-1.3B architecture (seeded weights),
+    latent [1,16,5,32,32] (17 frames 256x256), 10 flow-match steps with CFG 5 — the loop of svi_video.py:392-421 on
+    WanModel.forward — then WanVideoVAE.decode in fp32 (svi_video.py:384-389).  fp32 run = the value reference; the same loop the
+    way the pipelines run it (bf16 weights, activations and latents) gives the reference's own bf16-vs-fp32 gap as the yardstick."""
+    import time
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    t0 = time.time()
+    m = build_ref_dit(dit_mod, cfg, seed)
+    print(f"c1: reference WanModel 1.3B built in {time.time() - t0:.0f} s")
+    noise = torch.randn((1, 16, 5, 32, 32), generator=torch.Generator("cpu").manual_seed(0), dtype=torch.float32)   # base.py:140-143
+    pos = t(synth.text_context(seed + 1, 512, cfg["text_dim"], 64))
+    neg = t(synth.text_context(seed + 2, 512, cfg["text_dim"], 64))
+
+    def loop(model, lat, pos, neg):
+        s = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        s.set_timesteps(10, shift=5.0)
+        with torch.no_grad():
+            for i, ts in enumerate(s.timesteps):
+                tt = ts.unsqueeze(0)
+                c = model(lat, tt, pos)
+                u = model(lat, tt, neg)
+                lat = s.step(u + 5.0 * (c - u), s.timesteps[i], lat)
+        return lat
+
+    t0 = time.time()
+    lat32 = loop(m, noise, pos, neg)
+    print(f"c1: fp32 loop {time.time() - t0:.0f} s")
+    t0 = time.time()
+    mb = m.to(torch.bfloat16)
+    lat16 = loop(mb, noise.to(torch.bfloat16), pos.to(torch.bfloat16), neg.to(torch.bfloat16)).float()
+    print(f"c1: bf16 loop {time.time() - t0:.0f} s")
+    del m, mb
+    v = vae_mod.WanVideoVAE()
+    v.load_state_dict({k: t(a) for k, a in synth.vae_state_dict(500).items()}, strict=True)
+    with torch.no_grad():
+        t0 = time.time()
+        video = v.decode([lat32[0]], device="cpu")[0]                                  # [3,17,256,256] fp32, clamped
+        print(f"c1: VAE decode {time.time() - t0:.0f} s")
+    k = C1_VIDEO_STRIDE
+    np.savez(os.path.join(OUT, "c1_e2e.npz"), latents_fp32=lat32[0].numpy(), latents_bf16=lat16[0].numpy(),
+             video_sample=video[:, :, ::k, ::k].contiguous().numpy(), video_shape=np.array(video.shape),
+             video_absmean=np.array(float(video.abs().mean())))
+
+
+def gen_vae_c2(vae_mod):
+    """The VAE at BASELINE config 2's spatial size (latent 60x104 <-> 480x832 px): the reference's decode of 2 latent frames
+    (-> 5 frames) and encode of 5 frames (-> 2 latent frames).  The decoded video is stored on a stride-7 pixel lattice
+    (7 is odd, so every pixel-tile alignment class of the kernels is hit); the latents whole."""
+    v = vae_mod.WanVideoVAE()
+    v.load_state_dict({k: t(a) for k, a in synth.vae_state_dict(500).items()}, strict=True)
+    k = synth.C2_VIDEO_STRIDE
+    with torch.no_grad():
+        z = t(synth.randn(511, 16, 2, 60, 104))
+        video = v.decode([z], device="cpu")[0]                                         # [3,5,480,832]
+        vid = t(np.tanh(synth.randn(512, 3, 5, 480, 832)))
+        lat = v.encode([vid], device="cpu")[0]                                         # [16,2,60,104]
+    np.savez(os.path.join(OUT, "vae_c2.npz"), decode_sample=video[:, :, ::k, ::k].contiguous().numpy(), encode=lat.numpy())
+
+
+def gen_block_14b(dit_mod):
+    """One DiTBlock at the Wan2.1-I2V-14B widths (dim 5120, 40 heads, ffn 13824, image branch with 257 CLIP tokens;
+    wan_video_dit.py:699-712) on a (3,20,36) grid = 2160 tokens, fp32 and bf16, sampled rows."""
+    cfg = dict(synth.WAN_14B_I2V, num_layers=1)
+    seed, grid, nt = synth.B14_SEED, synth.B14_GRID, 512
+    f, h, w = grid
+    L = f * h * w
+    sd = synth.dit_state_dict(seed, **cfg)
+    blk = dit_mod.DiTBlock(True, cfg["dim"], cfg["dim"] // 128, cfg["ffn_dim"], 1e-6).eval()
+    blk.load_state_dict({k[len("blocks.0."):]: t(a) for k, a in sd.items() if k.startswith("blocks.0.")}, strict=True)
+    del sd
+    bx = t(synth.randn(seed + 5, 1, L, cfg["dim"]))
+    bctx = t(synth.randn(seed + 6, 1, nt + 257, cfg["dim"]))
+    btm = t(0.5 * synth.randn(seed + 7, 1, 6, cfg["dim"]))
+    fr = dit_mod.precompute_freqs_cis_3d(128)
+    freqs = torch.cat([fr[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1), fr[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                       fr[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(L, 1, -1)
+    rows = synth.B14_ROWS(L)
+    with torch.no_grad():
+        o32 = blk(bx, bctx, btm, freqs)[0, rows].numpy()
+        blk = blk.to(torch.bfloat16)
+        o16 = blk(bx.to(torch.bfloat16), bctx.to(torch.bfloat16), btm.to(torch.bfloat16), freqs)[0, rows].float().numpy()
+    np.savez(os.path.join(OUT, "dit_block_14b.npz"), block_fp32=o32, block_bf16=o16, rows=np.asarray(rows))
+
+
+def gen_vae_tiled(vae_mod):
+    """WanVideoVAE.tiled_decode / tiled_encode (wan_video_vae.py:643-744) on multi-tile problems, through the public
+    decode/encode(tiled=True): 3x3 and ragged tile grids, including tile values beyond +-1 before the blend's final clamp."""
+    v = vae_mod.WanVideoVAE()
+    v.load_state_dict({k: t(a) for k, a in synth.vae_state_dict(500).items()}, strict=True)
+    out = {}
+    with torch.no_grad():
+        for name, zshape, size, stride, seed in synth.TILED_DECODE_CASES:
+            z = t(2.0 * synth.randn(seed, *zshape))
+            out["decode_" + name] = v.decode([z], device="cpu", tiled=True, tile_size=size, tile_stride=stride)[0].numpy()
+        for name, vshape, size, stride, seed in synth.TILED_ENCODE_CASES:
+            vid = t(np.tanh(synth.randn(seed, *vshape)))
+            out["encode_" + name] = v.encode([vid], device="cpu", tiled=True, tile_size=size, tile_stride=stride)[0].numpy()
+            # a batch of two: the reference rescales tile_size inside its per-video loop (vae:765-767) -> the second video sees 8x larger tiles
+            out["encode_" + name + "_batch_second"] = v.encode([vid, vid], device="cpu", tiled=True, tile_size=size, tile_stride=stride)[1].numpy()
+    np.savez(os.path.join(OUT, "vae_tiled.npz"), **out)
+
+
+def _reference_clip_loop(namespace):
+    """The clip loop of the reference's inference script — the `for chunk_idx in range(num_clips):` statement of the script body
+    (test_svi.py:424-485) — compiled out of the script and executed in `namespace` (which supplies pipe, args, prompts, ...)."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, "test_svi.py")).read())
+    loop = next(n for n in ast.walk(tree) if isinstance(n, ast.For) and isinstance(n.target, ast.Name) and n.target.id == "chunk_idx")
+    exec(compile(ast.Module(body=[loop], type_ignores=[]), os.path.join(REF, "test_svi.py"), "exec"), namespace)
+    return namespace
+
+
+def gen_clip_stream(dit_mod, vae_mod, fm):
+    """Rows a23 / b: the reference's OWN clip loop (test_svi.py:424-485) around the reference's OWN SVIVideoPipeline.__call__
+    (svi_video.py:423-520, with encode_images_adaptive, _sample_with_regular_video, decode_video, tensor2video and the
+    BasePipeline helpers), every one of them compiled out of its source file and run on a stand-in pipeline object that carries
+    the reference WanModel (tiny I2V config, bf16 as the pipelines run it), the reference WanVideoVAE (fp32) and the reference
+    FlowMatchScheduler.  Outside SURVEY §8 and therefore injected: the T5 prompt embeddings (a table prompt -> seeded tensor)
+    and the CLIP image feature (a seeded constant).  Stored: per clip the call's arguments (seed, prompt, motion frames), the
+    8-bit frames it returned, the stitched video, and clip 0's float video before tensor2video."""
+    import contextlib
+    import io
+    import types as _types
+    from PIL import Image
+    from einops import rearrange
+    c = synth.TINY_DIT_I2V
+    ns = {"torch": torch, "np": np, "Image": Image, "rearrange": rearrange, "tqdm": lambda x, **k: x, "Optional": None, "os": os,
+          "WanModel": dit_mod.WanModel, "sinusoidal_embedding_1d": dit_mod.sinusoidal_embedding_1d}
+    ns["TeaCache"] = _reference_toplevel("diffsynth/pipelines/svi_video.py", "TeaCache", ns)
+    ns["model_fn_wan_video"] = _reference_toplevel("diffsynth/pipelines/svi_video.py", "model_fn_wan_video", ns)
+    members = {}
+    for name in ("__call__", "encode_images_adaptive", "tensor2video", "prepare_extra_input", "decode_video",
+                 "_sample_with_regular_video", "prepare_unified_sequence_parallel"):
+        members[name] = _reference_method("diffsynth/pipelines/svi_video.py", "SVIVideoPipeline", name, ns)
+    for name in ("check_resize_height_width", "preprocess_image", "generate_noise"):
+        members[name] = _reference_method("diffsynth/pipelines/base.py", "BasePipeline", name, ns)
+    Pipe = type("StandInPipeline", (), members)
+
+    class Clip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def encode_image(self, images):
+            return t(synth.randn(synth.STREAM_CLIP_SEED, 1, 257, 1280))
+
+    out = {}
+    for case in synth.STREAM_CASES:
+        name, n_motion, num_frames, num_clips, steps = case["name"], case["num_motion_frames"], case["num_frames"], case["num_clips"], case["steps"]
+        H, W = synth.STREAM_HW
+        pipe = Pipe()
+        pipe.torch_dtype, pipe.device = torch.bfloat16, "cpu"
+        pipe.height_division_factor = pipe.width_division_factor = 16                # SVIVideoPipeline.__init__, svi_video.py:151-152
+        pipe.use_unified_sequence_parallel = False
+        pipe.scheduler = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True, num_train_timesteps=1000)   # :144
+        m = dit_mod.WanModel(eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+        m.load_state_dict({k: t(a) for k, a in synth.dit_state_dict(200, **c).items()}, strict=True)
+        pipe.dit = m.to(torch.bfloat16).eval()
+        v = vae_mod.WanVideoVAE()
+        v.load_state_dict({k: t(a) for k, a in synth.vae_state_dict(500).items()}, strict=True)
+        pipe.vae, pipe.image_encoder = v, Clip()
+        pipe.load_models_to_device = lambda names=[]: None
+        prompts = [f"prompt {i}" for i in range(case["num_prompts"])]
+        table = {p: t(synth.text_context(synth.STREAM_PROMPT_SEED + i, 16, c["text_dim"], 9)).to(torch.bfloat16) for i, p in enumerate(prompts)}
+        table["negative"] = t(synth.text_context(synth.STREAM_PROMPT_SEED + 50, 16, c["text_dim"], 5)).to(torch.bfloat16)
+        pipe.encode_prompt = lambda prompt, positive=True: {"context": table[prompt]}
+        calls, floats = [], []
+        real_t2v = pipe.tensor2video
+        pipe.tensor2video = lambda frames: (floats.append(frames.float().clone()), real_t2v(frames))[1]
+
+        def call(**kw):
+            img = kw["input_image"]
+            img = img if isinstance(img, list) else [img]
+            frames = pipe(num_frames=num_frames, **kw)                               # the loop leaves num_frames at its default (81)
+            calls.append(dict(seed=kw["seed"], prompt=prompts.index(kw["prompt"]), motion=np.stack([np.array(i) for i in img]),
+                              frames=np.stack([np.array(f) for f in frames])))
+            return frames
+
+        first = Image.fromarray(synth.condition_frames(synth.STREAM_IMAGE_SEED, 1, H, W)[0])
+        args = _types.SimpleNamespace(seed_times=42, use_first_prompt_only=case["use_first_prompt_only"], prompt_repeat_times=case["prompt_repeat_times"],
+                                      prompt_prefix="none", num_steps=steps, cfg_scale_text=5.0, tiled=False, ref_pad_cfg=case["ref_pad_cfg"],
+                                      ref_pad_num=case["ref_pad_num"])
+        loop_ns = dict(num_clips=num_clips, seeds=range(0, 10000), args=args, loaded_prompts=prompts, path_dir_per={"negative_prompt": "negative", "prompt_name": name},
+                       pipe=call, rand_ref_frame_final=first, rand_ref_frame_final_gt=torch.from_numpy(np.array(first)).clone(), height=H, width=W,
+                       use_teacache=False, num_motion_frames=n_motion, video_list=[], sample_output_dir="", base_filename="", os=os,
+                       save_video=lambda *a, **k: None, ref_name=name)
+        with contextlib.redirect_stdout(io.StringIO()):
+            _reference_clip_loop(loop_ns)
+        stitched = np.stack([np.array(f) for f in loop_ns["video_list"]])
+        out[name + "_stitched"] = stitched
+        out[name + "_frames"] = np.stack([cl["frames"] for cl in calls])
+        out[name + "_seeds"] = np.array([cl["seed"] for cl in calls])
+        out[name + "_prompts"] = np.array([cl["prompt"] for cl in calls])
+        for k, cl in enumerate(calls):
+            out[f"{name}_motion{k}"] = cl["motion"]
+        out[name + "_video_f32_clip0"] = floats[0].numpy()
+        print("stream", name, "stitched", stitched.shape, "seeds", out[name + "_seeds"], "prompts", out[name + "_prompts"])
+    np.savez_compressed(os.path.join(OUT, "clip_stream.npz"), **out)
+
+
+def main(argv=None):
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     dit_mod, vae_mod, fm = import_reference()
-    gen_flow_match(fm)
-    dit_case(dit_mod, "tiny_t2v", synth.TINY_DIT, (3, 4, 6), 20, 13, 637.5, 100)
-    dit_case(dit_mod, "small_t2v", synth.SMALL_DIT, (2, 5, 7), 24, 24, 991.7355, 150)
-    dit_case(dit_mod, "tiny_i2v", synth.TINY_DIT_I2V, (2, 4, 4), 16, 10, 92.5926, 200)
-    gen_denoise(dit_mod, fm)
-    gen_vae(vae_mod)
-    gen_image_condition(vae_mod)
-    gen_teacache(dit_mod, fm)
+    jobs = {
+        "flow_match": lambda: gen_flow_match(fm),
+        "dit_tiny_t2v": lambda: dit_case(dit_mod, "tiny_t2v", synth.TINY_DIT, (3, 4, 6), 20, 13, 637.5, 100),
+        "dit_small_t2v": lambda: dit_case(dit_mod, "small_t2v", synth.SMALL_DIT, (2, 5, 7), 24, 24, 991.7355, 150),
+        "dit_tiny_i2v": lambda: dit_case(dit_mod, "tiny_i2v", synth.TINY_DIT_I2V, (2, 4, 4), 16, 10, 92.5926, 200),
+        "denoise_tiny": lambda: gen_denoise(dit_mod, fm),
+        "vae": lambda: gen_vae(vae_mod),
+        "image_condition": lambda: gen_image_condition(vae_mod),
+        "teacache_tiny": lambda: gen_teacache(dit_mod, fm),
+        "vae_tiled": lambda: gen_vae_tiled(vae_mod),
+        "vae_c2": lambda: gen_vae_c2(vae_mod),
+        "dit_block_14b": lambda: gen_block_14b(dit_mod),
+        "clip_stream": lambda: gen_clip_stream(dit_mod, vae_mod, fm),
+        "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),
+    }
+    names = list(argv if argv is not None else sys.argv[1:]) or list(jobs)
+    for n in names:
+        jobs[n]()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

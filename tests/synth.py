@@ -206,3 +206,29 @@ IMAGE_CONDITION_CASES = [("first_only_zero_pad", 1, False, 0), ("first_only_ref_
 # tests/golden/teacache_tiny.npz (tests/gen_golden.py::gen_teacache): steps, threshold, model id and the timesteps used
 TEA_STEPS, TEA_THRESH, TEA_MODEL = 8, 0.01, "Wan2.1-T2V-1.3B"
 TEA_TIMESTEPS = [500.0, 500.01, 500.03, 500.035, 500.075, 500.08, 500.15, 500.155]
+
+
+# ----------------------------------------------------------------------------------- fixtures at BASELINE sizes (gen_golden.py)
+C1_SEED, C1_VIDEO_STRIDE = 900, 5            # golden/c1_e2e.npz: 1.3B weights seed; decoded video kept on a stride-5 lattice
+C2_VIDEO_STRIDE = 7                          # golden/vae_c2.npz
+B14_SEED, B14_GRID = 950, (3, 20, 36)        # golden/dit_block_14b.npz: one 14B-I2V block on 2160 tokens
+
+
+def B14_ROWS(L: int):
+    return list(range(0, L, 67))
+
+
+# (name, latent shape, tile_size, tile_stride, seed) / (name, video shape, tile_size, tile_stride, seed): golden/vae_tiled.npz
+TILED_DECODE_CASES = [("3x3", (16, 2, 8, 8), (4, 4), (2, 2), 520),
+                      ("ragged", (16, 2, 9, 11), (4, 6), (3, 4), 521)]
+TILED_ENCODE_CASES = [("3x4", (3, 5, 64, 80), (4, 4), (2, 2), 530)]
+
+
+# golden/clip_stream.npz: the reference's clip loop + __call__ on a tiny I2V stream (gen_golden.py::gen_clip_stream)
+STREAM_HW, STREAM_CLIP_SEED, STREAM_PROMPT_SEED, STREAM_IMAGE_SEED = (32, 48), 33, 40, 31
+STREAM_CASES = [
+    dict(name="m1", num_motion_frames=1, num_frames=17, num_clips=3, steps=2, num_prompts=3, prompt_repeat_times=1,
+         use_first_prompt_only=False, ref_pad_cfg=False, ref_pad_num=-1),
+    dict(name="m5", num_motion_frames=5, num_frames=17, num_clips=4, steps=2, num_prompts=2, prompt_repeat_times=2,
+         use_first_prompt_only=False, ref_pad_cfg=True, ref_pad_num=2),
+]

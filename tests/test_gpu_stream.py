@@ -64,3 +64,64 @@ def test_stream_loop_composition(n_motion):
         assert torch.equal(svi_hip.video_to_u8(vae.decode(lat.float(), device="cuda")[0]), tr[k]["frames"])
     stitched = torch.cat([t["frames"][:-n_motion] for t in tr[:-1]] + [tr[-1]["frames"]])
     assert torch.equal(video, stitched)
+
+
+@pytest.mark.parametrize("case", synth.STREAM_CASES, ids=lambda c: c["name"])
+def test_stream_against_the_reference_clip_loop(case, golden):
+    """Rows a23 / b against the reference itself: golden/clip_stream.npz holds what the reference's own clip loop (test_svi.py:424-485)
+    around its own SVIVideoPipeline.__call__ (svi_video.py:423-520) produced on a tiny I2V stream (gen_golden.py::gen_clip_stream).
+      * tensor2video on the reference's float video: bit-identical 8-bit frames;
+      * schedule: seeds, prompt cycling, which (clip, frame) every stitched frame is;
+      * values: every clip re-run from the reference's own hand-off frames (teacher-forced), and the free-running stream.
+    The reference ran its DiT in bf16 on the CPU; two bf16 implementations differ in rounding order, so 8-bit frames agree to within a
+    level or two, not bit for bit: mean |diff| <= 1 level teacher-forced (<= 1.5 free-running), no pixel off by more than 16."""
+    import svi_hip
+    from svi_hip.parallel import clip_prompt_index, clip_seed
+    g, name = golden("clip_stream.npz"), case["name"]
+    ref_frames, stitched_ref = g[name + "_frames"], g[name + "_stitched"]
+    got0 = svi_hip.video_to_u8(torch.from_numpy(g[name + "_video_f32_clip0"]).cuda()).cpu().numpy()
+    assert np.array_equal(got0, ref_frames[0])
+    c = synth.TINY_DIT_I2V
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(200, **c).items()}
+    dit = svi_hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    vae = svi_hip.WanVideoVAE.from_state_dict({k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()})
+    H, W = synth.STREAM_HW
+    n_motion, NF, CLIPS = case["num_motion_frames"], case["num_frames"], case["num_clips"]
+    img = torch.from_numpy(synth.condition_frames(synth.STREAM_IMAGE_SEED, 1, H, W))
+    neg = dev(synth.text_context(synth.STREAM_PROMPT_SEED + 50, 16, c["text_dim"], 5))
+    prompts = [(dev(synth.text_context(synth.STREAM_PROMPT_SEED + i, 16, c["text_dim"], 9)), neg) for i in range(case["num_prompts"])]
+    clipf = dev(synth.randn(synth.STREAM_CLIP_SEED, 1, 257, 1280))
+    sl = svi_hip.StreamLoop(dit, vae, clip_encoder=lambda first: clipf, num_motion_frames=n_motion, num_frames=NF,
+                            num_inference_steps=case["steps"], ref_pad_cfg=case["ref_pad_cfg"], ref_pad_num=case["ref_pad_num"])
+    kw = dict(prompt_repeat_times=case["prompt_repeat_times"], use_first_prompt_only=case["use_first_prompt_only"])
+    # ---- schedule
+    assert [clip_seed(k) for k in range(CLIPS)] == [int(s) for s in g[name + "_seeds"]]
+    assert [clip_prompt_index(k, len(prompts), case["prompt_repeat_times"], case["use_first_prompt_only"]) for k in range(CLIPS)] == \
+        [int(p) for p in g[name + "_prompts"]]
+    assert np.array_equal(g[name + "_motion0"], img.numpy())
+    for k in range(1, CLIPS):                                   # the reference hands over the last frames of the previous clip
+        assert np.array_equal(g[f"{name}_motion{k}"], ref_frames[k - 1][-n_motion:])
+    where = []                                                  # stitched frame i = frame j of clip k in the reference's video
+    for k in range(CLIPS):
+        keep = NF if k == CLIPS - 1 else NF - n_motion
+        where += [(k, j) for j in range(keep)]
+    assert len(where) == len(stitched_ref) and all(np.array_equal(stitched_ref[i], ref_frames[k][j]) for i, (k, j) in enumerate(where))
+    # ---- values, teacher-forced: clip k from the reference's own hand-off frames
+    worst_mean, worst_max = 0.0, 0
+    for k in range(CLIPS):
+        motion = torch.from_numpy(g[f"{name}_motion{k}"])
+        out = sl.run(motion, img[0], prompts, k + 1, start_clip=k, **kw).cpu().numpy().astype(np.int32)
+        assert [t["seed"] for t in sl.trace] == [42 * k]
+        d = np.abs(out - ref_frames[k].astype(np.int32))
+        worst_mean, worst_max = max(worst_mean, float(d.mean())), max(worst_max, int(d.max()))
+    # ---- the free-running stream
+    video = sl.run(img, img[0], prompts, CLIPS, **kw)
+    tr = sl.trace
+    assert tuple(video.shape) == stitched_ref.shape
+    assert all(torch.equal(video[i], tr[k]["frames"][j]) for i, (k, j) in enumerate(where))
+    d = np.abs(video.cpu().numpy().astype(np.int32) - stitched_ref.astype(np.int32))
+    from gpu_util import report
+    report("clip_stream", case=name, forced_mean_levels=worst_mean, forced_max_levels=worst_max, stream_mean_levels=float(d.mean()),
+           stream_max_levels=int(d.max()), stream_frac_equal=float((d == 0).mean()))
+    assert worst_mean <= 1.0 and worst_max <= 16, (worst_mean, worst_max)
+    assert float(d.mean()) <= 1.5 and int(d.max()) <= 16, (float(d.mean()), int(d.max()))

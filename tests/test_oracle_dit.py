@@ -115,3 +115,21 @@ def test_denoise_loop_matches_reference(golden):
     neg = torch.from_numpy(synth.text_context(seed + 3, 16, c["text_dim"], 4))
     out = fmo.denoise_loop(lambda x, t, ctx: wdo.dit_forward(sd, cfg, x, t, ctx), lat, pos, neg, 4, 5.0, 5.0)
     assert rel_l2(out.numpy(), g["latents"]) < 5e-5
+
+
+def test_block_at_14b_i2v_widths_matches_reference(golden):
+    """One DiTBlock at the Wan2.1-I2V-14B widths (dim 5120, 40 heads, ffn 13824, 257 CLIP tokens in the image branch) on 2160 tokens:
+    the oracle against sampled rows of the reference's own DiTBlock.forward (golden/dit_block_14b.npz)."""
+    g = golden("dit_block_14b.npz")
+    c = dict(synth.WAN_14B_I2V, num_layers=1)
+    seed, grid = synth.B14_SEED, synth.B14_GRID
+    f, h, w = grid
+    L = f * h * w
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items() if k.startswith("blocks.0.")}
+    bx = torch.from_numpy(synth.randn(seed + 5, 1, L, c["dim"]))
+    bctx = torch.from_numpy(synth.randn(seed + 6, 1, 512 + 257, c["dim"]))
+    btm = torch.from_numpy(0.5 * synth.randn(seed + 7, 1, 6, c["dim"]))
+    rows = [int(r) for r in g["rows"]]
+    with torch.no_grad():
+        out = wdo.dit_block(sd, "blocks.0.", bx, bctx, btm, wdo.rope_table_3d(128, grid), make_cfg(c), None)[0, rows].numpy()
+    assert rel_l2(out, g["block_fp32"]) < 2e-5

@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd"))
 import torch  # noqa: E402
 
 import svi_hip  # noqa: E402
+from svi_hip import _lib as L  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda")
@@ -36,7 +37,7 @@ def ref(q, k, v, n):
 
 
 def run(kind, q, k, v, n):
-    os.environ["SVI_FLASH_KERNEL"] = kind
+    L.set_switch("SVI_FLASH_KERNEL", kind)
     return svi_hip.flash_attention(q, k, v, n)
 
 
@@ -80,5 +81,5 @@ for (sq, sk, n, name) in [(32760, 32760, 12, "self  L=32760"), (32760, 512, 12, 
         med, mn = statistics.median(times[kind]), min(times[kind])
         msg += f" | v{kind}: med {med:.3f} ms {fl/med/1e9:.0f} TF, best {fl/mn/1e9:.0f} TF (incl. V transpose)"
     print(msg, flush=True)
-os.environ.pop("SVI_FLASH_KERNEL", None)
+L.set_switch("SVI_FLASH_KERNEL")
 print("ALL OK" if ok else "FAILURES")

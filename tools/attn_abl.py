@@ -7,25 +7,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd"))
 import torch
 import svi_hip
+from svi_hip import _lib as L
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda")
 g = torch.Generator(device=dev).manual_seed(0)
 sq = sk = 32760; n = 12
 q, k, v = [(torch.randn((1, sq, n * 128), generator=g, device=dev)).to(torch.bfloat16) for _ in range(3)]
-os.environ["SVI_FLASH_KERNEL"] = "2"
-os.environ["SVI_FLASH_ASSUME_PRESCALED"] = "1"
+L.set_switch("SVI_FLASH_KERNEL", "2")
+L.set_switch("SVI_FLASH_ASSUME_PRESCALED", "1")
 variants = (os.environ.get("ATTN_ABL_SET") or "0,4,8,15,0").split(",")
 times = {a: [] for a in variants}
 variants_run = list(variants)
 q_scaled = (q.float() * (1.4426950408889634 / 128 ** 0.5)).to(torch.bfloat16)   # what the DiT's RMSNorm+RoPE kernel hands over
 def run(a):
     if a == "v1":
-        os.environ["SVI_FLASH_KERNEL"] = "1"
+        L.set_switch("SVI_FLASH_KERNEL", "1")
     elif a == "mulc":
-        os.environ.pop("SVI_FLASH_ASSUME_PRESCALED", None); os.environ["SVI_FLASH_KERNEL"] = "2"; os.environ["SVI_FLASH_ABL"] = "0"
+        L.set_switch("SVI_FLASH_ASSUME_PRESCALED"); L.set_switch("SVI_FLASH_KERNEL", "2"); L.set_switch("SVI_FLASH_ABL", "0")
     else:
-        os.environ["SVI_FLASH_ASSUME_PRESCALED"] = "1"
-        os.environ["SVI_FLASH_KERNEL"] = "2"; os.environ["SVI_FLASH_ABL"] = a
+        L.set_switch("SVI_FLASH_ASSUME_PRESCALED", "1")
+        L.set_switch("SVI_FLASH_KERNEL", "2"); L.set_switch("SVI_FLASH_ABL", a)
     return svi_hip.flash_attention(q if a in ("v1", "mulc") else q_scaled, k, v, n)
 for a in variants:
     run(a)

@@ -26,7 +26,7 @@ def rnd(*shape, scale=1.0):
     return (torch.randn(shape, generator=g, device=dev) * scale).to(torch.bfloat16)
 
 
-KINDS = tuple(os.environ.get("GEMM_AB_KINDS", "256,256p1,256p2").split(","))
+KINDS = tuple(os.environ.get("GEMM_AB_KINDS", "128,256,257").split(","))
 SHAPES = {
     # name: (M, N, K, epilogue, bias_along_m)
     "qkv   [L,D]x[D,D]": (Ltok, D, D, L.EPI_BIAS, 0),
@@ -48,7 +48,7 @@ for name, (M, N, K, epi, bam) in SHAPES.items():
     outs = {}
 
     def run(kind, out):
-        os.environ["SVI_GEMM_KERNEL"] = kind
+        L.set_switch("SVI_GEMM_KERNEL", kind)
         L.check(lib.svi_gemm_bf16(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), ldc, M, N, K, b.data_ptr(), bam, epi,
                                   gate.data_ptr() if epi == L.EPI_BIAS_GATE_RES else None,
                                   res.data_ptr() if epi == L.EPI_BIAS_GATE_RES else None, ldc, st))
@@ -75,4 +75,4 @@ for name, (M, N, K, epi, bam) in SHAPES.items():
         med, mn = statistics.median(times[kind]), min(times[kind])
         msg += f" | k{kind}: med {med*1e3:.0f} us {fl/med/1e9:.0f} TF, best {fl/mn/1e9:.0f} TF"
     print(msg, flush=True)
-os.environ.pop("SVI_GEMM_KERNEL", None)
+L.set_switch("SVI_GEMM_KERNEL")

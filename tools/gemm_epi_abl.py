@@ -21,7 +21,7 @@ for name, (M, N, K, epi) in SHAPES.items():
     times = {s: [] for s in SETS}
     for _ in range(5):
         for sset in SETS:
-            os.environ["SVI_GEMM_EPI_ABL"] = sset
+            L.set_switch("SVI_GEMM_EPI_ABL", sset)
             run(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -15,7 +15,7 @@ for name, (M, N, K, epi) in {"qkv": (Ltok, D, D, L.EPI_BIAS), "ffn1": (Ltok, F, 
     times = {k: [] for k in gms}
     for _ in range(5):
         for gm in gms:
-            os.environ["SVI_GEMM_GM"] = gm
+            L.set_switch("SVI_GEMM_GM", gm)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
