@@ -72,9 +72,11 @@ def device_weights(cfg: dict, seed: int, device) -> dict:
 
 
 def cpu_baseline_worker() -> None:
-    """Child process: time the oracle's DiTBlock at the full C2 size (L=32760, fp32) and print seconds."""
+    """Child process: time the oracle's DiTBlock at the full C2 size (L=32760, fp32) and the oracle's VAE decode of two latent
+    frames (5 video frames) at the C2 spatial size; print seconds."""
     import synth
     from oracle import wan_dit_oracle as wdo
+    from oracle import wan_vae_oracle as wvo
     c = dict(synth.WAN_1_3B)
     c["num_layers"] = 1
     sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(0, **c).items()}
@@ -87,12 +89,23 @@ def cpu_baseline_worker() -> None:
     t0 = time.time()
     with torch.no_grad():
         wdo.dit_block(sd, "blocks.0.", x, ctx, tm, rope, cfg)
-    print(json.dumps({"block_seconds": time.time() - t0, "threads": torch.get_num_threads()}), flush=True)
+    block_s = time.time() - t0
+    del sd, x
+    vsd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()}
+    z = torch.from_numpy(synth.randn(511, 1, 16, 2, 60, 104))
+    t0 = time.time()
+    with torch.no_grad():
+        wvo.vae_decode(vsd, z)
+    vae_s = time.time() - t0
+    print(json.dumps({"block_seconds": block_s, "vae_2_latent_frames_seconds": vae_s, "threads": torch.get_num_threads()}), flush=True)
 
 
-def cpu_baseline(max_threads: int = 32, timeout_s: int = 240) -> dict:
-    """The CPU oracle (restatement of the reference) on this box's host cores: one of the 30 blocks of one of the 100
-    forwards of a clip, at full size, in a child process pinned to `threads` OpenMP threads; extrapolated to a clip."""
+def cpu_baseline(max_threads: int = 32, timeout_s: int = 300) -> dict:
+    """The CPU oracle (restatement of the reference) on this box's host cores, in a child process pinned to `threads` OpenMP
+    threads, on a bounded sample of the workload: one of the 30 blocks of one of the 100 forwards of a clip at full size, and the
+    VAE decode of 2 of the clip's 21 latent frames (5 of its 81 frames); extrapolated to a clip.  kind "port": the reference is
+    absent on the GPU box; profiles/r2_cpu_reference_vs_port.json (tools/ref_vs_oracle_block.py, build container) times the
+    reference's own DiTBlock / VAE decode beside the oracle's on the same inputs."""
     import subprocess
     threads = max(1, min(max_threads, os.cpu_count() or 1))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
@@ -100,13 +113,21 @@ def cpu_baseline(max_threads: int = 32, timeout_s: int = 240) -> dict:
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], env=env, capture_output=True,
                            text=True, timeout=timeout_s)
-        dt = json.loads(r.stdout.strip().splitlines()[-1])["block_seconds"]
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        dt, vt = res["block_seconds"], res["vae_2_latent_frames_seconds"]
     except Exception as ex:  # timeout or failure: say so instead of inventing a number
-        return dict(base, value=None, sample=f"oracle DiTBlock at L=32760 did not finish within {timeout_s}s on {threads} threads ({type(ex).__name__})")
-    clip_s = dt * 30 * 100
+        return dict(base, value=None, sample=f"oracle DiTBlock at L=32760 + VAE sample did not finish within {timeout_s}s on {threads} threads ({type(ex).__name__})")
+    clip_s = dt * 30 * 100 + vt * 81.0 / 5.0
+    rel = ""
+    try:
+        rv = json.load(open(os.path.join(ROOT, "profiles", "r2_cpu_reference_vs_port.json")))
+        rel = (f"; on the build container ({rv['threads']} threads) the reference's own DiTBlock took {rv['reference_block_s']:.1f}s against the oracle's "
+               f"{rv['oracle_block_s']:.1f}s and its VAE decode {rv['reference_vae_decode_2_latent_frames_s']:.1f}s against {rv['oracle_vae_decode_2_latent_frames_s']:.1f}s")
+    except Exception:
+        pass
     return dict(base, value=21.0 / clip_s,
-                sample=f"1 DiTBlock forward (fp32 oracle, oracle/wan_dit_oracle.py) at L=32760 took {dt:.1f}s on {threads} threads; "
-                       f"extrapolated x30 blocks x100 forwards per clip, VAE excluded")
+                sample=f"1 DiTBlock forward (fp32 oracle, oracle/wan_dit_oracle.py) at L=32760 took {dt:.1f}s and the VAE decode of 2 latent frames "
+                       f"(5 frames 480x832, oracle/wan_vae_oracle.py) {vt:.1f}s on {threads} threads; extrapolated x30 blocks x100 forwards + decode x81/5 per clip{rel}")
 
 
 def main() -> None:
@@ -264,16 +285,23 @@ def main() -> None:
         ach = alg / (per_launch_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel from PMC counters: collected in separate rocprofv3 --pmc passes
         # (tools/profile_round.sh -> profiles/*_flash_pmc.json, corrected as MI355X_MICROARCH.md prescribes); not measurable live
-        traffic = None
+        traffic, traffic_src = None, None
         try:
             import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_flash_pmc.json")))
-            if pm and args.workload == "c2":
-                traffic = json.load(open(pm[-1])).get("hbm_bytes")
+            import hashlib
+            src_sha = hashlib.sha256(open(os.path.join(ROOT, "stable-video-infinity_amd", "csrc", "svi_attention.hip"), "rb").read()).hexdigest()[:16]
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_flash_pmc.json")), key=os.path.getmtime)
+            for f in reversed(pm):                 # the newest summary collected on THIS kernel source; none -> null, not a stale number
+                rec = json.load(open(f))
+                if rec.get("attention_src_sha") == src_sha and args.workload == "c2":
+                    traffic, traffic_src = rec.get("hbm_bytes"), os.path.relpath(f, ROOT)
+                    break
+            if traffic is None:
+                traffic_src = f"no profiles/*_flash_pmc.json was collected on csrc/svi_attention.hip sha {src_sha} (tools/profile_round.sh)"
         except Exception:
             traffic = None
         roof = {"kernel": "flash_fwd2_kernel (self-attention)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4)}
     line = {
         "metric": {"c2": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step", "c1": "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",

@@ -4,7 +4,9 @@ host can afford it, the CPU oracle on the same box.
 
   C1  (BASELINE configs[0]): full 30-layer Wan2.1-T2V-1.3B, 17 frames 256x256, 10 flow-match steps, CFG 5, then VAE decode.
       latents rel-L2 <= 5e-2 against the reference's fp32 run; the decoded video of the reference's latents
-      rel-L2 <= 2e-5 (VAE alone at the C1 size); the end-to-end video rel-L2 <= 1e-1 (latent error through a random decoder).
+      rel-L2 <= 2e-5 (VAE alone at the C1 size); the end-to-end video rel-L2 <= 5e-2 (latent error through a random decoder).
+      Measured (profiles/r2a_parity_report.jsonl): latents 2.34e-2 vs the reference's fp32 run — the reference's own bf16 run differs
+      from it by 2.33e-2 — and 1.29e-2 vs its bf16 run; video 2.5e-2; VAE on the reference's latents 4.0e-6.
   C2  (configs[1]) VAE size: 2 latent frames at 60x104 -> 5 frames 480x832 and back, rel-L2 <= 2e-5, max-abs <= 2e-4; the
       headline 21-frame decode is tied to it by frame causality (its first 5 frames are that decode).
   C4  (configs[3]) widths: one DiTBlock at dim 5120 / 40 heads / ffn 13824 with the 257-token image branch,
@@ -58,7 +60,7 @@ def test_c1_end_to_end_vs_reference(hip, vae, golden):
            vae_on_ref_latents_maxabs=mxv, video_e2e=re2e, video_e2e_maxabs=mxe)
     assert r32 < 5e-2, (r32, r16, ref_gap)
     assert rv < 2e-5 and mxv < 2e-4, (rv, mxv)
-    assert re2e < 1e-1, (re2e, mxe)
+    assert re2e < 5e-2, (re2e, mxe)
 
 
 # ------------------------------------------------------------------------------------------------------------------ C2 VAE

@@ -74,7 +74,8 @@ def test_stream_against_the_reference_clip_loop(case, golden):
       * schedule: seeds, prompt cycling, which (clip, frame) every stitched frame is;
       * values: every clip re-run from the reference's own hand-off frames (teacher-forced), and the free-running stream.
     The reference ran its DiT in bf16 on the CPU; two bf16 implementations differ in rounding order, so 8-bit frames agree to within a
-    level or two, not bit for bit: mean |diff| <= 1 level teacher-forced (<= 1.5 free-running), no pixel off by more than 16."""
+    level or two, not bit for bit: mean |diff| <= 0.75 level teacher-forced and free-running, no pixel off by more than 6
+    (measured: mean 0.41-0.44 levels, max 3, 59-60 % of all pixels identical; profiles/r2a_parity_report.jsonl)."""
     import svi_hip
     from svi_hip.parallel import clip_prompt_index, clip_seed
     g, name = golden("clip_stream.npz"), case["name"]
@@ -123,5 +124,5 @@ def test_stream_against_the_reference_clip_loop(case, golden):
     from gpu_util import report
     report("clip_stream", case=name, forced_mean_levels=worst_mean, forced_max_levels=worst_max, stream_mean_levels=float(d.mean()),
            stream_max_levels=int(d.max()), stream_frac_equal=float((d == 0).mean()))
-    assert worst_mean <= 1.0 and worst_max <= 16, (worst_mean, worst_max)
-    assert float(d.mean()) <= 1.5 and int(d.max()) <= 16, (float(d.mean()), int(d.max()))
+    assert worst_mean <= 0.75 and worst_max <= 6, (worst_mean, worst_max)
+    assert float(d.mean()) <= 0.75 and int(d.max()) <= 6, (float(d.mean()), int(d.max()))
