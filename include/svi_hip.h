@@ -245,6 +245,21 @@ svi_status svi_vae_tiled_decode(svi_vae* h, const float* latents, float* video, 
 svi_status svi_vae_tiled_encode(svi_vae* h, const float* video, float* latents, int32_t T, int32_t H, int32_t W,
                                 int32_t size_h, int32_t size_w, int32_t stride_h, int32_t stride_w, svi_stream stream);
 
+/* ------------------------------------------------------------------ dance variant: pose embedder ------- */
+/* The `dwpose_embedding` of SVIDanceVideoPipeline (pipelines/svi_video_dance.py:255-269): seven fp32 Conv3d layers with SiLU between
+ * them, 3 -> hidden (16) channels at full resolution down to dim channels at the DiT's token grid.  svi_pose_forward also does what
+ * :527-530 does around it: the pose video's first frame is repeated three more times in front, values are divided by 255, the result
+ * is cast to bf16 and laid out 'b c f h w -> b (f h w) c' — exactly the `add_condition` input of svi_dit_forward (:423, :103-104).
+ *   pose  f32 [3, F, H, W] (values 0..255)   ->   out bf16 [f*h*w, dim],  (f, h, w) from svi_pose_tokens (F = 81, 480x832: 21, 30, 52)
+ * Weight names are the nn.Sequential's state-dict keys "0.weight", "0.bias", "2.weight", ... "12.bias" (fp32). */
+typedef struct svi_pose svi_pose;
+svi_status svi_pose_create(int32_t hidden, int32_t dim, svi_pose** out);
+svi_status svi_pose_destroy(svi_pose* h);
+svi_status svi_pose_bind_weight(svi_pose* h, const char* name, const void* dev_ptr, svi_dtype dtype, const int64_t* shape, int32_t rank);
+svi_status svi_pose_check_bound(svi_pose* h);
+svi_status svi_pose_tokens(svi_pose* h, int32_t F, int32_t H, int32_t W, int32_t* f, int32_t* hh, int32_t* ww);
+svi_status svi_pose_forward(svi_pose* h, const float* pose, void* out, int32_t F, int32_t H, int32_t W, svi_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

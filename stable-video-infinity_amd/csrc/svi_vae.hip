@@ -28,6 +28,7 @@
 #include <vector>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "svi_common.h"
 
@@ -47,6 +48,8 @@ struct ConvP {
     int abl;                                         // timing ablations of conv_igemm_x3_kernel (SVI_VAE_ABL; results wrong): 1 no global loads, 2 no LDS stores, 4 no MFMAs, 8 no epilogue, 16 no K loop
     int t_out_off;                                   // added to the output frame index (mode 0)
     const float* res; int ld_res;                    // optional residual, same pixel indexing as out (mode 0)
+    int act_silu;                                    // conv_igemm_kernel, mode 0: out = silu(conv + bias)  (pose embedder)
+    bf16* out_bf16;                                  // conv_igemm_kernel, mode 0: store bf16 [pixel][ld_out] here instead of fp32 `out`
 };
 
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -157,7 +160,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             if (p.out_mode == 0) {
                 const long po = pp + (long)p.t_out_off * HoWo;
                 if (p.res) v += p.res[po * p.ld_res + co];
-                p.out[po * p.ld_out + co] = v;
+                if (p.act_silu) v = v / (1.0f + expf(-v));
+                if (p.out_bf16) p.out_bf16[po * p.ld_out + co] = (bf16)v;
+                else p.out[po * p.ld_out + co] = v;
             } else {
                 // upsample3d time_conv (vae:153-156): output channel halves become two consecutive frames
                 const int half = p.Cout >> 1;
@@ -561,7 +566,7 @@ svi_status launch_conv(const ConvP& p, hipStream_t st) {
     const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
     if (pixels <= 0) return SVI_OK;
     const bool no_x3 = svi_switches().vae_exact_fp32 != 0;                 // A/B aid: force the exact-fp32 MFMA kernel
-    if (p.w3 && !no_x3 && p.Cout >= 64 && p.Cout % 4 == 0 && p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) &&
+    if (p.w3 && !no_x3 && !p.act_silu && !p.out_bf16 && p.Cout >= 64 && p.Cout % 4 == 0 && p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) &&
         (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) && (((uintptr_t)p.bias | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0 &&
         p.kt * p.kh * p.kw <= 32 &&                                                   // tap bit mask
         (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 4 < 0xFFFFF000L &&               // 32-bit offsets inside the buffer window
@@ -1416,5 +1421,166 @@ extern "C" svi_status svi_vae_tiled_encode(svi_vae* h, const float* video, float
     const long plane = (long)Ho * Wo, planes = 16L * To;
     hipLaunchKernelGGL(tile_finalize_kernel, dim3((unsigned)((planes * plane + 255) / 256)), dim3(256), 0, st, latents, h->blend_w, planes, plane, 0);
     SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+
+// =================================================================================================================================
+// Dance variant: the pose embedder.  pipelines/svi_video_dance.py:255-269 builds
+//   Conv3d(3,16,3,p1) SiLU Conv3d(16,16,3,p1) SiLU Conv3d(16,16,3,p1) SiLU Conv3d(16,16,3,s(1,2,2),p1) SiLU
+//   Conv3d(16,16,3,s2,p1) SiLU Conv3d(16,16,3,s2,p1) SiLU Conv3d(16,dim,(1,2,2),s(1,2,2))
+// (ordinary, non-causal convolutions, fp32) and :527-530 applies it to the pose video with its first frame repeated three more
+// times, divided by 255; the result, cast to bf16 and flattened 'b c f h w -> b (f h w) c', is the `add_condition` of every
+// conditional forward (:423).  Here: the same seven convolutions on the exact-fp32 MFMA kernel (conv_igemm_kernel, channels-last),
+// SiLU fused into the producing convolution, the last one storing bf16 token rows directly.
+// =================================================================================================================================
+struct svi_pose {
+    int device = -1;
+    int hidden = 16, dim = 5120;
+    ConvW conv[7];
+    bool pack_pending = false;
+    char* pool = nullptr;
+    size_t pool_bytes = 0;
+};
+
+namespace {
+// pose f32 [3, F, H, W] -> channels-last [F + 3, H, W, 4]: frame 0 three more times in front (dance:529), / 255, 4th channel zero
+__global__ void pose_in_kernel(const float* __restrict__ pose, float* __restrict__ out, int F, long hw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)(F + 3) * hw * 4;
+    if (i >= n) return;
+    const int c = (int)(i & 3);
+    const long sp = i >> 2;
+    const int t = (int)(sp / hw);
+    const long pix = sp - (long)t * hw;
+    const int ts = t < 3 ? 0 : t - 3;
+    out[i] = c < 3 ? pose[((long)c * F + ts) * hw + pix] / 255.f : 0.f;
+}
+struct PoseGeom { int T[8], H[8], W[8]; };
+PoseGeom pose_geometry(int F, int H, int W) {
+    PoseGeom g;
+    g.T[0] = F + 3; g.H[0] = H; g.W[0] = W;
+    const int st[7] = {1, 1, 1, 1, 2, 2, 1}, ss[7] = {1, 1, 1, 2, 2, 2, 2};
+    for (int i = 0; i < 7; ++i) {
+        const bool last = i == 6;            // kernel (1,2,2), no padding
+        g.T[i + 1] = last ? g.T[i] : (g.T[i] + 2 - 3) / st[i] + 1;
+        g.H[i + 1] = last ? (g.H[i] - 2) / 2 + 1 : (g.H[i] + 2 - 3) / ss[i] + 1;
+        g.W[i + 1] = last ? (g.W[i] - 2) / 2 + 1 : (g.W[i] + 2 - 3) / ss[i] + 1;
+    }
+    return g;
+}
+}  // namespace
+
+extern "C" svi_status svi_pose_create(int32_t hidden, int32_t dim, svi_pose** out) {
+    SVI_REQUIRE(out && hidden > 0 && hidden % 4 == 0 && dim > 0, "svi_pose_create: hidden must be a positive multiple of 4, dim positive");
+    svi_pose* h = new (std::nothrow) svi_pose();
+    if (!h) { svi_set_error("out of host memory"); return SVI_ERR_OOM; }
+    h->hidden = hidden; h->dim = dim;
+    for (int i = 0; i < 7; ++i) {
+        ConvW& c = h->conv[i];
+        c.Cin = i == 0 ? 3 : hidden; c.Cout = i == 6 ? dim : hidden;
+        c.kt = i == 6 ? 1 : 3; c.kh = c.kw = i == 6 ? 2 : 3;
+        c.ldw = (c.Cin + 3) / 4 * 4;
+        c.shape = {c.Cout, c.Cin, c.kt, c.kh, c.kw};
+    }
+    *out = h;
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_pose_destroy(svi_pose* h) {
+    if (!h) return SVI_OK;
+    for (auto& c : h->conv) if (c.packed) (void)hipFree(c.packed);
+    if (h->pool) (void)hipFree(h->pool);
+    delete h;
+    return SVI_OK;
+}
+
+// name = state-dict key of the reference's nn.Sequential: "<2i>.weight" / "<2i>.bias" for convolution i = 0..6 (dance:270-275 strips
+// the "dwpose_embedding." prefix the checkpoint carries).  fp32, as the reference keeps this module.
+extern "C" svi_status svi_pose_bind_weight(svi_pose* h, const char* name, const void* dev_ptr, svi_dtype dtype, const int64_t* shape, int32_t rank) {
+    SVI_REQUIRE(h && name && dev_ptr && shape, "svi_pose_bind_weight: null argument");
+    SVI_REQUIRE(dtype == SVI_F32, "pose embedder parameter '%s' must be fp32", name);
+    SVI_REQUIRE(((uintptr_t)dev_ptr % 16) == 0, "pose embedder parameter '%s' is not 16-byte aligned", name);
+    char* end = nullptr;
+    const long idx = strtol(name, &end, 10);
+    if (end == name || *end != '.' || idx < 0 || idx > 12 || (idx & 1) || (strcmp(end, ".weight") != 0 && strcmp(end, ".bias") != 0)) {
+        svi_set_error("unknown pose embedder parameter '%s'", name);
+        return SVI_ERR_INVALID;
+    }
+    ConvW& c = h->conv[idx / 2];
+    if (strcmp(end, ".bias") == 0) {
+        if (!(rank == 1 && shape[0] == c.Cout)) { svi_set_error("shape mismatch for '%s'", name); return SVI_ERR_INVALID; }
+        c.b_user = reinterpret_cast<const float*>(dev_ptr);
+        return SVI_OK;
+    }
+    bool ok = rank == 5;
+    for (int i = 0; ok && i < 5; ++i) ok = shape[i] == c.shape[i];
+    if (!ok) { svi_set_error("shape mismatch for '%s'", name); return SVI_ERR_INVALID; }
+    SVI_REQUIRE_DEVICE(h);
+    c.w_user = reinterpret_cast<const float*>(dev_ptr);
+    const int taps = c.kt * c.kh * c.kw;
+    const size_t n = (size_t)taps * c.Cout * c.ldw;
+    if (!c.packed) {
+        hipError_t e = hipMalloc((void**)&c.packed, n * 4);
+        if (e != hipSuccess) { svi_set_error("hipMalloc(packed pose weight) failed: %s", hipGetErrorString(e)); return SVI_ERR_OOM; }
+    }
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, c.w_user, c.packed, c.Cout, c.Cin, taps, c.ldw);
+    SVI_LAUNCH_CHECK();
+    h->pack_pending = true;
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_pose_check_bound(svi_pose* h) {
+    SVI_REQUIRE(h, "null handle");
+    for (int i = 0; i < 7; ++i)
+        if (!h->conv[i].w_user || !h->conv[i].b_user) { svi_set_error("pose embedder parameter '%d.weight/.bias' was never bound", 2 * i); return SVI_ERR_UNBOUND; }
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_pose_tokens(svi_pose* h, int32_t F, int32_t H, int32_t W, int32_t* f, int32_t* hh, int32_t* ww) {
+    SVI_REQUIRE(h && F > 0 && H >= 16 && W >= 16 && f && hh && ww, "svi_pose_tokens: bad argument");
+    const PoseGeom g = pose_geometry(F, H, W);
+    *f = g.T[7]; *hh = g.H[7]; *ww = g.W[7];
+    return SVI_OK;
+}
+
+extern "C" svi_status svi_pose_forward(svi_pose* h, const float* pose, void* out, int32_t F, int32_t H, int32_t W, svi_stream stream) {
+    SVI_REQUIRE(h && pose && out && F > 0 && H >= 16 && W >= 16, "svi_pose_forward: bad argument");
+    SVI_REQUIRE_DEVICE(h);
+    SVI_TRY(svi_pose_check_bound(h));
+    if (h->pack_pending) { SVI_CHECK_HIP(hipStreamSynchronize(nullptr)); h->pack_pending = false; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PoseGeom g = pose_geometry(F, H, W);
+    // two ping-pong activation buffers sized by the largest layer (the full-resolution ones): [T0, H, W, hidden] fp32
+    const size_t slot = (((size_t)g.T[0] * g.H[0] * g.W[0] * (size_t)std::max(h->hidden, 4) * 4) + 255) & ~(size_t)255;
+    if (h->pool_bytes < 2 * slot) {
+        if (h->pool) { SVI_CHECK_HIP(hipFree(h->pool)); h->pool = nullptr; h->pool_bytes = 0; }
+        hipError_t e = hipMalloc((void**)&h->pool, 2 * slot);
+        if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B pose embedder activations) failed: %s", 2 * slot, hipGetErrorString(e)); return SVI_ERR_OOM; }
+        h->pool_bytes = 2 * slot;
+    }
+    float* buf[2] = {reinterpret_cast<float*>(h->pool), reinterpret_cast<float*>(h->pool + slot)};
+    {
+        const long hw = (long)H * W, n = (long)(F + 3) * hw * 4;
+        hipLaunchKernelGGL(pose_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pose, buf[0], F, hw);
+        SVI_LAUNCH_CHECK();
+    }
+    const int st_t[7] = {1, 1, 1, 1, 2, 2, 1}, st_s[7] = {1, 1, 1, 2, 2, 2, 2};
+    int cur = 0, ld_in = 4;
+    for (int i = 0; i < 7; ++i) {
+        const ConvW& c = h->conv[i];
+        const bool last = i == 6;
+        ConvP p{};
+        p.in = buf[cur]; p.Ti = g.T[i]; p.Hi = g.H[i]; p.Wi = g.W[i]; p.Cin = (c.Cin + 3) / 4 * 4; p.ld_in = ld_in;
+        p.w = c.packed; p.ld_w = c.ldw; p.bias = c.b_user;
+        p.kt = c.kt; p.kh = c.kh; p.kw = c.kw; p.st = st_t[i]; p.sh = p.sw = st_s[i];
+        p.pt = last ? 0 : 1; p.ph = p.pw = last ? 0 : 1;
+        p.To = g.T[i + 1]; p.Ho = g.H[i + 1]; p.Wo = g.W[i + 1]; p.Cout = c.Cout; p.ld_out = c.Cout;
+        p.act_silu = last ? 0 : 1;
+        if (last) { p.out = nullptr; p.out_bf16 = reinterpret_cast<bf16*>(out); }
+        else p.out = buf[cur ^ 1];
+        SVI_TRY(launch_conv(p, st));
+        cur ^= 1; ld_in = c.Cout;
+    }
     return SVI_OK;
 }

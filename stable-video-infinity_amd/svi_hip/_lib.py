@@ -64,6 +64,12 @@ SYMBOLS = [
     ("svi_vae_encode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_vae_tiled_decode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_vae_tiled_encode", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_pose_create", _i32, [_i32, _i32, C.POINTER(_vp)]),
+    ("svi_pose_destroy", _i32, [_vp]),
+    ("svi_pose_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
+    ("svi_pose_check_bound", _i32, [_vp]),
+    ("svi_pose_tokens", _i32, [_vp, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    ("svi_pose_forward", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
 ]
 
 _lib = None

@@ -119,9 +119,12 @@ class CfgPair:
 
     def step(self, forward: Callable[..., torch.Tensor], cfg_step: Callable[..., None], latents: torch.Tensor,
              timestep: torch.Tensor, dsigma: float, ctx_pos: torch.Tensor, ctx_neg: torch.Tensor, cfg_scale: float,
-             **cond) -> torch.Tensor:
+             uncond_overrides: Optional[dict] = None, **cond) -> torch.Tensor:
         """One scheduler step in place on `latents`.  forward(latents, timestep, context, **cond) -> noise_pred;
-        cfg_step(latents, cond_pred, uncond_pred, cfg_scale, dsigma) applies u + s(c - u) and the Euler update."""
+        cfg_step(latents, cond_pred, uncond_pred, cfg_scale, dsigma) applies u + s(c - u) and the Euler update.
+        `uncond_overrides`: keyword inputs that differ for the unconditional branch (the dance sampler's add_condition=None)."""
+        if self.role == 1 and uncond_overrides:
+            cond = dict(cond, **uncond_overrides)
         mine = forward(latents, timestep, ctx_pos if self.role == 0 else ctx_neg, **cond).contiguous()
         both = [torch.empty_like(mine), torch.empty_like(mine)]
         dist.all_gather(both, mine, group=self.group)

@@ -39,9 +39,16 @@ class DenoiseLoop:
         self._cond = self._uncond = None
 
     def step(self, latents: torch.Tensor, timestep: torch.Tensor, dsigma: float, ctx_pos: torch.Tensor,
-             ctx_neg: Optional[torch.Tensor], cfg_scale: float, tea_cache_posi=None, tea_cache_nega=None, **cond) -> torch.Tensor:
+             ctx_neg: Optional[torch.Tensor], cfg_scale: float, tea_cache_posi=None, tea_cache_nega=None, cond_wo_pose: bool = False,
+             **cond) -> torch.Tensor:
         """One scheduler step, in place on `latents` (bf16 [B,16,T,H,W]).  tea_cache_posi / _nega: one TeaCache per CFG branch
-        (svi_video.py:500-501); with them the two forwards go through model_fn_wan_video separately, as in the reference."""
+        (svi_video.py:500-501); with them the two forwards go through model_fn_wan_video separately, as in the reference.
+        `add_condition` (in **cond; the dance variant's pose embedding) goes to the conditional forward only, unless `cond_wo_pose`
+        (SVIDanceVideoPipeline._sample_with_dance_video, svi_video_dance.py:423-430)."""
+        ucond = cond                                # keyword inputs of the unconditional forward
+        if cond.get("add_condition") is not None and not cond_wo_pose:
+            ucond = dict(cond, add_condition=None)
+        split = ucond is not cond                   # the two branches differ in more than the prompt
         if tea_cache_posi is not None:
             if self.cfg_pair is not None or self.sequence_parallel:
                 # model_fn_wan_video refuses TeaCache + sequence parallelism; taking the TeaCache branch here would silently run both
@@ -50,7 +57,7 @@ class DenoiseLoop:
             from .dit import model_fn_wan_video
             cpred = model_fn_wan_video(self.dit, latents, timestep, ctx_pos, tea_cache=tea_cache_posi, **cond)
             if cfg_scale != 1.0:
-                upred = model_fn_wan_video(self.dit, latents, timestep, ctx_neg, tea_cache=tea_cache_nega, **cond)
+                upred = model_fn_wan_video(self.dit, latents, timestep, ctx_neg, tea_cache=tea_cache_nega, **ucond)
                 ops.cfg_step_(latents, cpred, upred, cfg_scale, dsigma)
             else:
                 ops.cfg_step_(latents, cpred, None, 1.0, dsigma)
@@ -60,21 +67,22 @@ class DenoiseLoop:
             from .sequence_parallel import forward_distributed
             fwd = lambda x, t, c, **kw: forward_distributed(self.dit, x, t, c, group=self.sp_group, **kw)      # noqa: E731
         if self.cfg_pair is not None and cfg_scale != 1.0:
-            return self.cfg_pair.step(fwd, ops.cfg_step_, latents, timestep, dsigma, ctx_pos, ctx_neg, cfg_scale, **cond)
+            return self.cfg_pair.step(fwd, ops.cfg_step_, latents, timestep, dsigma, ctx_pos, ctx_neg, cfg_scale,
+                                      uncond_overrides=dict(add_condition=None) if split else None, **cond)
         if self.sequence_parallel:
             cpred = fwd(latents, timestep, ctx_pos, **cond)
-            upred = fwd(latents, timestep, ctx_neg, **cond) if cfg_scale != 1.0 else None
+            upred = fwd(latents, timestep, ctx_neg, **ucond) if cfg_scale != 1.0 else None
             ops.cfg_step_(latents, cpred, upred, cfg_scale if upred is not None else 1.0, dsigma)
             return latents
         if self._cond is None or self._cond.shape != latents.shape:
             self._cond = torch.empty_like(latents)
             self._uncond = torch.empty_like(latents)
         if cfg_scale != 1.0:
-            if ctx_neg.shape == ctx_pos.shape:      # one call: the prompt-independent head of the forward is shared, results unchanged
+            if ctx_neg.shape == ctx_pos.shape and not split:      # one call: the prompt-independent head of the forward is shared, results unchanged
                 self.dit.forward_cfg_pair(latents, timestep, ctx_pos, ctx_neg, out_cond=self._cond, out_uncond=self._uncond, **cond)
             else:
                 self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
-                self.dit.forward(latents, timestep, ctx_neg, out=self._uncond, **cond)
+                self.dit.forward(latents, timestep, ctx_neg, out=self._uncond, **ucond)
             ops.cfg_step_(latents, self._cond, self._uncond, cfg_scale, dsigma)
         else:
             self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
@@ -85,8 +93,9 @@ class DenoiseLoop:
     def sample(self, latents: torch.Tensor, ctx_pos: torch.Tensor, ctx_neg: Optional[torch.Tensor],
                num_inference_steps: int = 50, cfg_scale: float = 5.0, sigma_shift: float = 5.0,
                denoising_strength: float = 1.0, progress_bar_cmd: Callable = lambda x: x, tea_cache_l1_thresh: Optional[float] = None,
-               tea_cache_model_id: str = "", **cond) -> torch.Tensor:
-        """tea_cache_l1_thresh / tea_cache_model_id: as SVIVideoPipeline.__call__ (svi_video.py:442-443, 500-501); None = off."""
+               tea_cache_model_id: str = "", cond_wo_pose: bool = False, **cond) -> torch.Tensor:
+        """tea_cache_l1_thresh / tea_cache_model_id: as SVIVideoPipeline.__call__ (svi_video.py:442-443, 500-501); None = off.
+        add_condition (+ cond_wo_pose): the dance variant's pose embedding, see step()."""
         self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
         tea = {}
         if tea_cache_l1_thresh is not None:
@@ -103,7 +112,7 @@ class DenoiseLoop:
         self.dit.context_cache(True)
         try:
             for i, t in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
-                self.step(latents, ts_dev[i:i + 1], self.scheduler.step_delta(t), ctx_pos, ctx_neg, cfg_scale, **tea, **cond)
+                self.step(latents, ts_dev[i:i + 1], self.scheduler.step_delta(t), ctx_pos, ctx_neg, cfg_scale, cond_wo_pose=cond_wo_pose, **tea, **cond)
         finally:
             self.dit.context_cache(False)
         return latents

@@ -466,6 +466,76 @@ def gen_clip_stream(dit_mod, vae_mod, fm):
     np.savez_compressed(os.path.join(OUT, "clip_stream.npz"), **out)
 
 
+def gen_pose_embed():
+    """Row N3: the dance variant's pose embedder.  The nn.Sequential is built by evaluating the reference's OWN expression (the value
+    assigned to self.dwpose_embedding in SVIDanceVideoPipeline.fetch_models, svi_video_dance.py:255-269) and driven by the reference's
+    OWN statements (the body of `if humanpose_data is not None:` in __call__, :527-530), both compiled out of the source file."""
+    import ast
+    from einops import rearrange
+    import torch.nn as nn
+    path = os.path.join(REF, "diffsynth/pipelines/svi_video_dance.py")
+    tree = ast.parse(open(path).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "SVIDanceVideoPipeline")
+    fetch = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "fetch_models")
+    assign = next(n for n in ast.walk(fetch) if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Attribute)
+                  and n.targets[0].attr == "dwpose_embedding")
+    seq = eval(compile(ast.Expression(assign.value), path, "eval"), {"nn": nn, "concat_dim": 4})
+    seq.load_state_dict({k: t(a) for k, a in synth.pose_state_dict(synth.POSE_SEED).items()}, strict=True)
+    call = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__call__")
+    branch = next(n for n in ast.walk(call) if isinstance(n, ast.If) and isinstance(n.test, ast.Compare)
+                  and isinstance(n.test.left, ast.Name) and n.test.left.id == "humanpose_data")
+    code = compile(ast.Module(body=branch.body, type_ignores=[]), path, "exec")
+
+    class Self:
+        device = "cpu"
+        dwpose_embedding = seq
+
+    out = {}
+    with torch.no_grad():
+        for name, shape, seed in synth.POSE_CASES:
+            ns = {"self": Self(), "torch": torch, "rearrange": rearrange, "humanpose_data": t(synth.pose_video(seed, *shape)),
+                  "latents": torch.zeros(1, dtype=torch.bfloat16)}
+            exec(code, ns)
+            out[name] = ns["condition"].float().numpy()
+            print("pose", name, out[name].shape)
+    np.savez(os.path.join(OUT, "pose_embed.npz"), **out)
+
+
+def gen_dance_sampler(dit_mod, fm):
+    """The dance variant's sampler: SVIDanceVideoPipeline._sample_with_dance_video and that module's own model_fn_wan_video
+    (svi_video_dance.py:414-443, :74-137), compiled out of the source file, on the reference WanModel (tiny I2V config, bf16 as the
+    pipelines run it): `add_condition` reaches the conditional forward only — unless cond_wo_pose."""
+    rel = "diffsynth/pipelines/svi_video_dance.py"
+    ns = {"torch": torch, "np": np, "WanModel": dit_mod.WanModel, "Optional": None, "sinusoidal_embedding_1d": dit_mod.sinusoidal_embedding_1d}
+    ns["TeaCache"] = _reference_toplevel(rel, "TeaCache", ns)
+    ns["model_fn_wan_video"] = _reference_toplevel(rel, "model_fn_wan_video", ns)
+    sample = _reference_method(rel, "SVIDanceVideoPipeline", "_sample_with_dance_video", ns)
+    c, seed, grid = synth.TINY_DIT_I2V, 200, (2, 4, 4)
+    f, h, w = grid
+    m = dit_mod.WanModel(eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    m.load_state_dict({k: t(a) for k, a in synth.dit_state_dict(seed, **c).items()}, strict=True)
+
+    class Self:
+        device = "cpu"
+
+    me = Self()
+    me.dit = m.to(torch.bfloat16).eval()
+    out = {}
+    bf = lambda a: t(a).to(torch.bfloat16)      # noqa: E731
+    for name, wo in (("cond_only", False), ("cond_wo_pose", True)):
+        me.scheduler = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        me.scheduler.set_timesteps(3, shift=5.0)
+        lat = torch.randn((1, 16, f, 2 * h, 2 * w), generator=torch.Generator("cpu").manual_seed(21), dtype=torch.float32).to(torch.bfloat16)
+        image_emb = {"clip_feature": bf(synth.randn(seed + 3, 1, 257, 1280)), "y": bf(synth.randn(seed + 4, 1, 20, f, 2 * h, 2 * w))}
+        with torch.no_grad():
+            r = sample(me, lat, {"context": bf(synth.text_context(seed + 2, 16, c["text_dim"], 10))},
+                       {"context": bf(synth.text_context(seed + 12, 16, c["text_dim"], 4))}, image_emb, {}, {"tea_cache": None}, {"tea_cache": None},
+                       {"use_unified_sequence_parallel": False}, False, {"text": 5.0}, lambda x: x,
+                       add_condition=bf(0.5 * synth.randn(seed + 9, 1, f * h * w, c["dim"])), cond_wo_pose=wo)
+        out[name] = r.float().numpy()
+    np.savez(os.path.join(OUT, "dance_sampler.npz"), **out)
+
+
 def main(argv=None):
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -483,6 +553,8 @@ def main(argv=None):
         "vae_c2": lambda: gen_vae_c2(vae_mod),
         "dit_block_14b": lambda: gen_block_14b(dit_mod),
         "clip_stream": lambda: gen_clip_stream(dit_mod, vae_mod, fm),
+        "pose_embed": gen_pose_embed,
+        "dance_sampler": lambda: gen_dance_sampler(dit_mod, fm),
         "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),
     }
     names = list(argv if argv is not None else sys.argv[1:]) or list(jobs)

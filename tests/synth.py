@@ -232,3 +232,31 @@ STREAM_CASES = [
     dict(name="m5", num_motion_frames=5, num_frames=17, num_clips=4, steps=2, num_prompts=2, prompt_repeat_times=2,
          use_first_prompt_only=False, ref_pad_cfg=True, ref_pad_num=2),
 ]
+
+
+# ----------------------------------------------------------------------------------- dance pose embedder (golden/pose_embed.npz)
+def pose_param_shapes(hidden: int = 16, dim: int = 5120) -> "OrderedDict[str, tuple]":
+    """State dict of the nn.Sequential at pipelines/svi_video_dance.py:255-269 (convolutions at indices 0, 2, ..., 12)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    for i in range(7):
+        cin, cout = (3 if i == 0 else hidden), (dim if i == 6 else hidden)
+        k = (1, 2, 2) if i == 6 else (3, 3, 3)
+        s[f"{2 * i}.weight"] = (cout, cin, *k)
+        s[f"{2 * i}.bias"] = (cout,)
+    return s
+
+
+def pose_state_dict(seed: int, hidden: int = 16, dim: int = 5120) -> Dict[str, np.ndarray]:
+    rs = np.random.RandomState(seed)
+    return OrderedDict((k, _fill(rs, k, shp)) for k, shp in pose_param_shapes(hidden, dim).items())
+
+
+POSE_SEED = 700
+POSE_CASES = [("f9", (3, 9, 32, 48), 701), ("f5_odd", (3, 5, 48, 80), 702)]        # (name, humanpose_data shape, seed)
+
+
+def pose_video(seed: int, *shape) -> np.ndarray:
+    """A pose video as the loader hands it over: float32 values 0..255 (sparse coloured strokes on black)."""
+    rs = np.random.RandomState(seed)
+    v = rs.randint(0, 256, size=shape).astype(np.float32)
+    return v * (rs.uniform(size=shape) < 0.3)
