@@ -196,6 +196,11 @@ svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw,
 svi_status svi_cfg_step(void* latents, const void* cond, const void* uncond, int64_t n, float cfg_scale,
                         float dsigma, svi_stream stream);
 
+/* FP8 weight storage: the reference's `torch_dtype=torch.float8_e4m3fn` mode (test_svi.py:337) keeps parameters as OCP e4m3fn and
+ * casts them to bf16 in front of every use (vram_management/layers.py:65-71, cast_to).  The cast is exact, so it is done once:
+ * out bf16 [n] = bf16(in e4m3fn [n]); bind the result with svi_dit_bind_weight.  (svi_hip.WanDiT.bind does this for fp8 tensors.) */
+svi_status svi_fp8_e4m3_to_bf16(const void* in, void* out, int64_t n, svi_stream stream);
+
 /* ------------------------------------------------------------------ measurement ----------- */
 /* Per-kernel timing with HIP events recorded on the launch stream (so it measures the kernels where
  * they run, inside the caller's timed region).  Off by default; when on, every tagged launch inside

@@ -303,3 +303,8 @@ extern "C" svi_status svi_cfg_step(void* latents, const void* cond, const void* 
                                reinterpret_cast<const bf16*>(uncond), n, cfg_scale, dsigma,
                                reinterpret_cast<hipStream_t>(stream));
 }
+
+extern "C" svi_status svi_fp8_e4m3_to_bf16(const void* in, void* out, int64_t n, svi_stream stream) {
+    SVI_REQUIRE(in && out && n >= 0, "svi_fp8_e4m3_to_bf16: bad argument");
+    return svi_launch_fp8_e4m3_to_bf16(reinterpret_cast<const unsigned char*>(in), reinterpret_cast<bf16*>(out), n, reinterpret_cast<hipStream_t>(stream));
+}

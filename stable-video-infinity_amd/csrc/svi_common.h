@@ -167,3 +167,4 @@ svi_status svi_launch_add_bf16(bf16* a_inout, const bf16* b, int64_t n, hipStrea
 svi_status svi_launch_video_to_u8(const float* video, unsigned char* out, long thw, hipStream_t st);
 svi_status svi_launch_u8_to_video(const unsigned char* frames, float* out, int n, long hw, hipStream_t st);
 svi_status svi_launch_sub_bf16(bf16* out, const bf16* a, const bf16* b, int64_t n, hipStream_t st);
+svi_status svi_launch_fp8_e4m3_to_bf16(const unsigned char* in, bf16* out, int64_t n, hipStream_t st);

@@ -327,3 +327,30 @@ svi_status svi_launch_u8_to_video(const unsigned char* frames, float* out, int n
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// FP8 weight storage (BASELINE configs[4]).  The reference's "FP8 quantization" (test_svi.py:337,
+// vram_management/layers.py:65-71) stores every parameter as float8_e4m3fn and casts it to the computation dtype (bf16) in front of
+// every use: W_eff = bf16(e4m3(W)) — arithmetic stays bf16.  e4m3fn -> bf16 is exact (3 mantissa bits, exponents 2^-9 .. 2^8), so
+// the cast is done ONCE at bind time: 288 GB of HBM hold the bf16 copy next to the fp8 original, and every forward is then the
+// ordinary bf16 forward on exactly the reference's effective weights.
+// OCP e4m3fn: 1-4-3, bias 7, no infinities, S.1111.111 = NaN, subnormals m * 2^-9.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fp8_e4m3_to_bf16_kernel(const unsigned char* __restrict__ in, bf16* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned b = in[i];
+    const unsigned sign = (b & 0x80u) << 24, e = (b >> 3) & 15u, m = b & 7u;
+    unsigned bits;
+    if (e == 15u && m == 7u) bits = sign | 0x7fc00000u;                                  // NaN
+    else if (e == 0u) bits = sign | __builtin_bit_cast(unsigned, (float)m * 0.001953125f);   // subnormal: m * 2^-9 (exact in fp32)
+    else bits = sign | ((e + 120u) << 23) | (m << 20);
+    out[i] = (bf16)__builtin_bit_cast(float, bits);                                      // exact: the low 16 bits are zero
+}
+svi_status svi_launch_fp8_e4m3_to_bf16(const unsigned char* in, bf16* out, int64_t n, hipStream_t st) {
+    if (n <= 0) return SVI_OK;
+    hipLaunchKernelGGL(fp8_e4m3_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}

@@ -52,6 +52,7 @@ SYMBOLS = [
     ("svi_rmsnorm_rope", _i32, [_vp, _i32, _i32, _i32, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_gemm_bf16", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     ("svi_cfg_step", _i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
+    ("svi_fp8_e4m3_to_bf16", _i32, [_vp, _vp, _i64, _vp]),
     ("svi_prof_enable", _i32, [_i32]),
     ("svi_prof_summary", _i32, [C.c_char_p, _i64]),
     ("svi_vae_create", _i32, [C.POINTER(_vp)]),

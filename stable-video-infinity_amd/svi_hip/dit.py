@@ -69,6 +69,7 @@ class WanDiT:
         L.check(L.lib().svi_dit_create(C.byref(cfg), C.byref(h)), "svi_dit_create")
         self._h = h
         self._params: Dict[str, torch.Tensor] = {}
+        self._fp8_sources: Dict[str, torch.Tensor] = {}        # fp8-stored parameters whose bf16 copies are bound (FP8 storage mode)
         self._param_versions = []
         self._ctx_cache_on = False
         self._ctx_pins = PromptPins()
@@ -77,7 +78,8 @@ class WanDiT:
     @classmethod
     def from_state_dict(cls, state_dict: Dict[str, torch.Tensor], device="cuda", **cfg) -> "WanDiT":
         m = cls(**cfg)
-        m.bind({k: v.to(device=device, dtype=torch.bfloat16).contiguous() for k, v in state_dict.items()})
+        m.bind({k: (v.to(device=device) if v.dtype == torch.float8_e4m3fn else v.to(device=device, dtype=torch.bfloat16)).contiguous()
+                for k, v in state_dict.items()})
         return m
 
     @classmethod
@@ -96,6 +98,12 @@ class WanDiT:
     def bind(self, state_dict: Dict[str, torch.Tensor]) -> None:
         lib = L.lib()
         for name, t in state_dict.items():
+            if t.is_cuda and t.dtype == torch.float8_e4m3fn:
+                # the reference's FP8 mode (test_svi.py:337): parameters live as e4m3 and are cast to bf16 in front of every use; the
+                # cast is exact, so it is done once here and the bf16 copy is what the kernels read (ops.fp8_e4m3_to_bf16)
+                from .ops import fp8_e4m3_to_bf16
+                self._fp8_sources[name] = t
+                t = fp8_e4m3_to_bf16(t)
             if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
                 raise RuntimeError(f"parameter {name} must be a contiguous CUDA bf16 tensor (got {t.device}, {t.dtype})")
             shape = (C.c_int64 * t.dim())(*t.shape)

@@ -106,3 +106,14 @@ def cfg_step_(latents: torch.Tensor, cond: torch.Tensor, uncond: Optional[torch.
     L.check(L.lib().svi_cfg_step(L.ptr(latents), L.ptr(cond), L.ptr(uncond), latents.numel(), float(cfg_scale),
                                  float(dsigma), L.current_stream()), "cfg_step")
     return latents
+
+
+def fp8_e4m3_to_bf16(t: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a float8_e4m3fn tensor (exact): the cast the reference's FP8 mode performs in front of every use
+    (vram_management/layers.py:65-71), done once."""
+    if t.dtype != torch.float8_e4m3fn:
+        raise ValueError(f"expected a float8_e4m3fn tensor, got {t.dtype}")
+    src = t.to(device="cuda").contiguous()
+    out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    L.check(L.lib().svi_fp8_e4m3_to_bf16(L.ptr(src.view(torch.uint8)), L.ptr(out), src.numel(), L.current_stream()), "fp8_e4m3_to_bf16")
+    return out

@@ -536,6 +536,26 @@ def gen_dance_sampler(dit_mod, fm):
     np.savez(os.path.join(OUT, "dance_sampler.npz"), **out)
 
 
+def gen_fp8_storage(dit_mod):
+    """SURVEY F4/F5 (BASELINE configs[4], north_star "bf16/fp8"): the reference's FP8 mode stores every parameter as float8_e4m3fn
+    (test_svi.py:337: load_models(torch_dtype=torch.float8_e4m3fn)) and casts it to the bf16 computation dtype in front of every use
+    (vram_management/layers.py:65-71, cast_to = weight.to(dtype)).  Its result is therefore the bf16 forward of the reference model on
+    weights bf16(e4m3(W)): exactly that, on the tiny T2V config."""
+    c, grid, nt, nv, ts, seed = synth.TINY_DIT, (3, 4, 6), 20, 13, 637.5, 100
+    f, h, w = grid
+    m = build_ref_dit(dit_mod, c, seed)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.data = p.data.to(torch.float8_e4m3fn).to(torch.bfloat16)
+        m = m.to(torch.bfloat16).eval()
+        x = t(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w)).to(torch.bfloat16)
+        ctx = t(synth.text_context(seed + 2, nt, c["text_dim"], nv)).to(torch.bfloat16)
+        out = m(x, torch.tensor([ts]), ctx).float().numpy()
+    # every e4m3fn code point through torch's own cast, as the known-answer table of the decode
+    codes = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).to(torch.bfloat16).view(torch.int16).numpy()
+    np.savez(os.path.join(OUT, "fp8_storage.npz"), out_bf16=out, e4m3_to_bf16_bits=codes)
+
+
 def main(argv=None):
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -553,6 +573,7 @@ def main(argv=None):
         "vae_c2": lambda: gen_vae_c2(vae_mod),
         "dit_block_14b": lambda: gen_block_14b(dit_mod),
         "clip_stream": lambda: gen_clip_stream(dit_mod, vae_mod, fm),
+        "fp8_storage": lambda: gen_fp8_storage(dit_mod),
         "pose_embed": gen_pose_embed,
         "dance_sampler": lambda: gen_dance_sampler(dit_mod, fm),
         "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),
