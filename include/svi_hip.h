@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 1
+#define SVI_HIP_ABI_VERSION 2
 
 typedef enum {
     SVI_OK = 0,
@@ -138,8 +138,13 @@ svi_status svi_dit_context_cache(svi_dit* h, int32_t enable);
  * [row0, row0 + nrows) of the (f h w) sequence for everything row-local and trades tokens for heads around self-attention; the
  * exchanges (RCCL all-to-all / all-gather) are the caller's, between these calls (svi_hip/sequence_parallel.py):
  *   svi_dit_sp_begin        timestep embedding, context (cache honoured), patchify of the rank's rows
- *   svi_dit_sp_block_qkv    block `layer`: LN + modulate, q | k (RMSNorm + RoPE at the rows' true positions, q pre-scaled by
- *                           softmax_scale*log2e) -> qk_out bf16 [nrows, 2*dim];  V^T -> vt_out bf16 [dim, ldvt] (cols >= nrows untouched)
+ *   svi_dit_sp_block_qkv    block `layer`: LN + modulate, q | k projections, RMSNorm + RoPE at the rows' true positions (q pre-scaled by
+ *                           softmax_scale*log2e) stored IN SEND ORDER: q_send / k_send bf16 [G][P][nrows][Dg] — destination rank j owns
+ *                           channel block [j*Dp, (j+1)*Dp), Dp = dim/P, split into G head groups of Dg = Dp/G channels — so each
+ *                           (operand, head group) is one contiguous all-to-all input; V^T -> vt_out bf16 [dim, ldvt] (cols >= nrows
+ *                           untouched), whose row block j is rank j's piece.  No packing pass on either side of the exchange.
+ *   svi_sp_unpack_vt        received V^T pieces [P(src)][Dp][lds] -> [Dp][L8] (token axis source-major)
+ *   svi_sp_unpack_out       received attention pieces [G][P(src)][nrows][Dg] -> attn bf16 [nrows, dim]
  *   svi_attention_vt_fwd    attention of a head group on those layouts (after the exchange: all tokens, n = heads/P)
  *   svi_dit_sp_block_rest   attn bf16 [nrows, dim] (after the exchange back) -> output projection + gate + residual,
  *                           cross-attention, MLP of block `layer`
@@ -148,7 +153,10 @@ svi_status svi_dit_context_cache(svi_dit* h, int32_t enable);
 svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* timestep, const void* context, const void* clip_feature,
                             const void* y, const void* add_condition, int32_t T, int32_t H, int32_t W, int32_t Lc,
                             int32_t row0, int32_t nrows, svi_stream stream);
-svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* qk_out, void* vt_out, int32_t ldvt, svi_stream stream);
+svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* q_send, void* k_send, void* vt_out, int32_t ldvt, int32_t P, int32_t G,
+                                svi_stream stream);
+svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, svi_stream stream);
+svi_status svi_sp_unpack_out(const void* recv, void* out, int32_t P, int32_t G, int32_t Ls, int32_t Dg, svi_stream stream);
 svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const void* attn, svi_stream stream);
 svi_status svi_dit_sp_head(svi_dit* h, void* head_rows_out, svi_stream stream);
 svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void* out, int32_t T, int32_t H, int32_t W, svi_stream stream);

@@ -342,7 +342,7 @@ static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16
 // sequence-parallel shard can exchange heads for tokens around the attention (svi_dit_sp_*): (1) q | k (RMSNorm + RoPE applied,
 // q pre-scaled) and V^T of the shard's rows [row0, row0 + L), (2) attention, (3) output projection + gate + residual.
 static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* modf, int L, int row0, bf16* QK, bf16* VT, int ldvt,
-                            hipStream_t st) {
+                            hipStream_t st, const SviScatter* scatter = nullptr) {
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
     Workspace& w = h->ws;
@@ -356,7 +356,7 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st)); }
     // q and k in one launch (grid.y = operand): q additionally carries softmax_scale * log2(e) into its single final rounding
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope2(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope2(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st, scatter)); }
     return SVI_OK;
 }
 
@@ -763,12 +763,25 @@ extern "C" svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* t
     return SVI_OK;
 }
 
-extern "C" svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* qk_out, void* vt_out, int32_t ldvt, svi_stream stream) {
-    SVI_REQUIRE(h && h->sp_active && qk_out && vt_out, "svi_dit_sp_block_qkv: no shard in flight (svi_dit_sp_begin) or null buffer");
+extern "C" svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* q_send, void* k_send, void* vt_out, int32_t ldvt, int32_t P, int32_t G,
+                                           svi_stream stream) {
+    SVI_REQUIRE(h && h->sp_active && q_send && k_send && vt_out, "svi_dit_sp_block_qkv: no shard in flight (svi_dit_sp_begin) or null buffer");
     SVI_REQUIRE_DEVICE(h);
+    const int D = h->cfg.dim;
     SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && ldvt >= h->sp_rows && ldvt % 8 == 0, "svi_dit_sp_block_qkv: bad layer / ldvt");
-    return block_qkv(h, layer, h->ws.X, h->ws.modf + (size_t)layer * 6 * h->cfg.dim, h->sp_rows, h->sp_row0,
-                     reinterpret_cast<bf16*>(qk_out), reinterpret_cast<bf16*>(vt_out), ldvt, reinterpret_cast<hipStream_t>(stream));
+    SVI_REQUIRE(P > 0 && G > 0 && h->cfg.num_heads % (P * G) == 0, "svi_dit_sp_block_qkv: %d heads do not split into %d ranks x %d head groups", h->cfg.num_heads, P, G);
+    SviScatter sc{reinterpret_cast<bf16*>(q_send), reinterpret_cast<bf16*>(k_send), P, D / P, D / P / G};
+    return block_qkv(h, layer, h->ws.X, h->ws.modf + (size_t)layer * 6 * D, h->sp_rows, h->sp_row0, h->ws.QK, reinterpret_cast<bf16*>(vt_out), ldvt,
+                     reinterpret_cast<hipStream_t>(stream), &sc);
+}
+
+extern "C" svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, svi_stream stream) {
+    SVI_REQUIRE(recv && out, "svi_sp_unpack_vt: null argument");
+    return svi_launch_sp_unpack_vt(reinterpret_cast<const bf16*>(recv), reinterpret_cast<bf16*>(out), P, Dp, Ls, lds, L8, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" svi_status svi_sp_unpack_out(const void* recv, void* out, int32_t P, int32_t G, int32_t Ls, int32_t Dg, svi_stream stream) {
+    SVI_REQUIRE(recv && out, "svi_sp_unpack_out: null argument");
+    return svi_launch_sp_unpack_out(reinterpret_cast<const bf16*>(recv), reinterpret_cast<bf16*>(out), P, G, Ls, Dg, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const void* attn, svi_stream stream) {

@@ -107,10 +107,10 @@ svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int row
 // ------------------------------------------------------------------------------------------------
 // blockIdx.y selects one of up to two [rows, dim] operands that sit side by side in a row (q | k of the DiT's QK buffer): operand
 // p starts at column p * dim and has its own weight and output scale — one launch normalises both.
-template <int MAXC>
+template <int MAXC, bool SCATTER>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x, int ld, int rows, int dim,
                                                            const bf16* __restrict__ weight, const bf16* __restrict__ weight1, float eps, int use_rope,
-                                                           SviRope r, float out_scale, float out_scale1) {
+                                                           SviRope r, float out_scale, float out_scale1, SviScatter sc) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -164,7 +164,13 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (bf16)(y[j] * out_scale);
             }
-            st_bf16x8(xr + col, o);
+            if constexpr (SCATTER) {
+                const int j = col / sc.Dp, cl = col - j * sc.Dp, gq = cl / sc.Dg, cg = cl - gq * sc.Dg;
+                bf16* ob = blockIdx.y ? sc.out1 : sc.out0;
+                st_bf16x8(ob + ((size_t)(gq * sc.P + j) * rows + row) * sc.Dg + cg, o);
+            } else {
+                st_bf16x8(xr + col, o);
+            }
         }
     }
 }
@@ -176,7 +182,7 @@ svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf1
 
 // weight1 != nullptr: a second operand at columns [dim, 2 dim) of every row gets weight1 / out_scale1 in the same launch
 svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf16* weight, const bf16* weight1, float eps,
-                                    const SviRope* rope, float out_scale, float out_scale1, hipStream_t st) {
+                                    const SviRope* rope, float out_scale, float out_scale1, hipStream_t st, const SviScatter* scatter) {
     SVI_REQUIRE(dim % 8 == 0 && ld % 8 == 0, "rmsnorm: dim/ld must be multiples of 8");
     SVI_REQUIRE(dim <= 8192, "rmsnorm: dim %d > 8192 unsupported", dim);
     if (rows <= 0) return SVI_OK;
@@ -190,12 +196,21 @@ svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf
     dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, weight1 ? 2 : 1), block(256);
     const int nchunk = dim / 8;
     const int use = rope ? 1 : 0;
-    if (nchunk <= 64 * 3)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1);
-    else if (nchunk <= 64 * 10)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<10>, grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1);
-    else
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<16>, grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1);
+    SviScatter sc{};
+    if (scatter) {
+        sc = *scatter;
+        SVI_REQUIRE(sc.out0 && (!weight1 || sc.out1) && sc.P > 0 && sc.Dp > 0 && sc.Dg > 0 && sc.P * sc.Dp == dim && sc.Dp % sc.Dg == 0 && sc.Dg % 8 == 0,
+                    "rmsnorm: bad send layout (P=%d Dp=%d Dg=%d for dim %d)", sc.P, sc.Dp, sc.Dg, dim);
+    }
+#define SVI_RMS_LAUNCH(MAXC)                                                                                                             \
+    do {                                                                                                                                 \
+        if (scatter) hipLaunchKernelGGL((rmsnorm_rope_kernel<MAXC, true>), grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1, sc);  \
+        else hipLaunchKernelGGL((rmsnorm_rope_kernel<MAXC, false>), grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1, sc);        \
+    } while (0)
+    if (nchunk <= 64 * 3) SVI_RMS_LAUNCH(3);
+    else if (nchunk <= 64 * 10) SVI_RMS_LAUNCH(10);
+    else SVI_RMS_LAUNCH(16);
+#undef SVI_RMS_LAUNCH
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
@@ -351,6 +366,59 @@ __global__ __launch_bounds__(256) void fp8_e4m3_to_bf16_kernel(const unsigned ch
 svi_status svi_launch_fp8_e4m3_to_bf16(const unsigned char* in, bf16* out, int64_t n, hipStream_t st) {
     if (n <= 0) return SVI_OK;
     hipLaunchKernelGGL(fp8_e4m3_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Sequence-parallel exchanges, receive side (svi_hip/sequence_parallel.py).  The send side needs no kernel: q | k leave the
+// RMSNorm+RoPE launch in send order (SviScatter), V^T [D, ldvt] and the attention output [G][L][Dg] already are contiguous per peer.
+// ------------------------------------------------------------------------------------------------
+// V^T pieces [P(src)][Dp][lds] (columns >= Ls of a piece are padding) -> out [Dp][L8], column src*Ls + i.  VEC elements per thread.
+template <int VEC>
+__global__ __launch_bounds__(256) void sp_unpack_vt_kernel(const bf16* __restrict__ recv, bf16* __restrict__ out, int P, int Dp, int Ls, int lds, int L8) {
+    const int per_row = Ls / VEC;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)P * Dp * per_row;
+    if (idx >= n) return;
+    const int i = (int)(idx % per_row) * VEC;
+    const int64_t rc = idx / per_row;
+    const int c = (int)(rc % Dp), src = (int)(rc / Dp);
+    const bf16* ip = recv + ((size_t)src * Dp + c) * lds + i;
+    bf16* op = out + (size_t)c * L8 + (size_t)src * Ls + i;
+    if constexpr (VEC == 8) st_bf16x8(op, ld_bf16x8(ip));
+    else if constexpr (VEC == 2) *reinterpret_cast<unsigned*>(op) = *reinterpret_cast<const unsigned*>(ip);
+    else *op = *ip;
+}
+svi_status svi_launch_sp_unpack_vt(const bf16* recv, bf16* out, int P, int Dp, int Ls, int lds, int L8, hipStream_t st) {
+    SVI_REQUIRE(P > 0 && Dp > 0 && Ls > 0 && lds >= Ls && L8 >= P * Ls, "sp_unpack_vt: bad sizes");
+    const int vec = (Ls % 8 == 0 && lds % 8 == 0 && L8 % 8 == 0) ? 8 : (Ls % 2 == 0 && lds % 2 == 0 && L8 % 2 == 0) ? 2 : 1;
+    const int64_t n = (int64_t)P * Dp * (Ls / vec);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (vec == 8) hipLaunchKernelGGL(sp_unpack_vt_kernel<8>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8);
+    else if (vec == 2) hipLaunchKernelGGL(sp_unpack_vt_kernel<2>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8);
+    else hipLaunchKernelGGL(sp_unpack_vt_kernel<1>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+// attention output pieces [G][P(src)][Ls][Dg] -> out [Ls][P * G * Dg]: source j's head block at columns [j*Dp, (j+1)*Dp), Dp = G*Dg
+__global__ __launch_bounds__(256) void sp_unpack_out_kernel(const bf16* __restrict__ recv, bf16* __restrict__ out, int P, int G, int Ls, int Dg) {
+    const int cpr = Dg >> 3;                                            // 16-byte chunks per piece row
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)G * P * Ls * cpr;
+    if (idx >= n) return;
+    const int ch = (int)(idx % cpr);
+    int64_t t = idx / cpr;
+    const int row = (int)(t % Ls); t /= Ls;
+    const int j = (int)(t % P), g = (int)(t / P);
+    const int D = P * G * Dg;
+    st_bf16x8(out + (size_t)row * D + (size_t)j * G * Dg + (size_t)g * Dg + ch * 8, ld_bf16x8(recv + idx * 8));
+}
+svi_status svi_launch_sp_unpack_out(const bf16* recv, bf16* out, int P, int G, int Ls, int Dg, hipStream_t st) {
+    SVI_REQUIRE(P > 0 && G > 0 && Ls > 0 && Dg > 0 && Dg % 8 == 0, "sp_unpack_out: bad sizes");
+    const int64_t n = (int64_t)G * P * Ls * (Dg / 8);
+    hipLaunchKernelGGL(sp_unpack_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, recv, out, P, G, Ls, Dg);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }

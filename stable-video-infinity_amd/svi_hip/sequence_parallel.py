@@ -9,13 +9,25 @@ distributed/xdit_context_parallel.py: all-to-all around attention).  Here:
     attention runs on whole sequences of a head group, a second all-to-all turns the result back;
   * after the head an all-gather of [Ls, 64] rows rebuilds the latent.
 
+Layouts are chosen so that NEITHER side of an exchange runs a packing pass (r1 had six layout copies per block):
+    q, k   leave the RMSNorm+RoPE launch in send order  [G][P(dest)][Ls][Dg]   (svi_dit_sp_block_qkv, SviScatter), so one
+           (operand, head group) is a contiguous all-to-all input, and what arrives, [P(src)][Ls][Dg], IS the token-major
+           [L, Dg] operand the attention kernel reads (row stride Dg);
+    V^T    [D, ldvt] as the swapped projection GEMM writes it: row block j is rank j's piece; what arrives, [P(src)][Dp][ldvt],
+           is put side by side along the token axis by ONE copy kernel (svi_sp_unpack_vt) — the only pass the exchange adds;
+    out    the attention kernel writes [G][L][Dg] = [G][P(dest)][Ls][Dg]: contiguous per destination; what arrives is turned
+           into [Ls, D] token rows by one copy kernel (svi_sp_unpack_out).
+All exchange buffers are allocated once per (rank, world, tokens) and reused by every block of every forward.  With G > 1 head
+groups the exchange of group g+1 is issued (async collective) before the attention of group g is enqueued, so transport overlaps
+attention; G is chosen so that a group still fills the chip (>= 256 workgroups of 256 query rows).
+
 Per block and rank the exchanges move 3*Ls*D/P*(P-1) + Ls*D/P*(P-1) bf16 values: at C2 on 4 ranks 2 x 75 MB out and back per
-block over xGMI, ~1 ms at 150 GB/s per link, against ~4 ms of compute per block and rank.  Constraints: L % P == 0 and
-heads % P == 0 (1.3B: 12 heads -> P in {2,3,4,6}; 14B: 40 heads -> {2,4,5,8}).  Composes with CfgPair: 8 GPUs = 2 x 4.
+block over xGMI.  Constraints: L % P == 0 and heads % P == 0 (1.3B: 12 heads -> P in {2,3,4,6}; 14B: 40 heads -> {2,4,5,8}).
+Composes with CfgPair: 8 GPUs = 2 x 4.
 
 Every arithmetic kernel is the one the single-GPU forward uses, on the same operands per row / per head, so the result is
-bit-identical to `WanDiT.forward` for any P (tests/test_gpu_sp.py runs P = 1, 2, 4 shards on one GPU with the exchange
-simulated in-process; tests/test_dist_gloo.py runs the pack / all-to-all / unpack layout code over gloo).
+bit-identical to `WanDiT.forward` for any P and G (tests/test_gpu_sp.py runs P = 1, 2, 4 shards on one GPU with the exchange
+simulated in-process and with real process groups; tests/test_dist_gloo.py runs the layout algebra over gloo on CPU tensors).
 """
 from __future__ import annotations
 
@@ -28,41 +40,40 @@ from . import _lib as L
 from .dit import WanDiT
 
 
-# ---- layout code of the two exchanges (pure tensor reshuffles, device-agnostic) ------------------------------------------------
-def pack_qkv(qk: torch.Tensor, vt: torch.Tensor, P: int) -> torch.Tensor:
-    """qk [Ls, 2D] (q | k), vt [D, >=Ls] -> send [P, 3, Ls*D/P]: slot j = this rank's rows of head group j's q, k and V^T."""
-    Ls, D2 = qk.shape
-    D = D2 // 2
-    Dp = D // P
-    send = torch.empty((P, 3, Ls * Dp), dtype=qk.dtype, device=qk.device)
-    send[:, 0] = qk[:, :D].reshape(Ls, P, Dp).permute(1, 0, 2).reshape(P, Ls * Dp)
-    send[:, 1] = qk[:, D:].reshape(Ls, P, Dp).permute(1, 0, 2).reshape(P, Ls * Dp)
-    send[:, 2] = vt[:, :Ls].reshape(P, Dp, Ls).reshape(P, Dp * Ls)
-    return send
+# ---- the layouts, stated in plain tensor algebra (device-agnostic; the CPU tests run the exchange algebra on these, the GPU tests
+# ---- hold the kernels to them) ----------------------------------------------------------------------------------------------
+def send_layout_qk(x: torch.Tensor, P: int, G: int = 1) -> torch.Tensor:
+    """x [Ls, D] (q or k rows of this rank) -> [G, P, Ls*Dg]: what svi_dit_sp_block_qkv stores."""
+    Ls, D = x.shape
+    Dg = D // P // G
+    return x.reshape(Ls, P, G, Dg).permute(2, 1, 0, 3).reshape(G, P, Ls * Dg).contiguous()
 
 
-def unpack_qkv(recv: torch.Tensor, Ls: int, Dp: int):
-    """recv [P(source rank), 3, Ls*Dp] -> Q, K [L, Dp] (source-major = token order), V^T [Dp, L8] (zero beyond L)."""
-    P = recv.shape[0]
+def unpack_vt(recv: torch.Tensor, Ls: int) -> torch.Tensor:
+    """recv [P(src), Dp, lds] -> V^T [Dp, L8] (zero beyond L): what svi_sp_unpack_vt writes."""
+    P, Dp, _ = recv.shape
     Lfull = P * Ls
-    L8 = (Lfull + 7) // 8 * 8
-    q = recv[:, 0].reshape(Lfull, Dp)
-    k = recv[:, 1].reshape(Lfull, Dp)
-    vt = torch.zeros((Dp, L8), dtype=recv.dtype, device=recv.device)
-    vt[:, :Lfull] = recv[:, 2].reshape(P, Dp, Ls).permute(1, 0, 2).reshape(Dp, Lfull)
-    return q.contiguous(), k.contiguous(), vt
+    vt = torch.zeros((Dp, (Lfull + 7) // 8 * 8), dtype=recv.dtype, device=recv.device)
+    vt[:, :Lfull] = recv[:, :, :Ls].permute(1, 0, 2).reshape(Dp, Lfull)
+    return vt
 
 
-def pack_out(o: torch.Tensor, P: int) -> torch.Tensor:
-    """o [L, Dp] (all tokens, this rank's head group) -> send [P, Ls*Dp]: slot r = the rows rank r owns."""
-    Lfull, Dp = o.shape
-    return o.reshape(P, (Lfull // P) * Dp)
+def unpack_out(recv: torch.Tensor, Ls: int) -> torch.Tensor:
+    """recv [G, P(src), Ls*Dg] -> attn [Ls, D], source j's head block at columns [j*Dp, (j+1)*Dp): what svi_sp_unpack_out writes."""
+    G, P, n = recv.shape
+    Dg = n // Ls
+    return recv.reshape(G, P, Ls, Dg).permute(2, 1, 0, 3).reshape(Ls, P * G * Dg).contiguous()
 
 
-def unpack_out(recv: torch.Tensor, Ls: int, Dp: int) -> torch.Tensor:
-    """recv [P(head group), Ls*Dp] -> attn [Ls, D] with head group g at columns [g*Dp, (g+1)*Dp)."""
-    P = recv.shape[0]
-    return recv.reshape(P, Ls, Dp).permute(1, 0, 2).reshape(Ls, P * Dp).contiguous()
+def head_groups(heads_local: int, tokens: int) -> int:
+    """Number of head groups the exchange is pipelined in: as many as possible while one group's attention still fills the chip
+    (256 CUs x one 256-row query block each) and divides the rank's heads."""
+    blocks_per_head = (tokens + 255) // 256
+    best = 1
+    for g in range(1, heads_local + 1):
+        if heads_local % g == 0 and (heads_local // g) * blocks_per_head >= 256:
+            best = g
+    return best
 
 
 def _staged(t: torch.Tensor, group) -> bool:
@@ -91,19 +102,42 @@ def all_gather_rows(rows: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def all_to_all_local(sends: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-    """The same exchange among P shards living in one process (single-GPU test of the whole scheme)."""
+    """The all-to-all among P shards living in one process: sends[i] is [..., P, n] with the peer axis second to last;
+    returns recv with recv[j][..., i, :] = sends[i][..., j, :]."""
     P = len(sends)
-    return [torch.stack([sends[i][j] for i in range(P)]) for j in range(P)]
+    return [torch.stack([sends[i][..., j, :] for i in range(P)], dim=-2) for j in range(P)]
 
 
 # ---- one rank's share --------------------------------------------------------------------------------------------------------
+class _Buffers:
+    """Exchange buffers of one (rank, world, tokens, head groups) configuration; allocated once, reused by every block."""
+
+    def __init__(self, d: WanDiT, world: int, Ls: int, G: int, dev):
+        D, Dp = d.dim, d.dim // world
+        Dg, Lfull = Dp // G, Ls * world
+        self.ldvt, self.L8 = (Ls + 7) // 8 * 8, (Lfull + 7) // 8 * 8
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        self.qk_send = torch.empty((2, G, world, Ls * Dg), **bf)       # [q|k][group][dest][rows of this rank]
+        self.qk_recv = torch.empty((2, G, world, Ls * Dg), **bf)       # [q|k][group][src] = [q|k][group] x token-major [L, Dg]
+        self.vt_send = torch.zeros((world, Dp, self.ldvt), **bf)       # = V^T [D, ldvt] of this rank's rows (pad columns stay zero)
+        self.vt_recv = torch.empty((world, Dp, self.ldvt), **bf)
+        self.vt_full = torch.zeros((Dp, self.L8), **bf)                # V^T of this rank's head block over all tokens (pad stays zero)
+        self.o_send = torch.empty((G, world, Ls * Dg), **bf)           # attention output [group][L, Dg] = [group][dest][Ls*Dg]
+        self.o_recv = torch.empty((G, world, Ls * Dg), **bf)
+        self.attn = torch.empty((Ls, D), **bf)
+        self.head_rows = None
+
+
 class SequenceShard:
-    def __init__(self, dit: WanDiT, rank: int, world: int):
+    def __init__(self, dit: WanDiT, rank: int, world: int, groups: Optional[int] = None):
         if dit.num_heads % world:
             raise ValueError(f"{dit.num_heads} heads do not divide over {world} ranks")
         self.dit, self.rank, self.world = dit, rank, world
         self.Dp = dit.dim // world
         self.heads_local = dit.num_heads // world
+        if groups is not None and (groups < 1 or self.heads_local % groups):
+            raise ValueError(f"{self.heads_local} heads per rank do not split into {groups} head groups")
+        self._groups = groups
 
     def begin(self, x, timestep, context, clip_feature=None, y=None, add_condition=None):
         d = self.dit
@@ -119,7 +153,15 @@ class SequenceShard:
         if self.L % self.world:
             raise ValueError(f"{self.L} tokens do not divide over {self.world} ranks")
         self.Ls = self.L // self.world
-        self.ldvt = (self.Ls + 7) // 8 * 8
+        self.G = self._groups if self._groups is not None else head_groups(self.heads_local, self.L)
+        self.Dg = self.Dp // self.G
+        cache = d.__dict__.setdefault("_sp_buffers", {})
+        key = (self.rank, self.world, self.L, self.G, x.device)
+        if key not in cache:
+            if len(cache) >= 4:
+                cache.clear()
+            cache[key] = _Buffers(d, self.world, self.Ls, self.G, x.device)
+        self.buf = cache[key]
         context, clip_feature = d._prompt_args(context, clip_feature)
         self._keep = [x, context, timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(), clip_feature,
                       None if y is None else y.to(torch.bfloat16).contiguous(),
@@ -127,32 +169,35 @@ class SequenceShard:
         x, context, ts, clip, yy, addc = self._keep
         L.check(L.lib().svi_dit_sp_begin(d._h, L.ptr(x), L.ptr(ts), L.ptr(context), L.ptr(clip), L.ptr(yy), L.ptr(addc), T, H, W,
                                          context.shape[1], self.rank * self.Ls, self.Ls, L.current_stream()), "svi_dit_sp_begin")
-        dev = x.device
-        self.qk = torch.empty((self.Ls, 2 * d.dim), dtype=torch.bfloat16, device=dev)
-        self.vt = torch.zeros((d.dim, self.ldvt), dtype=torch.bfloat16, device=dev)
-        self.o = torch.empty((self.L, self.Dp), dtype=torch.bfloat16, device=dev)
 
-    def block_qkv(self, layer: int) -> torch.Tensor:
-        L.check(L.lib().svi_dit_sp_block_qkv(self.dit._h, layer, L.ptr(self.qk), L.ptr(self.vt), self.ldvt, L.current_stream()), "svi_dit_sp_block_qkv")
-        return pack_qkv(self.qk, self.vt, self.world)
+    def block_qkv(self, layer: int) -> None:
+        """-> buf.qk_send (q | k in send order), buf.vt_send (V^T, row block j = rank j's piece)."""
+        b = self.buf
+        L.check(L.lib().svi_dit_sp_block_qkv(self.dit._h, layer, L.ptr(b.qk_send[0]), L.ptr(b.qk_send[1]), L.ptr(b.vt_send), b.ldvt,
+                                             self.world, self.G, L.current_stream()), "svi_dit_sp_block_qkv")
 
-    def attention(self, recv: torch.Tensor) -> torch.Tensor:
-        q, k, vt = unpack_qkv(recv, self.Ls, self.Dp)
-        L.check(L.lib().svi_attention_vt_fwd(L.ptr(q), self.Dp, L.ptr(k), self.Dp, L.ptr(vt), vt.shape[1], L.ptr(self.o), self.Dp,
-                                             self.L, self.L, self.heads_local, 1, L.current_stream()), "svi_attention_vt_fwd")
-        self._alive = (q, k, vt)                      # keep the operands until the stream has consumed them
-        return pack_out(self.o, self.world)
+    def unpack_v(self) -> None:
+        b = self.buf
+        L.check(L.lib().svi_sp_unpack_vt(L.ptr(b.vt_recv), L.ptr(b.vt_full), self.world, self.Dp, self.Ls, b.ldvt, b.L8, L.current_stream()), "svi_sp_unpack_vt")
 
-    def block_rest(self, layer: int, recv: torch.Tensor) -> None:
-        attn = unpack_out(recv, self.Ls, self.Dp)
-        L.check(L.lib().svi_dit_sp_block_rest(self.dit._h, layer, L.ptr(attn), L.current_stream()), "svi_dit_sp_block_rest")
-        self._alive2 = attn
+    def attention(self, g: int) -> None:
+        """Attention of head group g on the received operands -> buf.o_send[g] ([L, Dg], contiguous per destination)."""
+        b = self.buf
+        L.check(L.lib().svi_attention_vt_fwd(L.ptr(b.qk_recv[0, g]), self.Dg, L.ptr(b.qk_recv[1, g]), self.Dg, L.ptr(b.vt_full[g * self.Dg:]), b.L8,
+                                             L.ptr(b.o_send[g]), self.Dg, self.L, self.L, self.heads_local // self.G, 1, L.current_stream()), "svi_attention_vt_fwd")
+
+    def block_rest(self, layer: int) -> None:
+        b = self.buf
+        L.check(L.lib().svi_sp_unpack_out(L.ptr(b.o_recv), L.ptr(b.attn), self.world, self.G, self.Ls, self.Dg, L.current_stream()), "svi_sp_unpack_out")
+        L.check(L.lib().svi_dit_sp_block_rest(self.dit._h, layer, L.ptr(b.attn), L.current_stream()), "svi_dit_sp_block_rest")
 
     def head(self) -> torch.Tensor:
         ld = L.lib().svi_dit_head_ld(self.dit._h)
-        rows = torch.empty((self.Ls, ld), dtype=torch.bfloat16, device=self.qk.device)
-        L.check(L.lib().svi_dit_sp_head(self.dit._h, L.ptr(rows), L.current_stream()), "svi_dit_sp_head")
-        return rows
+        b = self.buf
+        if b.head_rows is None or tuple(b.head_rows.shape) != (self.Ls, ld):
+            b.head_rows = torch.empty((self.Ls, ld), dtype=torch.bfloat16, device=b.attn.device)
+        L.check(L.lib().svi_dit_sp_head(self.dit._h, L.ptr(b.head_rows), L.current_stream()), "svi_dit_sp_head")
+        return b.head_rows
 
     def unpatchify(self, head_rows: torch.Tensor) -> torch.Tensor:
         out = torch.empty((1, self.dit.out_dim, self.T, self.H, self.W), dtype=torch.bfloat16, device=head_rows.device)
@@ -162,29 +207,72 @@ class SequenceShard:
 
 
 # ---- drivers -----------------------------------------------------------------------------------------------------------------
-def forward_distributed(dit: WanDiT, x, timestep, context, group=None, **cond) -> torch.Tensor:
+def _exchange(recv: torch.Tensor, send: torch.Tensor, group, overlap: bool):
+    """all-to-all of [P, n] pieces.  RCCL: an async collective on the communicator's stream (the caller waits on the returned
+    handle where the data is needed, so the next kernels enqueue meanwhile); gloo (tests): staged through the host, synchronous."""
+    if _staged(send, group):
+        host = send.cpu().contiguous()
+        out = torch.empty_like(host)
+        dist.all_to_all_single(out, host, group=group)
+        recv.copy_(out)
+        return None
+    return dist.all_to_all_single(recv, send, group=group, async_op=overlap)
+
+
+def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: Optional[int] = None, **cond) -> torch.Tensor:
     """model_fn_wan_video(..., use_unified_sequence_parallel=True) for this rank of `group`: every rank passes the same inputs
-    and receives the full output.  Two all-to-alls per block, one all-gather per forward."""
+    and receives the full output.  Per block: the q | k | V^T exchange pipelined over G head groups against attention, the output
+    exchange pipelined the same way; one all-gather per forward."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    sh = SequenceShard(dit, rank, world)
+    sh = SequenceShard(dit, rank, world, groups)
     sh.begin(x, timestep, context, **cond)
+    b, G = sh.buf, None
+    G = sh.G
     for layer in range(dit.num_layers):
-        o_send = sh.attention(all_to_all(sh.block_qkv(layer), group))
-        sh.block_rest(layer, all_to_all(o_send, group))
+        sh.block_qkv(layer)
+        wv = _exchange(b.vt_recv, b.vt_send, group, True)
+        wq = [(_exchange(b.qk_recv[0, g], b.qk_send[0, g], group, True), _exchange(b.qk_recv[1, g], b.qk_send[1, g], group, True)) for g in range(G)]
+        if wv is not None:
+            wv.wait()
+        sh.unpack_v()
+        wo = []
+        for g in range(G):
+            for w_ in wq[g]:
+                if w_ is not None:
+                    w_.wait()
+            sh.attention(g)
+            wo.append(_exchange(b.o_recv[g], b.o_send[g], group, True))
+        for w_ in wo:
+            if w_ is not None:
+                w_.wait()
+        sh.block_rest(layer)
     return sh.unpatchify(all_gather_rows(sh.head(), group))
 
 
-def forward_local(dits: Sequence[WanDiT], x, timestep, context, **cond) -> torch.Tensor:
+def forward_local(dits: Sequence[WanDiT], x, timestep, context, groups: Optional[int] = None, **cond) -> torch.Tensor:
     """The same schedule with P = len(dits) shards in ONE process (each shard needs its own handle: a handle holds one
-    workspace); the exchanges are in-process gathers.  For tests and for checking a sharding on a single GPU."""
+    workspace); the exchanges are device copies between the shards' buffers.  For tests and for measuring what the schedule costs
+    besides the transport on a single GPU (tools/sp_overhead.py)."""
     P = len(dits)
-    shards = [SequenceShard(d, r, P) for r, d in enumerate(dits)]
+    shards = [SequenceShard(d, r, P, groups) for r, d in enumerate(dits)]
     for sh in shards:
         sh.begin(x, timestep, context, **cond)
+    G = shards[0].G
     for layer in range(dits[0].num_layers):
-        recv = all_to_all_local([sh.block_qkv(layer) for sh in shards])
-        back = all_to_all_local([sh.attention(r) for sh, r in zip(shards, recv)])
-        for sh, r in zip(shards, back):
-            sh.block_rest(layer, r)
+        for sh in shards:
+            sh.block_qkv(layer)
+        for j, sj in enumerate(shards):                 # rank j receives piece j of every rank i
+            for i, si in enumerate(shards):
+                sj.buf.vt_recv[i].copy_(si.buf.vt_send[j])
+                sj.buf.qk_recv[:, :, i].copy_(si.buf.qk_send[:, :, j])
+        for sh in shards:
+            sh.unpack_v()
+            for g in range(G):
+                sh.attention(g)
+        for j, sj in enumerate(shards):
+            for i, si in enumerate(shards):
+                sj.buf.o_recv[:, i].copy_(si.buf.o_send[:, j])
+        for sh in shards:
+            sh.block_rest(layer)
     rows = torch.cat([sh.head() for sh in shards], dim=0)
     return shards[0].unpatchify(rows)

@@ -121,20 +121,28 @@ def _sp_worker(rank, world, port, queue):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from svi_hip import sequence_parallel as sp
-        Lfull, D = 12 * world, 128 * world
+        Lfull, D, G = 12 * world, 256 * world, 2
         Ls, Dp = Lfull // world, D // world
+        Dg = Dp // G
         g = torch.Generator("cpu").manual_seed(5)
         Q, K, V = [torch.randn((Lfull, D), generator=g).to(torch.bfloat16) for _ in range(3)]     # the global tensors, known to all
         rows = slice(rank * Ls, (rank + 1) * Ls)
-        qk = torch.cat([Q[rows], K[rows]], dim=1)                        # what svi_dit_sp_block_qkv leaves on this rank
-        vt = torch.zeros((D, (Ls + 7) // 8 * 8), dtype=torch.bfloat16)
+        ldvt = (Ls + 7) // 8 * 8
+        vt = torch.zeros((D, ldvt), dtype=torch.bfloat16)               # what svi_dit_sp_block_qkv leaves on this rank: V^T ...
         vt[:, :Ls] = V[rows].t()
-        q, k, vt_full = sp.unpack_qkv(sp.all_to_all(sp.pack_qkv(qk, vt, world)), Ls, Dp)
+        qs, ks = sp.send_layout_qk(Q[rows], world, G), sp.send_layout_qk(K[rows], world, G)   # ... and q | k in send order
+        a2a = lambda t: sp.all_to_all(t.contiguous())                    # noqa: E731
+        vt_full = sp.unpack_vt(a2a(vt.reshape(world, Dp * ldvt)).reshape(world, Dp, ldvt), Ls)
         cols = slice(rank * Dp, (rank + 1) * Dp)
-        ok_qkv = torch.equal(q, Q[:, cols]) and torch.equal(k, K[:, cols]) and torch.equal(vt_full[:, :Lfull], V[:, cols].t()) \
-            and bool((vt_full[:, Lfull:] == 0).all())
+        ok_qkv = torch.equal(vt_full[:, :Lfull], V[:, cols].t()) and bool((vt_full[:, Lfull:] == 0).all())
         O = (Q.float() * 0.5 + K.float()).to(torch.bfloat16)             # any [L, D] result of "attention", column block = head group
-        attn = sp.unpack_out(sp.all_to_all(sp.pack_out(O[:, cols].contiguous(), world)), Ls, Dp)
+        o_send = []
+        for gi in range(G):
+            gc = slice(rank * Dp + gi * Dg, rank * Dp + (gi + 1) * Dg)
+            q, k = a2a(qs[gi]).reshape(Lfull, Dg), a2a(ks[gi]).reshape(Lfull, Dg)    # what arrives is the token-major operand itself
+            ok_qkv = ok_qkv and torch.equal(q, Q[:, gc]) and torch.equal(k, K[:, gc])
+            o_send.append(O[:, gc].reshape(world, Ls * Dg))              # the attention output [L, Dg]: contiguous per destination
+        attn = sp.unpack_out(torch.stack([a2a(o) for o in o_send]), Ls)
         queue.put((rank, ok_qkv, torch.equal(attn, O[rows])))
     finally:
         dist.destroy_process_group()
@@ -143,7 +151,7 @@ def _sp_worker(rank, world, port, queue):
 @pytest.mark.parametrize("world", [2, 4])
 def test_sequence_parallel_exchange_layout(world):
     """tokens -> heads and back over a real all-to-all (gloo): after the first exchange a rank holds ALL tokens of ITS head
-    group (q, k row-major, V transposed, zero padded), after the second its OWN rows of all heads."""
+    group (q, k row-major per head group without any unpacking, V transposed, zero padded), after the second its OWN rows of all heads."""
     res = _run_ranks(_sp_worker, world)
     assert sorted(r for r, _, _ in res) == list(range(world))
     assert all(a and b for _, a, b in res), res

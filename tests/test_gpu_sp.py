@@ -25,20 +25,43 @@ def handles(hip, c, seed, n):
     return out
 
 
-@pytest.mark.parametrize("P", [1, 2, 4])
-@pytest.mark.parametrize("grid", [(2, 4, 6), (4, 16, 32)])     # 48 tokens (ragged tiles); 2048 tokens (the long-sequence attention kernel)
-def test_sequence_parallel_is_bit_identical_t2v(P, grid):
+@pytest.mark.parametrize("P,G", [(1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (4, 1)])      # 4 heads: ranks x head groups
+@pytest.mark.parametrize("grid", [(2, 4, 6), (4, 16, 32), (3, 5, 14)])     # 48 tokens (ragged tiles); 2048 (the long-sequence attention kernel); 210 (odd shard lengths)
+def test_sequence_parallel_is_bit_identical_t2v(P, G, grid):
     import svi_hip
     from svi_hip import sequence_parallel as sp
     f, h, w = grid
+    if (f * h * w) % P:
+        pytest.skip("tokens do not divide")
     ms = handles(svi_hip, WIDE_T2V, 900, P + 1)
     x = dev(synth.randn(901, 1, 16, f, 2 * h, 2 * w))
     ctx = dev(synth.text_context(902, 24, 64, 17))
     t = torch.tensor([712.5])
     want = ms[-1].forward(x, t, ctx)
-    got = sp.forward_local(ms[:P], x, t, ctx)
+    got = sp.forward_local(ms[:P], x, t, ctx, groups=G)
     assert got.shape == want.shape and torch.isfinite(got.float()).all()
     assert torch.equal(got, want)
+    again = sp.forward_local(ms[:P], x, t, ctx, groups=G)            # second forward reuses the exchange buffers
+    assert torch.equal(again, want) and len(ms[0]._sp_buffers) == 1
+
+
+@pytest.mark.parametrize("P,Dp,Ls", [(2, 128, 24), (4, 256, 105), (3, 128, 7), (2, 384, 8190)])
+def test_unpack_kernels_follow_the_layout_algebra(P, Dp, Ls):
+    """svi_sp_unpack_vt / svi_sp_unpack_out against their statement in tensor algebra (sequence_parallel.unpack_vt / unpack_out):
+    shard lengths that are multiples of 8, even, and odd take the three copy widths."""
+    from svi_hip import _lib as L
+    from svi_hip import sequence_parallel as sp
+    lds, L8 = (Ls + 7) // 8 * 8, (P * Ls + 7) // 8 * 8
+    recv = dev(synth.randn(7, P, Dp, lds))
+    out = torch.zeros((Dp, L8), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().svi_sp_unpack_vt(recv.data_ptr(), out.data_ptr(), P, Dp, Ls, lds, L8, L.current_stream()))
+    assert torch.equal(out, sp.unpack_vt(recv, Ls))
+    for G in (1, 2):
+        Dg = Dp // G
+        r2 = dev(synth.randn(8, G, P, Ls * Dg))
+        o2 = torch.empty((Ls, P * Dp), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().svi_sp_unpack_out(r2.data_ptr(), o2.data_ptr(), P, G, Ls, Dg, L.current_stream()))
+        assert torch.equal(o2, sp.unpack_out(r2, Ls))
 
 
 def test_sequence_parallel_i2v_and_add_condition():

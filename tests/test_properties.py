@@ -26,49 +26,67 @@ def _ids(L, D):
 
 
 @FAST
-@given(P=st.sampled_from([1, 2, 3, 4, 6, 8]), heads_per=st.integers(1, 3), Ls=st.integers(1, 21), seed=st.integers(0, 2 ** 16))
-def test_tokens_to_heads_and_back(P, heads_per, Ls, seed):
-    Dp = 8 * heads_per                       # stands in for heads_per x 128 columns; the layout code only sees column blocks
+@given(P=st.sampled_from([1, 2, 3, 4, 6, 8]), G=st.sampled_from([1, 2, 3]), heads_per=st.integers(1, 2), Ls=st.integers(1, 21), seed=st.integers(0, 2 ** 16))
+def test_tokens_to_heads_and_back(P, G, heads_per, Ls, seed):
+    Dg = 8 * heads_per                       # stands in for heads_per x 128 columns; the layout code only sees column blocks
+    Dp = G * Dg
     D, L = P * Dp, P * Ls
     g = torch.Generator().manual_seed(seed)
     Q, K, V = (torch.randn((L, D), generator=g).to(torch.bfloat16) for _ in range(3))
     ldvt = (Ls + 7) // 8 * 8
-    sends = []
+    qs, ks, vs = [], [], []
     for r in range(P):
         rows = slice(r * Ls, (r + 1) * Ls)
-        qk = torch.cat([Q[rows], K[rows]], dim=1).contiguous()
+        qs.append(sp.send_layout_qk(Q[rows], P, G))          # [G, P, Ls*Dg]
+        ks.append(sp.send_layout_qk(K[rows], P, G))
         vt = torch.zeros((D, ldvt), dtype=torch.bfloat16)
         vt[:, :Ls] = V[rows].t()
-        vt[:, Ls:] = 7.0                     # whatever sits in the pad columns of a shard must not travel
-        sends.append(sp.pack_qkv(qk, vt, P))
-    recv = sp.all_to_all_local(sends)
+        vt[:, Ls:] = 7.0                     # whatever sits in the pad columns of a shard must not reach the attention operand
+        vs.append(vt.reshape(P, Dp, ldvt))   # V^T as the projection writes it: row block j = rank j's piece
+    qr, kr, vr = sp.all_to_all_local(qs), sp.all_to_all_local(ks), sp.all_to_all_local([v.reshape(P, Dp * ldvt) for v in vs])
     outs = []
     for j in range(P):
         cols = slice(j * Dp, (j + 1) * Dp)
-        q, k, vt = sp.unpack_qkv(recv[j], Ls, Dp)
-        assert q.shape == (L, Dp) and torch.equal(q, Q[:, cols]) and torch.equal(k, K[:, cols])
+        vt = sp.unpack_vt(vr[j].reshape(P, Dp, ldvt), Ls)
         assert vt.shape == (Dp, (L + 7) // 8 * 8)
         assert torch.equal(vt[:, :L], V[:, cols].t()) and not vt[:, L:].any()      # zero pad: the kernel reads those columns
-        outs.append(sp.pack_out((q.float() + 2 * k.float()).to(torch.bfloat16).contiguous(), P))
+        o = []
+        for gi in range(G):
+            gc = slice(j * Dp + gi * Dg, j * Dp + (gi + 1) * Dg)
+            q, k = qr[j][gi].reshape(L, Dg), kr[j][gi].reshape(L, Dg)              # what arrived IS the token-major operand
+            assert torch.equal(q, Q[:, gc]) and torch.equal(k, K[:, gc])
+            o.append((q.float() + 2 * k.float()).to(torch.bfloat16).reshape(P, Ls * Dg))   # "attention" of the group, [L, Dg]
+        outs.append(torch.stack(o))          # [G, P, Ls*Dg]: contiguous per destination
     back = sp.all_to_all_local(outs)
     want = (Q.float() + 2 * K.float()).to(torch.bfloat16)
     for r in range(P):
-        attn = sp.unpack_out(back[r], Ls, Dp)
+        attn = sp.unpack_out(back[r], Ls)
         assert attn.shape == (Ls, D) and torch.equal(attn, want[r * Ls:(r + 1) * Ls])
 
 
 @FAST
-@given(P=st.integers(1, 8), Ls=st.integers(1, 9), Dp=st.sampled_from([8, 16, 24]))
-def test_exchange_moves_every_element_exactly_once(P, Ls, Dp):
-    """Coordinates survive the round trip: nothing is duplicated or dropped by pack / exchange / unpack."""
+@given(P=st.integers(1, 8), G=st.integers(1, 3), Ls=st.integers(1, 9), Dg=st.sampled_from([8, 16, 24]))
+def test_exchange_moves_every_element_exactly_once(P, G, Ls, Dg):
+    """Coordinates survive the round trip: nothing is duplicated or dropped by send layout / exchange / unpack."""
+    Dp = G * Dg
     D, L = P * Dp, P * Ls
     X = _ids(L, D)
-    packs = []
+    back = sp.all_to_all_local([sp.send_layout_qk(X[r * Ls:(r + 1) * Ls], P, G) for r in range(P)])
     for j in range(P):
-        packs.append(sp.pack_out(X[:, j * Dp:(j + 1) * Dp].contiguous(), P))
-    back = sp.all_to_all_local(packs)
-    got = torch.cat([sp.unpack_out(back[r], Ls, Dp) for r in range(P)], dim=0)
+        for gi in range(G):
+            assert torch.equal(back[j][gi].reshape(L, Dg), X[:, j * Dp + gi * Dg:j * Dp + (gi + 1) * Dg])
+    packs = [torch.stack([X[:, j * Dp + gi * Dg:j * Dp + (gi + 1) * Dg].reshape(P, Ls * Dg) for gi in range(G)]) for j in range(P)]
+    got = torch.cat([sp.unpack_out(b, Ls) for b in sp.all_to_all_local(packs)], dim=0)
     assert torch.equal(got, X)
+
+
+@FAST
+@given(heads=st.integers(1, 40), tokens=st.integers(1, 80000))
+def test_head_group_choice(heads, tokens):
+    g = sp.head_groups(heads, tokens)
+    assert 1 <= g <= heads and heads % g == 0
+    if g > 1:
+        assert (heads // g) * ((tokens + 255) // 256) >= 256          # a group still fills the chip
 
 
 @FAST

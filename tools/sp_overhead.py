@@ -33,9 +33,17 @@ print(f"plain forward, {layers} blocks: {base:.1f} ms")
 for P in (2, 4, 6):
     hs = [handle() for _ in range(P)]
     for m in hs: m.context_cache(True)
-    ms = timeit(lambda: sp.forward_local(hs, x, t, ctx))
-    per_rank = ms / P
-    bytes_a2a = 2 * (32760 // P) * 1536 // P * (P - 1) * 2 * (3 + 1) / 2     # out + back per block and rank (q,k,v out; o back), bf16
-    print(f"P={P}: all shards back to back {ms:.1f} ms -> per rank {per_rank:.1f} ms ({per_rank / (base / P) - 1:+.1%} over an ideal 1/P split); "
-          f"exchange volume per block and rank {(32760 // P) * (1536 // P) * (P - 1) * 2 * 4 / 1e6:.1f} MB")
+    for G in sorted({1, sp.head_groups(12 // P, 32760)}):
+        ms = timeit(lambda: sp.forward_local(hs, x, t, ctx, groups=G))
+        # the simulated transport: the same device copies forward_local makes between the shards' buffers, timed alone
+        bufs = [m._sp_buffers[k] for m in hs for k in m._sp_buffers if k[3] == G]
+        def copies():
+            for _ in range(layers):
+                for j, bj in enumerate(bufs):
+                    for i, bi in enumerate(bufs):
+                        bj.vt_recv[i].copy_(bi.vt_send[j]); bj.qk_recv[:, :, i].copy_(bi.qk_send[:, :, j]); bj.o_recv[:, i].copy_(bi.o_send[:, j])
+        cp = timeit(copies)
+        per_rank = (ms - cp) / P
+        print(f"P={P} G={G}: all shards back to back {ms:.1f} ms, of which simulated transport {cp:.1f} ms -> per rank compute + unpack {per_rank:.1f} ms "
+              f"({per_rank / (base / P) - 1:+.1%} over an ideal 1/P split); exchange volume per block and rank {(32760 // P) * (1536 // P) * (P - 1) * 2 * 4 / 1e6:.1f} MB")
     del hs
