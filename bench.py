@@ -142,6 +142,8 @@ def main() -> None:
                     "(one 4.2 MB all-gather per step); needs an even --gpus. Default is one clip per rank.")
     ap.add_argument("--seq-parallel", action="store_true", help="SURVEY 8e-3: ONE clip on all ranks (strong scaling): every forward is "
                     "spread Ulysses-style over the ranks (heads must divide); with --cfg-pair: 2 CFG branches x N/2 sequence shards")
+    ap.add_argument("--graph", action="store_true", help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)): for the "
+                    "launch-bound regime (--workload c1); per-kernel event timing is off under capture, so `roofline` is null")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -181,7 +183,7 @@ def main() -> None:
         assert dist is not None and world % 2 == 0, "--cfg-pair needs an even number of ranks"
         from svi_hip.parallel import CfgPair
         pair, pair_idx, units = CfgPair.split_world()
-    loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp)
+    loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp, graph=args.graph)
     spc = wl["steps_per_clip"]
     loop.scheduler.set_timesteps(spc, shift=5.0)
 
@@ -215,7 +217,7 @@ def main() -> None:
     for i in range(args.warmup):
         one_step(i)
     sync()
-    _lib.prof_enable(True)
+    _lib.prof_enable(not args.graph)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
@@ -318,6 +320,7 @@ def main() -> None:
                    "value_includes_vae_decode": vae_ms is not None,
                    "dit_only_value": round(units * frames / clip_s_dit, 5),
                    "dit_tflops": round(2 * flops_forward / (ms_per_step * 1e-3) / 1e12, 1),
+                   "hip_graph": bool(args.graph),
                    "outputs_finite": finite},
         "roofline": roof,
         "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},

@@ -158,6 +158,9 @@ svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* q_send, void* k
 svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, svi_stream stream);
 svi_status svi_sp_unpack_out(const void* recv, void* out, int32_t P, int32_t G, int32_t Ls, int32_t Dg, svi_stream stream);
 svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const void* attn, svi_stream stream);
+/* TeaCache on a shard's rows (the reference combines TeaCache and USP, pipelines/svi_video.py:112-131): mode 0 snapshot before the blocks,
+ * 1 residual bf16 [nrows, dim] = x_after - x_before, 2 x += residual in place of the blocks. */
+svi_status svi_dit_sp_tea(svi_dit* h, int32_t mode, void* residual, svi_stream stream);
 svi_status svi_dit_sp_head(svi_dit* h, void* head_rows_out, svi_stream stream);
 svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void* out, int32_t T, int32_t H, int32_t W, svi_stream stream);
 int32_t svi_dit_head_ld(svi_dit* h);

@@ -784,6 +784,20 @@ extern "C" svi_status svi_sp_unpack_out(const void* recv, void* out, int32_t P, 
     return svi_launch_sp_unpack_out(reinterpret_cast<const bf16*>(recv), reinterpret_cast<bf16*>(out), P, G, Ls, Dg, reinterpret_cast<hipStream_t>(stream));
 }
 
+// TeaCache inside a sequence-parallel forward (the reference allows the combination: svi_video.py:112-131 checks on the full x, then
+// chunks it, and store / update act on the rank's chunk).  mode 0: snapshot the shard's rows before the blocks; 1: residual =
+// bf16(x_after - x_before) of the shard's rows (TeaCache.store, :64-66); 2: x = bf16(x + residual) in place of the blocks (:68-70).
+extern "C" svi_status svi_dit_sp_tea(svi_dit* h, int32_t mode, void* residual, svi_stream stream) {
+    SVI_REQUIRE(h && h->sp_active && mode >= 0 && mode <= 2 && (mode == 0 || residual), "svi_dit_sp_tea: no shard in flight, bad mode or null residual");
+    SVI_REQUIRE_DEVICE(h);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    Workspace& w = h->ws;
+    const int64_t n = (int64_t)h->sp_rows * h->cfg.dim;
+    if (mode == 0) { SVI_CHECK_HIP(hipMemcpyAsync(w.X2, w.X, (size_t)n * 2, hipMemcpyDeviceToDevice, st)); return SVI_OK; }
+    if (mode == 1) return svi_launch_sub_bf16(reinterpret_cast<bf16*>(residual), w.X, w.X2, n, st);
+    return svi_launch_add_bf16(w.X, reinterpret_cast<const bf16*>(residual), n, st);
+}
+
 extern "C" svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const void* attn, svi_stream stream) {
     SVI_REQUIRE(h && h->sp_active && attn, "svi_dit_sp_block_rest: no shard in flight or null buffer");
     SVI_REQUIRE_DEVICE(h);

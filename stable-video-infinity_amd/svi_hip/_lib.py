@@ -40,6 +40,7 @@ SYMBOLS = [
     ("svi_sp_unpack_vt", _i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_sp_unpack_out", _i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_sp_block_rest", _i32, [_vp, _i32, _vp, _vp]),
+    ("svi_dit_sp_tea", _i32, [_vp, _i32, _vp, _vp]),
     ("svi_dit_sp_head", _i32, [_vp, _vp, _vp]),
     ("svi_dit_unpatchify", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_dit_head_ld", _i32, [_vp]),

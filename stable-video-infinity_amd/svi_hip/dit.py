@@ -289,31 +289,34 @@ def model_fn_wan_video(dit: WanDiT, x: torch.Tensor, timestep: torch.Tensor, con
     (`previous_residual` holds our [B, L, dim] buffer).
     use_unified_sequence_parallel: with an initialised process group of more than one rank (dit.sp_group, default: the world) the
     forward is spread Ulysses-style over the ranks (svi_hip/sequence_parallel.py); with one rank it is the plain forward, as in
-    the reference."""
+    the reference.  The two combine as in the reference (svi_video.py:112-131): the skip decision is taken on t_mod (identical on every
+    rank), the residual a rank stores / adds covers its own token rows."""
+    fwd, rows = dit.forward, None
     if use_unified_sequence_parallel:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(getattr(dit, "sp_group", None)) > 1:   # svi_video.py:119-121
-            if tea_cache is not None:
-                raise NotImplementedError("TeaCache together with sequence parallelism is not served by the HIP backend")
+        grp = getattr(dit, "sp_group", None)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(grp) > 1:   # svi_video.py:119-121
             from .sequence_parallel import forward_distributed
-            return forward_distributed(dit, x, timestep, context, group=getattr(dit, "sp_group", None), clip_feature=clip_feature, y=y,
-                                       add_condition=add_condition)
+            fwd = lambda *a, **kw: forward_distributed(dit, *a, group=grp, **kw)      # noqa: E731
+            B, _, T, H, W = x.shape
+            rows = dit.tokens(T, H, W) // dist.get_world_size(grp)                     # TeaCache residuals hold this rank's rows only
     if tea_cache is None:
-        return dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition)
+        return fwd(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition)
     t_mod = dit.time_mod(timestep)
     # check() clones `x` only to form the residual later (store()); the residual is formed on the device here, so a token suffices
     skip = tea_cache.check(dit, t_mod[:, :1, :1], t_mod)
     B, _, T, H, W = x.shape
+    shape = (B, dit.tokens(T, H, W), dit.dim) if rows is None else (rows, dit.dim)
     if skip:
         res = tea_cache.previous_residual
         if res is None:
             raise RuntimeError("TeaCache asked to skip before any residual was stored")
-        return dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition, tea_mode=2, residual=res)
+        return fwd(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition, tea_mode=2, residual=res)
     res = getattr(tea_cache, "_svi_residual", None)
-    if res is None or res.shape != (B, dit.tokens(T, H, W), dit.dim):
-        res = torch.empty((B, dit.tokens(T, H, W), dit.dim), dtype=torch.bfloat16, device=x.device)
+    if res is None or tuple(res.shape) != shape:
+        res = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
         tea_cache._svi_residual = res
-    out = dit.forward(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition, tea_mode=1, residual=res)
+    out = fwd(x, timestep, context, clip_feature=clip_feature, y=y, add_condition=add_condition, tea_mode=1, residual=res)
     tea_cache.previous_residual = res            # what TeaCache.store() would have computed (svi_video.py:64-66)
     tea_cache.previous_hidden_states = None
     return out

@@ -28,15 +28,54 @@ def generate_noise(shape, seed=None, device="cpu", dtype=torch.float16):
 class DenoiseLoop:
     """50 x { cond forward, uncond forward, CFG combine, Euler step } with latents resident in HBM."""
 
-    def __init__(self, dit: WanDiT, scheduler: Optional[FlowMatchScheduler] = None, cfg_pair=None, sp_group=None, sequence_parallel: bool = False):
+    def __init__(self, dit: WanDiT, scheduler: Optional[FlowMatchScheduler] = None, cfg_pair=None, sp_group=None, sequence_parallel: bool = False,
+                 graph: bool = False):
         """`cfg_pair`: an svi_hip.parallel.CfgPair — this rank then runs only its half of every CFG pair of forwards.
         `sequence_parallel` (+ `sp_group`, default: the world): every forward is spread Ulysses-style over the ranks of the group
-        (svi_hip/sequence_parallel.py); all of them hold the full latents and apply the same CFG/Euler update."""
+        (svi_hip/sequence_parallel.py); all of them hold the full latents and apply the same CFG/Euler update.
+        `graph`: the two forwards of a step are captured ONCE into a hipGraph (through torch.cuda.CUDAGraph) and replayed for every
+        later step of the clip — the ~1500 launches of a step become one; the timestep is read from a device scalar that is
+        refreshed before each replay.  Pays where a step is launch-bound (BASELINE configs[0]: 1280 tokens); results are bit-identical
+        (the same kernels on the same operands).  Single-rank path without TeaCache only."""
         self.dit = dit
         self.cfg_pair = cfg_pair
         self.sequence_parallel, self.sp_group = sequence_parallel, sp_group
         self.scheduler = scheduler or FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
         self._cond = self._uncond = None
+        self.graph = graph
+        self._graph = None            # (key, torch.cuda.CUDAGraph, static timestep tensor)
+        if graph and (cfg_pair is not None or sequence_parallel):
+            raise ValueError("graph capture covers the single-rank step only")
+
+    def _forwards(self, latents, timestep, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond) -> None:
+        """The DiT forward(s) of one step into self._cond / self._uncond."""
+        if cfg_scale != 1.0:
+            if ctx_neg.shape == ctx_pos.shape and not split:      # one call: the prompt-independent head of the forward is shared, results unchanged
+                self.dit.forward_cfg_pair(latents, timestep, ctx_pos, ctx_neg, out_cond=self._cond, out_uncond=self._uncond, **cond)
+            else:
+                self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
+                self.dit.forward(latents, timestep, ctx_neg, out=self._uncond, **ucond)
+        else:
+            self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
+
+    def _forwards_graphed(self, latents, timestep, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond) -> None:
+        """Replay (capture on first use) the hipGraph of this step's forwards.  The graph is tied to the addresses of everything it
+        reads and writes: latents, prompt embeddings, conditioning tensors, output buffers — a new clip (new tensors) re-captures."""
+        def ident(t):
+            return None if t is None else (t.data_ptr(), tuple(t.shape))
+        key = (ident(latents), ident(ctx_pos), ident(ctx_neg), float(cfg_scale), bool(split),
+               tuple(sorted((k, ident(v)) for k, v in cond.items())), ident(self._cond), self.dit.weights_changed())
+        if self._graph is None or self._graph[0] != key:
+            ts_static = timestep.clone()
+            self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)      # warm-up outside capture: workspaces, context cache
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)
+            self._graph = (key, g, ts_static)
+        _, g, ts_static = self._graph
+        ts_static.copy_(timestep)
+        g.replay()
 
     def step(self, latents: torch.Tensor, timestep: torch.Tensor, dsigma: float, ctx_pos: torch.Tensor,
              ctx_neg: Optional[torch.Tensor], cfg_scale: float, tea_cache_posi=None, tea_cache_nega=None, cond_wo_pose: bool = False,
@@ -50,14 +89,18 @@ class DenoiseLoop:
             ucond = dict(cond, add_condition=None)
         split = ucond is not cond                   # the two branches differ in more than the prompt
         if tea_cache_posi is not None:
-            if self.cfg_pair is not None or self.sequence_parallel:
-                # model_fn_wan_video refuses TeaCache + sequence parallelism; taking the TeaCache branch here would silently run both
-                # full forwards on every rank and skip the collectives
-                raise NotImplementedError("TeaCache together with the CFG pair / sequence parallelism is not served by the HIP backend")
+            if self.cfg_pair is not None:
+                # each rank of a CFG pair would need only its branch's TeaCache; taking this branch would silently run both forwards on
+                # every rank and skip the exchange
+                raise NotImplementedError("TeaCache together with the CFG pair is not served by the HIP backend")
             from .dit import model_fn_wan_video
-            cpred = model_fn_wan_video(self.dit, latents, timestep, ctx_pos, tea_cache=tea_cache_posi, **cond)
+            usp = {}
+            if self.sequence_parallel:          # as the reference: TeaCache + USP (svi_video.py:112-131), residuals per rank
+                self.dit.sp_group = self.sp_group
+                usp = dict(use_unified_sequence_parallel=True)
+            cpred = model_fn_wan_video(self.dit, latents, timestep, ctx_pos, tea_cache=tea_cache_posi, **usp, **cond)
             if cfg_scale != 1.0:
-                upred = model_fn_wan_video(self.dit, latents, timestep, ctx_neg, tea_cache=tea_cache_nega, **ucond)
+                upred = model_fn_wan_video(self.dit, latents, timestep, ctx_neg, tea_cache=tea_cache_nega, **usp, **ucond)
                 ops.cfg_step_(latents, cpred, upred, cfg_scale, dsigma)
             else:
                 ops.cfg_step_(latents, cpred, None, 1.0, dsigma)
@@ -77,15 +120,11 @@ class DenoiseLoop:
         if self._cond is None or self._cond.shape != latents.shape:
             self._cond = torch.empty_like(latents)
             self._uncond = torch.empty_like(latents)
+        run = self._forwards_graphed if self.graph else self._forwards
+        run(latents, timestep, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)
         if cfg_scale != 1.0:
-            if ctx_neg.shape == ctx_pos.shape and not split:      # one call: the prompt-independent head of the forward is shared, results unchanged
-                self.dit.forward_cfg_pair(latents, timestep, ctx_pos, ctx_neg, out_cond=self._cond, out_uncond=self._uncond, **cond)
-            else:
-                self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
-                self.dit.forward(latents, timestep, ctx_neg, out=self._uncond, **ucond)
             ops.cfg_step_(latents, self._cond, self._uncond, cfg_scale, dsigma)
         else:
-            self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
             ops.cfg_step_(latents, self._cond, None, 1.0, dsigma)
         return latents
 

@@ -191,6 +191,12 @@ class SequenceShard:
         L.check(L.lib().svi_sp_unpack_out(L.ptr(b.o_recv), L.ptr(b.attn), self.world, self.G, self.Ls, self.Dg, L.current_stream()), "svi_sp_unpack_out")
         L.check(L.lib().svi_dit_sp_block_rest(self.dit._h, layer, L.ptr(b.attn), L.current_stream()), "svi_dit_sp_block_rest")
 
+    def tea(self, mode: int, residual: Optional[torch.Tensor] = None) -> None:
+        """TeaCache on this shard's rows: 0 snapshot before the blocks, 1 residual [Ls, dim] = x_after - x_before, 2 x += residual."""
+        if mode and (residual is None or tuple(residual.shape) != (self.Ls, self.dit.dim) or residual.dtype != torch.bfloat16 or not residual.is_contiguous()):
+            raise ValueError("TeaCache residual of a shard must be a contiguous bf16 [Ls, dim] tensor")
+        L.check(L.lib().svi_dit_sp_tea(self.dit._h, mode, L.ptr(residual), L.current_stream()), "svi_dit_sp_tea")
+
     def head(self) -> torch.Tensor:
         ld = L.lib().svi_dit_head_ld(self.dit._h)
         b = self.buf
@@ -219,15 +225,22 @@ def _exchange(recv: torch.Tensor, send: torch.Tensor, group, overlap: bool):
     return dist.all_to_all_single(recv, send, group=group, async_op=overlap)
 
 
-def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: Optional[int] = None, **cond) -> torch.Tensor:
+def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: Optional[int] = None, tea_mode: int = 0,
+                        residual: Optional[torch.Tensor] = None, **cond) -> torch.Tensor:
     """model_fn_wan_video(..., use_unified_sequence_parallel=True) for this rank of `group`: every rank passes the same inputs
     and receives the full output.  Per block: the q | k | V^T exchange pipelined over G head groups against attention, the output
-    exchange pipelined the same way; one all-gather per forward."""
+    exchange pipelined the same way; one all-gather per forward.
+    tea_mode / residual (TeaCache, as WanDiT.forward): 1 = also write this rank's residual rows [Ls, dim]; 2 = skip the blocks and add
+    `residual` — no exchange at all in that forward besides the final all-gather."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     sh = SequenceShard(dit, rank, world, groups)
     sh.begin(x, timestep, context, **cond)
-    b, G = sh.buf, None
-    G = sh.G
+    b, G = sh.buf, sh.G
+    if tea_mode == 2:
+        sh.tea(2, residual)
+        return sh.unpatchify(all_gather_rows(sh.head(), group))
+    if tea_mode == 1:
+        sh.tea(0)
     for layer in range(dit.num_layers):
         sh.block_qkv(layer)
         wv = _exchange(b.vt_recv, b.vt_send, group, True)
@@ -246,6 +259,8 @@ def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: O
             if w_ is not None:
                 w_.wait()
         sh.block_rest(layer)
+    if tea_mode == 1:
+        sh.tea(1, residual)
     return sh.unpatchify(all_gather_rows(sh.head(), group))
 
 

@@ -204,3 +204,23 @@ def test_cfg_pair_is_bit_identical_to_two_forwards(hip, name, cache):
     finally:
         m.context_cache(False)
     assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
+def test_graph_replay_is_bit_identical(hip, name):
+    """DenoiseLoop(graph=True): the two forwards of a step captured once into a hipGraph and replayed with a refreshed device
+    timestep — the same kernels on the same operands, so the same bits as the eager loop, over a whole (short) clip and a second clip
+    (new latents / prompts: re-capture)."""
+    c, grid, nt, nv, ts, seed = CASES[name]
+    f, h, w = grid
+    m, _ = build(hip, c, seed)
+    _, ctx, kw = inputs(c, grid, nt, nv, seed)
+    kw = {k: dev(v) for k, v in kw.items()}
+    for clip in range(2):
+        lat = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=5 + clip, device="cpu", dtype=torch.float32)
+        cp, cn = dev(np.asarray(ctx) * (1 + clip)), dev(-np.asarray(ctx))
+        want = hip.DenoiseLoop(m).sample(dev(lat), cp, cn, num_inference_steps=5, cfg_scale=5.0, **kw)
+        loop = hip.DenoiseLoop(m, graph=True)
+        got = loop.sample(dev(lat), cp, cn, num_inference_steps=5, cfg_scale=5.0, **kw)
+        assert torch.equal(got, want)
+        assert loop._graph is not None

@@ -2,8 +2,8 @@
 (golden/pose_embed.npz) and the oracle, and the sampler's branch rule (add_condition on the conditional forward only) against the
 reference's own _sample_with_dance_video (golden/dance_sampler.npz).
 
-Embedder: fp32 convolutions, one final rounding to bf16 -> compared as bf16 values: rel-L2 <= 2e-3 and at most one bf16 ulp apart
-(summation order inside the convolutions decides ties)."""
+Embedder: fp32 convolutions, one final rounding to bf16 -> compared as bf16 values: rel-L2 <= 2e-3 and no element more than one bf16 ulp of the
+reference value apart (summation order inside the convolutions decides rounding ties; measured rel-L2 7e-6)."""
 import numpy as np
 import pytest
 import torch
@@ -29,9 +29,10 @@ def test_pose_embedder_matches_reference(embedder, golden, case):
     got = m(torch.from_numpy(synth.pose_video(seed, *shape)).cuda())
     assert got.dtype == torch.bfloat16 and tuple(got.shape) == want.shape
     r, mx, wmax = errs(got, want)
-    ulp = np.abs(got.float().cpu().numpy().view(np.int32) // 65536 - want.view(np.int32) // 65536).max()
-    report("pose_embed", case=name, rel_l2=r, max_abs=mx, max_bf16_ulps=int(ulp))
-    assert r < 2e-3 and ulp <= 1, (r, mx, ulp)
+    g = got.float().cpu().numpy()
+    off = np.abs(g - want) > np.maximum(np.abs(want) * 2.0 ** -7, 1e-6)        # more than one bf16 ulp of the reference value apart
+    report("pose_embed", case=name, rel_l2=r, max_abs=mx, frac_differing=float((g != want).mean()), beyond_one_ulp=int(off.sum()))
+    assert r < 2e-3 and not off.any(), (r, mx, int(off.sum()))
 
 
 def test_pose_embedder_c2_geometry(embedder):

@@ -111,7 +111,19 @@ def _dist_worker(rank, world, port, queue):
         loop.step(lat, t.cuda(), -0.05, ctx, dev(synth.text_context(903, 24, 64, 11)), 5.0)
         ref = x.clone()
         svi_hip.DenoiseLoop(m).step(ref, t.cuda(), -0.05, ctx, dev(synth.text_context(903, 24, 64, 11)), 5.0)
-        queue.put((rank, bool(torch.equal(got, want)), bool(torch.equal(lat, ref))))
+        # TeaCache + sequence parallelism (allowed by the reference, svi_video.py:112-131): same skip pattern and the same bits as the
+        # single-rank TeaCache loop; a huge threshold makes every middle step a skip, step 0 and the last step compute
+        outs = {}
+        for usp in (False, True):
+            tc = svi_hip.TeaCache(5, 1e9, "Wan2.1-T2V-1.3B")
+            xs, pattern = x.clone(), []
+            for i in range(5):
+                o = svi_hip.model_fn_wan_video(m, xs, torch.tensor([500.0 + 0.01 * i]).cuda(), ctx, tea_cache=tc, use_unified_sequence_parallel=usp)
+                pattern.append(tc.previous_residual.shape[0])
+                xs = (xs.float() + 0.05 * o.float()).to(torch.bfloat16)
+            outs[usp] = (xs, tuple(pattern))
+        ok_tea = bool(torch.equal(outs[False][0], outs[True][0])) and outs[True][1] == (x.shape[2] * (x.shape[3] // 2) * (x.shape[4] // 2) // world,) * 5
+        queue.put((rank, bool(torch.equal(got, want)) and ok_tea, bool(torch.equal(lat, ref))))
     finally:
         dist.destroy_process_group()
 

@@ -52,14 +52,13 @@ def test_forward_checks_before_touching_the_device():
         m.forward(torch.zeros(1, 16, 3, 8, 12), torch.tensor([1.0]), torch.zeros(1, 20, 64))
 
 
-def test_teacache_with_a_parallel_axis_is_refused():
-    """model_fn_wan_video raises for TeaCache + sequence parallelism (as the HIP backend documents); DenoiseLoop.step must not take the
-    TeaCache branch silently and run both full forwards on every rank."""
+def test_teacache_with_the_cfg_pair_is_refused():
+    """TeaCache + sequence parallelism is served (as the reference allows it); TeaCache on a CFG pair is not: DenoiseLoop.step must not
+    take the TeaCache branch silently and run both full forwards on every rank."""
     import svi_hip
     m = _dit(synth.TINY_DIT)
     lat, ctx = torch.zeros(1, 16, 3, 8, 12), torch.zeros(1, 20, 64)
     tea = svi_hip.TeaCache(4, 0.1, "Wan2.1-T2V-1.3B")
-    for kw in (dict(sequence_parallel=True), dict(cfg_pair=object())):
-        loop = svi_hip.DenoiseLoop(m, **kw)
-        with pytest.raises(NotImplementedError):
-            loop.step(lat, torch.tensor([500.0]), -0.1, ctx, ctx, 5.0, tea_cache_posi=tea, tea_cache_nega=tea)
+    loop = svi_hip.DenoiseLoop(m, cfg_pair=object())
+    with pytest.raises(NotImplementedError):
+        loop.step(lat, torch.tensor([500.0]), -0.1, ctx, ctx, 5.0, tea_cache_posi=tea, tea_cache_nega=tea)
