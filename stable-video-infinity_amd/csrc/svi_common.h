@@ -135,6 +135,8 @@ struct SviGemmArgs {
     int epi;
     const float* gate;
     const bf16* res; int ldres;
+    int sel_m, sel_n;           // > 0: choose the kernel as for a problem with this many rows / columns (stacked samples keep the per-sample choice,
+                                // so every row sees the same kernel — and the same bits — as in a per-sample launch); 0: by M / N
 };
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
 
@@ -154,6 +156,7 @@ struct SviRope {                // device tables of (cos,sin) pairs, fp32
     int npf, nph, npw;          // complex pairs per head owned by the frame / height / width axis
     int f, h, w;
     int row0;                   // token index of row 0 of the launch (sequence-parallel shards start mid-grid)
+    int period;                 // > 0: rows are `rows / period` samples stacked one under the other; token = (row0 + row) % period
 };
 // Sequence-parallel send layout (svi_hip/sequence_parallel.py): instead of in place, operand p of the q | k launch is stored as
 // out[p][g][j][row][cg] — destination rank j = col / Dp owns head-channel block [j*Dp, (j+1)*Dp), inside it head group g = (col % Dp) / Dg,

@@ -326,15 +326,17 @@ static svi_status ensure_rope(svi_dit* h, int f, int hh, int ww) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// nb > 1: the M rows are nb samples stacked one under the other; the kernel is chosen as for ONE sample (M / nb rows), so a stacked
+// launch computes every row with the kernel — and the bits — a per-sample launch would.
 static svi_status linear(const bf16* A, int lda, const Lin& l, bf16* C, int ldc, int M, int N, int K, int epi,
-                         hipStream_t st, const float* gate = nullptr, const bf16* res = nullptr, int ldres = 0) {
-    SviGemmArgs g{A, lda, l.w, K, C, ldc, M, N, K, l.b, 0, epi, gate, res, ldres};
+                         hipStream_t st, const float* gate = nullptr, const bf16* res = nullptr, int ldres = 0, int nb = 1) {
+    SviGemmArgs g{A, lda, l.w, K, C, ldc, M, N, K, l.b, 0, epi, gate, res, ldres, nb > 1 ? M / nb : 0, 0};
     return svi_launch_gemm(g, st);
 }
 // V^T[D, n_tok] = Wv · X^T + bv (bias along rows): same GEMM with the operands swapped.
 static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16* CT, int ldct, int n_tok, int N, int K,
-                                    hipStream_t st) {
-    SviGemmArgs g{l.w, K, Xin, ldx, CT, ldct, N, n_tok, K, l.b, 1, SVI_EPI_BIAS, nullptr, nullptr, 0};
+                                    hipStream_t st, int nb = 1) {
+    SviGemmArgs g{l.w, K, Xin, ldx, CT, ldct, N, n_tok, K, l.b, 1, SVI_EPI_BIAS, nullptr, nullptr, 0, 0, nb > 1 ? n_tok / nb : 0};
     return svi_launch_gemm(g, st);
 }
 
@@ -342,7 +344,8 @@ static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16
 // sequence-parallel shard can exchange heads for tokens around the attention (svi_dit_sp_*): (1) q | k (RMSNorm + RoPE applied,
 // q pre-scaled) and V^T of the shard's rows [row0, row0 + L), (2) attention, (3) output projection + gate + residual.
 static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* modf, int L, int row0, bf16* QK, bf16* VT, int ldvt,
-                            hipStream_t st, const SviScatter* scatter = nullptr) {
+                            hipStream_t st, const SviScatter* scatter = nullptr, int nb = 1) {
+    // L = rows of this launch (nb samples of L / nb tokens each, stacked: the two CFG branches of a step on short sequences)
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
     Workspace& w = h->ws;
@@ -350,68 +353,86 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
     const float *sh_a = modf, *sc_a = modf + D;
     SviRope rope = h->rope;
     rope.row0 = row0;
+    rope.period = nb > 1 ? L / nb : 0;
     // --- self attention: x += gate_msa * o(attn(rope(rms(q)), rope(rms(k)), v))     dit:358,369,226-242
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_a, sc_a, st)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, QK, 2 * D, L, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
+    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st, nb)); }
     // q and k in one launch (grid.y = operand): q additionally carries softmax_scale * log2(e) into its single final rounding
     { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope2(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st, scatter)); }
     return SVI_OK;
 }
 
-static svi_status block_attn_out(svi_dit* h, int layer, bf16* X, const bf16* attn, const float* modf, int L, hipStream_t st) {
+static svi_status block_attn_out(svi_dit* h, int layer, bf16* X, const bf16* attn, const float* modf, int L, hipStream_t st, int nb = 1) {
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
     const int D = c.dim;
     const float* g_a = modf + 2 * D;
-    { SviProfScope _p(PROF_GEMM_O, st); SVI_TRY(linear(attn, D, b.sa.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D)); }
+    { SviProfScope _p(PROF_GEMM_O, st); SVI_TRY(linear(attn, D, b.sa.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D, nb)); }
     return SVI_OK;
 }
 
-static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* modf, int L, hipStream_t st) {
+// L = tokens of ONE sample; X holds nb samples stacked (nb * L rows).
+static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* modf, int L, hipStream_t st, int nb = 1) {
     Workspace& w = h->ws;
     const int D = h->cfg.dim;
-    SVI_TRY(block_qkv(h, layer, X, modf, L, 0, w.QK, w.VT, w.ldvt, st));
-    { SviProfScope _p(PROF_FLASH_SELF, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, w.QK + D, 2 * D, w.VT, w.ldvt, w.Hb, D, L, L, h->cfg.num_heads, 1, st)); }
-    return block_attn_out(h, layer, X, w.Hb, modf, L, st);
+    SVI_TRY(block_qkv(h, layer, X, modf, nb * L, 0, w.QK, w.VT, w.ldvt, st, nullptr, nb));
+    for (int s = 0; s < nb; ++s) {          // sample s attends over its own token rows / V^T columns [s L, (s+1) L)
+        const size_t ro = (size_t)s * L;
+        SviProfScope _p(PROF_FLASH_SELF, st);
+        SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, w.QK + ro * 2 * D + D, 2 * D, w.VT + ro, w.ldvt, w.Hb + ro * D, D, L, L, h->cfg.num_heads, 1, st));
+    }
+    return block_attn_out(h, layer, X, w.Hb, modf, nb * L, st, nb);
 }
 
 // Cross-attention and MLP thirds of a block.
-static svi_status run_block_rest(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
-                                 const CtxKV& kv, hipStream_t st) {
+// nb > 1: X holds nb samples stacked (nb * L rows); sample s attends to its own context (CTXs[s], kvs[s]) — the conditional and the
+// unconditional prompt of a CFG step.  Row-local work (norms, projections, MLP) runs once over all rows.
+static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* const* CTXs, const float* modf, int L, int Lc,
+                                   const CtxKV* kvs, int nb, hipStream_t st) {
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
     Workspace& w = h->ws;
     const int D = c.dim, F = c.ffn_dim, H = c.num_heads;
     const int img = c.has_image_input ? 257 : 0;
-    const bf16* ctx_txt = CTX + (size_t)img * D;
+    const int R = nb * L;
     const float *sh_m = modf + 3 * D, *sc_m = modf + 4 * D, *g_m = modf + 5 * D;
     // --- cross attention: x += o(attn(rms(q(norm3 x)), rms(k ctx), v ctx) [+ image branch])   dit:370,266-303
-    { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, b.norm3_w, b.norm3_b, nullptr, nullptr, st)); }
-    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, L, D, b.ca.norm_q, c.eps, nullptr, SVI_QK_SCALE_LOG2E, st)); }
-    if (kv.compute) {
-        { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(ctx_txt, D, b.ca.k, kv.CK, D, Lc, D, D, SVI_EPI_BIAS, st)); }
-        { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(kv.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, 1.0f, st)); }
-        { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, kv.CVT, w.ldcvt, Lc, D, D, st)); }
-    }
-    { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb, D, L, Lc, H, 1, st)); }
-    if (img) {
+    { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, R, D, c.eps, b.norm3_w, b.norm3_b, nullptr, nullptr, st)); }
+    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.q, w.QK, 2 * D, R, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, R, D, b.ca.norm_q, c.eps, nullptr, SVI_QK_SCALE_LOG2E, st)); }
+    for (int s = 0; s < nb; ++s) {
+        const CtxKV& kv = kvs[s];
+        const bf16* CTX = CTXs[s];
+        const bf16* ctx_txt = CTX + (size_t)img * D;
+        const size_t ro = (size_t)s * L;
         if (kv.compute) {
-            SVI_TRY(linear(CTX, D, b.ca.k_img, kv.CKi, D, img, D, D, SVI_EPI_BIAS, st));
-            SVI_TRY(svi_launch_rmsnorm_rope(kv.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, 1.0f, st));
-            SVI_TRY(linear_transposed(CTX, D, b.ca.v_img, kv.CVTi, w.ldcvti, img, D, D, st));
+            { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(ctx_txt, D, b.ca.k, kv.CK, D, Lc, D, D, SVI_EPI_BIAS, st)); }
+            { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(kv.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, 1.0f, st)); }
+            { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, kv.CVT, w.ldcvt, Lc, D, D, st)); }
         }
-        SVI_TRY(svi_launch_flash(w.QK, 2 * D, kv.CKi, D, kv.CVTi, w.ldcvti, w.A2, D, L, img, H, 1, st));
-        SVI_TRY(svi_launch_add_bf16(w.Hb, w.A2, (int64_t)L * D, st));
+        { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb + ro * D, D, L, Lc, H, 1, st)); }
+        if (img) {
+            if (kv.compute) {
+                SVI_TRY(linear(CTX, D, b.ca.k_img, kv.CKi, D, img, D, D, SVI_EPI_BIAS, st));
+                SVI_TRY(svi_launch_rmsnorm_rope(kv.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, 1.0f, st));
+                SVI_TRY(linear_transposed(CTX, D, b.ca.v_img, kv.CVTi, w.ldcvti, img, D, D, st));
+            }
+            SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CKi, D, kv.CVTi, w.ldcvti, w.A2 + ro * D, D, L, img, H, 1, st));
+        }
     }
-    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D)); }
+    if (img) SVI_TRY(svi_launch_add_bf16(w.Hb, w.A2, (int64_t)R * D, st));
+    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.o, X, D, R, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D, nb)); }
     // --- MLP: x += gate_mlp * W2 gelu_tanh(W1 modulate(norm2 x))                  dit:372-373,334-335
-    { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_m, sc_m, st)); }
-    { SviProfScope _p(PROF_GEMM_FFN1, st); SVI_TRY(linear(w.Hb, D, b.ffn0, w.Fb, F, L, F, D, SVI_EPI_BIAS_GELU_TANH, st)); }
-    { SviProfScope _p(PROF_GEMM_FFN2, st); SVI_TRY(linear(w.Fb, F, b.ffn2, X, D, L, D, F, SVI_EPI_BIAS_GATE_RES, st, g_m, X, D)); }
+    { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, R, D, c.eps, nullptr, nullptr, sh_m, sc_m, st)); }
+    { SviProfScope _p(PROF_GEMM_FFN1, st); SVI_TRY(linear(w.Hb, D, b.ffn0, w.Fb, F, R, F, D, SVI_EPI_BIAS_GELU_TANH, st, nullptr, nullptr, 0, nb)); }
+    { SviProfScope _p(PROF_GEMM_FFN2, st); SVI_TRY(linear(w.Fb, F, b.ffn2, X, D, R, D, F, SVI_EPI_BIAS_GATE_RES, st, g_m, X, D, nb)); }
     return SVI_OK;
+}
+static svi_status run_block_rest(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
+                                 const CtxKV& kv, hipStream_t st) {
+    return run_block_rest_n(h, layer, X, &CTX, modf, L, Lc, &kv, 1, st);
 }
 
 static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
@@ -542,13 +563,13 @@ static CtxKV kv_of(svi_dit* h, const CtxUse& u, int l) {
 
 // head (dit:401-404): LN + modulation + Linear(dim -> out_dim * patch volume) on the rows in X -> HO [L, ho_ld]
 static int head_ld(const svi_dit_config& c) { return (c.out_dim * c.patch_t * c.patch_h * c.patch_w + 7) / 8 * 8; }
-static svi_status stage_head_rows(svi_dit* h, bf16* HO, int L, hipStream_t st) {
+static svi_status stage_head_rows(svi_dit* h, bf16* HO, int L, hipStream_t st, int nb = 1) {
     const svi_dit_config& c = h->cfg;
     Workspace& w = h->ws;
     const int D = c.dim;
     const int ho = c.out_dim * c.patch_t * c.patch_h * c.patch_w;
     SVI_TRY(svi_launch_ln_mod(w.X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, w.headf, w.headf + D, st));
-    return linear(w.Hb, D, h->head, HO, head_ld(c), L, ho, D, SVI_EPI_BIAS, st);
+    return linear(w.Hb, D, h->head, HO, head_ld(c), L, ho, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb);
 }
 // unpatchify (dit:479-484) of all L = f*h*w head rows
 static svi_status stage_unpatchify(svi_dit* h, const bf16* HO, bf16* out, int T, int H, int W, hipStream_t st) {
@@ -598,25 +619,52 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
 // the 31 modulation rows, patchify + patch embedding, and block 0's self-attention third (LN, q/k/v, RMSNorm+RoPE, flash, o) —
 // is computed once and its X snapshot restored for the second forward: 1/60 of a step's self-attention work, results bit-
 // identical to two svi_dit_forward calls (same kernels on the same operands; tests/test_gpu_dit.py).
+//
+// Short sequences (L <= SVI_PAIR_STACK_MAX tokens, e.g. BASELINE configs[0] with 1280): after the shared part the two branches are
+// STACKED — X holds 2 L rows, conditional on top — and every row-local kernel (norms, projections, MLP, head) runs once over both:
+// half the launches, and GEMMs that offered 120 tiles to 256 CUs offer 240.  Attention runs per branch (own rows; own prompt K / V).
+// Each GEMM keeps the kernel a one-branch launch would pick (SviGemmArgs.sel_m / sel_n), so outputs stay bit-identical to two
+// svi_dit_forward calls.  Needs the context cache (each prompt's projected context and K / V in buffers of its own).
+#define SVI_PAIR_STACK_MAX 8192
 static svi_status forward_pair(svi_dit* h, const bf16* x, const float* timestep, const bf16* ctx_a, const bf16* ctx_b, const bf16* clip,
                                const bf16* y, const bf16* addc, bf16* out_a, bf16* out_b, int T, int H, int W, int Lc, hipStream_t st) {
     const svi_dit_config& c = h->cfg;
     const int D = c.dim;
     const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
     const int L = f * hh * ww;
-    SVI_TRY(ensure_workspace(h, L, Lc));
+    const bool stacked = h->ctx_cache_on && L <= SVI_PAIR_STACK_MAX && L % 8 == 0 && ctx_a != ctx_b;
+    SVI_TRY(ensure_workspace(h, stacked ? 2 * L : L, Lc));
     SVI_TRY(ensure_rope(h, f, hh, ww));
     Workspace& w = h->ws;
     SVI_TRY(stage_time(h, timestep, st));
     SVI_TRY(stage_embed(h, x, y, addc, T, H, W, L, st));
     SVI_TRY(run_block_self(h, 0, w.X, w.modf, L, st));
-    SVI_CHECK_HIP(hipMemcpyAsync(w.X2, w.X, (size_t)L * D * 2, hipMemcpyDeviceToDevice, st));
     const bf16* ctxs[2] = {ctx_a, ctx_b};
     bf16* outs[2] = {out_a, out_b};
+    if (stacked) {
+        SVI_CHECK_HIP(hipMemcpyAsync(w.X + (size_t)L * D, w.X, (size_t)L * D * 2, hipMemcpyDeviceToDevice, st));
+        CtxUse cu[2]{};
+        const bf16* CTXs[2];
+        for (int k = 0; k < 2; ++k) {
+            SVI_TRY(stage_context(h, ctxs[k], clip, y, Lc, &cu[k], st));
+            SVI_REQUIRE(cu[k].ce != nullptr, "stacked CFG pair needs the context cache");
+            CTXs[k] = cu[k].CTXp;
+        }
+        for (int l = 0; l < c.num_layers; ++l) {
+            const float* modf = w.modf + (size_t)l * 6 * D;
+            if (l) SVI_TRY(run_block_self(h, l, w.X, modf, L, st, 2));
+            CtxKV kvs[2] = {kv_of(h, cu[0], l), kv_of(h, cu[1], l)};
+            SVI_TRY(run_block_rest_n(h, l, w.X, CTXs, modf, L, Lc, kvs, 2, st));
+        }
+        SVI_TRY(stage_head_rows(h, w.HO, 2 * L, st, 2));
+        for (int k = 0; k < 2; ++k) SVI_TRY(stage_unpatchify(h, w.HO + (size_t)k * L * head_ld(c), outs[k], T, H, W, st));
+        return SVI_OK;
+    }
+    SVI_CHECK_HIP(hipMemcpyAsync(w.X2, w.X, (size_t)L * D * 2, hipMemcpyDeviceToDevice, st));
     for (int k = 0; k < 2; ++k) {
         if (k) SVI_CHECK_HIP(hipMemcpyAsync(w.X, w.X2, (size_t)L * D * 2, hipMemcpyDeviceToDevice, st));
         CtxUse cu{};
-        SVI_TRY(stage_context(h, ctxs[k], clip, y, Lc, &cu, st));      // uses w.Hb as scratch for the CLIP branch only: X is untouched
+        SVI_TRY(stage_context(h, ctxs[k], clip, y, Lc, &cu, st));      // the CLIP branch has scratch rows of its own: X is untouched
         SVI_TRY(run_block_rest(h, 0, w.X, cu.CTXp, w.modf, L, Lc, kv_of(h, cu, 0), st));
         for (int l = 1; l < c.num_layers; ++l)
             SVI_TRY(run_block(h, l, w.X, cu.CTXp, w.modf + (size_t)l * 6 * D, L, Lc, kv_of(h, cu, l), st));

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
     const float rs = rsqrtf(wave_sum(ss) / (float)dim + eps);
     int pf = 0, ph = 0, pw = 0;
     if (use_rope) {
-        const int hw = r.h * r.w, tok = row + r.row0;
+        const int hw = r.h * r.w;
+        int tok = row + r.row0;
+        if (r.period > 0) tok %= r.period;
         pf = tok / hw;
         const int rem = tok - pf * hw;
         ph = rem / r.w;
@@ -190,7 +192,8 @@ svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf
     if (rope) {
         r = *rope;
         SVI_REQUIRE(dim % 128 == 0 && r.npf + r.nph + r.npw == 64, "rope needs head_dim 128");
-        SVI_REQUIRE(r.row0 >= 0 && r.row0 + rows <= r.f * r.h * r.w, "rope grid %dx%dx%d does not cover rows [%d, %d)", r.f, r.h, r.w, r.row0, r.row0 + rows);
+        SVI_REQUIRE(r.row0 >= 0 && (r.period > 0 ? r.period == r.f * r.h * r.w : r.row0 + rows <= r.f * r.h * r.w),
+                    "rope grid %dx%dx%d does not cover rows [%d, %d)", r.f, r.h, r.w, r.row0, r.row0 + rows);
     }
     SVI_REQUIRE(!weight1 || ld >= 2 * dim, "rmsnorm: a second operand needs ld >= 2 dim");
     dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, weight1 ? 2 : 1), block(256);

@@ -745,7 +745,8 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     }
     // 256^2 LDS-DMA kernel when the problem fills at least half the chip with 256^2 tiles (and K tiles are whole)
     {
-        const long t256 = (long)((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN);
+        const int selM = g.sel_m > 0 ? g.sel_m : g.M, selN = g.sel_n > 0 ? g.sel_n : g.N;
+        const long t256 = (long)((selM + TM - 1) / TM) * ((selN + TN - 1) / TN);
         const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
         const SviSwitches& sw = svi_switches();
         const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 256 : (t256 >= 128);

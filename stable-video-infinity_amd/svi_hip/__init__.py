@@ -13,7 +13,7 @@ from .vae import WanVideoVAE
 from .conditioning import condition_mask, condition_video, image_condition
 from .teacache import TeaCache
 from .pose import PoseEmbedder
-from . import lora, sequence_parallel
+from . import checkpoint, lora, sequence_parallel
 from .stream import StreamLoop, u8_to_video, video_to_u8
 
 __all__ = ["WanDiT", "model_fn_wan_video", "flash_attention", "layernorm_modulate", "rmsnorm_rope_", "linear",

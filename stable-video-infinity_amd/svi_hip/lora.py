@@ -13,7 +13,7 @@ notices in-place writes to its bound parameters by itself (version counters, Wan
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Iterable, Tuple
 
 import torch
 
@@ -48,3 +48,35 @@ def merge_state_dict_(state_dict: Dict[str, torch.Tensor], pairs: Dict[str, Tupl
     if dit is not None:
         dit.rebind()
     return len(pairs)
+
+
+def name_pairs(lora_keys: Iterable[str]) -> Dict[str, Tuple[str, str]]:
+    """Which LoRA tensors patch which parameter — GeneralLoRAFromPeft.get_name_dict (models/lora.py:204-217): for every key holding
+    ".lora_B." the target parameter name is the key without the "lora_B" component, without the adapter name that may follow it,
+    and without a leading "diffusion_model"; the pair is (up = the lora_B key, down = the same key with lora_A)."""
+    out: Dict[str, Tuple[str, str]] = {}
+    for key in lora_keys:
+        if ".lora_B." not in key:
+            continue
+        parts = key.split(".")
+        i = parts.index("lora_B")
+        if len(parts) > i + 2:
+            parts.pop(i + 1)
+        parts.pop(i)
+        if parts[0] == "diffusion_model":
+            parts.pop(0)
+        out[".".join(parts)] = (key, key.replace(".lora_B.", ".lora_A."))
+    return out
+
+
+def load_lora_(dit, lora_state_dict: Dict[str, torch.Tensor], alpha: float = 1.0) -> int:
+    """ModelManager.load_lora_v2 -> GeneralLoRAFromPeft.load (models/lora.py:246-267) for a WanDiT: every matched parameter is patched
+    in place on the device (one GEMM launch each), the handle re-bound.  Returns the number of tensors updated (the reference prints it).
+    Raises if a LoRA target is not a parameter of the model (the reference's `match` would have refused the file)."""
+    pairs = name_pairs(lora_state_dict.keys())
+    missing = [n for n in pairs if n not in dit._params]
+    if missing:
+        raise KeyError(f"LoRA targets that are not parameters of this model: {missing[:3]}{' ...' if len(missing) > 3 else ''}")
+    if dit._fp8_sources:
+        raise NotImplementedError("LoRA merge into fp8-stored parameters (the reference merges in fp32 and re-quantises) is not served")
+    return merge_state_dict_(dit._params, {n: (lora_state_dict[u], lora_state_dict[d]) for n, (u, d) in pairs.items()}, alpha, dit=dit)

@@ -556,6 +556,16 @@ def gen_fp8_storage(dit_mod):
     np.savez(os.path.join(OUT, "fp8_storage.npz"), out_bf16=out, e4m3_to_bf16_bits=codes)
 
 
+def gen_lora_names():
+    """GeneralLoRAFromPeft.get_name_dict (models/lora.py:204-217), compiled out of the source file, on the key styles SVI's LoRA files use."""
+    import json
+    fn = _reference_method("diffsynth/models/lora.py", "GeneralLoRAFromPeft", "get_name_dict", {})
+    keys = synth.LORA_KEY_EXAMPLES
+    got = fn(None, {k: None for k in keys})
+    with open(os.path.join(OUT, "lora_names.json"), "w") as f:
+        json.dump({k: list(v) for k, v in got.items()}, f, indent=1, sort_keys=True)
+
+
 def main(argv=None):
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -574,6 +584,7 @@ def main(argv=None):
         "dit_block_14b": lambda: gen_block_14b(dit_mod),
         "clip_stream": lambda: gen_clip_stream(dit_mod, vae_mod, fm),
         "fp8_storage": lambda: gen_fp8_storage(dit_mod),
+        "lora_names": gen_lora_names,
         "pose_embed": gen_pose_embed,
         "dance_sampler": lambda: gen_dance_sampler(dit_mod, fm),
         "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),

@@ -260,3 +260,13 @@ def pose_video(seed: int, *shape) -> np.ndarray:
     rs = np.random.RandomState(seed)
     v = rs.randint(0, 256, size=shape).astype(np.float32)
     return v * (rs.uniform(size=shape) < 0.3)
+
+
+# key styles of LoRA files (PEFT with / without an adapter name, with / without the "diffusion_model." prefix, an unrelated key)
+LORA_KEY_EXAMPLES = [
+    "diffusion_model.blocks.0.self_attn.q.lora_A.default.weight", "diffusion_model.blocks.0.self_attn.q.lora_B.default.weight",
+    "blocks.3.ffn.0.lora_A.weight", "blocks.3.ffn.0.lora_B.weight",
+    "diffusion_model.blocks.29.cross_attn.k_img.lora_A.weight", "diffusion_model.blocks.29.cross_attn.k_img.lora_B.weight",
+    "blocks.1.self_attn.o.lora_B.adapter2.weight", "blocks.1.self_attn.o.lora_A.adapter2.weight",
+    "dwpose_embedding.0.weight",
+]

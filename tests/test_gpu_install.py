@@ -148,3 +148,40 @@ def test_install_rebinds_vae_methods(golden, pipeline_module):
     lat = pipe.vae.encode([vid], device="cuda")[0]           # models/wan_video_vae.py:759
     r, mx, _ = errs(lat, g["encode_9f"])
     assert r < 2e-5 and mx < 2e-4, (r, mx)
+
+
+def test_checkpoint_and_lora_file_on_the_device(tmp_path):
+    """SURVEY §8f N4 end to end: safetensors shards -> HBM -> bound WanDiT (svi_hip.checkpoint.load_dit), then a PEFT-style LoRA file merged
+    on the device (svi_hip.lora.load_lora_, name matching = the reference's get_name_dict): the forward equals the forward of a model
+    whose weights were patched with the reference's arithmetic  W + alpha * (B @ A)  in bf16 on the host."""
+    from safetensors.torch import save_file
+    import svi_hip
+    from svi_hip import checkpoint, lora
+    c, seed = synth.TINY_DIT, 100
+    sd = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in synth.dit_state_dict(seed, **c).items()}
+    keys = list(sd)
+    save_file({k: sd[k] for k in keys[: len(keys) // 2]}, str(tmp_path / "m1.safetensors"))
+    save_file({k: sd[k] for k in keys[len(keys) // 2:]}, str(tmp_path / "m2.safetensors"))
+    cfg = dict(eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    m = checkpoint.load_dit([str(tmp_path / "m1.safetensors"), str(tmp_path / "m2.safetensors")], cfg)
+    ref = svi_hip.WanDiT.from_state_dict(sd, **cfg)
+    x = torch.from_numpy(synth.randn(seed + 1, 1, 16, 3, 8, 12)).cuda()
+    ctx = torch.from_numpy(synth.text_context(seed + 2, 20, c["text_dim"], 13)).cuda()
+    t = torch.tensor([637.5])
+    assert torch.equal(m.forward(x, t, ctx), ref.forward(x, t, ctx))
+    r = 8
+    targets = ["blocks.0.self_attn.q.weight", "blocks.1.ffn.0.weight"]
+    lsd, patched = {}, dict(sd)
+    for i, name in enumerate(targets):
+        o, inn = sd[name].shape
+        up = torch.from_numpy(0.05 * synth.randn(900 + i, o, r)).to(torch.bfloat16)
+        down = torch.from_numpy(0.05 * synth.randn(910 + i, r, inn)).to(torch.bfloat16)
+        base = "diffusion_model." + name[: -len(".weight")]
+        lsd[base + ".lora_B.default.weight"], lsd[base + ".lora_A.default.weight"] = up, down
+        patched[name] = sd[name] + 0.7 * torch.mm(up, down)               # models/lora.py:259-262 in the model dtype
+    assert lora.load_lora_(m, {k: v.cuda() for k, v in lsd.items()}, alpha=0.7) == 2
+    want = svi_hip.WanDiT.from_state_dict(patched, **cfg).forward(x, t, ctx)
+    got = m.forward(x, t, ctx)
+    rel = float((got.float() - want.float()).norm() / want.float().norm())
+    assert rel < 2e-3, rel            # the merge differs from torch.mm only in fp32 summation order on bf16 ties
+    assert not torch.equal(got, ref.forward(x, t, ctx))
