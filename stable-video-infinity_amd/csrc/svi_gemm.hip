@@ -730,6 +730,281 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g
 
 
 
+// =================================================================================================
+// Persistent variant of the v3 kernel (same tile, same main loop, same arithmetic per element): one workgroup per CU walks
+// several output tiles, and the LDS-DMA pipeline never drains between them.
+//
+// What a non-persistent tile pays besides its MFMAs (K = 1536: 38 us of main loop in ~47 us): the workgroup launch, a prologue
+// that waits for two K tiles to land with nothing to compute, and an epilogue that takes all of the LDS ([256][264] C tile) behind
+// two workgroup barriers, so nothing of the next tile can be in flight.  Here:
+//   * while the last K tile of output tile i is being multiplied, K tile 0 of output tile i+1 streams into the stage that just
+//     fell free; after the final MFMAs one barrier (all waves have read the other stage; K tile 0 is visible) and K tile 1
+//     follows — both land under the epilogue;
+//   * the epilogue is PRIVATE to a wave: its 128 x 64 sub-tile goes through its own 4 KiB of LDS (the 32 KiB above the four
+//     operand stages) in four 32-row pieces — written in accumulator order, read back as whole 128-byte row segments (8 rows per
+//     store instruction) — with wave-local ordering only, no workgroup barrier;
+//   * tile i+1 starts on registers and LDS that are already there.
+// Same bits as gemm_bf16_nt_256p_kernel: per element the K-summation order and the epilogue arithmetic are unchanged.
+// K / 64 must be even (the stage parity of a tile's first K tile is then always 0).
+//
+// MEASURED (tools/gemm_ab.py, one box, interleaved; profiles/r2e_gemm_persistent_ab.txt): bit-identical on every C2 shape and
+// within +-3 % of the v3 kernel (q/k/v 948 vs 935 TF, attn-out 929 vs 901, V^T 1061 vs 1048, ffn1 1020 vs 1033, ffn2 1196 vs 1203).
+// The launch / prologue latency this removes was not what a tile pays for: the epilogue is WORK (tools/gemm_epi_abl.py on a variant
+// build, profiles/r2e_gemm_epilogue_ablation.txt: per launch q/k/v 15 us = 4 staging + 2 read-back + 9 stores; attn-out 35 us;
+// ffn1 159 us, 112 of them GELU arithmetic on 293 M elements; ffn2 44 us), it runs with the matrix pipe idle, and the next barrier
+// waits for its stores either way.  Hiding it needs the MFMAs of the next tile in the same wave's instruction stream, i.e. a second
+// accumulator set — 1 wave per SIMD with 512 registers.  Kept selectable (SVI_GEMM_KERNEL=258) as the recorded negative result;
+// NOT the default.  One lesson is baked into its shape: the accumulating asm statements must stay in straight-line code — the same
+// k-step on both sides of a branch made the register allocator shuttle the accumulators through scratch, and a spill store right
+// behind an asm MFMA reads the accumulator without the wait states the compiler would insert for its own MFMAs (wrong results).
+// =================================================================================================
+#define LDS256Q_BYTES (4 * T_STAGE + 8 * 4096)
+__device__ __forceinline__ int priv_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }   // [32 rows][8 x 16 B]
+
+template <int EPI>
+__device__ __forceinline__ void gemm256_epilogue_private(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* priv, int m0, int n0, int lane,
+                                                         int wm, int wn, int l31, int hi) {
+    // this lane's 16-byte chunk in the read-back / store phase: row rb + 8 i of a 32-row piece, columns cb .. cb + 7 of the tile
+    const int rb = lane >> 3, ch = lane & 7;
+    const int cb = wn * 64 + ch * 8, en = n0 + cb;
+    const bool col_ok = en + 8 <= g.N;                       // N is a multiple of 8 chunks or the chunk is handled element-wise below
+    float gatev[8];
+    if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gatev[e] = (g.gate && en + e < g.N) ? g.gate[en + e] : 0.f;
+    }
+    // bias in accumulator order: columns wn*64 + ni*32 + 8 rg + 4 hi + e
+    u32x2 bnp[2][4];
+    const bool bias_n = g.bias && !g.bias_along_m, bias_m = g.bias && g.bias_along_m;
+    const bool bias_vec = bias_n && (n0 + TN <= g.N) && (((uintptr_t)g.bias & 7) == 0);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int n = n0 + wn * 64 + ni * 32 + 8 * rg + 4 * hi;
+            if (bias_vec) {
+                bnp[ni][rg] = *reinterpret_cast<const u32x2*>(g.bias + n);
+            } else {
+                unsigned short h4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h4[e] = (bias_n && n + e < g.N) ? reinterpret_cast<const unsigned short*>(g.bias)[n + e] : (unsigned short)0;
+                bnp[ni][rg][0] = (unsigned)h4[0] | ((unsigned)h4[1] << 16);
+                bnp[ni][rg][1] = (unsigned)h4[2] | ((unsigned)h4[3] << 16);
+            }
+        }
+    const bool has_gate = g.gate != nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int mrow0 = m0 + wm * 128 + mi * 32;           // first global row of this 32-row piece
+        // residual rows of the piece requested up front: their latency runs under the LDS round trip
+        u32x4 resv[4];
+        if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mrow0 + rb + 8 * i;
+                if (m < g.M && col_ok) resv[i] = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + en);
+            }
+        }
+        const int mg = mrow0 + l31;
+        const float bmv = (bias_m && mg < g.M) ? (float)g.bias[mg] : 0.f;
+        // y = bf16(acc + bias) in accumulator order -> private LDS piece [32][64]
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const unsigned b01 = bnp[ni][rg][0], b23 = bnp[ni][rg][1];
+                const float bv[4] = {__builtin_bit_cast(float, b01 << 16) + bmv, __builtin_bit_cast(float, b01 & 0xffff0000u) + bmv,
+                                     __builtin_bit_cast(float, b23 << 16) + bmv, __builtin_bit_cast(float, b23 & 0xffff0000u) + bmv};
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[ni][mi][rg * 4 + e] + bv[e]);
+                *reinterpret_cast<bf16x4*>(priv + priv_off(l31, ni * 4 + rg) + hi * 8) = pk;
+            }
+        // wave-local ordering: LDS operations of one wave complete in order, the compiler's memory model inserts the lgkmcnt wait
+        u32x4 yv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yv[i] = *reinterpret_cast<const u32x4*>(priv + priv_off(rb + 8 * i, ch));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mrow0 + rb + 8 * i;
+            const bf16x8 t = __builtin_bit_cast(bf16x8, yv[i]);
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = (float)t[e];
+            u32x4 rvv = resv[i];
+            if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
+                if (!col_ok && m < g.M) {
+                    bf16x8 tt;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) tt[e] = (en + e < g.N) ? g.res[(size_t)m * g.ldres + en + e] : (bf16)0.f;
+                    rvv = __builtin_bit_cast(u32x4, tt);
+                }
+            }
+            gemm256_apply<EPI>(y, rvv, gatev, has_gate);
+            if (m < g.M) {
+                bf16* cp = g.C + (size_t)m * g.ldc + en;
+                if (col_ok) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
+                    st_bf16x8(cp, o);
+                } else {
+                    for (int e = 0; e < 8 && en + e < g.N; ++e) cp[e] = (bf16)y[e];
+                }
+            }
+        }
+        // the piece is rewritten by the next mi: its reads above have returned (their values were consumed)
+    }
+}
+
+__device__ __forceinline__ void gemm256q_tile_coords(int seq, int nwg, int tiles_m, int tiles_n, int GM, int& m0, int& n0) {
+    const int xcd = seq & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (seq >> 3);
+    const int group = swz / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = swz - group * GM * tiles_n;
+    const int tile_n = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n * gm);
+    m0 = tile_m * TM; n0 = tile_n * TN;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256q_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    char* priv = smem + 4 * T_STAGE + wave * 4096;
+    const int nwg = tiles_m * tiles_n;
+    const int nk = g.K / BK;                               // even, >= 4 (launcher)
+
+    int a_addr[4], w_addr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
+        w_addr[kk] = lds0 + T_STAGE + lds_tile_off(wn * 64 + l31, 2 * kk + hi);
+    }
+    // LDS-DMA source chunks: piece j of a tile covers rows rj[j] .. (8 rows per wave instruction), this lane reads 16-byte chunk c8/8 of
+    // its row (swizzled on the source side).  Tile-invariant; the element offset for the tile with corner row `base` is formed at the
+    // point of use (4 VALU per piece, hidden under the MFMAs) instead of being carried in 16 registers across the tile loop.
+    int rj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rj[j] = (j * 8 + wave) * 8 + (lane >> 3);
+    const int c8 = ((lane & 7) ^ ((rj[0] >> 1) & 7)) * 8;          // (r >> 1) & 7 is the same for all four pieces (rows differ by 64)
+    auto a_src = [&](int base, int j) { return (unsigned)min(base + rj[j], g.M - 1) * (unsigned)g.lda + (unsigned)c8; };
+    auto w_src = [&](int base, int j) { return (unsigned)min(base + rj[j], g.N - 1) * (unsigned)g.ldw + (unsigned)c8; };
+    int seq = blockIdx.x;
+    int m0, n0;
+    gemm256q_tile_coords(seq, nwg, tiles_m, tiles_n, GM, m0, n0);
+
+    int tok = 0;
+
+    // one k-step (see gemm_bf16_nt_256p_kernel); AM / WN: corner row / column of the tile the DMA pieces belong to
+#define SVI_KSTEPQ(KK, G0, READ, DMA, rso, dk, dso, AM, WN)                                                                     \
+    static_for8([&](auto ic) {                                                                                                  \
+        constexpr int i = decltype(ic)::value;                                                                                  \
+        constexpr int ni = i >> 2, mi = i & 3, cs = (KK) & 1, ns = cs ^ 1, kn = ((KK) + 1) & 3, gi = (G0) + i;                   \
+        int& pin = (i < 4) ? a_addr[kn] : w_addr[kn];                                                                           \
+        gemm_mfma_v(tok, acc[ni][mi], wb[cs][ni], xa[cs][mi], pin);                                                             \
+        if constexpr (READ) {                                                                                                   \
+            if constexpr (i < 4) xa[ns][i] = *(lds_u32x4_t)(a_addr[kn] + (rso) + i * 32 * 128);                                 \
+            else if constexpr (i < 6) wb[ns][i - 4] = *(lds_u32x4_t)(w_addr[kn] + (rso) + (i - 4) * 32 * 128);                  \
+        }                                                                                                                       \
+        if constexpr ((DMA) && gi < 8) {                                                                                        \
+            constexpr int j = gi >> 1;                                                                                          \
+            if constexpr ((gi & 1) == 0)                                                                                        \
+                __builtin_amdgcn_global_load_lds((gptr_t)(g.A + (dk) + a_src(AM, j)), (lptr_t)(smem + (dso) + (j * 8 + wave) * 1024), 16, 0, 0);            \
+            else                                                                                                                \
+                __builtin_amdgcn_global_load_lds((gptr_t)(g.W + (dk) + w_src(WN, j)), (lptr_t)(smem + (dso) + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);  \
+        }                                                                                                                       \
+    })
+
+    // prologue of the FIRST tile: K tiles 0 and 1 in flight, tile 0 landed
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.A + a_src(m0, j)), (lptr_t)(smem + (j * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.W + w_src(n0, j)), (lptr_t)(smem + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.A + BK + a_src(m0, j)), (lptr_t)(smem + 2 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.W + BK + w_src(n0, j)), (lptr_t)(smem + 3 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (;;) {
+        const int seq_next = seq + (int)gridDim.x;
+        const bool has_next = seq_next < nwg;
+        // the tile whose first two K tiles are fetched while this one finishes; on the last tile of the walk the fetch is repeated for the
+        // current tile (32 KiB once per workgroup, never read) so that the accumulating statements stay in straight-line code: two
+        // copies of a k-step on the two sides of a branch make the register allocator shuttle and spill the accumulators
+        int m0n = m0, n0n = n0;
+        if (has_next) gemm256q_tile_coords(seq_next, nwg, tiles_m, tiles_n, GM, m0n, n0n);
+        u32x4 xa[2][4], wb[2][2];
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // K tile 0 of this output tile is in stage 0 and visible (prologue barrier / the barrier at the end of the previous tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[0][i] = *(lds_u32x4_t)(a_addr[0] + i * 32 * 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wb[0][i] = *(lds_u32x4_t)(w_addr[0] + i * 32 * 128);
+        SVI_KSTEPQ(0, 8, true, false, 0, 0, 0, m0, n0);
+        SVI_KSTEPQ(1, 16, true, false, 0, 0, 0, m0, n0);
+        SVI_KSTEPQ(2, 24, true, false, 0, 0, 0, m0, n0);
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) {
+            const int nso = ((kt + 1) & 1) * 2 * T_STAGE;          // stage of K tile kt+1 (read)
+            const int dso = (kt & 1) * 2 * T_STAGE;                // stage K tile kt vacates (DMA target of K tile kt+2)
+            const int dk = (kt + 2) * BK;
+            __syncthreads();                                       // vmcnt(0): K tile kt+1 landed; barrier: K tile kt fully read by all waves
+            SVI_KSTEPQ(3, 0, true, true, nso, dk, dso, m0, n0);
+            SVI_KSTEPQ(0, 8, true, false, nso, dk, dso, m0, n0);
+            SVI_KSTEPQ(1, 16, true, false, nso, dk, dso, m0, n0);
+            SVI_KSTEPQ(2, 24, true, false, nso, dk, dso, m0, n0);
+        }
+        {   // kt = nk - 2 (even): the last K tile sits in stage 1; stage 0 falls free -> K tile 0 of the NEXT output tile
+            const int nso = 2 * T_STAGE;
+            __syncthreads();
+            SVI_KSTEPQ(3, 0, true, true, nso, 0, 0, m0n, n0n);
+            SVI_KSTEPQ(0, 8, true, false, nso, 0, 0, m0, n0);
+            SVI_KSTEPQ(1, 16, true, false, nso, 0, 0, m0, n0);
+            SVI_KSTEPQ(2, 24, true, false, nso, 0, 0, m0, n0);
+        }
+        SVI_KSTEPQ(3, 0, false, false, 0, 0, 0, m0, n0);
+        asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
+        asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+        // my pieces of the next tile's K tile 0 have landed (issued a whole K tile ago); the barrier makes everyone's visible and says
+        // every wave is done reading stage 1 -> K tile 1 of the next tile may stream in under the epilogue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.A + BK + a_src(m0n, j)), (lptr_t)(smem + 2 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.W + BK + w_src(n0n, j)), (lptr_t)(smem + 3 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+        switch (g.epi) {        // uniform: one scalar branch per tile
+            case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_private<SVI_EPI_BIAS_GELU_TANH>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
+            case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_private<SVI_EPI_BIAS_GATE_RES>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
+            case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_private<SVI_EPI_BIAS_GELU_ERF>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
+            case SVI_EPI_BIAS_SILU:      gemm256_epilogue_private<SVI_EPI_BIAS_SILU>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
+            default:                     gemm256_epilogue_private<SVI_EPI_BIAS>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
+        }
+        if (!has_next) break;
+        seq = seq_next; m0 = m0n; n0 = n0n;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the redundant fetch of the last tile must not outlive the workgroup's LDS
+#undef SVI_KSTEPQ
+}
+
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     SVI_REQUIRE(g.M >= 0 && g.N >= 0 && g.K > 0, "gemm: bad sizes M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0 || g.N == 0) return SVI_OK;
@@ -756,6 +1031,15 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             // N = 8960 (35 column panels, ffn1): 5-6 give 1050 vs 1022 at 2 and 980 at 8 — a 5 x 6 block of concurrent tiles per XCD
             // needs the fewest operand panels (HBM fetch per launch at 2: 2.2 GB against 0.13 GB of operands, profiles/r1h_gemm_ffn1_pmc.txt)
             const int gm_rows = sw.gemm_gm ? sw.gemm_gm : (tn >= 16 ? 5 : 2);
+            const int nkq = g.K / BK;
+            const bool can_q = (nkq % 2 == 0) && nkq >= 4 && true;
+            const int ncu = 256;
+            if (can_q && sw.gemm_kernel == 258) {     // persistent variant (A/B only, see its header: bit-identical, no faster)
+                SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256q_kernel), LDS256Q_BYTES));
+                hipLaunchKernelGGL(gemm_bf16_nt_256q_kernel, dim3(std::min(tm * tn, ncu)), dim3(512), LDS256Q_BYTES, st, g, tm, tn, gm_rows);
+                SVI_LAUNCH_CHECK();
+                return SVI_OK;
+            }
             if (sw.gemm_kernel == 256) {      // the v2 main loop (barrier at the tile boundary), kept for A/B
                 SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<false>), LDS256_BYTES));
                 hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
