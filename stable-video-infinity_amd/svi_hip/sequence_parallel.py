@@ -25,6 +25,13 @@ Per block and rank the exchanges move 3*Ls*D/P*(P-1) + Ls*D/P*(P-1) bf16 values:
 block over xGMI.  Constraints: L % P == 0 and heads % P == 0 (1.3B: 12 heads -> P in {2,3,4,6}; 14B: 40 heads -> {2,4,5,8}).
 Composes with CfgPair: 8 GPUs = 2 x 4.
 
+When the heads do NOT divide over the ranks (1.3B on 8 ranks) the reference's USP falls back to ring attention (xfuser's hybrid,
+distributed/xdit_context_parallel.py:108-129).  The fallback here is `mode="gather"`: a rank keeps its Ls query rows of ALL heads and
+all-gathers K and V^T of all tokens (2*L*D*(P-1)/P values per block and rank — twice the Ulysses volume, any P that divides L),
+attention runs with Lq = Ls against Lk = L, and no second exchange is needed.  Same kernels; rows are grouped into 64-row wavefronts
+from the shard's first row, so the deferred-rescale events of the softmax (taken per wavefront) can fall differently than on one rank:
+results agree within the attention kernel's stated tolerance, bit for bit when Ls is a multiple of 256.
+
 Every arithmetic kernel is the one the single-GPU forward uses, on the same operands per row / per head, so the result is
 bit-identical to `WanDiT.forward` for any P and G (tests/test_gpu_sp.py runs P = 1, 2, 4 shards on one GPU with the exchange
 simulated in-process and with real process groups; tests/test_dist_gloo.py runs the layout algebra over gloo on CPU tensors).
@@ -128,13 +135,38 @@ class _Buffers:
         self.head_rows = None
 
 
+class _GatherBuffers:
+    """Buffers of the K / V all-gather mode (heads need not divide): q | k rows of this rank, K and V^T of all tokens."""
+
+    def __init__(self, d: WanDiT, world: int, Ls: int, dev):
+        D, Lfull = d.dim, Ls * world
+        self.ldvt, self.L8 = (Ls + 7) // 8 * 8, (Lfull + 7) // 8 * 8
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        self.q = torch.empty((Ls, D), **bf)
+        self.k = torch.empty((Ls, D), **bf)
+        self.vt = torch.zeros((D, self.ldvt), **bf)
+        self.k_all = torch.empty((world, Ls, D), **bf)                 # = K [L, D], token-major
+        self.vt_all = torch.empty((world, D, self.ldvt), **bf)
+        self.vt_full = torch.zeros((D, self.L8), **bf)
+        self.attn = torch.empty((Ls, D), **bf)
+        self.head_rows = None
+
+
 class SequenceShard:
-    def __init__(self, dit: WanDiT, rank: int, world: int, groups: Optional[int] = None):
-        if dit.num_heads % world:
+    def __init__(self, dit: WanDiT, rank: int, world: int, groups: Optional[int] = None, mode: Optional[str] = None):
+        """mode "ulysses" (heads traded for tokens; needs heads % world == 0), "gather" (K / V^T all-gathered; any world that divides
+        the tokens), or None: ulysses when the heads divide, else gather."""
+        if mode is None:
+            mode = "ulysses" if dit.num_heads % world == 0 else "gather"
+        if mode not in ("ulysses", "gather"):
+            raise ValueError(f"unknown sequence-parallel mode {mode!r}")
+        if mode == "ulysses" and dit.num_heads % world:
             raise ValueError(f"{dit.num_heads} heads do not divide over {world} ranks")
-        self.dit, self.rank, self.world = dit, rank, world
-        self.Dp = dit.dim // world
-        self.heads_local = dit.num_heads // world
+        self.dit, self.rank, self.world, self.mode = dit, rank, world, mode
+        self.Dp = dit.dim // world if mode == "ulysses" else dit.dim
+        self.heads_local = dit.num_heads // world if mode == "ulysses" else dit.num_heads
+        if mode == "gather":
+            groups = 1
         if groups is not None and (groups < 1 or self.heads_local % groups):
             raise ValueError(f"{self.heads_local} heads per rank do not split into {groups} head groups")
         self._groups = groups
@@ -156,11 +188,11 @@ class SequenceShard:
         self.G = self._groups if self._groups is not None else head_groups(self.heads_local, self.L)
         self.Dg = self.Dp // self.G
         cache = d.__dict__.setdefault("_sp_buffers", {})
-        key = (self.rank, self.world, self.L, self.G, x.device)
+        key = (self.rank, self.world, self.L, self.G if self.mode == "ulysses" else "gather", x.device)
         if key not in cache:
             if len(cache) >= 4:
                 cache.clear()
-            cache[key] = _Buffers(d, self.world, self.Ls, self.G, x.device)
+            cache[key] = _Buffers(d, self.world, self.Ls, self.G, x.device) if self.mode == "ulysses" else _GatherBuffers(d, self.world, self.Ls, x.device)
         self.buf = cache[key]
         context, clip_feature = d._prompt_args(context, clip_feature)
         self._keep = [x, context, timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(), clip_feature,
@@ -170,6 +202,24 @@ class SequenceShard:
         L.check(L.lib().svi_dit_sp_begin(d._h, L.ptr(x), L.ptr(ts), L.ptr(context), L.ptr(clip), L.ptr(yy), L.ptr(addc), T, H, W,
                                          context.shape[1], self.rank * self.Ls, self.Ls, L.current_stream()), "svi_dit_sp_begin")
 
+    # ---- gather mode: q stays, K / V^T of all ranks are gathered ---------------------------------------------------------------
+    def block_qkv_rows(self, layer: int) -> None:
+        """-> buf.q, buf.k ([Ls, dim] token rows, RMSNorm + RoPE applied, q pre-scaled), buf.vt (V^T [dim, ldvt]) of this rank's rows
+        (svi_dit_sp_block_qkv with one destination and one head group: the send order IS the plain row-major order)."""
+        b = self.buf
+        L.check(L.lib().svi_dit_sp_block_qkv(self.dit._h, layer, L.ptr(b.q), L.ptr(b.k), L.ptr(b.vt), b.ldvt, 1, 1, L.current_stream()), "svi_dit_sp_block_qkv")
+
+    def attention_rows(self) -> None:
+        """This rank's query rows against the gathered K (buf.k_all = [L, dim]) and V^T (buf.vt_all -> buf.vt_full) -> buf.attn [Ls, dim]."""
+        b = self.buf
+        L.check(L.lib().svi_sp_unpack_vt(L.ptr(b.vt_all), L.ptr(b.vt_full), self.world, self.dit.dim, self.Ls, b.ldvt, b.L8, L.current_stream()), "svi_sp_unpack_vt")
+        L.check(L.lib().svi_attention_vt_fwd(L.ptr(b.q), self.dit.dim, L.ptr(b.k_all), self.dit.dim, L.ptr(b.vt_full), b.L8, L.ptr(b.attn), self.dit.dim,
+                                             self.Ls, self.L, self.dit.num_heads, 1, L.current_stream()), "svi_attention_vt_fwd")
+
+    def block_rest_rows(self, layer: int) -> None:
+        L.check(L.lib().svi_dit_sp_block_rest(self.dit._h, layer, L.ptr(self.buf.attn), L.current_stream()), "svi_dit_sp_block_rest")
+
+    # ---- ulysses mode ----------------------------------------------------------------------------------------------------------------
     def block_qkv(self, layer: int) -> None:
         """-> buf.qk_send (q | k in send order), buf.vt_send (V^T, row block j = rank j's piece)."""
         b = self.buf
@@ -225,15 +275,26 @@ def _exchange(recv: torch.Tensor, send: torch.Tensor, group, overlap: bool):
     return dist.all_to_all_single(recv, send, group=group, async_op=overlap)
 
 
+def _all_gather_into(out: torch.Tensor, mine: torch.Tensor, group) -> None:
+    """out [P, ...] <- every rank's `mine` (RCCL all-gather; gloo in the tests goes through the host)."""
+    if _staged(mine, group):
+        host = mine.cpu().contiguous()
+        got = [torch.empty_like(host) for _ in range(out.shape[0])]
+        dist.all_gather(got, host, group=group)
+        out.copy_(torch.stack(got))
+        return
+    dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+
+
 def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: Optional[int] = None, tea_mode: int = 0,
-                        residual: Optional[torch.Tensor] = None, **cond) -> torch.Tensor:
+                        residual: Optional[torch.Tensor] = None, mode: Optional[str] = None, **cond) -> torch.Tensor:
     """model_fn_wan_video(..., use_unified_sequence_parallel=True) for this rank of `group`: every rank passes the same inputs
     and receives the full output.  Per block: the q | k | V^T exchange pipelined over G head groups against attention, the output
     exchange pipelined the same way; one all-gather per forward.
     tea_mode / residual (TeaCache, as WanDiT.forward): 1 = also write this rank's residual rows [Ls, dim]; 2 = skip the blocks and add
     `residual` — no exchange at all in that forward besides the final all-gather."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    sh = SequenceShard(dit, rank, world, groups)
+    sh = SequenceShard(dit, rank, world, groups, mode)
     sh.begin(x, timestep, context, **cond)
     b, G = sh.buf, sh.G
     if tea_mode == 2:
@@ -241,6 +302,16 @@ def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: O
         return sh.unpatchify(all_gather_rows(sh.head(), group))
     if tea_mode == 1:
         sh.tea(0)
+    if sh.mode == "gather":
+        for layer in range(dit.num_layers):
+            sh.block_qkv_rows(layer)
+            _all_gather_into(b.k_all, b.k, group)
+            _all_gather_into(b.vt_all, b.vt, group)
+            sh.attention_rows()
+            sh.block_rest_rows(layer)
+        if tea_mode == 1:
+            sh.tea(1, residual)
+        return sh.unpatchify(all_gather_rows(sh.head(), group))
     for layer in range(dit.num_layers):
         sh.block_qkv(layer)
         wv = _exchange(b.vt_recv, b.vt_send, group, True)
@@ -264,15 +335,28 @@ def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: O
     return sh.unpatchify(all_gather_rows(sh.head(), group))
 
 
-def forward_local(dits: Sequence[WanDiT], x, timestep, context, groups: Optional[int] = None, **cond) -> torch.Tensor:
+def forward_local(dits: Sequence[WanDiT], x, timestep, context, groups: Optional[int] = None, mode: Optional[str] = None, **cond) -> torch.Tensor:
     """The same schedule with P = len(dits) shards in ONE process (each shard needs its own handle: a handle holds one
     workspace); the exchanges are device copies between the shards' buffers.  For tests and for measuring what the schedule costs
     besides the transport on a single GPU (tools/sp_overhead.py)."""
     P = len(dits)
-    shards = [SequenceShard(d, r, P, groups) for r, d in enumerate(dits)]
+    shards = [SequenceShard(d, r, P, groups, mode) for r, d in enumerate(dits)]
     for sh in shards:
         sh.begin(x, timestep, context, **cond)
     G = shards[0].G
+    if shards[0].mode == "gather":
+        for layer in range(dits[0].num_layers):
+            for sh in shards:
+                sh.block_qkv_rows(layer)
+            for sj in shards:
+                for i, si in enumerate(shards):
+                    sj.buf.k_all[i].copy_(si.buf.k)
+                    sj.buf.vt_all[i].copy_(si.buf.vt)
+            for sh in shards:
+                sh.attention_rows()
+                sh.block_rest_rows(layer)
+        rows = torch.cat([sh.head() for sh in shards], dim=0)
+        return shards[0].unpatchify(rows)
     for layer in range(dits[0].num_layers):
         for sh in shards:
             sh.block_qkv(layer)

@@ -80,12 +80,34 @@ def test_sequence_parallel_i2v_and_add_condition():
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("P,grid,exact", [(3, (3, 4, 6), False), (3, (6, 16, 16), True), (2, (2, 4, 6), False), (8, (4, 16, 32), True)])
+def test_gather_mode_serves_head_counts_that_do_not_divide(P, grid, exact):
+    """4 heads over 3 or 8 ranks: the reference's USP falls back to ring attention there; here K / V^T are all-gathered and every rank
+    attends with its own query rows of all heads.  Same kernels, rows regrouped into wavefronts from the shard's first row: within the
+    attention tolerance (3e-3 on the forward), bit-identical when the shard length is a multiple of 256."""
+    import svi_hip
+    from svi_hip import sequence_parallel as sp
+    f, h, w = grid
+    ms = handles(svi_hip, WIDE_T2V, 900, P + 1)
+    x = dev(synth.randn(901, 1, 16, f, 2 * h, 2 * w))
+    ctx = dev(synth.text_context(902, 24, 64, 17))
+    t = torch.tensor([712.5])
+    want = ms[-1].forward(x, t, ctx)
+    got = sp.forward_local(ms[:P], x, t, ctx, mode=None if 4 % P else "gather")
+    assert got.shape == want.shape and torch.isfinite(got.float()).all()
+    rel = float((got.float() - want.float()).norm() / want.float().norm())
+    assert rel < 3e-3, rel
+    if exact:
+        assert (f * h * w // P) % 256 == 0 and torch.equal(got, want)
+
+
 def test_shard_refuses_bad_divisions():
     import svi_hip
     from svi_hip import sequence_parallel as sp
     m = handles(svi_hip, WIDE_T2V, 900, 1)[0]
     with pytest.raises(ValueError):
-        sp.SequenceShard(m, 0, 3)                        # 4 heads over 3 ranks
+        sp.SequenceShard(m, 0, 3, mode="ulysses")        # 4 heads over 3 ranks (the default would pick the gather mode)
+    assert sp.SequenceShard(m, 0, 3).mode == "gather"
     sh = sp.SequenceShard(m, 0, 4)
     with pytest.raises(ValueError):                      # 2*3*5 = 30 tokens over 4 ranks
         sh.begin(dev(synth.randn(1, 1, 16, 2, 6, 10)), torch.tensor([500.0]), dev(synth.text_context(2, 8, 64, 5)))
