@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 2
+#define SVI_HIP_ABI_VERSION 3
 
 typedef enum {
     SVI_OK = 0,
@@ -56,6 +56,7 @@ typedef struct {
     int32_t patch_t, patch_h, patch_w;
     int32_t num_heads, num_layers;
     int32_t has_image_input;
+    int32_t enable_multitalk;   /* talk variant: per-block audio cross-attention + audio_proj (models/wan_video_dit.py:338-351,455-470) */
 } svi_dit_config;
 
 /* GEMM epilogues (fused; see svi_gemm_bf16). */
@@ -64,7 +65,8 @@ typedef enum {
     SVI_EPI_BIAS_GELU_TANH = 1, /* C = bf16(gelu_tanh(bf16(acc + bias)))                  ffn.0+GELU  dit:334  */
     SVI_EPI_BIAS_GATE_RES = 2,  /* C = bf16(res + bf16(gate[n] * bf16(acc + bias)))       dit:369,370,373      */
     SVI_EPI_BIAS_GELU_ERF = 3,  /* exact GELU                                             img_emb     dit:383  */
-    SVI_EPI_BIAS_SILU = 4       /* C = bf16(silu(bf16(acc+bias)))                         time_embedding       */
+    SVI_EPI_BIAS_SILU = 4,      /* C = bf16(silu(bf16(acc+bias)))                         time_embedding       */
+    SVI_EPI_BIAS_RELU = 5       /* C = bf16(relu(bf16(acc+bias)))                         AudioProjModel dit:97-106 */
 } svi_epilogue;
 
 const char* svi_last_error(void);
@@ -104,6 +106,17 @@ svi_status svi_dit_forward(svi_dit* h, const void* x, const float* timestep, con
                            const void* clip_feature, const void* y, const void* add_condition,
                            void* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc,
                            svi_stream stream);
+
+/* Talk variant — model_fn_wan_talk_video (pipelines/svi_video_talk.py:83-160) = WanModel.forward with audio_embed_tuple
+ * (models/wan_video_dit.py:486-567): the audio windows are projected to 32 context tokens of width 768 per latent frame
+ * (AudioProjModel, dit:44-115) and every block adds, after its text cross-attention,
+ *     x += proj(attention_per_frame(q_linear(norm_x(x)), kv_linear(audio tokens of the frame)))     (dit:361-366, models/attention.py:318-371)
+ * svi_dit_set_audio arms the handle for the following forwards (svi_dit_forward / _forward_tea; the CFG pair and the sequence-parallel
+ * entry points refuse while audio is set) and NULL pointers disarm it:
+ *   audio_first  bf16 [1, seq_len = 5, 12, 768]          the first frame's audio window          (audio_embed_tuple[0])
+ *   audio_latter bf16 [T - 1, seq_len_vf = 8, 12, 768]   the later latent frames' windows        (audio_embed_tuple[1])
+ * The pointers are borrowed until the next svi_dit_set_audio. */
+svi_status svi_dit_set_audio(svi_dit* h, const void* audio_first, const void* audio_latter, int32_t n_latter);
 
 /* TeaCache support (pipelines/svi_video.py:23-72 class TeaCache, :117-131 its use inside model_fn_wan_video).
  * svi_dit_time_mod: t_mod bf16 [B, 6, dim], the tensor TeaCache.check() compares between steps (host logic decides).
@@ -206,6 +219,12 @@ svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw,
  * (cfg_scale == 1 path). */
 svi_status svi_cfg_step(void* latents, const void* cond, const void* uncond, int64_t n, float cfg_scale,
                         float dsigma, svi_stream stream);
+
+/* Three-way guidance of the talk sampler + FlowMatchScheduler.step (pipelines/svi_video_talk.py:455-461):
+ *   v = uncond + s_text*(cond - drop_text) + s_audio*(drop_text - uncond);  lat += v * (sigma_next - sigma)
+ * bf16, rounded after every op in the reference's evaluation order. */
+svi_status svi_cfg3_step(void* latents, const void* cond, const void* uncond, const void* drop_text, int64_t n, float s_text,
+                         float s_audio, float dsigma, svi_stream stream);
 
 /* FP8 weight storage: the reference's `torch_dtype=torch.float8_e4m3fn` mode (test_svi.py:337) keeps parameters as OCP e4m3fn and
  * casts them to bf16 in front of every use (vram_management/layers.py:65-71, cast_to).  The cast is exact, so it is done once:

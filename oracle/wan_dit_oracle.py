@@ -58,6 +58,7 @@ class DiTConfig:
     num_heads: int = 12
     num_layers: int = 30
     has_image_input: bool = False
+    enable_multitalk: bool = False
 
     @property
     def head_dim(self) -> int:
@@ -204,10 +205,36 @@ def cross_attention(sd: Dict[str, Tensor], p: str, x: Tensor, context: Tensor, c
     return rnd(linear(a, sd[p + "o.weight"], sd[p + "o.bias"]))
 
 
+def audio_tokens(sd: Dict[str, Tensor], audio_first: Tensor, audio_latter: Tensor, rnd) -> Tensor:
+    """AudioProjModel.forward (dit:82-115) for one clip: audio_first [1, 5, 12, 768], audio_latter [f-1, 8, 12, 768] ->
+    [f, 32, 768] context tokens (LayerNorm(768) applied: norm_output_audio=True, dit:461)."""
+    p = "audio_proj."
+    h0 = rnd(torch.relu(rnd(linear(audio_first.reshape(audio_first.shape[0], -1), sd[p + "proj1.weight"], sd[p + "proj1.bias"]))))
+    h1 = rnd(torch.relu(rnd(linear(audio_latter.reshape(audio_latter.shape[0], -1), sd[p + "proj1_vf.weight"], sd[p + "proj1_vf.bias"]))))
+    h = torch.cat([h0, h1], dim=0)
+    h = rnd(torch.relu(rnd(linear(h, sd[p + "proj2.weight"], sd[p + "proj2.bias"]))))
+    tok = rnd(linear(h, sd[p + "proj3.weight"], sd[p + "proj3.bias"])).reshape(h.shape[0], 32, 768)
+    return rnd(layer_norm(tok, 1e-5, sd[p + "norm.weight"], sd[p + "norm.bias"]))
+
+
+def audio_cross_attention(sd: Dict[str, Tensor], prefix: str, x: Tensor, audio: Tensor, frames: int, cfg: DiTConfig, rnd) -> Tensor:
+    """x_a of DiTBlock.forward (dit:361-366): SingleStreamAttention.forward with human_num == 1 (models/attention.py:318-371) on
+    norm_x(x): every frame's tokens attend to that frame's 32 audio tokens; no q/k norm, no RoPE, scale head_dim^-0.5.
+    x [1, L, D], audio [f, 32, 768]."""
+    p = prefix + "audio_cross_attn."
+    D = cfg.dim
+    xn = rnd(layer_norm(x, cfg.eps, sd[prefix + "norm_x.weight"], sd[prefix + "norm_x.bias"]))          # WanLayerNorm: fp32, one rounding
+    q = rnd(linear(xn, sd[p + "q_linear.weight"], sd[p + "q_linear.bias"])).reshape(frames, -1, D)       # '(B N_t) S C'
+    kv = rnd(linear(audio, sd[p + "kv_linear.weight"], sd[p + "kv_linear.bias"]))                       # [f, 32, 2D]: (2, H, hd) split
+    k, v = kv[..., :D], kv[..., D:]
+    a = rnd(attention(q, k, v, cfg.num_heads)).reshape(1, -1, D)
+    return rnd(linear(a, sd[p + "proj.weight"], sd[p + "proj.bias"]))
+
+
 def dit_block(sd: Dict[str, Tensor], prefix: str, x: Tensor, context: Tensor, t_mod: Tensor, rope: Tensor,
-              cfg: DiTConfig, rounding: Optional[str] = None) -> Tensor:
+              cfg: DiTConfig, rounding: Optional[str] = None, audio: Optional[Tensor] = None, frames: int = 0) -> Tensor:
     """One DiTBlock (dit:354-374).  x [B,L,D], context [B,Lc,D] (already text-embedded),
-    t_mod [B,6,D], rope complex128 [L, dh/2]."""
+    t_mod [B,6,D], rope complex128 [L, dh/2]; audio [f, 32, 768] (talk variant) or None."""
     rnd = _rounder(rounding)
     mod = rnd(sd[prefix + "modulation"] + t_mod)                       # [B,6,D]
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = [mod[:, i:i + 1] for i in range(6)]
@@ -215,6 +242,8 @@ def dit_block(sd: Dict[str, Tensor], prefix: str, x: Tensor, context: Tensor, t_
     x = rnd(x + rnd(g_a * self_attention(sd, prefix + "self_attn.", h, rope, cfg, rnd)))
     h = rnd(layer_norm(x, cfg.eps, sd[prefix + "norm3.weight"], sd[prefix + "norm3.bias"]))
     x = rnd(x + cross_attention(sd, prefix + "cross_attn.", h, context, cfg, rnd))
+    if audio is not None:
+        x = rnd(x + audio_cross_attention(sd, prefix, x, audio, frames, cfg, rnd))                     # dit:364-366
     h = modulated_norm(x, sh_m, sc_m, cfg.eps, rnd)
     u = rnd(gelu_tanh(rnd(linear(h, sd[prefix + "ffn.0.weight"], sd[prefix + "ffn.0.bias"]))))
     x = rnd(x + rnd(g_m * rnd(linear(u, sd[prefix + "ffn.2.weight"], sd[prefix + "ffn.2.bias"]))))
@@ -279,8 +308,9 @@ def head(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, rnd) -> Te
 def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, timestep: Tensor, context: Tensor,
                 clip_feature: Optional[Tensor] = None, y: Optional[Tensor] = None,
                 add_condition: Optional[Tensor] = None, rounding: Optional[str] = None,
-                return_tokens: bool = False) -> Tensor:
-    """Velocity prediction for latents x [B,C,T,H,W]; mirrors model_fn_wan_video (svi_video.py:74-137).
+                return_tokens: bool = False, audio_embed_tuple=None) -> Tensor:
+    """Velocity prediction for latents x [B,C,T,H,W]; mirrors model_fn_wan_video (svi_video.py:74-137) and, with
+    audio_embed_tuple = (first [1,1,5,12,768], latter [1,f-1,8,12,768]), model_fn_wan_talk_video (svi_video_talk.py:83-160).
 
     sd holds fp32 tensors keyed by the reference state-dict names.  In "bf16" rounding mode the
     caller is expected to pass weights already rounded to bf16 values (as the bf16 model holds)."""
@@ -296,8 +326,11 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, timestep: Tens
     if add_condition is not None:
         tok = rnd(add_condition + tok)
     rope = rope_table_3d(cfg.head_dim, grid)
+    audio = None
+    if audio_embed_tuple is not None:
+        audio = audio_tokens(sd, rnd(audio_embed_tuple[0][0].to(torch.float32)), rnd(audio_embed_tuple[1][0].to(torch.float32)), rnd)
     for i in range(cfg.num_layers):
-        tok = dit_block(sd, f"blocks.{i}.", tok, ctx, t_mod, rope, cfg, rounding)
+        tok = dit_block(sd, f"blocks.{i}.", tok, ctx, t_mod, rope, cfg, rounding, audio, grid[0])
     if return_tokens:
         return tok
     out = head(sd, cfg, tok, t, rnd)

@@ -308,3 +308,10 @@ extern "C" svi_status svi_fp8_e4m3_to_bf16(const void* in, void* out, int64_t n,
     SVI_REQUIRE(in && out && n >= 0, "svi_fp8_e4m3_to_bf16: bad argument");
     return svi_launch_fp8_e4m3_to_bf16(reinterpret_cast<const unsigned char*>(in), reinterpret_cast<bf16*>(out), n, reinterpret_cast<hipStream_t>(stream));
 }
+
+extern "C" svi_status svi_cfg3_step(void* latents, const void* cond, const void* uncond, const void* drop_text, int64_t n, float s_text,
+                                    float s_audio, float dsigma, svi_stream stream) {
+    SVI_REQUIRE(latents && cond && uncond && drop_text && n >= 0, "svi_cfg3_step: bad argument");
+    return svi_launch_cfg3_step(reinterpret_cast<bf16*>(latents), reinterpret_cast<const bf16*>(cond), reinterpret_cast<const bf16*>(uncond),
+                                reinterpret_cast<const bf16*>(drop_text), n, s_text, s_audio, dsigma, reinterpret_cast<hipStream_t>(stream));
+}

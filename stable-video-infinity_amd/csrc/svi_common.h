@@ -175,6 +175,8 @@ svi_status svi_launch_transpose(const bf16* in, int ldi, bf16* out, int ldo, int
 svi_status svi_launch_cfg_step(bf16* lat, const bf16* cond, const bf16* uncond, int64_t n, float s, float dsigma,
                                hipStream_t st);
 svi_status svi_launch_add_bf16(bf16* a_inout, const bf16* b, int64_t n, hipStream_t st);
+svi_status svi_launch_cfg3_step(bf16* lat, const bf16* cond, const bf16* uncond, const bf16* drop, int64_t n, float st, float sa, float dsigma,
+                                hipStream_t stream);
 svi_status svi_launch_video_to_u8(const float* video, unsigned char* out, long thw, hipStream_t st);
 svi_status svi_launch_u8_to_video(const unsigned char* frames, float* out, int n, long hw, hipStream_t st);
 svi_status svi_launch_sub_bf16(bf16* out, const bf16* a, const bf16* b, int64_t n, hipStream_t st);

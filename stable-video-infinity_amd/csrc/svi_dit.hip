@@ -36,6 +36,10 @@ struct BlockW {
     const bf16* norm3_w = nullptr;
     const bf16* norm3_b = nullptr;
     Lin ffn0, ffn2;
+    // talk variant (enable_multitalk): audio cross-attention (models/attention.py:283-371) and its pre-norm (dit:351)
+    Lin aud_q, aud_kv, aud_proj;
+    const bf16* normx_w = nullptr;
+    const bf16* normx_b = nullptr;
 };
 struct Slot { const bf16** ptr; std::vector<int64_t> shape; };
 
@@ -87,6 +91,15 @@ struct svi_dit {
     bool ctx_cache_on = false;
     CtxEntry ctx_entries[4];
     unsigned long long ctx_clock = 0;
+    // talk variant: audio projection weights (AudioProjModel, dit:44-115), the armed audio windows and the per-size audio workspace
+    Lin ap1, ap1vf, ap2, ap3;
+    const bf16 *ap_norm_w = nullptr, *ap_norm_b = nullptr;
+    const bf16 *aud_first = nullptr, *aud_latter = nullptr;
+    int aud_latter_n = 0;
+    char* aud_base = nullptr;
+    int aud_frames = 0;
+    bf16 *AH0 = nullptr, *AH1 = nullptr, *AP3 = nullptr, *AUD = nullptr, *AK = nullptr, *AVT = nullptr;
+    int ldavt = 0;
     // sequence-parallel shard in flight (svi_dit_sp_begin .. svi_dit_sp_head)
     int sp_rows = 0, sp_row0 = 0, sp_Lc = 0;
     bool sp_active = false;
@@ -199,6 +212,21 @@ extern "C" svi_status svi_dit_create(const svi_dit_config* c, svi_dit** out) {
         add_slot(h, p + "norm3.bias", &b.norm3_b, {D});
         add_lin(h, p + "ffn.0", &b.ffn0, F, D);
         add_lin(h, p + "ffn.2", &b.ffn2, D, F);
+        if (c->enable_multitalk) {          // dit:338-351: encoder_hidden_states_dim = 768, qkv_bias, no qk norm
+            add_lin(h, p + "audio_cross_attn.q_linear", &b.aud_q, D, D);
+            add_lin(h, p + "audio_cross_attn.kv_linear", &b.aud_kv, 2 * D, 768);
+            add_lin(h, p + "audio_cross_attn.proj", &b.aud_proj, D, D);
+            add_slot(h, p + "norm_x.weight", &b.normx_w, {D});
+            add_slot(h, p + "norm_x.bias", &b.normx_b, {D});
+        }
+    }
+    if (c->enable_multitalk) {              // dit:455-470: audio_window 5, vae_scale 4, 12 blocks x 768 channels, 512 hidden, 32 tokens x 768
+        add_lin(h, "audio_proj.proj1", &h->ap1, 512, 5 * 12 * 768);
+        add_lin(h, "audio_proj.proj1_vf", &h->ap1vf, 512, 8 * 12 * 768);
+        add_lin(h, "audio_proj.proj2", &h->ap2, 512, 512);
+        add_lin(h, "audio_proj.proj3", &h->ap3, 32 * 768, 512);
+        add_slot(h, "audio_proj.norm.weight", &h->ap_norm_w, {768});
+        add_slot(h, "audio_proj.norm.bias", &h->ap_norm_b, {768});
     }
     add_slot(h, "head.modulation", &h->head_mod, {1, 2, D});
     add_lin(h, "head.head", &h->head, (int64_t)c->out_dim * c->patch_t * c->patch_h * c->patch_w, D);
@@ -217,6 +245,7 @@ extern "C" svi_status svi_dit_create(const svi_dit_config* c, svi_dit** out) {
 extern "C" svi_status svi_dit_destroy(svi_dit* h) {
     if (!h) return SVI_OK;
     if (h->ws.base) (void)hipFree(h->ws.base);
+    if (h->aud_base) (void)hipFree(h->aud_base);
     if (h->rope_dev) (void)hipFree(h->rope_dev);
     for (auto& e : h->ctx_entries)
         if (e.base) (void)hipFree(e.base);
@@ -389,8 +418,9 @@ static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* mo
 // Cross-attention and MLP thirds of a block.
 // nb > 1: X holds nb samples stacked (nb * L rows); sample s attends to its own context (CTXs[s], kvs[s]) — the conditional and the
 // unconditional prompt of a CFG step.  Row-local work (norms, projections, MLP) runs once over all rows.
+static svi_status block_audio(svi_dit* h, int layer, bf16* X, int L, int f, hipStream_t st);
 static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* const* CTXs, const float* modf, int L, int Lc,
-                                   const CtxKV* kvs, int nb, hipStream_t st) {
+                                   const CtxKV* kvs, int nb, hipStream_t st, int audio_frames = 0) {
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
     Workspace& w = h->ws;
@@ -424,6 +454,8 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
     }
     if (img) SVI_TRY(svi_launch_add_bf16(w.Hb, w.A2, (int64_t)R * D, st));
     { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.o, X, D, R, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D, nb)); }
+    // --- talk variant: audio cross-attention between the text cross-attention and the MLP (dit:361-366)
+    if (audio_frames > 0) SVI_TRY(block_audio(h, layer, X, L, audio_frames, st));
     // --- MLP: x += gate_mlp * W2 gelu_tanh(W1 modulate(norm2 x))                  dit:372-373,334-335
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, R, D, c.eps, nullptr, nullptr, sh_m, sc_m, st)); }
     { SviProfScope _p(PROF_GEMM_FFN1, st); SVI_TRY(linear(w.Hb, D, b.ffn0, w.Fb, F, R, F, D, SVI_EPI_BIAS_GELU_TANH, st, nullptr, nullptr, 0, nb)); }
@@ -431,14 +463,67 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
     return SVI_OK;
 }
 static svi_status run_block_rest(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
-                                 const CtxKV& kv, hipStream_t st) {
-    return run_block_rest_n(h, layer, X, &CTX, modf, L, Lc, &kv, 1, st);
+                                 const CtxKV& kv, hipStream_t st, int audio_frames = 0) {
+    return run_block_rest_n(h, layer, X, &CTX, modf, L, Lc, &kv, 1, st, audio_frames);
 }
 
 static svi_status run_block(svi_dit* h, int layer, bf16* X, const bf16* CTX, const float* modf, int L, int Lc,
-                            const CtxKV& kv, hipStream_t st) {
+                            const CtxKV& kv, hipStream_t st, int audio_frames = 0) {
     SVI_TRY(run_block_self(h, layer, X, modf, L, st));
-    return run_block_rest(h, layer, X, CTX, modf, L, Lc, kv, st);
+    return run_block_rest(h, layer, X, CTX, modf, L, Lc, kv, st, audio_frames);
+}
+
+// ---- talk variant ---------------------------------------------------------------------------------------------------------------
+#define SVI_AUD_TOK 32          // context tokens per latent frame (AudioProjModel context_tokens, dit:459)
+#define SVI_AUD_DIM 768         // their width = encoder_hidden_states_dim of the audio cross-attention (dit:342)
+static svi_status ensure_audio(svi_dit* h, int f) {
+    if (h->aud_base && h->aud_frames == f) return SVI_OK;
+    const size_t D = h->cfg.dim, na = (size_t)f * SVI_AUD_TOK;
+    const int ldavt = (int)((na + 7) / 8 * 8);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t oh0 = take((size_t)f * 512 * 2), oh1 = take((size_t)f * 512 * 2), op3 = take(na * SVI_AUD_DIM * 2), oaud = take(na * SVI_AUD_DIM * 2);
+    const size_t oak = take(na * D * 2), oavt = take(D * ldavt * 2);
+    if (h->aud_base) { SVI_CHECK_HIP(hipFree(h->aud_base)); h->aud_base = nullptr; }
+    hipError_t e = hipMalloc((void**)&h->aud_base, off);
+    if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B audio workspace) failed: %s", off, hipGetErrorString(e)); return SVI_ERR_OOM; }
+    SVI_CHECK_HIP(hipMemset(h->aud_base, 0, off));
+    SVI_CHECK_HIP(hipDeviceSynchronize());
+    auto P = [&](size_t o) { return reinterpret_cast<bf16*>(h->aud_base + o); };
+    h->AH0 = P(oh0); h->AH1 = P(oh1); h->AP3 = P(op3); h->AUD = P(oaud); h->AK = P(oak); h->AVT = P(oavt);
+    h->ldavt = ldavt; h->aud_frames = f;
+    return SVI_OK;
+}
+// audio_embed = audio_proj(first, latter) (AudioProjModel.forward, dit:82-115) -> AUD bf16 [f * 32, 768]: 32 context tokens per frame
+static svi_status stage_audio(svi_dit* h, int f, hipStream_t st) {
+    SVI_REQUIRE(h->cfg.enable_multitalk, "audio was set on a model without enable_multitalk");
+    SVI_REQUIRE(h->aud_latter_n == f - 1, "audio windows cover %d latent frames, the latents have %d", h->aud_latter_n + 1, f);
+    SVI_TRY(ensure_audio(h, f));
+    const int k0 = 5 * 12 * SVI_AUD_DIM, k1 = 8 * 12 * SVI_AUD_DIM;
+    SVI_TRY(linear(h->aud_first, k0, h->ap1, h->AH0, 512, 1, 512, k0, SVI_EPI_BIAS_RELU, st));                       // relu(proj1), frame 0
+    if (f > 1) SVI_TRY(linear(h->aud_latter, k1, h->ap1vf, h->AH0 + 512, 512, f - 1, 512, k1, SVI_EPI_BIAS_RELU, st));   // relu(proj1_vf), frames 1..
+    SVI_TRY(linear(h->AH0, 512, h->ap2, h->AH1, 512, f, 512, 512, SVI_EPI_BIAS_RELU, st));                          // relu(proj2)
+    SVI_TRY(linear(h->AH1, 512, h->ap3, h->AP3, SVI_AUD_TOK * SVI_AUD_DIM, f, SVI_AUD_TOK * SVI_AUD_DIM, 512, SVI_EPI_BIAS, st));   // proj3 -> [f, 32*768]
+    // nn.LayerNorm(768) (eps 1e-5) over every context token
+    return svi_launch_ln_mod(h->AP3, SVI_AUD_DIM, h->AUD, SVI_AUD_DIM, f * SVI_AUD_TOK, SVI_AUD_DIM, 1e-5f, h->ap_norm_w, h->ap_norm_b, nullptr, nullptr, st);
+}
+// x += proj(attention_per_frame(q_linear(norm_x(x)), kv_linear(audio)))   (DiTBlock.forward dit:361-366; SingleStreamAttention.forward,
+// models/attention.py:318-371 with human_num == 1): frame fr's h*w tokens attend to that frame's 32 audio tokens, scale head_dim^-0.5,
+// no q/k norm, no RoPE.  K | V of the audio tokens depend on (audio, weights) only; they are re-projected per forward (3 GFLOP per block).
+static svi_status block_audio(svi_dit* h, int layer, bf16* X, int L, int f, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const BlockW& b = h->blocks[layer];
+    Workspace& w = h->ws;
+    const int D = c.dim, na = f * SVI_AUD_TOK, S = L / f;
+    const Lin lk{b.aud_kv.w, b.aud_kv.b}, lv{b.aud_kv.w + (size_t)D * SVI_AUD_DIM, b.aud_kv.b + D};      // kv_linear rows [0, D) = K, [D, 2D) = V
+    SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, b.normx_w, b.normx_b, nullptr, nullptr, st));
+    SVI_TRY(linear(w.Hb, D, b.aud_q, w.QK, 2 * D, L, D, D, SVI_EPI_BIAS, st));
+    SVI_TRY(linear(h->AUD, SVI_AUD_DIM, lk, h->AK, D, na, D, SVI_AUD_DIM, SVI_EPI_BIAS, st));
+    SVI_TRY(linear_transposed(h->AUD, SVI_AUD_DIM, lv, h->AVT, h->ldavt, na, D, SVI_AUD_DIM, st));
+    for (int fr = 0; fr < f; ++fr)
+        SVI_TRY(svi_launch_flash(w.QK + (size_t)fr * S * 2 * D, 2 * D, h->AK + (size_t)fr * SVI_AUD_TOK * D, D, h->AVT + (size_t)fr * SVI_AUD_TOK, h->ldavt,
+                                 w.Hb + (size_t)fr * S * D, D, S, SVI_AUD_TOK, c.num_heads, 0, st));
+    return linear(w.Hb, D, b.aud_proj, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D);
 }
 
 // modf[i][c] = bf16(modulation[i][c] + t_mod[i][c]); rows in scale_mask store bf16(1 + that)
@@ -607,9 +692,11 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
     CtxUse cu{};
     SVI_TRY(stage_context(h, context, clip, y, Lc, &cu, st));
     SVI_TRY(stage_embed(h, x, y, addc, T, H, W, L, st));
+    const int audio_frames = h->aud_first ? f : 0;                       // talk variant armed (svi_dit_set_audio)
+    if (audio_frames) SVI_TRY(stage_audio(h, f, st));
     if (tea_mode == 1) SVI_CHECK_HIP(hipMemcpyAsync(w.X2, w.X, (size_t)L * D * 2, hipMemcpyDeviceToDevice, st));
     for (int l = 0; l < c.num_layers; ++l)
-        SVI_TRY(run_block(h, l, w.X, cu.CTXp, w.modf + (size_t)l * 6 * D, L, Lc, kv_of(h, cu, l), st));
+        SVI_TRY(run_block(h, l, w.X, cu.CTXp, w.modf + (size_t)l * 6 * D, L, Lc, kv_of(h, cu, l), st, audio_frames));
     if (tea_mode == 1) SVI_TRY(svi_launch_sub_bf16(residual, w.X, w.X2, (int64_t)L * D, st));
     return stage_head(h, out, T, H, W, L, st);
 }
@@ -673,12 +760,25 @@ static svi_status forward_pair(svi_dit* h, const bf16* x, const float* timestep,
     return SVI_OK;
 }
 
+extern "C" svi_status svi_dit_set_audio(svi_dit* h, const void* audio_first, const void* audio_latter, int32_t n_latter) {
+    SVI_REQUIRE(h, "null handle");
+    if (!audio_first) { h->aud_first = h->aud_latter = nullptr; h->aud_latter_n = 0; return SVI_OK; }
+    SVI_REQUIRE(h->cfg.enable_multitalk, "svi_dit_set_audio: the model was created without enable_multitalk");
+    SVI_REQUIRE(n_latter >= 0 && (n_latter == 0 || audio_latter), "svi_dit_set_audio: %d later frames but no audio_latter", n_latter);
+    SVI_REQUIRE(((uintptr_t)audio_first % 16) == 0 && ((uintptr_t)audio_latter % 16) == 0, "svi_dit_set_audio: audio windows must be 16-byte aligned");
+    h->aud_first = reinterpret_cast<const bf16*>(audio_first);
+    h->aud_latter = reinterpret_cast<const bf16*>(audio_latter);
+    h->aud_latter_n = n_latter;
+    return SVI_OK;
+}
+
 extern "C" svi_status svi_dit_forward(svi_dit* h, const void* x, const float* timestep, const void* context,
                                       const void* clip_feature, const void* y, const void* add_condition, void* out,
                                       int32_t B, int32_t T, int32_t H, int32_t W, int32_t Lc, svi_stream stream) {
     SVI_REQUIRE(h && x && timestep && context && out, "svi_dit_forward: null argument");
     SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward: bad sizes");
+    SVI_REQUIRE(!h->aud_first || B == 1, "the talk variant takes one sample per forward (audio windows of one clip)");
     SVI_REQUIRE(y || h->cfg.in_dim == 16, "this model takes %d extra input channels: y must be given", h->cfg.in_dim - 16);
     SVI_REQUIRE(!h->cfg.has_image_input || clip_feature, "has_image_input model needs clip_feature");
     const svi_dit_config& c = h->cfg;
@@ -707,6 +807,7 @@ extern "C" svi_status svi_dit_forward_tea(svi_dit* h, const void* x, const float
     SVI_REQUIRE(h && x && timestep && context && out, "svi_dit_forward_tea: null argument");
     SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward_tea: bad sizes");
+    SVI_REQUIRE(!h->aud_first || B == 1, "the talk variant takes one sample per forward (audio windows of one clip)");
     SVI_REQUIRE(y || h->cfg.in_dim == 16, "this model takes %d extra input channels: y must be given", h->cfg.in_dim - 16);
     SVI_REQUIRE(!h->cfg.has_image_input || clip_feature, "has_image_input model needs clip_feature");
     SVI_REQUIRE(tea_mode >= 0 && tea_mode <= 2 && (tea_mode == 0 || residual), "svi_dit_forward_tea: tea_mode %d needs a residual buffer", tea_mode);
@@ -754,6 +855,7 @@ extern "C" svi_status svi_dit_forward_cfg_pair(svi_dit* h, const void* x, const 
     SVI_REQUIRE(h && x && timestep && context_cond && context_uncond && out_cond && out_uncond, "svi_dit_forward_cfg_pair: null argument");
     SVI_REQUIRE_DEVICE(h);
     SVI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Lc > 0, "svi_dit_forward_cfg_pair: bad sizes");
+    if (h->aud_first) { svi_set_error("svi_dit_forward_cfg_pair: the talk variant's branches differ in their audio; run them as separate forwards"); return SVI_ERR_UNSUPPORTED; }
     SVI_REQUIRE(y || h->cfg.in_dim == 16, "this model takes %d extra input channels: y must be given", h->cfg.in_dim - 16);
     SVI_REQUIRE(!h->cfg.has_image_input || clip_feature, "has_image_input model needs clip_feature");
     const svi_dit_config& c = h->cfg;
@@ -791,6 +893,7 @@ extern "C" svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* t
     SVI_REQUIRE_DEVICE(h);
     const svi_dit_config& c = h->cfg;
     SVI_REQUIRE(T > 0 && H > 0 && W > 0 && Lc > 0 && T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0, "svi_dit_sp_begin: bad sizes");
+    if (h->aud_first) { svi_set_error("svi_dit_sp_begin: the talk variant's per-frame audio attention is not served on sequence shards"); return SVI_ERR_UNSUPPORTED; }
     SVI_REQUIRE(y || c.in_dim == 16, "this model takes %d extra input channels: y must be given", c.in_dim - 16);
     SVI_REQUIRE(!c.has_image_input || clip_feature, "has_image_input model needs clip_feature");
     const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w, L = f * hh * ww;

@@ -425,3 +425,30 @@ svi_status svi_launch_sp_unpack_out(const bf16* recv, bf16* out, int P, int G, i
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Three-way guidance of the talk sampler + Euler step (pipelines/svi_video_talk.py:455-461, schedulers/flow_match.py:63):
+//   v = uncond + s_text * (cond - drop_text) + s_audio * (drop_text - uncond)      (bf16 tensor ops, left to right, each rounded)
+//   lat = lat + v * (sigma_next - sigma)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg3_step_kernel(bf16* __restrict__ lat, const bf16* __restrict__ cond, const bf16* __restrict__ uncond,
+                                                        const bf16* __restrict__ drop, int64_t n, float st, float sa, float dsigma) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float c = (float)cond[i], u = (float)uncond[i], d = (float)drop[i];
+        const float a = rbf(st * rbf(c - d));
+        const float b = rbf(sa * rbf(d - u));
+        const float v = rbf(rbf(u + a) + b);
+        lat[i] = (bf16)((float)lat[i] + rbf(v * dsigma));
+    }
+}
+svi_status svi_launch_cfg3_step(bf16* lat, const bf16* cond, const bf16* uncond, const bf16* drop, int64_t n, float st, float sa, float dsigma,
+                                hipStream_t stream) {
+    if (n <= 0) return SVI_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cfg3_step_kernel, dim3(blocks), dim3(256), 0, stream, lat, cond, uncond, drop, n, st, sa, dsigma);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}

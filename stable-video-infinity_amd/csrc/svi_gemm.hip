@@ -173,6 +173,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
         } else if (g.epi == SVI_EPI_BIAS_SILU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+        } else if (g.epi == SVI_EPI_BIAS_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
         } else if (g.epi == SVI_EPI_BIAS_GATE_RES) {
             const bf16* rp = g.res + (size_t)m * g.ldres + n;
             float rv[8];
@@ -265,6 +268,9 @@ __device__ __forceinline__ void gemm256_apply(float (&y)[8], const u32x4& res, c
     } else if constexpr (EPI == SVI_EPI_BIAS_SILU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+    } else if constexpr (EPI == SVI_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
     } else if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
         const bf16x8 t = __builtin_bit_cast(bf16x8, res);
 #pragma unroll
@@ -428,6 +434,7 @@ __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&
         case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
         case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
         case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
         default:                     gemm256_epilogue_t<SVI_EPI_BIAS>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
     }
 }
@@ -996,6 +1003,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256q_kernel(SviGemmArgs g
             case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_private<SVI_EPI_BIAS_GATE_RES>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
             case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_private<SVI_EPI_BIAS_GELU_ERF>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
             case SVI_EPI_BIAS_SILU:      gemm256_epilogue_private<SVI_EPI_BIAS_SILU>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
+            case SVI_EPI_BIAS_RELU:      gemm256_epilogue_private<SVI_EPI_BIAS_RELU>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
             default:                     gemm256_epilogue_private<SVI_EPI_BIAS>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
         }
         if (!has_next) break;
@@ -1013,7 +1021,7 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     SVI_REQUIRE(g.lda >= g.K && g.ldw >= g.K && g.ldc >= g.N, "gemm: leading dims too small");
     SVI_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && ((uintptr_t)g.C % 16) == 0,
                 "gemm: operands must be 16-byte aligned");
-    SVI_REQUIRE(g.epi >= 0 && g.epi <= SVI_EPI_BIAS_SILU, "gemm: unknown epilogue %d", g.epi);
+    SVI_REQUIRE(g.epi >= 0 && g.epi <= SVI_EPI_BIAS_RELU, "gemm: unknown epilogue %d", g.epi);
     if (g.epi == SVI_EPI_BIAS_GATE_RES) {
         SVI_REQUIRE(g.res != nullptr && g.ldres % 8 == 0 && ((uintptr_t)g.res % 16) == 0,
                     "gemm: gate/residual epilogue needs an aligned residual");

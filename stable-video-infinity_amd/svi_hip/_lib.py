@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SVI_HIP_LIB") or os.path.join(_HERE, "libsvi_hip.so")
 
 SVI_OK = 0
 SVI_BF16, SVI_F32 = 0, 1
-EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RES, EPI_BIAS_GELU_ERF, EPI_BIAS_SILU = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RES, EPI_BIAS_GELU_ERF, EPI_BIAS_SILU, EPI_BIAS_RELU = 0, 1, 2, 3, 4, 5
 
 # every symbol include/svi_hip.h declares: (name, restype, argtypes)
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -22,7 +22,7 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 class DitConfig(C.Structure):
     _fields_ = [("dim", _i32), ("in_dim", _i32), ("ffn_dim", _i32), ("out_dim", _i32), ("text_dim", _i32),
                 ("freq_dim", _i32), ("eps", _f32), ("patch_t", _i32), ("patch_h", _i32), ("patch_w", _i32),
-                ("num_heads", _i32), ("num_layers", _i32), ("has_image_input", _i32)]
+                ("num_heads", _i32), ("num_layers", _i32), ("has_image_input", _i32), ("enable_multitalk", _i32)]
 
 
 SYMBOLS = [
@@ -45,6 +45,8 @@ SYMBOLS = [
     ("svi_dit_unpatchify", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_dit_head_ld", _i32, [_vp]),
     ("svi_attention_vt_fwd", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_dit_set_audio", _i32, [_vp, _vp, _vp, _i32]),
+    ("svi_cfg3_step", _i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
     ("svi_dit_time_mod", _i32, [_vp, _vp, _vp, _i32, _vp]),
     ("svi_dit_forward_tea", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     ("svi_dit_forward_cfg_pair", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

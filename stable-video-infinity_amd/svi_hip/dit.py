@@ -59,12 +59,14 @@ class PromptPins:
 
 class WanDiT:
     def __init__(self, dim: int, in_dim: int, ffn_dim: int, out_dim: int, text_dim: int, freq_dim: int, eps: float,
-                 patch_size: Tuple[int, int, int], num_heads: int, num_layers: int, has_image_input: bool):
+                 patch_size: Tuple[int, int, int], num_heads: int, num_layers: int, has_image_input: bool, enable_multitalk: bool = False):
         self.dim, self.in_dim, self.ffn_dim, self.out_dim = dim, in_dim, ffn_dim, out_dim
         self.text_dim, self.freq_dim, self.eps, self.patch_size = text_dim, freq_dim, eps, tuple(patch_size)
         self.num_heads, self.num_layers, self.has_image_input = num_heads, num_layers, bool(has_image_input)
+        self.enable_multitalk = bool(enable_multitalk)
+        self._audio = None                  # the armed audio windows (kept alive: the C side borrows their pointers)
         cfg = L.DitConfig(dim, in_dim, ffn_dim, out_dim, text_dim, freq_dim, eps, *self.patch_size, num_heads,
-                          num_layers, int(self.has_image_input))
+                          num_layers, int(self.has_image_input), int(self.enable_multitalk))
         h = C.c_void_p()
         L.check(L.lib().svi_dit_create(C.byref(cfg), C.byref(h)), "svi_dit_create")
         self._h = h
@@ -91,7 +93,8 @@ class WanDiT:
                 // (pe.kernel_size[0] * pe.kernel_size[1] * pe.kernel_size[2]),
                 text_dim=wan_model.text_embedding[0].in_features, freq_dim=wan_model.freq_dim,
                 eps=blk.norm1.eps, patch_size=tuple(pe.kernel_size), num_heads=blk.num_heads,
-                num_layers=len(wan_model.blocks), has_image_input=wan_model.has_image_input)
+                num_layers=len(wan_model.blocks), has_image_input=wan_model.has_image_input,
+                enable_multitalk=getattr(wan_model, "enable_multitalk", False))
         m.bind(dict(wan_model.state_dict()))
         return m
 
@@ -186,11 +189,17 @@ class WanDiT:
     def forward(self, x: torch.Tensor, timestep: torch.Tensor, context: torch.Tensor,
                 clip_feature: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
                 add_condition: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                tea_mode: int = 0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                tea_mode: int = 0, residual: Optional[torch.Tensor] = None, audio_embed_tuple=None) -> torch.Tensor:
         """tea_mode / residual: TeaCache plumbing (svi_dit_forward_tea): 1 = also write residual [B, L, dim] = x_after_blocks -
-        x_before_blocks, 2 = skip the blocks and add `residual` instead."""
+        x_before_blocks, 2 = skip the blocks and add `residual` instead.  audio_embed_tuple: the talk variant (set_audio) for this call."""
         if not x.is_cuda:
             raise RuntimeError("svi_hip runs on the GPU only")
+        if audio_embed_tuple is not None:       # given for this call: arm it (None leaves whatever set_audio() armed in place)
+            same = self._audio is not None and all(a.data_ptr() == b.data_ptr() and a.dtype == b.dtype for a, b in zip(self._audio, audio_embed_tuple))
+            if not same:
+                self.set_audio(audio_embed_tuple)
+        if self._audio is not None and self._audio[1].shape[1] != x.shape[2] - 1:
+            raise ValueError(f"audio windows cover {self._audio[1].shape[1] + 1} latent frames, the latents have {x.shape[2]}")
         self.check_inputs(x, (context,), clip_feature, y, add_condition)
         if not self.has_image_input:
             clip_feature = None                    # the reference ignores it without an image branch (svi_video.py:96-99)
@@ -218,6 +227,23 @@ class WanDiT:
                                         L.ptr(add_condition), L.ptr(out), B, T, H, W, context.shape[1],
                                         L.current_stream()), "svi_dit_forward")
         return out
+
+    def set_audio(self, audio_embed_tuple) -> None:
+        """Arm (or, with None, disarm) the talk variant for the following forward() calls: audio_embed_tuple = (first [1, 1, 5, 12, 768],
+        latter [1, T-1, 8, 12, 768]) as SVITalkVideoPipeline builds it (svi_video_talk.py:425-444; model_fn_wan_talk_video :126-127)."""
+        if audio_embed_tuple is None:
+            L.check(L.lib().svi_dit_set_audio(self._h, None, None, 0), "svi_dit_set_audio")
+            self._audio = None
+            return
+        if not self.enable_multitalk:
+            raise ValueError("audio_embed_tuple was given to a model without enable_multitalk")
+        a0, a1 = audio_embed_tuple
+        if tuple(a0.shape) != (1, 1, 5, 12, 768) or a1.dim() != 5 or tuple(a1.shape[:1] + a1.shape[2:]) != (1, 8, 12, 768):
+            raise ValueError(f"audio_embed_tuple must be ([1,1,5,12,768], [1,T-1,8,12,768]) (got {tuple(a0.shape)}, {tuple(a1.shape)})")
+        a0 = a0.to(device="cuda", dtype=torch.bfloat16).contiguous()
+        a1 = a1.to(device="cuda", dtype=torch.bfloat16).contiguous()
+        L.check(L.lib().svi_dit_set_audio(self._h, L.ptr(a0), L.ptr(a1) if a1.shape[1] else None, a1.shape[1]), "svi_dit_set_audio")
+        self._audio = (a0, a1)
 
     def tokens(self, T: int, H: int, W: int) -> int:
         pt, ph, pw = self.patch_size
@@ -320,3 +346,25 @@ def model_fn_wan_video(dit: WanDiT, x: torch.Tensor, timestep: torch.Tensor, con
     tea_cache.previous_residual = res            # what TeaCache.store() would have computed (svi_video.py:64-66)
     tea_cache.previous_hidden_states = None
     return out
+
+
+def model_fn_wan_talk_video(dit: WanDiT, x: torch.Tensor, timestep: torch.Tensor, context: torch.Tensor,
+                            clip_feature: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None, tea_cache=None,
+                            add_condition=None, audio_embed_tuple=None, use_unified_sequence_parallel: bool = False,
+                            use_controlnet: bool = False, **kwargs) -> torch.Tensor:
+    """Same signature as pipelines/svi_video_talk.py:83-96.  The audio windows arm the per-block audio cross-attention for this call
+    (WanDiT.set_audio); everything else is model_fn_wan_video.  Not served: use_controlnet (blocks that also return add_condition) and
+    sequence parallelism together with audio."""
+    if use_controlnet:
+        raise NotImplementedError("the talk variant's controlnet blocks are not served by the HIP backend")
+    if audio_embed_tuple is None:
+        raise ValueError("model_fn_wan_talk_video needs audio_embed_tuple (the reference dereferences it unconditionally, svi_video_talk.py:126)")
+    if use_unified_sequence_parallel:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(getattr(dit, "sp_group", None)) > 1:
+            raise NotImplementedError("the talk variant's per-frame audio attention is not served on sequence shards")
+    dit.set_audio(audio_embed_tuple)
+    try:
+        return model_fn_wan_video(dit, x, timestep, context, clip_feature=clip_feature, y=y, tea_cache=tea_cache, add_condition=add_condition)
+    finally:
+        dit.set_audio(None)

@@ -117,3 +117,14 @@ def fp8_e4m3_to_bf16(t: torch.Tensor) -> torch.Tensor:
     out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
     L.check(L.lib().svi_fp8_e4m3_to_bf16(L.ptr(src.view(torch.uint8)), L.ptr(out), src.numel(), L.current_stream()), "fp8_e4m3_to_bf16")
     return out
+
+
+def cfg3_step_(latents: torch.Tensor, cond: torch.Tensor, uncond: torch.Tensor, drop_text: torch.Tensor, text_scale: float, audio_scale: float,
+               dsigma: float) -> torch.Tensor:
+    """latents += (uncond + text_scale*(cond - drop_text) + audio_scale*(drop_text - uncond)) * dsigma, in place, bf16 op-by-op
+    (the talk sampler's guidance, svi_video_talk.py:455-461)."""
+    for t, n in ((latents, "latents"), (cond, "cond"), (uncond, "uncond"), (drop_text, "drop_text")):
+        _chk(t, n)
+    L.check(L.lib().svi_cfg3_step(L.ptr(latents), L.ptr(cond), L.ptr(uncond), L.ptr(drop_text), latents.numel(), float(text_scale),
+                                  float(audio_scale), float(dsigma), L.current_stream()), "cfg3_step")
+    return latents

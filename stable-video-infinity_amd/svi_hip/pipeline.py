@@ -129,6 +129,38 @@ class DenoiseLoop:
         return latents
 
     @torch.no_grad()
+    def sample_multitalk(self, latents: torch.Tensor, ctx_pos: torch.Tensor, ctx_neg: torch.Tensor, audio_embed_tuple, audio_embed_tuple_null,
+                         num_inference_steps: int = 50, text_scale: float = 5.0, audio_scale: float = 4.0, sigma_shift: float = 5.0,
+                         denoising_strength: float = 1.0, progress_bar_cmd: Callable = lambda x: x, add_condition=None, **cond) -> torch.Tensor:
+        """SVITalkVideoPipeline._sample_with_multitalk (svi_video_talk.py:448-463): per step three forwards — conditional (prompt, audio,
+        add_condition), unconditional (negative prompt, null audio, no add_condition), drop-text (negative prompt, audio, add_condition) —
+        combined as uncond + text*(cond - drop_text) + audio*(drop_text - uncond); one forward when both scales are 1."""
+        from .dit import model_fn_wan_talk_video as fn
+        self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
+        latents = latents.to(torch.bfloat16).contiguous().clone()
+        ts_dev = self.scheduler.timesteps.to(device=latents.device, dtype=torch.float32)
+        ctx_pos = ctx_pos.to(device=latents.device, dtype=torch.bfloat16).contiguous()
+        ctx_neg = ctx_neg.to(device=latents.device, dtype=torch.bfloat16).contiguous()
+        if cond.get("clip_feature") is not None:
+            cond["clip_feature"] = cond["clip_feature"].to(device=latents.device, dtype=torch.bfloat16).contiguous()
+        aud = tuple(a.to(device=latents.device, dtype=torch.bfloat16).contiguous() for a in audio_embed_tuple)
+        aud0 = tuple(a.to(device=latents.device, dtype=torch.bfloat16).contiguous() for a in audio_embed_tuple_null)
+        self.dit.context_cache(True)
+        try:
+            for i, t in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
+                tt, ds = ts_dev[i:i + 1], self.scheduler.step_delta(t)
+                c = fn(self.dit, latents, tt, ctx_pos, add_condition=add_condition, audio_embed_tuple=aud, **cond)
+                if text_scale != 1.0 or audio_scale != 1.0:
+                    u = fn(self.dit, latents, tt, ctx_neg, audio_embed_tuple=aud0, **cond)
+                    d = fn(self.dit, latents, tt, ctx_neg, add_condition=add_condition, audio_embed_tuple=aud, **cond)
+                    ops.cfg3_step_(latents, c, u, d, text_scale, audio_scale, ds)
+                else:
+                    ops.cfg_step_(latents, c, None, 1.0, ds)
+        finally:
+            self.dit.context_cache(False)
+        return latents
+
+    @torch.no_grad()
     def sample(self, latents: torch.Tensor, ctx_pos: torch.Tensor, ctx_neg: Optional[torch.Tensor],
                num_inference_steps: int = 50, cfg_scale: float = 5.0, sigma_shift: float = 5.0,
                denoising_strength: float = 1.0, progress_bar_cmd: Callable = lambda x: x, tea_cache_l1_thresh: Optional[float] = None,

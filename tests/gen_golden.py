@@ -48,6 +48,10 @@ def import_reference():
               "xformers", "xformers.ops", "imageio", "torchvision"):
         sys.modules.setdefault(n, Stub(n))
     sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
+    # AudioProjModel(ModelMixin, ConfigMixin) (wan_video_dit.py:44) must be a real nn.Module for its parameters to register
+    if isinstance(sys.modules["diffusers"], Stub):
+        sys.modules["diffusers"].ModelMixin = torch.nn.Module
+        sys.modules["diffusers.configuration_utils"].ConfigMixin = type("ConfigMixin", (object,), {})
     dit = importlib.import_module("diffsynth.models.wan_video_dit")
     vae = importlib.import_module("diffsynth.models.wan_video_vae")
     fm = importlib.import_module("diffsynth.schedulers.flow_match")
@@ -566,6 +570,67 @@ def gen_lora_names():
         json.dump({k: list(v) for k, v in got.items()}, f, indent=1, sort_keys=True)
 
 
+def _sdpa_as_xformers(q, k, v, attn_bias=None, op=None):
+    """xformers.ops.memory_efficient_attention(q, k, v) on [B, M, H, K] operands, stated with torch's SDPA (xformers is absent here;
+    the reference treats its attention back ends as interchangeable)."""
+    assert attn_bias is None
+    o = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+    return o.transpose(1, 2)
+
+
+def _talk_model(dit_mod):
+    xf = sys.modules["xformers"]                                   # the import stub (import_reference); SingleStreamAttention calls
+    xf.ops = sys.modules["xformers.ops"]                           # xformers.ops.memory_efficient_attention (models/attention.py:357)
+    xf.ops.memory_efficient_attention = _sdpa_as_xformers
+    c = synth.TINY_DIT_TALK
+    m = dit_mod.WanModel(eps=1e-6, num_heads=synth.num_heads_of(c), **c).eval()
+    m.load_state_dict({k: t(a) for k, a in synth.dit_state_dict(synth.TALK_SEED, **c).items()}, strict=True)
+    return m, c
+
+
+def gen_talk(dit_mod, fm):
+    """Talk variant: the reference WanModel with enable_multitalk (per-block audio cross-attention, AudioProjModel) run on
+    seeded audio windows — WanModel.forward(audio_embed_tuple=...) (wan_video_dit.py:486-567) in fp32 and bf16 — and the three-way-guidance
+    sampler SVITalkVideoPipeline._sample_with_multitalk with that module's own model_fn_wan_talk_video (svi_video_talk.py:83-160,448-463)."""
+    m, c = _talk_model(dit_mod)
+    seed, (f, h, w) = synth.TALK_SEED, synth.TALK_GRID
+    x = t(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w))
+    ctx = t(synth.text_context(seed + 2, 20, c["text_dim"], 13))
+    clip = t(synth.randn(seed + 3, 1, 257, 1280))
+    y = t(synth.randn(seed + 4, 1, 20, f, 2 * h, 2 * w))
+    a0, a1 = (t(a) for a in synth.audio_windows(seed + 5, f))
+    ts = torch.tensor([637.5])
+    out = {}
+    with torch.no_grad():
+        out["out_fp32"] = m(x, ts, ctx, clip_feature=clip, y=y, audio_embed_tuple=(a0, a1)).numpy()
+        out["out_fp32_no_audio"] = m(x, ts, ctx, clip_feature=clip, y=y).numpy()
+        out["audio_tokens_fp32"] = m.audio_proj(a0, a1)[0].numpy()                    # [f, 32, 768]
+        mb = m.to(torch.bfloat16)
+        bf = lambda a: a.to(torch.bfloat16)      # noqa: E731
+        out["out_bf16"] = mb(bf(x), ts, bf(ctx), clip_feature=bf(clip), y=bf(y), audio_embed_tuple=(bf(a0), bf(a1))).float().numpy()
+        # the sampler (3 steps): cond / uncond / drop-text forwards, text scale 5, audio scale 4
+        rel = "diffsynth/pipelines/svi_video_talk.py"
+        ns = {"torch": torch, "np": np, "WanModel": dit_mod.WanModel, "Optional": None, "sinusoidal_embedding_1d": dit_mod.sinusoidal_embedding_1d}
+        ns["TeaCache"] = _reference_toplevel(rel, "TeaCache", ns)
+        ns["model_fn_wan_talk_video"] = _reference_toplevel(rel, "model_fn_wan_talk_video", ns)
+        sample = _reference_method(rel, "SVITalkVideoPipeline", "_sample_with_multitalk", ns)
+
+        class Self:
+            device = "cpu"
+
+        me = Self()
+        me.dit = mb
+        me.scheduler = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        me.scheduler.set_timesteps(3, shift=5.0)
+        lat = torch.randn((1, 16, f, 2 * h, 2 * w), generator=torch.Generator("cpu").manual_seed(31), dtype=torch.float32).to(torch.bfloat16)
+        n0, n1 = (bf(t(a)) for a in synth.audio_windows(seed + 7, f))                 # the "null" audio of the unconditional branch
+        r = sample(me, lat, {"context": bf(ctx)}, {"context": bf(t(synth.text_context(seed + 12, 20, c["text_dim"], 4)))},
+                   {"clip_feature": bf(clip), "y": bf(y)}, {}, {"tea_cache": None}, {"tea_cache": None}, {"use_unified_sequence_parallel": False},
+                   None, (bf(a0), bf(a1)), (n0, n1), False, {"text": 5.0, "audio": 4.0}, lambda x: x)
+        out["sampler_latents"] = r.float().numpy()
+    np.savez(os.path.join(OUT, "dit_tiny_talk.npz"), **out)
+
+
 def main(argv=None):
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -585,6 +650,7 @@ def main(argv=None):
         "clip_stream": lambda: gen_clip_stream(dit_mod, vae_mod, fm),
         "fp8_storage": lambda: gen_fp8_storage(dit_mod),
         "lora_names": gen_lora_names,
+        "dit_tiny_talk": lambda: gen_talk(dit_mod, fm),
         "pose_embed": gen_pose_embed,
         "dance_sampler": lambda: gen_dance_sampler(dit_mod, fm),
         "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),

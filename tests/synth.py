@@ -21,7 +21,8 @@ import numpy as np
 
 # ----------------------------------------------------------------------------------- DiT
 def dit_param_shapes(dim: int, in_dim: int, ffn_dim: int, out_dim: int, text_dim: int, freq_dim: int,
-                     patch_size: Tuple[int, int, int], num_layers: int, has_image_input: bool) -> "OrderedDict[str, tuple]":
+                     patch_size: Tuple[int, int, int], num_layers: int, has_image_input: bool,
+                     enable_multitalk: bool = False) -> "OrderedDict[str, tuple]":
     s: "OrderedDict[str, tuple]" = OrderedDict()
 
     def lin(name, o, i):
@@ -51,6 +52,12 @@ def dit_param_shapes(dim: int, in_dim: int, ffn_dim: int, out_dim: int, text_dim
         s[b + "norm3.bias"] = (dim,)
         lin(b + "ffn.0", ffn_dim, dim)
         lin(b + "ffn.2", dim, ffn_dim)
+        if enable_multitalk:                                  # wan_video_dit.py:338-351
+            lin(b + "audio_cross_attn.q_linear", dim, dim)
+            lin(b + "audio_cross_attn.proj", dim, dim)
+            lin(b + "audio_cross_attn.kv_linear", 2 * dim, 768)
+            s[b + "norm_x.weight"] = (dim,)
+            s[b + "norm_x.bias"] = (dim,)
     s["head.modulation"] = (1, 2, dim)
     lin("head.head", out_dim * int(np.prod(patch_size)), dim)
     if has_image_input:
@@ -60,6 +67,13 @@ def dit_param_shapes(dim: int, in_dim: int, ffn_dim: int, out_dim: int, text_dim
         lin("img_emb.proj.3", dim, 1280)
         s["img_emb.proj.4.weight"] = (dim,)
         s["img_emb.proj.4.bias"] = (dim,)
+    if enable_multitalk:                                      # AudioProjModel, wan_video_dit.py:455-470
+        lin("audio_proj.proj1", 512, 5 * 12 * 768)
+        lin("audio_proj.proj1_vf", 512, 8 * 12 * 768)
+        lin("audio_proj.proj2", 512, 512)
+        lin("audio_proj.proj3", 32 * 768, 512)
+        s["audio_proj.norm.weight"] = (768,)
+        s["audio_proj.norm.bias"] = (768,)
     return s
 
 
@@ -270,3 +284,14 @@ LORA_KEY_EXAMPLES = [
     "blocks.1.self_attn.o.lora_B.adapter2.weight", "blocks.1.self_attn.o.lora_A.adapter2.weight",
     "dwpose_embedding.0.weight",
 ]
+
+
+# ----------------------------------------------------------------------------------- talk variant (golden/dit_tiny_talk.npz, talk_sampler.npz)
+TINY_DIT_TALK = dict(dim=256, in_dim=36, ffn_dim=512, out_dim=16, text_dim=64, freq_dim=256, patch_size=(1, 2, 2), num_layers=2,
+                     has_image_input=True, enable_multitalk=True)
+TALK_SEED, TALK_GRID = 800, (3, 4, 6)
+
+
+def audio_windows(seed: int, frames: int):
+    """audio_embed_tuple of one clip (svi_video_talk.py:425-444): first-frame window [1, 1, 5, 12, 768], later frames [1, f-1, 8, 12, 768]."""
+    return 0.5 * randn(seed, 1, 1, 5, 12, 768), 0.5 * randn(seed + 1, 1, frames - 1, 8, 12, 768)

@@ -19,7 +19,7 @@ def make_cfg(c):
     return wdo.DiTConfig(dim=c["dim"], in_dim=c["in_dim"], ffn_dim=c["ffn_dim"], out_dim=c["out_dim"],
                          text_dim=c["text_dim"], freq_dim=c["freq_dim"], patch_size=c["patch_size"],
                          num_heads=synth.num_heads_of(c), num_layers=c["num_layers"],
-                         has_image_input=c["has_image_input"])
+                         has_image_input=c["has_image_input"], enable_multitalk=c.get("enable_multitalk", False))
 
 
 def inputs(c, grid, ctx_tokens, ctx_valid, seed):
@@ -133,3 +133,24 @@ def test_block_at_14b_i2v_widths_matches_reference(golden):
     with torch.no_grad():
         out = wdo.dit_block(sd, "blocks.0.", bx, bctx, btm, wdo.rope_table_3d(128, grid), make_cfg(c), None)[0, rows].numpy()
     assert rel_l2(out, g["block_fp32"]) < 2e-5
+
+
+def test_talk_variant_matches_reference(golden):
+    """model_fn_wan_talk_video / WanModel.forward(audio_embed_tuple=...): AudioProjModel + per-block audio cross-attention, against the
+    reference's own fp32 forward (golden/dit_tiny_talk.npz); the audio branch moves the output by 15 %, so its absence cannot hide."""
+    g = golden("dit_tiny_talk.npz")
+    c, seed, (f, h, w) = synth.TINY_DIT_TALK, synth.TALK_SEED, synth.TALK_GRID
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
+    x = torch.from_numpy(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w))
+    ctx = torch.from_numpy(synth.text_context(seed + 2, 20, c["text_dim"], 13))
+    kw = dict(clip_feature=torch.from_numpy(synth.randn(seed + 3, 1, 257, 1280)), y=torch.from_numpy(synth.randn(seed + 4, 1, 20, f, 2 * h, 2 * w)))
+    aud = tuple(torch.from_numpy(a) for a in synth.audio_windows(seed + 5, f))
+    cfg = make_cfg(c)
+    with torch.no_grad():
+        tok = wdo.audio_tokens(sd, aud[0][0], aud[1][0], lambda v: v)
+        assert rel_l2(tok.numpy(), g["audio_tokens_fp32"]) < 2e-5
+        out = wdo.dit_forward(sd, cfg, x, torch.tensor([637.5]), ctx, audio_embed_tuple=aud, **kw)
+        assert rel_l2(out.numpy(), g["out_fp32"]) < 2e-5
+        plain = wdo.dit_forward(sd, cfg, x, torch.tensor([637.5]), ctx, **kw)
+        assert rel_l2(plain.numpy(), g["out_fp32_no_audio"]) < 2e-5
+    assert rel_l2(g["out_fp32"], g["out_fp32_no_audio"]) > 0.1

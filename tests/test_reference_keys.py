@@ -31,6 +31,9 @@ CONFIGS = {
                     num_heads=40, num_layers=40, eps=1e-6),
     "14B-I2V": dict(has_image_input=True, patch_size=(1, 2, 2), in_dim=36, dim=5120, ffn_dim=13824, freq_dim=256, text_dim=4096, out_dim=16,
                     num_heads=40, num_layers=40, eps=1e-6),
+    # the talk variant: the I2V table with the audio modules switched on (WanModel(enable_multitalk=True), wan_video_dit.py:421,455-470)
+    "14B-I2V-talk": dict(has_image_input=True, patch_size=(1, 2, 2), in_dim=36, dim=5120, ffn_dim=13824, freq_dim=256, text_dim=4096, out_dim=16,
+                         num_heads=40, num_layers=40, eps=1e-6, enable_multitalk=True),
 }
 
 
@@ -50,7 +53,7 @@ def test_dit_weight_table_accepts_the_reference_state_dict(ref, name):
         m = dit_mod.WanModel(**cfg)
     sd = m.state_dict()
     c = L.DitConfig(cfg["dim"], cfg["in_dim"], cfg["ffn_dim"], cfg["out_dim"], cfg["text_dim"], cfg["freq_dim"], cfg["eps"], *cfg["patch_size"],
-                    cfg["num_heads"], cfg["num_layers"], int(cfg["has_image_input"]))
+                    cfg["num_heads"], cfg["num_layers"], int(cfg["has_image_input"]), int(cfg.get("enable_multitalk", False)))
     h = C.c_void_p()
     L.check(L.lib().svi_dit_create(C.byref(c), C.byref(h)), "svi_dit_create")
     try:
