@@ -141,7 +141,7 @@ def main() -> None:
     ap.add_argument("--cfg-pair", action="store_true", help="SURVEY 8e-2: ranks (2p,2p+1) split the cond/uncond forwards of clip p "
                     "(one 4.2 MB all-gather per step); needs an even --gpus. Default is one clip per rank.")
     ap.add_argument("--seq-parallel", action="store_true", help="SURVEY 8e-3: ONE clip on all ranks (strong scaling): every forward is "
-                    "spread Ulysses-style over the ranks (heads must divide); with --cfg-pair: 2 CFG branches x N/2 sequence shards")
+                    "spread Ulysses-style over the ranks (K / V all-gather fallback when the heads do not divide); with --cfg-pair: 2 CFG branches x N/2 sequence shards")
     ap.add_argument("--graph", action="store_true", help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)): for the "
                     "launch-bound regime (--workload c1); per-kernel event timing is off under capture, so `roofline` is null")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)

@@ -1316,6 +1316,11 @@ extern "C" svi_status svi_vae_encode(svi_vae* h, const float* video, float* late
 
 // ---- tiled paths ------------------------------------------------------------------------------------------------------------
 namespace {
+struct WinScope {            // h->win points at a stack object while one tile runs through a graph: never leave it dangling on an error return
+    svi_vae* h;
+    WinScope(svi_vae* hh, const TileWin* w) : h(hh) { h->win = w; }
+    ~WinScope() { h->win = nullptr; }
+};
 // The task list of vae:648-655 / :697-704: tiles start every `stride`; a start is dropped when the previous tile already reaches
 // the far edge.
 std::vector<std::pair<int, int>> tile_starts(int full, int size, int stride) {
@@ -1367,10 +1372,8 @@ extern "C" svi_status svi_vae_tiled_decode(svi_vae* h, const float* latents, flo
             // the reference writes a `border`-long ramp into the tile's mask: a clipped tile shorter than the ramp is an error there too
             if ((!w.lb || !w.rb) && w.th * f < w.border_h) { svi_set_error("tile of %d rows is shorter than the %d-row blend border", w.th * f, w.border_h); return SVI_ERR_INVALID; }
             if ((!w.tb || !w.bb) && w.tw * f < w.border_w) { svi_set_error("tile of %d columns is shorter than the %d-column blend border", w.tw * f, w.border_w); return SVI_ERR_INVALID; }
-            h->win = &w;
             h->slot_used.assign(h->nslots, 0);
-            rc = decode_graph(h, latents, video, T, w.th, w.tw, st);
-            h->win = nullptr;
+            { WinScope ws_(h, &w); rc = decode_graph(h, latents, video, T, w.th, w.tw, st); }
             if (rc != SVI_OK) return rc;
         }
     }
@@ -1411,10 +1414,8 @@ extern "C" svi_status svi_vae_tiled_encode(svi_vae* h, const float* video, float
             w.border_h = (size_h - stride_h) / f; w.border_w = (size_w - stride_w) / f;
             if ((!w.lb || !w.rb) && w.th / f < w.border_h) { svi_set_error("tile of %d latent rows is shorter than the %d-row blend border", w.th / f, w.border_h); return SVI_ERR_INVALID; }
             if ((!w.tb || !w.bb) && w.tw / f < w.border_w) { svi_set_error("tile of %d latent columns is shorter than the %d-column blend border", w.tw / f, w.border_w); return SVI_ERR_INVALID; }
-            h->win = &w;
             h->slot_used.assign(h->nslots, 0);
-            rc = encode_graph(h, video, latents, T, w.th, w.tw, st);
-            h->win = nullptr;
+            { WinScope ws_(h, &w); rc = encode_graph(h, video, latents, T, w.th, w.tw, st); }
             if (rc != SVI_OK) return rc;
         }
     }

@@ -225,6 +225,21 @@ def _hip_model_fn(dit_module, x, timestep, context, clip_feature=None, y=None, t
                               add_condition=add_condition, use_unified_sequence_parallel=use_unified_sequence_parallel)
 
 
+def _hip_talk_fn(dit_module, x, timestep, context, clip_feature=None, y=None, tea_cache=None, add_condition=None, audio_embed_tuple=None,
+                 use_unified_sequence_parallel=False, use_controlnet=False, **kwargs):
+    """model_fn_wan_talk_video with the reference's exact signature (pipelines/svi_video_talk.py:83-96), on the HIP twin of `dit_module`."""
+    from .dit import model_fn_wan_talk_video
+    hip = _INSTALLED.get(id(dit_module))
+    if hip is None:
+        raise RuntimeError("this WanModel was not passed through svi_hip.install(); refusing to fall back to PyTorch")
+    if not hip._ctx_cache_on:
+        hip.context_cache(True)
+    context, clip_feature = _stable_bf16(hip, context), _stable_bf16(hip, clip_feature)
+    return model_fn_wan_talk_video(hip, x, timestep, context, clip_feature=clip_feature, y=y, tea_cache=tea_cache, add_condition=add_condition,
+                                   audio_embed_tuple=audio_embed_tuple, use_unified_sequence_parallel=use_unified_sequence_parallel,
+                                   use_controlnet=use_controlnet)
+
+
 def install(pipe, vae: bool = True):
     """Route `pipe`'s hot path (SVIVideoPipeline / WanVideoPipeline of the reference) through libsvi_hip.
 
@@ -246,6 +261,10 @@ def install(pipe, vae: bool = True):
     if not hasattr(mod, "_svi_hip_original_model_fn"):
         mod._svi_hip_original_model_fn = getattr(mod, "model_fn_wan_video", None)
     mod.model_fn_wan_video = _hip_model_fn
+    if hasattr(mod, "model_fn_wan_talk_video"):        # the talk pipeline's own entry point (pipelines/svi_video_talk.py:83)
+        if not hasattr(mod, "_svi_hip_original_talk_fn"):
+            mod._svi_hip_original_talk_fn = mod.model_fn_wan_talk_video
+        mod.model_fn_wan_talk_video = _hip_talk_fn
     if vae and getattr(pipe, "vae", None) is not None:
         from .vae import WanVideoVAE
         hv = WanVideoVAE.from_module(pipe.vae)

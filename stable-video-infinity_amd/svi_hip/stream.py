@@ -42,7 +42,10 @@ def u8_to_video(frames: torch.Tensor) -> torch.Tensor:
 class StreamLoop:
     def __init__(self, dit, vae, clip_encoder: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, num_motion_frames: int = 1,
                  num_frames: int = 81, num_inference_steps: int = 50, cfg_scale: float = 5.0, sigma_shift: float = 5.0,
-                 ref_pad_cfg: bool = False, ref_pad_num: int = 0, seed_times: int = 42):
+                 ref_pad_cfg: bool = False, ref_pad_num: int = 0, seed_times: int = 42, tiled: bool = False, tile_size=(30, 52),
+                 tile_stride=(15, 26)):
+        """tiled / tile_size / tile_stride: the VAE tiling arguments SVIVideoPipeline.__call__ passes to decode_video (svi_video.py:439-441, 515;
+        test_svi.py passes args.tiled, default False).  The conditioning encode is never tiled, as in the reference (:350)."""
         if num_motion_frames < 1:
             raise ValueError("an image-conditioned stream hands at least one motion frame from clip to clip (test_svi.py:472-476)")
         self.loop = DenoiseLoop(dit)
@@ -50,6 +53,7 @@ class StreamLoop:
         self.num_motion_frames, self.num_frames = num_motion_frames, num_frames
         self.steps, self.cfg_scale, self.sigma_shift = num_inference_steps, cfg_scale, sigma_shift
         self.ref_pad_cfg, self.ref_pad_num, self.seed_times = ref_pad_cfg, ref_pad_num, seed_times
+        self.tiler = dict(tiled=tiled, tile_size=tuple(tile_size), tile_stride=tuple(tile_stride))
         self.trace: List[dict] = []                     # per clip: what conditioned it (for tests / inspection)
 
     @torch.no_grad()
@@ -80,7 +84,7 @@ class StreamLoop:
                 cond["clip_feature"] = cf
             lat = self.loop.sample(lat, ctx_pos, ctx_neg, num_inference_steps=self.steps, cfg_scale=self.cfg_scale,
                                    sigma_shift=self.sigma_shift, **cond)
-            video = self.vae.decode(lat.float(), device="cuda")[0]                # [3, num_frames, H, W] fp32
+            video = self.vae.decode(lat.float(), device="cuda", **self.tiler)[0]  # [3, num_frames, H, W] fp32
             frames = video_to_u8(video)
             self.trace.append(dict(clip=k, seed=seed, motion=motion, y=y, latents=lat, frames=frames))
             motion = frames[-self.num_motion_frames:]
