@@ -302,7 +302,8 @@ def main() -> None:
                 traffic_src = f"no profiles/*_flash_pmc.json was collected on csrc/svi_attention.hip sha {src_sha} (tools/profile_round.sh)"
         except Exception:
             traffic = None
-        roof = {"kernel": "flash_fwd2_kernel (self-attention)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+        roof = {"kernel": "flash_fwd2_kernel (self-attention; one launch = the optimistic pass <...,1> + the flagged second pass <...,2>, which exits "
+                          "at once unless a row's exponentials left the optimistic range)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4)}
     line = {

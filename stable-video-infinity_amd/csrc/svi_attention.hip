@@ -398,9 +398,18 @@ __device__ __forceinline__ void pv_stmt(int& tok, u32x4 vf, u32x4 vf2, u32x4 p, 
     const int vo = d.vo, so = d.so, m0v = d.m0v;
     float t1;
     static_assert(FILL != SVI_F_E2 && !(DMA && FILL != SVI_F_NONE), "unsupported PV statement");
-    if constexpr (!AMAX) {
-        static_assert(FILL == SVI_F_NONE && !DMA, "plain PV statement");
-        asm(SVI_PVM SVI_END : SVI_PV_OUT : SVI_PV_IN);
+    if constexpr (!AMAX) {          // no row-maximum piece (the optimistic kernel, or a bare statement): the other fillers as below
+        if constexpr (DMA) {
+            asm volatile(SVI_DMA_M0 SVI_PVM SVI_DMA SVI_END : SVI_PV_OUT : SVI_PV_IN, SVI_DMA_IN);
+        } else if constexpr (FILL == SVI_F_NONE) {
+            asm(SVI_PVM SVI_END : SVI_PV_OUT : SVI_PV_IN);
+        } else if constexpr (FILL == SVI_F_EA) {
+            if constexpr (MULC) asm(SVI_MEXP0 SVI_PVM SVI_ADD0 SVI_END : SVI_PV_OUT, [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_PV_IN, [x0] "v"(x0), [c] "s"(c));
+            else asm(SVI_EXP0 SVI_PVM SVI_ADD0 SVI_END : SVI_PV_OUT, [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_PV_IN, [x0] "v"(x0));
+        } else {
+            if constexpr (MULC) asm(SVI_MEXP1 SVI_PVM SVI_ADD1 SVI_CVT SVI_END : SVI_PV_OUT, [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_PV_IN, [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c));
+            else asm(SVI_EXP1 SVI_PVM SVI_ADD1 SVI_CVT SVI_END : SVI_PV_OUT, [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_PV_IN, [x1] "v"(x1), [t0] "v"(t0));
+        }
     } else if constexpr (DMA) {
         asm volatile(SVI_DMA_M0 SVI_PVM SVI_MAX3 SVI_DMA SVI_END : SVI_PV_OUT, [m] "+v"(m) : SVI_PV_IN, SVI_MAX_IN, SVI_DMA_IN);
     } else if constexpr (FILL == SVI_F_NONE) {
@@ -465,12 +474,33 @@ __device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) 
 // MULC = false: the caller's Q already carries softmax_scale*log2(e) (the DiT's RMSNorm+RoPE kernel emits it that way, one
 // rounding) and scale_log2e is unused.  MULC = true (the public seam): Q is used as given and the factor is applied to the
 // fp32 scores inside B (one more VALU per score); all reference / threshold arithmetic is then in raw score units.
-template <int TAG, int ABL = 0, bool MULC = false>
+// MODE: 0 = the complete kernel (reference maximum tracked per tile, deferred rescale).
+//       1 = OPTIMISTIC: the reference maximum of a row is fixed after tile 0 and never moves, so the per-score v_max3 stream (34 of the
+//           ~200 VALU instructions of a tile) and the per-tile decision disappear: -3.7 % on the C2 shape (tools/attn_abl.py, ABL 1024).
+//           That is the same softmax as long as no exponential leaves fp32: with a row's scores up to 64 log2 units above its tile-0
+//           maximum, P <= 2^64, the sums and O stay far inside fp32 (bf16 P keeps 8 exponent bits), and numerator and denominator
+//           carry the same reference.  A row group whose sum ends beyond 2^64 (or is not a number: an exponential overflowed) raises
+//           the workgroup's flag ...
+//       2 = ... and the complete kernel is launched behind it over the same grid: a workgroup whose flag is clear exits at once,
+//           a flagged one recomputes its 256 rows with the tracked maximum and overwrites the optimistic result.
+//       On benign operands (every DiT forward measured so far) no flag is ever raised and modes 1 + 2 give the bits of mode 0 (the
+//       reference does not move there either); adversarial operands (tests: spikes, ramps, a late giant key) take the second pass.
+template <int TAG, int ABL = 0, bool MULC = false, int MODE = 0>
 __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restrict__ Q, int ldq,
                                                             const bf16* __restrict__ K, int ldk,
                                                             const bf16* __restrict__ VT, int ldvt,
                                                             bf16* __restrict__ O, int ldo, int Lq, int Lk,
-                                                            float scale_log2e) {
+                                                            float scale_log2e, int* __restrict__ flags) {
+    constexpr bool OPT = MODE == 1;
+    const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x;
+    if constexpr (MODE == 2) {
+        if (flags[wg_linear] == 0) return;          // uniform: the whole workgroup leaves before any barrier
+    }
+    if constexpr (MODE == 1) {
+        // clear the flag with an atomic whose return is awaited: it has executed at L2 before this wave reaches the first workgroup
+        // barrier, and no wave can raise the flag (kernel end) without having passed that barrier
+        if (threadIdx.x == 0) { const int old = atomicExch(&flags[wg_linear], 0); asm volatile("" :: "v"(old)); }
+    }
     // LDS: K stages 0..3 at 0/16/32/48 KiB (tile t lives in stage t & 3), V^T stages 0..1 at 64/80 KiB (tile t in t & 1)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -656,13 +686,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     constexpr int pi = 20 + (j >> 1);                // pairs 20..31 on statements 0..23
                     constexpr int pg = pi & 1, w = (pi >> 1) & 7, r0 = 2 * w;          // tb = 1
                     constexpr int fill = (!WITH_B || j >= 24) ? SVI_F_NONE : (j & 1) ? SVI_F_EB : SVI_F_EA;
-                    constexpr bool amax = !((ABL & 2) || (ABL & 32));
+                    constexpr bool amax = !((ABL & 2) || (ABL & 32) || (ABL & 1024) || OPT);
+                    constexpr bool rest = amax || (ABL & 1024) || OPT;   // optimistic mode / ABL 1024: only the row-maximum pieces are left out
                     const SviDma d = {k_rs, koff0, so_k + ((j >> 1) & 3) * kstep, piece0 + kd + 4096 * ((j >> 1) & 3)};
                     unsigned wd = 0;
-                    pv_stmt<SVI_OREG0 + (g * 4 + d4) * 16, amax, amax ? fill : SVI_F_NONE, amax && dma, MULC>(
+                    pv_stmt<SVI_OREG0 + (g * 4 + d4) * 16, amax, rest ? fill : SVI_F_NONE, rest && dma, MULC>(
                         tok, vf[f & 3], vf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pw[g][tt][sb], pin, mch, sn[ga][ta][ra], sn[ga][ta][ra + 1], so[pg][1][r0], so[pg][1][r0 + 1],
                         scale_log2e, tcar, ps[pg][0], ps[pg][1], wd, dma ? d : no_dma);
-                    if constexpr (amax && fill == SVI_F_EB) pw[pg][1][w >> 2][w & 3] = wd;
+                    if constexpr (rest && fill == SVI_F_EB) pw[pg][1][w >> 2][w & 3] = wd;
                     if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
                         vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
                     if constexpr (g == 0 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
@@ -680,7 +711,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     };
     // does some row of this wave exceed its reference by more than the threshold?  (per-lane maxima are enough to decide)
     auto outgrown = [&]() -> bool {
-        if constexpr ((ABL & 2) || (ABL & 16)) return false;
+        if constexpr ((ABL & 2) || (ABL & 16) || (ABL & 1024) || OPT) return false;
         const float mx = vmax3(ma[0], mb[0], vmax3(ma[1], mb[1], mb[1]));
         return __any(mx * cs > ((ABL & 128) ? 1e30f : SVI_RESCALE_THR));
     };
@@ -815,6 +846,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         });
     }
 
+    if constexpr (MODE == 1) {
+        // did some exponential of this wave's rows leave the range the fixed reference covers?  (l holds a lane's half of the row sum;
+        // !(l < 2^64) also catches inf and NaN)
+        const bool bad = !(l_run[0] < 1.8446744e19f) || !(l_run[1] < 1.8446744e19f);
+        if (__any(bad) && lane == 0) atomicOr(&flags[wg_linear], 1);
+    }
     // ---- normalise and store: a[(g*4+d)*16 + r] is O[row][32 d + (r&3) + 8 (r>>2) + 4 hi] ----------------------
     asm("s_nop 15" : "+v"(tok));                // last MFMA result -> v_accvgpr_read wait states
     static_for<0, 2>([&](auto gc) {
@@ -838,6 +875,22 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     });
 }
 
+// One flag word per workgroup of the optimistic attention pass, per device (allocated once; launches on one stream are ordered, which
+// is the library's threading contract for everything process-wide).
+#define SVI_FLASH_MAX_FLAGS 65536
+static svi_status flash_flags(int** out) {
+    static int* buf[16] = {nullptr};
+    const int dev = svi_current_device();
+    if (dev < 0) return SVI_ERR_HIP;
+    SVI_REQUIRE(dev < 16, "device index %d beyond the flag table", dev);
+    if (!buf[dev]) {
+        hipError_t e = hipMalloc((void**)&buf[dev], SVI_FLASH_MAX_FLAGS * sizeof(int));
+        if (e != hipSuccess) { svi_set_error("hipMalloc(attention flags) failed: %s", hipGetErrorString(e)); return SVI_ERR_OOM; }
+    }
+    *out = buf[dev];
+    return SVI_OK;
+}
+
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt, bf16* O,
                             int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st) {
     SVI_REQUIRE(Lq > 0 && Lk > 0 && num_heads > 0, "attention: bad sizes Lq=%d Lk=%d heads=%d", Lq, Lk, num_heads);
@@ -850,10 +903,25 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     const SviSwitches& sw = svi_switches();
     const bool v2 = sw.flash_kernel ? sw.flash_kernel == 2 : (Lk >= 2048);     // short key axes (text context) are prologue-bound: v1
     if (v2) {
-        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float);
-        kern_t kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false> : flash_fwd2_kernel<1, 0, false>)
-                                  : (Lq == Lk ? flash_fwd2_kernel<0, 0, true> : flash_fwd2_kernel<1, 0, true>);
-#ifdef SVI_ABLATIONS       // timing-only ablations (tools/attn_ab.py; results wrong), see the kernel's ABL parameter: variant builds only
+        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*);
+        const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
+        dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
+        const long nwg = (long)grid2.x * grid2.y;
+        // optimistic pass + flagged second pass (see the kernel's MODE): needs the per-device flag words
+        int* flags = nullptr;
+        bool two_pass = sw.flash_two_pass != 0 && nwg <= SVI_FLASH_MAX_FLAGS;
+#ifdef SVI_ABLATIONS
+        if (sw.flash_abl) two_pass = false;
+#endif
+        if (two_pass) SVI_TRY(flash_flags(&flags));
+        kern_t kern;
+        if (two_pass)
+            kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false, 1> : flash_fwd2_kernel<1, 0, false, 1>)
+                               : (Lq == Lk ? flash_fwd2_kernel<0, 0, true, 1> : flash_fwd2_kernel<1, 0, true, 1>);
+        else
+            kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false> : flash_fwd2_kernel<1, 0, false>)
+                               : (Lq == Lk ? flash_fwd2_kernel<0, 0, true> : flash_fwd2_kernel<1, 0, true>);
+#ifdef SVI_ABLATIONS       // timing-only ablations (tools/attn_abl.py; results wrong), see the kernel's ABL parameter: variant builds only
         switch (q_prescaled ? sw.flash_abl : 0) {
             case 1: kern = flash_fwd2_kernel<0, 1>; break;
             case 2: kern = flash_fwd2_kernel<0, 2>; break;
@@ -868,14 +936,20 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
             case 128: kern = flash_fwd2_kernel<0, 128>; break;
             case 256: kern = flash_fwd2_kernel<0, 256>; break;
             case 768: kern = flash_fwd2_kernel<0, 768>; break;
+            case 1024: kern = flash_fwd2_kernel<0, 1024>; break;
             default: break;
         }
 #endif
-        const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
         SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(kern), lds2));
-        dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
-        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e);
+        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags);
         SVI_LAUNCH_CHECK();
+        if (two_pass) {
+            kern_t safe = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false, 2> : flash_fwd2_kernel<1, 0, false, 2>)
+                                      : (Lq == Lk ? flash_fwd2_kernel<0, 0, true, 2> : flash_fwd2_kernel<1, 0, true, 2>);
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(safe), lds2));
+            hipLaunchKernelGGL(safe, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags);
+            SVI_LAUNCH_CHECK();
+        }
         return SVI_OK;
     }
     SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(flash_fwd_kernel<0>), lds));
