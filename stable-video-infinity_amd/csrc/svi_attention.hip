@@ -937,6 +937,12 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
             case 256: kern = flash_fwd2_kernel<0, 256>; break;
             case 768: kern = flash_fwd2_kernel<0, 768>; break;
             case 1024: kern = flash_fwd2_kernel<0, 1024>; break;
+            case 1025: kern = flash_fwd2_kernel<0, 1025>; break;      // the combinations below: on top of the optimistic loop (1024)
+            case 1028: kern = flash_fwd2_kernel<0, 1028>; break;
+            case 1032: kern = flash_fwd2_kernel<0, 1032>; break;
+            case 1280: kern = flash_fwd2_kernel<0, 1280>; break;
+            case 1792: kern = flash_fwd2_kernel<0, 1792>; break;
+            case 1039: kern = flash_fwd2_kernel<0, 1039>; break;
             default: break;
         }
 #endif
