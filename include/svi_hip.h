@@ -74,7 +74,7 @@ int32_t svi_abi_version(void);
 /* Number of visible HIP devices (0 => every compute entry point will fail with SVI_ERR_HIP). */
 int32_t svi_device_count(void);
 
-/* A/B tooling: the library reads its environment switches (SVI_FLASH_KERNEL, SVI_GEMM_KERNEL, SVI_GEMM_GM, SVI_VAE_EXACT_FP32 —
+/* A/B tooling: the library reads its environment switches (SVI_FLASH_KERNEL, SVI_FLASH_TWO_PASS, SVI_GEMM_KERNEL, SVI_GEMM_GM, SVI_VAE_EXACT_FP32 —
  * all of them select between kernels that compute the same result) once, at first use; tools that flip them inside one process
  * call this afterwards.  Switches that change results exist only in variant builds (-DSVI_ABLATIONS), never in the product. */
 svi_status svi_switches_reload(void);
