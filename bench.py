@@ -142,6 +142,8 @@ def main() -> None:
                     "(one 4.2 MB all-gather per step); needs an even --gpus. Default is one clip per rank.")
     ap.add_argument("--seq-parallel", action="store_true", help="SURVEY 8e-3: ONE clip on all ranks (strong scaling): every forward is "
                     "spread Ulysses-style over the ranks (K / V all-gather fallback when the heads do not divide); with --cfg-pair: 2 CFG branches x N/2 sequence shards")
+    ap.add_argument("--fp8-storage", action="store_true", help="the reference's FP8 mode (test_svi.py:337): parameters stored as float8_e4m3fn; the exact "
+                    "cast to bf16 happens once at bind time, arithmetic stays bf16 (a separate line, never the headline)")
     ap.add_argument("--graph", action="store_true", help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)): for the "
                     "launch-bound regime (--workload c1); per-kernel event timing is off under capture, so `roofline` is null")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -152,7 +154,7 @@ def main() -> None:
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("SVI_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))      # SVI_BENCH_DEVICE: pin every rank to one device (a probe only)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -171,7 +173,10 @@ def main() -> None:
     cfg = dict(getattr(synth, wl.get("model", "WAN_1_3B")))
     D, F, NL, heads = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"], cfg["dim"] // 128
     dit = svi_hip.WanDiT(eps=1e-6, num_heads=heads, **cfg)
-    dit.bind(device_weights(cfg, 0, dev))
+    weights = device_weights(cfg, 0, dev)
+    if args.fp8_storage:
+        weights = {k: v.to(torch.float8_e4m3fn) for k, v in weights.items()}
+    dit.bind(weights)
     pair, units, sp_group, sp = None, world, None, False
     if args.seq_parallel and dist is not None:
         sp, units = True, 1
@@ -321,7 +326,7 @@ def main() -> None:
                    "value_includes_vae_decode": vae_ms is not None,
                    "dit_only_value": round(units * frames / clip_s_dit, 5),
                    "dit_tflops": round(2 * flops_forward / (ms_per_step * 1e-3) / 1e12, 1),
-                   "hip_graph": bool(args.graph),
+                   "hip_graph": bool(args.graph), "weights": "float8_e4m3fn storage, cast to bf16 at bind (reference FP8 mode)" if args.fp8_storage else "bf16",
                    "outputs_finite": finite},
         "roofline": roof,
         "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
