@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 3
+#define SVI_HIP_ABI_VERSION 4
 
 typedef enum {
     SVI_OK = 0,
@@ -294,6 +294,47 @@ svi_status svi_pose_bind_weight(svi_pose* h, const char* name, const void* dev_p
 svi_status svi_pose_check_bound(svi_pose* h);
 svi_status svi_pose_tokens(svi_pose* h, int32_t F, int32_t H, int32_t W, int32_t* f, int32_t* hh, int32_t* ww);
 svi_status svi_pose_forward(svi_pose* h, const float* pose, void* out, int32_t F, int32_t H, int32_t W, svi_stream stream);
+
+/* ------------------------------------------------------------------ prompt-side encoders ------- */
+/* WanTextEncoder (models/wan_video_text_encoder.py:209-256): the umT5 encoder behind WanPrompter.encode_prompt
+ * (prompters/wan_prompter.py:99-112), bf16 as the pipeline keeps it.  Per block: T5LayerNorm, attention WITHOUT the 1/sqrt(d) scale and
+ * with a relative-position bias (per layer unless shared_pos), gated-GELU feed-forward; dropout is the identity (eval).
+ * Weight names are the module's state-dict keys ("token_embedding.weight", "blocks.<i>.attn.q.weight", "blocks.<i>.ffn.gate.0.weight",
+ * "blocks.<i>.pos_embedding.embedding.weight", "norm.weight", ...), bf16, borrowed.
+ *   svi_t5_forward: ids int64 [L] (device); the reference's mask is the tokenizer's prefix mask, given as n_valid = mask.sum():
+ *   keys = positions < n_valid.  Query rows < `rows` (n_valid <= rows <= L) are computed, the rest of out bf16 [L, dim] is zero:
+ *   rows = L reproduces text_encoder(ids, mask); rows = n_valid reproduces encode_prompt (it zeroes rows >= n_valid, :110-111).
+ *   svi_t5_relative_buckets: host-only; T5RelativeEmbedding._relative_position_bucket (:175-194, bidirectional) for
+ *   rel = key - query in -(len-1) .. len-1, out[rel + len - 1]. */
+typedef struct svi_t5_config {
+    int32_t vocab, dim, dim_attn, dim_ffn, num_heads, num_layers, num_buckets, max_dist, shared_pos;
+} svi_t5_config;
+typedef struct svi_t5 svi_t5;
+svi_status svi_t5_create(const svi_t5_config* cfg, svi_t5** out);
+svi_status svi_t5_destroy(svi_t5* h);
+svi_status svi_t5_bind_weight(svi_t5* h, const char* name, const void* dev_ptr, svi_dtype dtype, const int64_t* shape, int32_t rank);
+svi_status svi_t5_check_bound(svi_t5* h);
+svi_status svi_t5_forward(svi_t5* h, const int64_t* ids, int32_t L, int32_t n_valid, int32_t rows, void* out, svi_stream stream);
+svi_status svi_t5_relative_buckets(int32_t num_buckets, int32_t max_dist, int32_t len, int32_t* out);
+
+/* WanImageEncoder.encode_image (models/wan_video_image_encoder.py:864-880): bicubic resize to image_size^2 (align_corners=False),
+ * v*0.5+0.5, CLIP mean/std normalisation, then VisionTransformer.forward(use_31_block=True) (:456-478): bias-free patch embedding,
+ * class token, positional embedding, pre_norm, and the first layers_used (= num_layers - 1) pre-norm blocks (fused qkv, softmax
+ * attention with 1/sqrt(d), exact GELU MLP).  fp32 throughout, as SVI runs this module (pipelines/svi_video.py:307-309) — on the exact
+ * fp32 MFMA kernel.  Weight names are VisionTransformer's state-dict keys (WanImageEncoder's "model.visual." prefix stripped), fp32,
+ * borrowed; post_norm.*, head and blocks >= layers_used are accepted and ignored.
+ *   images f32 [B, 3, H, W] in [-1, 1]  ->  out f32 [B, tokens, dim]   (tokens = (image_size/patch_size)^2 + 1: 257 x 1280 for ViT-H/14) */
+typedef struct svi_clip_config {
+    int32_t image_size, patch_size, dim, mlp_ratio, num_heads, num_layers, layers_used;
+    float norm_eps;
+} svi_clip_config;
+typedef struct svi_clip svi_clip;
+svi_status svi_clip_create(const svi_clip_config* cfg, svi_clip** out);
+svi_status svi_clip_destroy(svi_clip* h);
+svi_status svi_clip_bind_weight(svi_clip* h, const char* name, const void* dev_ptr, svi_dtype dtype, const int64_t* shape, int32_t rank);
+svi_status svi_clip_check_bound(svi_clip* h);
+svi_status svi_clip_tokens(svi_clip* h, int32_t* tokens, int32_t* dim);
+svi_status svi_clip_encode_image(svi_clip* h, const float* images, int32_t B, int32_t H, int32_t W, float* out, svi_stream stream);
 
 #ifdef __cplusplus
 }

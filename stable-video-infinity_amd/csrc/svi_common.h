@@ -183,3 +183,6 @@ svi_status svi_launch_video_to_u8(const float* video, unsigned char* out, long t
 svi_status svi_launch_u8_to_video(const unsigned char* frames, float* out, int n, long hw, hipStream_t st);
 svi_status svi_launch_sub_bf16(bf16* out, const bf16* a, const bf16* b, int64_t n, hipStream_t st);
 svi_status svi_launch_fp8_e4m3_to_bf16(const unsigned char* in, bf16* out, int64_t n, hipStream_t st);
+// fp32 C[M,N] = A[M,K] W[N,K]^T + bias[N] (+ res[M,N]) on the exact-fp32 MFMA kernel of the VAE (csrc/svi_vae.hip)
+svi_status svi_launch_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                               const float* res, int ldres, hipStream_t st);

@@ -593,6 +593,26 @@ svi_status launch_conv(const ConvP& p, hipStream_t st) {
     return SVI_OK;
 }
 
+}  // namespace
+
+// fp32 linear layer C = A W^T + bias (+ res) on the exact-fp32 MFMA kernel (a 1x1x1 "convolution": pixels = rows).  Used by the CLIP
+// image encoder, which the reference runs in fp32 (pipelines/svi_video.py:307-309).
+svi_status svi_launch_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* Cm, int ldc, int M, int N, int K,
+                               const float* res, int ldres, hipStream_t st) {
+    SVI_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm_f32: K and the leading dimensions must be multiples of 4");
+    SVI_REQUIRE(lda >= K && ldw >= K && ldc >= N && (!res || ldres >= N), "gemm_f32: leading dimensions too small");
+    SVI_REQUIRE((((uintptr_t)A | (uintptr_t)W) & 15) == 0, "gemm_f32: operands must be 16-byte aligned");
+    if (M == 0) return SVI_OK;
+    ConvP g{};
+    g.in = A; g.Ti = 1; g.Hi = 1; g.Wi = M; g.Cin = K; g.ld_in = lda;
+    g.w = W; g.ld_w = ldw; g.bias = bias;
+    g.out = Cm; g.To = 1; g.Ho = 1; g.Wo = M; g.Cout = N; g.ld_out = ldc;
+    g.kt = g.kh = g.kw = 1; g.st = g.sh = g.sw = 1;
+    g.res = res; g.ld_res = ldres;
+    return launch_conv(g, st);
+}
+
+namespace {
 // ---- RMS_norm over channels (+SiLU):  x / max(||x||_2, 1e-12) * sqrt(C) * gamma   (vae:55-70, 207-209) ----
 // One 32-lane half-wave per pixel; lane owns channels lane + 32 i.
 template <int MAXI>

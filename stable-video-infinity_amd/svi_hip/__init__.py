@@ -13,8 +13,9 @@ from .vae import WanVideoVAE
 from .conditioning import condition_mask, condition_video, image_condition
 from .teacache import TeaCache
 from .pose import PoseEmbedder
+from .encoders import WanImageEncoder, WanTextEncoder
 from . import checkpoint, lora, sequence_parallel
 from .stream import StreamLoop, u8_to_video, video_to_u8
 
 __all__ = ["WanDiT", "model_fn_wan_video", "model_fn_wan_talk_video", "cfg3_step_", "flash_attention", "layernorm_modulate", "rmsnorm_rope_", "linear",
-           "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "WanVideoVAE", "condition_mask", "condition_video", "image_condition", "TeaCache", "PoseEmbedder", "StreamLoop", "video_to_u8", "u8_to_video", "_lib"]
+           "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "WanVideoVAE", "condition_mask", "condition_video", "image_condition", "TeaCache", "PoseEmbedder", "WanTextEncoder", "WanImageEncoder", "StreamLoop", "video_to_u8", "u8_to_video", "_lib"]

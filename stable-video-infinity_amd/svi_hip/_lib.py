@@ -25,6 +25,16 @@ class DitConfig(C.Structure):
                 ("num_heads", _i32), ("num_layers", _i32), ("has_image_input", _i32), ("enable_multitalk", _i32)]
 
 
+class T5Config(C.Structure):
+    _fields_ = [("vocab", _i32), ("dim", _i32), ("dim_attn", _i32), ("dim_ffn", _i32), ("num_heads", _i32), ("num_layers", _i32),
+                ("num_buckets", _i32), ("max_dist", _i32), ("shared_pos", _i32)]
+
+
+class ClipConfig(C.Structure):
+    _fields_ = [("image_size", _i32), ("patch_size", _i32), ("dim", _i32), ("mlp_ratio", _i32), ("num_heads", _i32), ("num_layers", _i32),
+                ("layers_used", _i32), ("norm_eps", _f32)]
+
+
 SYMBOLS = [
     ("svi_last_error", C.c_char_p, []),
     ("svi_abi_version", _i32, []),
@@ -76,6 +86,18 @@ SYMBOLS = [
     ("svi_pose_check_bound", _i32, [_vp]),
     ("svi_pose_tokens", _i32, [_vp, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     ("svi_pose_forward", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("svi_t5_create", _i32, [C.POINTER(T5Config), C.POINTER(_vp)]),
+    ("svi_t5_destroy", _i32, [_vp]),
+    ("svi_t5_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
+    ("svi_t5_check_bound", _i32, [_vp]),
+    ("svi_t5_forward", _i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    ("svi_t5_relative_buckets", _i32, [_i32, _i32, _i32, C.POINTER(_i32)]),
+    ("svi_clip_create", _i32, [C.POINTER(ClipConfig), C.POINTER(_vp)]),
+    ("svi_clip_destroy", _i32, [_vp]),
+    ("svi_clip_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
+    ("svi_clip_check_bound", _i32, [_vp]),
+    ("svi_clip_tokens", _i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    ("svi_clip_encode_image", _i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
 ]
 
 _lib = None

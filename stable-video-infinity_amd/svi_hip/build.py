@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libsvi_hip.so")
-SOURCES = ["svi_api.hip", "svi_elementwise.hip", "svi_gemm.hip", "svi_attention.hip", "svi_dit.hip", "svi_vae.hip"]
+SOURCES = ["svi_api.hip", "svi_elementwise.hip", "svi_gemm.hip", "svi_attention.hip", "svi_dit.hip", "svi_vae.hip", "svi_encoders.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

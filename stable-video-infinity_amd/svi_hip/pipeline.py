@@ -240,7 +240,7 @@ def _hip_talk_fn(dit_module, x, timestep, context, clip_feature=None, y=None, te
                                    use_controlnet=use_controlnet)
 
 
-def install(pipe, vae: bool = True):
+def install(pipe, vae: bool = True, encoders: bool = True):
     """Route `pipe`'s hot path (SVIVideoPipeline / WanVideoPipeline of the reference) through libsvi_hip.
 
     * `model_fn_wan_video` in the pipeline's defining module is replaced by the HIP-backed function
@@ -248,6 +248,9 @@ def install(pipe, vae: bool = True):
     * `pipe.vae.encode/decode` are rebound to the HIP VAE (same signatures), when `vae` is true;
     * `pipe.dit` stays the reference nn.Module: weights are borrowed, so call `install` again (or
       `pipe._svi_hip_dit.rebind()`) after `load_lora_v2`, `.to()` or any offload that moves storage.
+    * with `encoders`: the prompter's `text_encoder(ids, mask)` (prompters/wan_prompter.py:109) and `pipe.image_encoder.encode_image`
+      (svi_video.py:317) go to the HIP encoders when those modules are on the GPU (text encoder in bf16; the image encoder's
+      parameters are copied to fp32, the precision SVI switches that module to around the call, :307-309).
     CPU offload / VRAM management must stay off (288 GB HBM holds every model resident).
     """
     dit_module = pipe.dit
@@ -273,4 +276,18 @@ def install(pipe, vae: bool = True):
                                            tile_stride=(18, 16): hv.encode(videos, device, tiled, tile_size, tile_stride), pipe.vae)
         pipe.vae.decode = types.MethodType(lambda self, hidden_states, device=None, tiled=False, tile_size=(34, 34),
                                            tile_stride=(18, 16): hv.decode(hidden_states, device, tiled, tile_size, tile_stride), pipe.vae)
+    if encoders:
+        from .encoders import WanImageEncoder, WanTextEncoder
+        te = getattr(pipe, "text_encoder", None)
+        prompter = getattr(pipe, "prompter", None)
+        if te is not None and prompter is not None:
+            q = next(te.parameters())
+            if q.is_cuda and q.dtype == torch.bfloat16:
+                pipe._svi_hip_text_encoder = ht = WanTextEncoder.from_module(te)
+                # encode_prompt zeroes the padded rows right after the call (:110-111): compute the valid ones only
+                prompter.text_encoder = lambda ids, mask=None: ht.forward(ids, mask, rows="valid")
+        ie = getattr(pipe, "image_encoder", None)
+        if ie is not None and next(ie.parameters()).is_cuda:
+            pipe._svi_hip_image_encoder = hi = WanImageEncoder.from_module(ie)
+            ie.encode_image = types.MethodType(lambda self, videos: hi.encode_image(videos), ie)
     return pipe

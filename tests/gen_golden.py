@@ -45,7 +45,7 @@ def import_reference():
             return type(k, (object,), {})
 
     for n in ("diffusers", "diffusers.configuration_utils", "xfuser", "xfuser.core", "xfuser.core.distributed",
-              "xformers", "xformers.ops", "imageio", "torchvision"):
+              "xformers", "xformers.ops", "imageio", "torchvision", "torchvision.transforms"):
         sys.modules.setdefault(n, Stub(n))
     sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
     # AudioProjModel(ModelMixin, ConfigMixin) (wan_video_dit.py:44) must be a real nn.Module for its parameters to register
@@ -631,6 +631,85 @@ def gen_talk(dit_mod, fm):
     np.savez(os.path.join(OUT, "dit_tiny_talk.npz"), **out)
 
 
+def gen_t5():
+    """Row N4: the reference's own WanTextEncoder (models/wan_video_text_encoder.py) on seeded weights, in fp32 and as the bf16 module the
+    pipeline keeps, driven through WanPrompter.encode_prompt (prompters/wan_prompter.py:99-112, compiled out of the source file) with a
+    stand-in tokenizer that hands over seeded (ids, mask); plus the relative-position bucket table of T5RelativeEmbedding."""
+    te = importlib.import_module("diffsynth.models.wan_video_text_encoder")
+    encode_prompt = _reference_method("diffsynth/prompters/wan_prompter.py", "WanPrompter", "encode_prompt", {"torch": torch})
+    out = {}
+    rel = torch.arange(512).unsqueeze(0) - torch.arange(512).unsqueeze(1)          # key - query, as T5RelativeEmbedding.forward builds it
+    buckets = te.T5RelativeEmbedding(32, 64, bidirectional=True)._relative_position_bucket(rel)
+    out["buckets_512"] = np.concatenate([buckets[-1, :511].numpy()[::1], buckets[0].numpy()]).astype(np.int32)     # rel = -511..-1, 0..511
+    assert all(int(buckets[i, j]) == int(out["buckets_512"][j - i + 511]) for i, j in ((0, 0), (5, 300), (300, 5), (511, 0), (0, 511), (100, 132)))
+
+    def run(cfg, seed, cases, rows=None):
+        sd = {k: t(a) for k, a in synth.t5_state_dict(seed, **cfg).items()}
+        for dtype, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+            m = te.WanTextEncoder(**cfg).eval()
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dtype)
+
+            class Prompter:
+                text_encoder = m
+
+                def process_prompt(self, prompt, positive=True):
+                    return prompt
+
+            for name, L, valid, cseed in cases:
+                ids, mask = synth.t5_ids(cseed, L, valid, cfg["vocab"])
+                me = Prompter()
+                me.tokenizer = lambda prompt, return_mask, add_special_tokens: (t(ids), t(mask))
+                with torch.no_grad():
+                    full = m(t(ids), t(mask)).float().numpy()[0]
+                    emb = encode_prompt(me, "a prompt", positive=True, device="cpu").float().numpy()[0]
+                assert np.array_equal(emb[:valid], full[:valid]) and not emb[valid:].any()
+                out[f"{name}_{tag}"] = full if rows is None else full[rows]
+                print("t5", name, tag, full.shape, float(np.abs(full).max()))
+
+    run(synth.T5_TINY, synth.T5_SEED, synth.T5_TINY_CASES)
+    run(synth.T5_XXL_BLOCK, synth.T5_SEED + 1, [synth.T5_XXL_CASE], synth.T5_XXL_ROWS)
+    np.savez(os.path.join(OUT, "t5_encoder.npz"), **out)
+
+
+def gen_clip():
+    """Row N4: WanImageEncoder.encode_image (models/wan_video_image_encoder.py:864-880), compiled out of the source file, around the
+    reference's own VisionTransformer built the way XLMRobertaCLIP builds it (:686-701), fp32 as SVI runs it.  torchvision is absent in
+    the build container: `self.transforms.transforms[-1]` is stated as what torchvision.transforms.Normalize does, (x - mean) / std
+    per channel with the CLIP constants of :783-784."""
+    ie = importlib.import_module("diffsynth.models.wan_video_image_encoder")
+    import torch.nn.functional as F
+    encode_image = _reference_method("diffsynth/models/wan_video_image_encoder.py", "WanImageEncoder", "encode_image", {"torch": torch, "F": F})
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    out = {}
+
+    def run(cfg, seed, cases, rows=None):
+        vis = ie.VisionTransformer(image_size=cfg["image_size"], patch_size=cfg["patch_size"], dim=cfg["dim"], mlp_ratio=cfg["mlp_ratio"],
+                                   out_dim=1024 if cfg["dim"] == 1280 else 64, num_heads=cfg["num_heads"], num_layers=cfg["num_layers"],
+                                   pool_type="token", pre_norm=True, post_norm=False, activation="gelu", norm_eps=1e-5).eval()
+        vis.load_state_dict({k: t(a) for k, a in synth.clip_state_dict(seed, **cfg).items()}, strict=True)
+
+        class Model:
+            image_size = cfg["image_size"]
+            visual = vis
+
+        class Self:
+            model = Model()
+            transforms = types.SimpleNamespace(transforms=[lambda x: x.sub_(mean).div_(std)])
+
+        for name, shape, cseed in cases:
+            img = synth.clip_image(cseed, *shape)
+            with torch.no_grad():
+                o = encode_image(Self(), [t(img.copy())]).numpy()
+            out[name] = o if rows is None else o[:, rows]
+            print("clip", name, o.shape, float(np.abs(o).max()))
+
+    run(synth.CLIP_TINY, synth.CLIP_SEED, synth.CLIP_TINY_CASES)
+    run(synth.CLIP_H_BLOCK, synth.CLIP_SEED + 1, [synth.CLIP_H_CASE], synth.CLIP_H_ROWS)
+    np.savez(os.path.join(OUT, "clip_encoder.npz"), **out)
+
+
 def main(argv=None):
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -653,6 +732,8 @@ def main(argv=None):
         "dit_tiny_talk": lambda: gen_talk(dit_mod, fm),
         "pose_embed": gen_pose_embed,
         "dance_sampler": lambda: gen_dance_sampler(dit_mod, fm),
+        "t5_encoder": gen_t5,
+        "clip_encoder": gen_clip,
         "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),
     }
     names = list(argv if argv is not None else sys.argv[1:]) or list(jobs)

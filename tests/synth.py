@@ -295,3 +295,111 @@ TALK_SEED, TALK_GRID = 800, (3, 4, 6)
 def audio_windows(seed: int, frames: int):
     """audio_embed_tuple of one clip (svi_video_talk.py:425-444): first-frame window [1, 1, 5, 12, 768], later frames [1, f-1, 8, 12, 768]."""
     return 0.5 * randn(seed, 1, 1, 5, 12, 768), 0.5 * randn(seed + 1, 1, frames - 1, 8, 12, 768)
+
+
+# ----------------------------------------------------------------------------------- prompt-side encoders (golden/t5_*.npz, clip_*.npz)
+T5_TINY = dict(vocab=200, dim=128, dim_attn=128, dim_ffn=256, num_heads=2, num_layers=2, num_buckets=32, shared_pos=False)
+T5_XXL_BLOCK = dict(vocab=512, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=1, num_buckets=32, shared_pos=False)   # text_encoder:211-220 widths
+T5_SEED = 900
+T5_TINY_CASES = [("short", 24, 13, 901), ("long", 160, 160, 902), ("one", 16, 1, 903)]      # (name, L, valid tokens, seed)
+T5_XXL_CASE = ("xxl", 64, 40, 905)
+T5_XXL_ROWS = [0, 1, 7, 19, 38, 39, 40, 63]
+
+
+def t5_param_shapes(vocab, dim, dim_attn, dim_ffn, num_heads, num_layers, num_buckets, shared_pos) -> "OrderedDict[str, tuple]":
+    """WanTextEncoder.state_dict() (wan_video_text_encoder.py:209-238)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["token_embedding.weight"] = (vocab, dim)
+    if shared_pos:
+        s["pos_embedding.embedding.weight"] = (num_buckets, num_heads)
+    for i in range(num_layers):
+        p = f"blocks.{i}."
+        s[p + "norm1.weight"] = (dim,)
+        for n in "qkv":
+            s[p + f"attn.{n}.weight"] = (dim_attn, dim)
+        s[p + "attn.o.weight"] = (dim, dim_attn)
+        s[p + "norm2.weight"] = (dim,)
+        s[p + "ffn.gate.0.weight"] = (dim_ffn, dim)
+        s[p + "ffn.fc1.weight"] = (dim_ffn, dim)
+        s[p + "ffn.fc2.weight"] = (dim, dim_ffn)
+        if not shared_pos:
+            s[p + "pos_embedding.embedding.weight"] = (num_buckets, num_heads)
+    s["norm.weight"] = (dim,)
+    return s
+
+
+def t5_state_dict(seed: int, **cfg) -> Dict[str, np.ndarray]:
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    for k, shp in t5_param_shapes(**cfg).items():
+        if k.endswith("pos_embedding.embedding.weight"):
+            out[k] = rs.standard_normal(shp).astype(np.float32)            # a bias of order 1 per bucket: a wrong bucket is visible
+        elif k == "token_embedding.weight":
+            out[k] = rs.standard_normal(shp).astype(np.float32)
+        else:
+            out[k] = _fill(rs, k, shp)
+    return out
+
+
+def t5_ids(seed: int, L: int, valid: int, vocab: int):
+    """(ids, mask) as the tokenizer hands them over: `valid` tokens then pad id 0."""
+    rs = np.random.RandomState(seed)
+    ids = np.zeros((1, L), np.int64)
+    ids[0, :valid] = rs.randint(1, vocab, size=valid)
+    mask = np.zeros((1, L), np.int64)
+    mask[0, :valid] = 1
+    return ids, mask
+
+
+CLIP_TINY = dict(image_size=28, patch_size=14, dim=160, mlp_ratio=4, num_heads=2, num_layers=3)
+CLIP_H_BLOCK = dict(image_size=224, patch_size=14, dim=1280, mlp_ratio=4, num_heads=16, num_layers=2)     # image_encoder:826-834 widths, 2 of 32 blocks
+CLIP_SEED = 950
+CLIP_TINY_CASES = [("down", (1, 3, 40, 56), 951), ("up", (1, 3, 20, 24), 952), ("batch2", (2, 3, 28, 28), 953)]      # (name, image shape, seed)
+CLIP_H_CASE = ("h14", (1, 3, 480, 832), 955)
+CLIP_H_ROWS = [0, 1, 2, 15, 16, 17, 100, 128, 200, 255, 256]
+
+
+def clip_param_shapes(image_size, patch_size, dim, mlp_ratio, num_heads, num_layers) -> "OrderedDict[str, tuple]":
+    """VisionTransformer.state_dict() as XLMRobertaCLIP builds it (wan_video_image_encoder.py:386-454: pool 'token', pre_norm, no
+    patch-embedding bias)."""
+    n = (image_size // patch_size) ** 2 + 1
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["cls_embedding"] = (1, 1, dim)
+    s["pos_embedding"] = (1, n, dim)
+    s["patch_embedding.weight"] = (dim, 3, patch_size, patch_size)
+    s["pre_norm.weight"] = (dim,)
+    s["pre_norm.bias"] = (dim,)
+    for i in range(num_layers):
+        p = f"transformer.{i}."
+        s[p + "norm1.weight"] = (dim,); s[p + "norm1.bias"] = (dim,)
+        s[p + "attn.to_qkv.weight"] = (3 * dim, dim); s[p + "attn.to_qkv.bias"] = (3 * dim,)
+        s[p + "attn.proj.weight"] = (dim, dim); s[p + "attn.proj.bias"] = (dim,)
+        s[p + "norm2.weight"] = (dim,); s[p + "norm2.bias"] = (dim,)
+        s[p + "mlp.0.weight"] = (dim * mlp_ratio, dim); s[p + "mlp.0.bias"] = (dim * mlp_ratio,)
+        s[p + "mlp.2.weight"] = (dim, dim * mlp_ratio); s[p + "mlp.2.bias"] = (dim,)
+    s["post_norm.weight"] = (dim,)
+    s["post_norm.bias"] = (dim,)
+    s["head"] = (dim, 1024 if dim == 1280 else 64)
+    return s
+
+
+def clip_state_dict(seed: int, **cfg) -> Dict[str, np.ndarray]:
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    for k, shp in clip_param_shapes(**cfg).items():
+        if k in ("cls_embedding", "pos_embedding", "head"):
+            out[k] = (rs.standard_normal(shp) / math.sqrt(cfg["dim"])).astype(np.float32)
+        elif k.endswith("to_qkv.weight"):
+            out[k] = (rs.standard_normal(shp) * (3.0 / math.sqrt(cfg["dim"]))).astype(np.float32)      # sharp (non-uniform) attention rows
+        else:
+            out[k] = _fill(rs, k, shp)
+    return out
+
+
+def clip_image(seed: int, *shape) -> np.ndarray:
+    """An image batch as preprocess_image hands it over: fp32 in [-1, 1], smooth + texture."""
+    rs = np.random.RandomState(seed)
+    b, c, h, w = shape
+    yy, xx = np.meshgrid(np.linspace(0, 3, h), np.linspace(0, 4, w), indexing="ij")
+    base = np.sin(yy[None, None] * (1 + np.arange(c)[None, :, None, None])) * np.cos(xx[None, None] + np.arange(b)[:, None, None, None])
+    return np.clip(0.7 * base + 0.3 * rs.uniform(-1, 1, size=shape), -1, 1).astype(np.float32)

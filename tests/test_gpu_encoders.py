@@ -1,0 +1,148 @@
+"""-m gpu: the prompt-side encoders through the C ABI against outputs of the reference's own WanTextEncoder (via
+WanPrompter.encode_prompt) and WanImageEncoder.encode_image (tests/golden/t5_encoder.npz, clip_encoder.npz) and the CPU oracle.
+
+Tolerances.  Text encoder (a bf16 module in the reference): rel-L2 <= 2e-3 against the oracle with the same bf16 rounding points
+(different summation order inside the matmuls only; measured 0 to 3e-4), <= 1.2e-2 against the reference in fp32 and <= 6e-3 against
+the reference module cast to bf16 — the reference's own bf16 run differs from its fp32 run by 4.7e-3 to 6.5e-3 (measured 4.6e-3 to
+6.4e-3 and 1.5e-3 to 2.6e-3, profiles/r2m_parity_report.jsonl).  Image encoder (fp32 in the reference): rel-L2 <= 2e-5, max-abs <= 2e-4 of a unit-scale output."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import rel_l2
+from gpu_util import bf16r, errs, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import svi_hip
+    return svi_hip
+
+
+def _t(d):
+    return {k: torch.from_numpy(v) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module")
+def t5_tiny(hip):
+    sd = _t(synth.t5_state_dict(synth.T5_SEED, **synth.T5_TINY))
+    return hip.WanTextEncoder.from_state_dict(sd), sd
+
+
+@pytest.mark.parametrize("name,L,valid,seed", synth.T5_TINY_CASES)
+def test_t5_tiny(t5_tiny, golden, name, L, valid, seed):
+    from oracle import encoders_oracle as eo
+    g = golden("t5_encoder.npz")
+    m, sd = t5_tiny
+    assert (m.dim, m.num_heads, m.num_layers, m.shared_pos) == (128, 2, 2, False)
+    ids, mask = synth.t5_ids(seed, L, valid, synth.T5_TINY["vocab"])
+    full = m(torch.from_numpy(ids), torch.from_numpy(mask))
+    assert full.dtype == torch.bfloat16 and tuple(full.shape) == (1, L, 128)
+    with torch.no_grad():
+        want = eo.t5_encode(sd, torch.from_numpy(ids[0]), valid, synth.T5_TINY, "bf16")
+    r_or, mx, _ = errs(full[0], want)
+    r32 = errs(full[0], g[f"{name}_fp32"])[0]
+    r16 = errs(full[0], g[f"{name}_bf16"])[0]
+    report(f"t5_tiny_{name}", vs_oracle_bf16=r_or, vs_ref_fp32=r32, vs_ref_bf16=r16, ref_bf16_vs_fp32=rel_l2(g[f"{name}_bf16"], g[f"{name}_fp32"]), max_abs=mx)
+    assert r_or < 2e-3 and r32 < 1.2e-2 and r16 < 6e-3, (r_or, r32, r16)
+    # encode_prompt's view: only the valid rows are computed, the rest is zero; the computed rows are the same bits
+    part = m.forward(torch.from_numpy(ids), torch.from_numpy(mask), rows="valid")
+    assert torch.equal(part[0, :valid], full[0, :valid]) and not bool(part[0, valid:].any())
+    again = m(torch.from_numpy(ids), torch.from_numpy(mask))
+    assert torch.equal(again, full)
+
+
+def test_t5_xxl_block_widths(hip, golden):
+    """One block at the umT5-XXL widths (dim 4096, 64 heads of 64, ffn 10240)."""
+    g = golden("t5_encoder.npz")
+    cfg = synth.T5_XXL_BLOCK
+    name, L, valid, seed = synth.T5_XXL_CASE
+    m = hip.WanTextEncoder.from_state_dict(_t(synth.t5_state_dict(synth.T5_SEED + 1, **cfg)))
+    ids, mask = synth.t5_ids(seed, L, valid, cfg["vocab"])
+    out = m(torch.from_numpy(ids), torch.from_numpy(mask))[0]
+    r32 = errs(out[synth.T5_XXL_ROWS], g["xxl_fp32"])[0]
+    r16 = errs(out[synth.T5_XXL_ROWS], g["xxl_bf16"])[0]
+    report("t5_xxl_block", vs_ref_fp32=r32, vs_ref_bf16=r16, ref_bf16_vs_fp32=rel_l2(g["xxl_bf16"], g["xxl_fp32"]))
+    assert r32 < 1.2e-2 and r16 < 6e-3, (r32, r16)
+
+
+def test_t5_text_len_512(t5_tiny):
+    """The pipelines' text_len (512 positions, prompter:86): every bucket of the table is in use; valid rows only."""
+    from oracle import encoders_oracle as eo
+    m, sd = t5_tiny
+    ids, mask = synth.t5_ids(910, 512, 300, synth.T5_TINY["vocab"])
+    out = m.forward(torch.from_numpy(ids), torch.from_numpy(mask), rows="valid")
+    with torch.no_grad():
+        want = eo.encode_prompt(sd, torch.from_numpy(ids[0]), 300, synth.T5_TINY, "bf16")
+    r = errs(out[0], want)[0]
+    report("t5_tiny_512", vs_oracle_bf16=r)
+    assert r < 2e-3 and not bool(out[0, 300:].any())
+
+
+def test_t5_input_contract(hip, t5_tiny):
+    m, sd = t5_tiny
+    ids, mask = synth.t5_ids(1, 16, 5, synth.T5_TINY["vocab"])
+    bad = ids.copy(); bad[0, 2] = synth.T5_TINY["vocab"]
+    with pytest.raises(IndexError):
+        m(torch.from_numpy(bad), torch.from_numpy(mask))
+    holes = mask.copy(); holes[0, 1] = 0
+    with pytest.raises(ValueError):
+        m(torch.from_numpy(ids), torch.from_numpy(holes))
+    with pytest.raises(ValueError):
+        m(torch.from_numpy(ids), torch.from_numpy(np.zeros_like(mask)))
+    part = {k: v for k, v in sd.items() if k != "blocks.1.ffn.fc2.weight"}
+    with pytest.raises(RuntimeError, match="blocks.1.ffn.fc2.weight"):
+        hip.WanTextEncoder.from_state_dict(part, num_layers=2)
+    wrong = dict(sd); wrong["norm.weight"] = torch.ones(64)
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        hip.WanTextEncoder.from_state_dict(wrong)
+
+
+@pytest.fixture(scope="module")
+def clip_tiny(hip):
+    sd = _t(synth.clip_state_dict(synth.CLIP_SEED, **synth.CLIP_TINY))
+    return hip.WanImageEncoder.from_state_dict(sd, num_heads=2), sd
+
+
+@pytest.mark.parametrize("name,shape,seed", synth.CLIP_TINY_CASES)
+def test_clip_tiny(clip_tiny, golden, name, shape, seed):
+    g = golden("clip_encoder.npz")
+    m, _ = clip_tiny
+    assert (m.image_size, m.patch_size, m.dim, m.num_layers, m.tokens) == (28, 14, 160, 3, 5)
+    img = torch.from_numpy(synth.clip_image(seed, *shape))
+    keep = img.clone()
+    out = m.encode_image([img])
+    assert out.dtype == torch.float32 and tuple(out.shape) == g[name].shape and torch.equal(img, keep)
+    r, mx, _ = errs(out, g[name])
+    report(f"clip_tiny_{name}", rel=r, max_abs=mx)
+    assert r < 2e-5 and mx < 2e-4, (r, mx)
+    if shape[0] == 2:           # a list of single images is the concatenation
+        two = m.encode_image([img[:1], img[1:]])
+        assert torch.equal(two, out)
+
+
+def test_clip_h14_block_widths(hip, golden):
+    """ViT-H/14 widths (dim 1280, 16 heads of 80, 257 tokens), a 480x832 frame, 1 of the 31 blocks."""
+    g = golden("clip_encoder.npz")
+    name, shape, seed = synth.CLIP_H_CASE
+    m = hip.WanImageEncoder.from_state_dict(_t(synth.clip_state_dict(synth.CLIP_SEED + 1, **synth.CLIP_H_BLOCK)), num_heads=16)
+    out = m.encode_image([torch.from_numpy(synth.clip_image(seed, *shape))])
+    assert tuple(out.shape) == (1, 257, 1280)
+    r, mx, _ = errs(out[:, synth.CLIP_H_ROWS], g[name])
+    report("clip_h14_block", rel=r, max_abs=mx)
+    assert r < 2e-5 and mx < 2e-4, (r, mx)
+
+
+def test_clip_checkpoint_key_styles(hip, clip_tiny):
+    """WanImageEncoder's own keys ("model.visual."), the open-clip checkpoint's ("visual." + a text tower to skip)."""
+    m, sd = clip_tiny
+    img = torch.from_numpy(synth.clip_image(960, 1, 3, 28, 28))
+    want = m.encode_image([img])
+    a = hip.WanImageEncoder.from_state_dict({"model.visual." + k: v for k, v in sd.items()} | {"model.log_scale": torch.zeros(())}, num_heads=2)
+    b = hip.WanImageEncoder.from_state_dict({"visual." + k: v for k, v in sd.items()} | {"textual.x.weight": torch.zeros(3)}, num_heads=2)
+    assert torch.equal(a.encode_image([img]), want) and torch.equal(b.encode_image([img]), want)
+    with pytest.raises(RuntimeError, match="transformer.1.mlp.2.bias"):
+        hip.WanImageEncoder.from_state_dict({k: v for k, v in sd.items() if k != "transformer.1.mlp.2.bias"}, num_heads=2)

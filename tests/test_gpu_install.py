@@ -150,6 +150,54 @@ def test_install_rebinds_vae_methods(golden, pipeline_module):
     assert r < 2e-5 and mx < 2e-4, (r, mx)
 
 
+def test_install_routes_the_encoders(golden, pipeline_module):
+    """install(pipe) with a text encoder (bf16, GPU), a prompter and an image encoder on the pipe: the prompter's call
+    `self.text_encoder(ids, mask)` (prompters/wan_prompter.py:109) and `pipe.image_encoder.encode_image([frame])` (svi_video.py:317)
+    land on the HIP encoders; the results are the reference's (golden t5_encoder.npz / clip_encoder.npz)."""
+    import svi_hip
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    dit, _ = wan_model_double(c, seed)
+    pipe = pipeline_module.SVIVideoPipeline(dit, None)
+    pipe.text_encoder = module_from_state_dict(synth.t5_state_dict(synth.T5_SEED, **synth.T5_TINY), "cuda", torch.bfloat16)
+    name, L, valid, cseed = synth.T5_TINY_CASES[0]
+    ids, mask = synth.t5_ids(cseed, L, valid, synth.T5_TINY["vocab"])
+
+    class Prompter:                          # call form of WanPrompter.encode_prompt (:99-112)
+        text_encoder = pipe.text_encoder
+
+        def encode_prompt(self, prompt, positive=True, device="cuda"):
+            i, m = torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device)
+            seq_lens = m.gt(0).sum(dim=1).long()
+            prompt_emb = self.text_encoder(i, m)
+            for k, v in enumerate(seq_lens):
+                prompt_emb[:, v:] = 0
+            return prompt_emb
+
+    pipe.prompter = Prompter()
+    vis = module_from_state_dict(synth.clip_state_dict(synth.CLIP_SEED, **synth.CLIP_TINY), "cuda", torch.bfloat16)
+    vis.num_heads, vis.norm_eps = synth.CLIP_TINY["num_heads"], 1e-5
+    ie = _Node()
+    ie.add_module("model", _Node())
+    ie.model.add_module("visual", vis)
+    ie.encode_image = lambda videos: (_ for _ in ()).throw(AssertionError("the PyTorch image encoder was called"))
+    pipe.image_encoder = ie
+    svi_hip.install(pipe, vae=False)
+    emb = pipe.prompter.encode_prompt("a prompt")
+    g = golden("t5_encoder.npz")
+    want = g[f"{name}_fp32"].copy()
+    want[valid:] = 0
+    assert emb.dtype == torch.bfloat16 and errs(emb[0], want)[0] < 1.2e-2 and not bool(emb[0, valid:].any())
+    # the image encoder's parameters live in bf16 on the pipe; SVI casts the module to fp32 around the call: fp32 arithmetic on the
+    # bf16-rounded parameters
+    cname, shape, iseed = synth.CLIP_TINY_CASES[0]
+    img = torch.from_numpy(synth.clip_image(iseed, *shape)).cuda()
+    got = pipe.image_encoder.encode_image([img])
+    sdr = {k: torch.from_numpy(v).to(torch.bfloat16).float() for k, v in synth.clip_state_dict(synth.CLIP_SEED, **synth.CLIP_TINY).items()}
+    direct = svi_hip.WanImageEncoder.from_state_dict(sdr, num_heads=2).encode_image([img])
+    assert got.dtype == torch.float32 and torch.equal(got, direct)
+    assert errs(got, golden("clip_encoder.npz")[cname])[0] < 2e-2          # bf16-rounded parameters against the fp32-parameter golden
+
+
 def test_checkpoint_and_lora_file_on_the_device(tmp_path):
     """SURVEY §8f N4 end to end: safetensors shards -> HBM -> bound WanDiT (svi_hip.checkpoint.load_dit), then a PEFT-style LoRA file merged
     on the device (svi_hip.lora.load_lora_, name matching = the reference's get_name_dict): the forward equals the forward of a model
