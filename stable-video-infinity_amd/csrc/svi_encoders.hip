@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const T* __restrict_
         for (int r = 0; r < ENC_RQ; ++r) {
             float s = acc[r] * scale;
             if (BF16PTS) s = rbf(s);
-            if (emb) {
+            if (emb && r < nq) {                  // rows past the last query have no table entry (and no output)
                 const float b = (float)emb[(size_t)bucket_tab[j - (q0 + r) + tab_zero] * heads + head];
                 s += b;
                 if (BF16PTS) s = rbf(s);

@@ -195,7 +195,11 @@ def test_install_routes_the_encoders(golden, pipeline_module):
     sdr = {k: torch.from_numpy(v).to(torch.bfloat16).float() for k, v in synth.clip_state_dict(synth.CLIP_SEED, **synth.CLIP_TINY).items()}
     direct = svi_hip.WanImageEncoder.from_state_dict(sdr, num_heads=2).encode_image([img])
     assert got.dtype == torch.float32 and torch.equal(got, direct)
-    assert errs(got, golden("clip_encoder.npz")[cname])[0] < 2e-2          # bf16-rounded parameters against the fp32-parameter golden
+    from oracle import encoders_oracle as eo
+    with torch.no_grad():
+        want_img = eo.clip_encode_image(sdr, img.cpu(), synth.CLIP_TINY)
+    assert errs(got, want_img)[0] < 2e-5                                    # the oracle (pinned to the reference) on the same bf16-rounded parameters
+    assert errs(got, golden("clip_encoder.npz")[cname])[0] < 1e-1          # and the fp32-parameter golden within what that rounding moves (4.4e-2)
 
 
 def test_checkpoint_and_lora_file_on_the_device(tmp_path):
