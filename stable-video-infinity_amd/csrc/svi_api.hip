@@ -33,6 +33,7 @@ static SviSwitches parse_switches() {
     s.gemm_gm = env_int("SVI_GEMM_GM", 1, 0);
     s.vae_exact_fp32 = getenv("SVI_VAE_EXACT_FP32") != nullptr;
     s.flash_two_pass = env_int("SVI_FLASH_TWO_PASS", 0, 1);
+    s.vae_no_x2h = env_int("SVI_VAE_X2H", 0, 1) == 0;
 #ifdef SVI_ABLATIONS
     s.flash_abl = env_int("SVI_FLASH_ABL", 0, 0);
     s.gemm_epi_abl = env_int("SVI_GEMM_EPI_ABL", 0, 0);

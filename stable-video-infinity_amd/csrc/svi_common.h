@@ -63,6 +63,7 @@ struct SviSwitches {
     int gemm_kernel = 0;         // SVI_GEMM_KERNEL = 128 | 256 | 257 | 258 : force the 128^2 kernel / the v2 256^2 main loop / the v3 loop / the persistent v3 (0: by tile count)
     int gemm_gm = 0;             // SVI_GEMM_GM = n >= 1 : row panels per tile group (0: per shape)
     int vae_exact_fp32 = 0;      // SVI_VAE_EXACT_FP32 : fp32-MFMA convolution everywhere
+    int vae_no_x2h = 0;          // SVI_VAE_X2H = 0 : the three-term bf16 convolution also where the two-term fp16 form applies (same parity bounds)
     int flash_two_pass = 1;      // SVI_FLASH_TWO_PASS = 0 : the long-sequence attention as ONE complete pass (tracked maximum) instead of the
                                  // optimistic pass + flagged second pass (same result within the attention tolerance; bit-identical on benign operands)
 #ifdef SVI_ABLATIONS

@@ -38,6 +38,8 @@ struct ConvP {
     const float* in; int Ti, Hi, Wi, Cin, ld_in;     // stored input dims; ld_in = floats between pixels
     const float* w; int ld_w;                        // packed [tap][Cout][ld_w] (ld_w >= Cin)
     const bf16* w3; int ld_w3; long plane_w3;        // the same weights as three bf16 planes (hi | mid | lo), [plane][tap][Cout][ld_w3]
+    const void* w2h; const float* w2_inv;            // and as two fp16 planes (hi | lo) of w * 2^k(cout), same layout; w2_inv[cout] = 2^-k
+    float in_scale;                                  // > 0: a power of two s with |in| * s <= 2^15 guaranteed by the producer (norm + SiLU): the fp16 two-term kernel may run
     const float* bias;
     float* out; int To, Ho, Wo, Cout, ld_out;
     int kt, kh, kw, st, sh, sw, pt, ph, pw;
@@ -199,11 +201,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 // registers, no ds_write, 6 fewer VALU per MFMA): bit-identical, the convolutions ran at the same speed and the pre-pass (110 ms)
 // and the 1.5x larger operand stream made the decode 5 % slower; six accumulator chains instead of three: no change.
 // =================================================================================================
+// ---- the same on fp16 words (template parameter H2) --------------------------------------------------------------------------
+// fp16 carries 11 significant bits, so TWO words already hold 22 bits and three partial products
+//   a·w ~= ah·wh + ah·wl + al·wh     (dropped: al·wl, 2^-22 relative)
+// give the accuracy the six bf16 products give — at half the matrix-pipe work (v_mfma_f32_32x32x16_f16 runs at the bf16 rate).
+// What fp16 lacks is range, so both operands are brought into it by exact power-of-two scales: weights per output channel at bind
+// time (row maximum -> [2^13, 2^14)), activations by a scale the PRODUCER guarantees: RMS_norm bounds every output by
+// sqrt(C)·max|gamma| and SiLU does not increase magnitudes, so the two 3x3x3 convolutions of every residual block, the head
+// convolutions and to_qkv — 94 % of the decoder's FLOP — have a static bound (Tens::bound).  The scales are undone in the epilogue
+// by one exact multiplication.  Convolutions whose input has no such bound (conv_in, shortcuts, resample / time convolutions,
+// attention proj) stay on the three-term bf16 kernel.  SVI_VAE_X2H=0 sends everything to the three-term kernel (A/B).
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+__device__ __forceinline__ unsigned short bits16(bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ unsigned short bits16(f16 v) { return __builtin_bit_cast(unsigned short, v); }
+
 #define X3_PIX 256
 #define X3_CO 96
 #define X3_A_PLANE (X3_PIX * 64)                 // 16 KiB
 #define X3_W_PLANE (X3_CO * 64)                  // 6 KiB
 #define X3_STAGE (3 * X3_A_PLANE + 3 * X3_W_PLANE)
+#define X2H_STAGE (2 * X3_A_PLANE + 2 * X3_W_PLANE)
 __device__ __forceinline__ int x3_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 // split 4 fp32 into three bf16x4 terms
@@ -218,6 +237,16 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16
     }
 }
 
+// split 4 fp32 (already scaled into fp16 range) into two fp16x4 terms
+__device__ __forceinline__ void split2h(const f32x4 x, u16x4& h, u16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const f16 hh = (f16)x[e];
+        h[e] = bits16(hh);
+        l[e] = bits16((f16)(x[e] - (float)hh));
+    }
+}
+
 // timing ablations (tools/vae_ab.py, SVI_VAE_ABL): compiled in only with -DSVI_ABLATIONS so that the product kernel has no
 // branches inside a K step
 #ifdef SVI_ABLATIONS
@@ -225,7 +254,12 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16
 #else
 #define SVI_X3_ABL(bit) false
 #endif
+template <bool H2>
 __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
+    constexpr int NPL = H2 ? 2 : 3;                                   // operand planes
+    constexpr int STAGE = NPL * (X3_A_PLANE + X3_W_PLANE);
+    constexpr int NWID = NPL * 384;                                   // weight vectors per stage: planes x 96 rows x 4 chunks
+    constexpr int NWV = (NWID + 511) / 512;                           // ... per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -274,21 +308,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     const long rem_bytes = ((long)p.Ti * p.Hi * p.Wi * p.ld_in - base_el) * 4;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + base_el), 0,
                                                                            (int)(unsigned)min(rem_bytes, 0xFFFFF000L), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w3), 0,
-                                                                          (int)(unsigned)min(3L * p.plane_w3 * 2, 0xFFFFF000L), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(H2 ? const_cast<void*>(p.w2h) : (void*)const_cast<bf16*>(p.w3), 0,
+                                                                          (int)(unsigned)min((long)NPL * p.plane_w3 * 2, 0xFFFFF000L), 0x00020000);
+    const float a_scale = H2 ? p.in_scale : 1.0f;
     const unsigned OOB = 0xFFFFFFF0u;
-    unsigned woff[3];                                // byte offset of this thread's weight chunks at tap 0, channel chunk 0
-    int wch[3];
+    unsigned woff[NWV];                              // byte offset of this thread's weight chunks at tap 0, channel chunk 0
+    int wch[NWV];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int id = tid + 512 * i;                // (plane, row, chunk): 3 x 96 x 4
+    for (int i = 0; i < NWV; ++i) {
+        const int id = tid + 512 * i;                // (plane, row, chunk): NPL x 96 x 4
         const int pl = id / 384, rem = id - pl * 384, row = rem >> 2, ch = rem & 3;
-        const bool ok = id < 1152 && co0 + row < p.Cout;
+        const bool ok = id < NWID && co0 + row < p.Cout;
         woff[i] = ok ? (unsigned)((pl * p.plane_w3 + (long)(co0 + row) * p.ld_w3 + ch * 8) * 2) : OOB;
         wch[i] = ch * 8;
     }
     f32x4 ra[2][4];
-    u32x4 rw[2][3];                                  // two register sets: the tile being staged and the one in flight
+    u32x4 rw[2][NWV];                                // two register sets: the tile being staged and the one in flight
 
     // One K step, written as six slices so that the work of three K steps overlaps inside one basic block: slice s issues the
     // 6 MFMAs of (k-step ks = s / 3, cout block n = s % 3) of the step held in LDS stage CBUF, then splits / stores ONE staged
@@ -304,68 +339,36 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     } while (0)
 #define SVI_X3_LOAD_W(S, i)                                                                                                      \
     do {                                                                                                                         \
-        const bool ok_ = wvalid_ && woff[i] != OOB && cc_ * 32 + wch[i] < p.ld_w3;                                               \
-        rw[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, ok_ ? woff[i] + wk_ : OOB, 0, 0);                                 \
+        if constexpr ((i) < NWV) {                                                                                               \
+            const bool ok_ = wvalid_ && woff[i] != OOB && cc_ * 32 + wch[i] < p.ld_w3;                                           \
+            rw[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, ok_ ? woff[i] + wk_ : OOB, 0, 0);                             \
+        }                                                                                                                        \
     } while (0)
 #define SVI_X3_STAGE_A(S, buf, j)                                                                                                \
     do {                                                                                                                         \
-        char* As_ = smem + (buf) * X3_STAGE;                                                                                     \
-        bf16x4 h_, m_, l_;                                                                                                       \
-        split3(ra[S][j], h_, m_, l_);                                                                                            \
+        char* As_ = smem + (buf) * STAGE;                                                                                        \
         const int off_ = x3_off((tid >> 3) + 64 * (j), a_c4 >> 1) + (a_c4 & 1) * 8;                                              \
-        *reinterpret_cast<bf16x4*>(As_ + off_) = h_;                                                                             \
-        *reinterpret_cast<bf16x4*>(As_ + X3_A_PLANE + off_) = m_;                                                                \
-        *reinterpret_cast<bf16x4*>(As_ + 2 * X3_A_PLANE + off_) = l_;                                                            \
+        if constexpr (H2) {                                                                                                      \
+            u16x4 h_, l_;                                                                                                        \
+            split2h(ra[S][j] * a_scale, h_, l_);                                                                                 \
+            *reinterpret_cast<u16x4*>(As_ + off_) = h_;                                                                          \
+            *reinterpret_cast<u16x4*>(As_ + X3_A_PLANE + off_) = l_;                                                             \
+        } else {                                                                                                                 \
+            bf16x4 h_, m_, l_;                                                                                                   \
+            split3(ra[S][j], h_, m_, l_);                                                                                        \
+            *reinterpret_cast<bf16x4*>(As_ + off_) = h_;                                                                         \
+            *reinterpret_cast<bf16x4*>(As_ + X3_A_PLANE + off_) = m_;                                                            \
+            *reinterpret_cast<bf16x4*>(As_ + 2 * X3_A_PLANE + off_) = l_;                                                        \
+        }                                                                                                                        \
     } while (0)
 #define SVI_X3_STAGE_W(S, buf, i)                                                                                                \
     do {                                                                                                                         \
         const int id_ = tid + 512 * (i);                                                                                         \
-        if (id_ < 1152) {                                                                                                        \
+        if ((i) < NWV && id_ < NWID) {                                                                                           \
             const int pl_ = id_ / 384, rem_ = id_ - pl_ * 384, row_ = rem_ >> 2, ch_ = rem_ & 3;                                 \
-            *reinterpret_cast<u32x4*>(smem + (buf) * X3_STAGE + 3 * X3_A_PLANE + pl_ * X3_W_PLANE + x3_off(row_, ch_)) = rw[S][i]; \
+            *reinterpret_cast<u32x4*>(smem + (buf) * STAGE + NPL * X3_A_PLANE + pl_ * X3_W_PLANE + x3_off(row_, ch_)) = rw[S][(i) < NWV ? (i) : 0]; \
         }                                                                                                                        \
     } while (0)
-#define SVI_X3_STEP(CBUF, SI, kidx, valid, SS, SBUF)                                                                             \
-    do {                                                                                                                         \
-        /* (tap, cc) of the step being requested: running counters (no divisions in the loop), advanced after the step */        \
-        const int cc_ = it_cc;                                             \
-        const int c_ = cc_ * 32 + a_c4 * 4;                                                                                      \
-        const bool wvalid_ = (valid) && !SVI_X3_ABL(1);                                                                          \
-        const bool cin_ = wvalid_ && c_ < p.Cin;                                                                                 \
-        const unsigned wk_ = it_wk;                                                                                              \
-        const char* As_c = smem + (CBUF) * X3_STAGE;                                                                             \
-        const char* Ws_c = As_c + 3 * X3_A_PLANE;                                                                                \
-        bf16x8 a_[3];                                                                                                            \
-        _Pragma("unroll") for (int s_ = 0; s_ < 6; ++s_) {                                                                       \
-            const int ks = s_ / 3, n = s_ % 3;                                                                                   \
-            if (!SVI_X3_ABL(4)) {                                                                                                \
-                if (n == 0) {                                                                                                    \
-                    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                             \
-                        a_[pl] = *reinterpret_cast<const bf16x8*>(As_c + pl * X3_A_PLANE + x3_off(32 * wave + l31, 2 * ks + hi)); \
-                }                                                                                                                \
-                bf16x8 w_[3];                                                                                                    \
-                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                 \
-                    w_[pl] = *reinterpret_cast<const bf16x8*>(Ws_c + pl * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));       \
-                /* smallest terms first */                                                                                       \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_[1], a_[1], acc[n], 0, 0, 0);   /* wm am */                  \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_[2], a_[0], acc[n], 0, 0, 0);   /* wl ah */                  \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_[0], a_[2], acc[n], 0, 0, 0);   /* wh al */                  \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_[1], a_[0], acc[n], 0, 0, 0);   /* wm ah */                  \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_[0], a_[1], acc[n], 0, 0, 0);   /* wh am */                  \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_[0], a_[0], acc[n], 0, 0, 0);   /* wh ah */                  \
-            }                                                                                                                    \
-            if (!SVI_X3_ABL(2)) {                                                                                                \
-                if (s_ < 4) SVI_X3_STAGE_A(SS, SBUF, s_);                                                                        \
-                else if (s_ == 4) { SVI_X3_STAGE_W(SS, SBUF, 0); SVI_X3_STAGE_W(SS, SBUF, 1); }                                  \
-                else SVI_X3_STAGE_W(SS, SBUF, 2);                                                                                \
-            }                                                                                                                    \
-            if (s_ < 4) SVI_X3_LOAD_A(SI, s_);                                                                                   \
-            else if (s_ == 4) { SVI_X3_LOAD_W(SI, 0); SVI_X3_LOAD_W(SI, 1); }                                                    \
-            else SVI_X3_LOAD_W(SI, 2);                                                                                           \
-        }                                                                                                                        \
-        SVI_X3_ADVANCE();                                                                                                        \
-    } while (0)
-    // next (tap, channel chunk): channel chunks innermost, then kw, kh, kt — all uniform (scalar) arithmetic
 #define SVI_X3_TAP_BASES()                                                                                                       \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                              \
         const int yi_ = (by[j] + it_tb) >> ups_sh, xi_ = (bx[j] + it_tc) >> ups_sh;                                              \
@@ -383,33 +386,65 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         }                                                                                                                        \
     } while (0)
 
-#ifndef SVI_X3_UNPINNED          /* default; -DSVI_X3_UNPINNED keeps hipcc's own order inside a slice (A/B: 1.79 vs 1.73 s per C2 decode) */
-    // The same step with every instruction's place fixed (sched_barrier between the pieces): each MFMA is followed by a piece of
-    // the staging / request work — one element of the three-way split, the three LDS stores, the address arithmetic and the
-    // buffer load — so that the vector ALU works in the MFMAs' shadows and the six MFMAs chained on one accumulator are spaced
-    // apart.  The fragments of slice s+1 are read behind the first MFMA of slice s.
-#undef SVI_X3_STEP
+    // One K step with every instruction's place fixed (sched_barrier between the pieces): each MFMA is followed by a piece of the
+    // staging / request work — elements of the operand split, the LDS stores, the address arithmetic and the buffer load — so that
+    // the vector ALU works in the MFMAs' shadows and the MFMAs chained on one accumulator are spaced apart.  The fragments of slice
+    // s+1 are read behind the first MFMA of slice s.  (Letting hipcc order a slice itself: 1.79 vs 1.73 s per C2 decode, r1.)
+    // Three-term bf16 form: six MFMAs per slice; two-term fp16 form (H2): three.
 #define SVI_SB() __builtin_amdgcn_sched_barrier(0)
 #define SVI_X3_SPLIT1(S, j, e)                                                                                                   \
     do {                                                                                                                         \
-        const float x_ = ra[S][j][e];                                                                                            \
-        const bf16 hh_ = (bf16)x_;                                                                                               \
-        const float r1_ = x_ - (float)hh_;                                                                                       \
-        const bf16 mm_ = (bf16)r1_;                                                                                              \
-        const float r2_ = r1_ - (float)mm_;                                                                                      \
-        hq_[e] = hh_; mq_[e] = mm_; lq_[e] = (bf16)r2_;                                                                          \
+        if constexpr (H2) {                                                                                                      \
+            const float x_ = ra[S][j][e] * a_scale;                                                                              \
+            const f16 hh_ = (f16)x_;                                                                                             \
+            hq_[e] = bits16(hh_); mq_[e] = bits16((f16)(x_ - (float)hh_));                                                       \
+        } else {                                                                                                                 \
+            const float x_ = ra[S][j][e];                                                                                        \
+            const bf16 hh_ = (bf16)x_;                                                                                           \
+            const float r1_ = x_ - (float)hh_;                                                                                   \
+            const bf16 mm_ = (bf16)r1_;                                                                                          \
+            const float r2_ = r1_ - (float)mm_;                                                                                  \
+            hq_[e] = bits16(hh_); mq_[e] = bits16(mm_); lq_[e] = bits16((bf16)r2_);                                              \
+        }                                                                                                                        \
+    } while (0)
+#define SVI_X3_MFMA(WP, AP)                                                                                                      \
+    do {                                                                                                                         \
+        if constexpr (H2) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf_[wc][WP]), __builtin_bit_cast(f16x8, af_[ks][AP]), acc[n], 0, 0, 0);\
+        else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][WP], af_[ks][AP], acc[n], 0, 0, 0);                        \
+    } while (0)
+#define SVI_X3_STORES(SS, SBUF)                                                                                                          \
+    do {                                                                                                                         \
+        if (!SVI_X3_ABL(2)) {                                                                                                    \
+            if (s_ < 4) {                                                                                                        \
+                char* As_ = smem + (SBUF) * STAGE;                                                                               \
+                const int off_ = x3_off((tid >> 3) + 64 * s_, a_c4 >> 1) + (a_c4 & 1) * 8;                                       \
+                *reinterpret_cast<u16x4*>(As_ + off_) = hq_;                                                                     \
+                *reinterpret_cast<u16x4*>(As_ + X3_A_PLANE + off_) = mq_;                                                        \
+                if constexpr (!H2) *reinterpret_cast<u16x4*>(As_ + 2 * X3_A_PLANE + off_) = lq_;                                 \
+            } else if (s_ == 4) { SVI_X3_STAGE_W(SS, SBUF, 0); SVI_X3_STAGE_W(SS, SBUF, 1); }                                    \
+            else SVI_X3_STAGE_W(SS, SBUF, 2);                                                                                    \
+        }                                                                                                                        \
+    } while (0)
+#define SVI_X3_LOADS(SI)                                                                                                           \
+    do {                                                                                                                         \
+        if (s_ == 0) SVI_X3_LOAD_A(SI, 0);                                                                                       \
+        else if (s_ == 1) SVI_X3_LOAD_A(SI, 1);                                                                                  \
+        else if (s_ == 2) SVI_X3_LOAD_A(SI, 2);                                                                                  \
+        else if (s_ == 3) SVI_X3_LOAD_A(SI, 3);                                                                                  \
+        else if (s_ == 4) { SVI_X3_LOAD_W(SI, 0); SVI_X3_LOAD_W(SI, 1); }                                                        \
+        else SVI_X3_LOAD_W(SI, 2);                                                                                               \
     } while (0)
 #define SVI_X3_STEP(CBUF, SI, kidx, valid, SS, SBUF)                                                                             \
     do {                                                                                                                         \
-        const int cc_ = it_cc;                                             \
+        const int cc_ = it_cc;                                                                                                   \
         const int c_ = cc_ * 32 + a_c4 * 4;                                                                                      \
         const bool wvalid_ = (valid) && !SVI_X3_ABL(1);                                                                          \
         const bool cin_ = wvalid_ && c_ < p.Cin;                                                                                 \
         const unsigned wk_ = it_wk;                                                                                              \
-        const char* As_c = smem + (CBUF) * X3_STAGE;                                                                             \
-        const char* Ws_c = As_c + 3 * X3_A_PLANE;                                                                                \
-        bf16x8 af_[2][3], wf_[2][3];                                                                                             \
-        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                                       \
+        const char* As_c = smem + (CBUF) * STAGE;                                                                                \
+        const char* Ws_c = As_c + NPL * X3_A_PLANE;                                                                              \
+        bf16x8 af_[2][NPL], wf_[2][NPL];                                                                                         \
+        _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                                     \
             af_[0][pl] = *reinterpret_cast<const bf16x8*>(As_c + pl * X3_A_PLANE + x3_off(32 * wave + l31, hi));                 \
             wf_[0][pl] = *reinterpret_cast<const bf16x8*>(Ws_c + pl * X3_W_PLANE + x3_off(l31, hi));                             \
         }                                                                                                                        \
@@ -417,54 +452,52 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         _Pragma("unroll") for (int s_ = 0; s_ < 6; ++s_) {                                                                       \
             const int ks = s_ / 3, n = s_ % 3, sn = s_ + 1, ksn = sn / 3, nn = sn % 3;                                           \
             const int wc = s_ & 1, wn = wc ^ 1;                                                                                  \
-            bf16x4 hq_, mq_, lq_;                                                                                                \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][1], af_[ks][1], acc[n], 0, 0, 0);   /* wm am */            \
+            u16x4 hq_, mq_, lq_;                                                                                                 \
+            if constexpr (H2) SVI_X3_MFMA(1, 0);   /* wl ah */                                                                   \
+            else SVI_X3_MFMA(1, 1);                /* wm am */                                                                   \
             SVI_SB();                                                                                                            \
             if (s_ < 5) {                                                                                                        \
-                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                 \
-                    wf_[wn][pl] = *reinterpret_cast<const bf16x8*>(Ws_c + pl * X3_W_PLANE + x3_off(32 * nn + l31, 2 * ksn + hi)); \
+                _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                                               \
+                    wf_[wn][pl] = *reinterpret_cast<const bf16x8*>(Ws_c + pl * X3_W_PLANE + x3_off(32 * nn + l31, 2 * ksn + hi));\
                 if (s_ == 1) {                                                                                                   \
-                    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                             \
+                    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                                           \
                         af_[1][pl] = *reinterpret_cast<const bf16x8*>(As_c + pl * X3_A_PLANE + x3_off(32 * wave + l31, 2 + hi)); \
                 }                                                                                                                \
             }                                                                                                                    \
             if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 0);                                                                                \
+            if constexpr (H2) { if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 1); }                                                          \
             SVI_SB();                                                                                                            \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][2], af_[ks][0], acc[n], 0, 0, 0);   /* wl ah */            \
-            SVI_SB();                                                                                                            \
-            if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 1);                                                                                \
-            SVI_SB();                                                                                                            \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][0], af_[ks][2], acc[n], 0, 0, 0);   /* wh al */            \
-            SVI_SB();                                                                                                            \
-            if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 2);                                                                                \
-            SVI_SB();                                                                                                            \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][1], af_[ks][0], acc[n], 0, 0, 0);   /* wm ah */            \
-            SVI_SB();                                                                                                            \
-            if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 3);                                                                                \
-            SVI_SB();                                                                                                            \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][0], af_[ks][1], acc[n], 0, 0, 0);   /* wh am */            \
-            SVI_SB();                                                                                                            \
-            if (!SVI_X3_ABL(2)) {                                                                                                \
-                if (s_ < 4) {                                                                                                    \
-                    char* As_ = smem + (SBUF) * X3_STAGE;                                                                        \
-                    const int off_ = x3_off((tid >> 3) + 64 * s_, a_c4 >> 1) + (a_c4 & 1) * 8;                                   \
-                    *reinterpret_cast<bf16x4*>(As_ + off_) = hq_;                                                                \
-                    *reinterpret_cast<bf16x4*>(As_ + X3_A_PLANE + off_) = mq_;                                                   \
-                    *reinterpret_cast<bf16x4*>(As_ + 2 * X3_A_PLANE + off_) = lq_;                                               \
-                } else if (s_ == 4) { SVI_X3_STAGE_W(SS, SBUF, 0); SVI_X3_STAGE_W(SS, SBUF, 1); }                                \
-                else SVI_X3_STAGE_W(SS, SBUF, 2);                                                                                \
+            if constexpr (H2) {                                                                                                  \
+                SVI_X3_MFMA(0, 1);                 /* wh al */                                                                   \
+                SVI_SB();                                                                                                        \
+                if (s_ < 4) { SVI_X3_SPLIT1(SS, s_, 2); SVI_X3_SPLIT1(SS, s_, 3); }                                              \
+                SVI_X3_STORES(SS, SBUF);                                                                                                 \
+                SVI_SB();                                                                                                        \
+            } else {                                                                                                             \
+                SVI_X3_MFMA(2, 0);                 /* wl ah */                                                                   \
+                SVI_SB();                                                                                                        \
+                if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 1);                                                                            \
+                SVI_SB();                                                                                                        \
+                SVI_X3_MFMA(0, 2);                 /* wh al */                                                                   \
+                SVI_SB();                                                                                                        \
+                if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 2);                                                                            \
+                SVI_SB();                                                                                                        \
+                SVI_X3_MFMA(1, 0);                 /* wm ah */                                                                   \
+                SVI_SB();                                                                                                        \
+                if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 3);                                                                            \
+                SVI_SB();                                                                                                        \
+                SVI_X3_MFMA(0, 1);                 /* wh am */                                                                   \
+                SVI_SB();                                                                                                        \
+                SVI_X3_STORES(SS, SBUF);                                                                                                 \
+                SVI_SB();                                                                                                        \
             }                                                                                                                    \
+            SVI_X3_MFMA(0, 0);                     /* wh ah */                                                                   \
             SVI_SB();                                                                                                            \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_[wc][0], af_[ks][0], acc[n], 0, 0, 0);   /* wh ah */            \
-            SVI_SB();                                                                                                            \
-            if (s_ < 4) SVI_X3_LOAD_A(SI, s_);                                                                                   \
-            else if (s_ == 4) { SVI_X3_LOAD_W(SI, 0); SVI_X3_LOAD_W(SI, 1); }                                                    \
-            else SVI_X3_LOAD_W(SI, 2);                                                                                           \
+            SVI_X3_LOADS(SI);                                                                                                      \
             SVI_SB();                                                                                                            \
         }                                                                                                                        \
         SVI_X3_ADVANCE();                                                                                                        \
     } while (0)
-#endif
 
     f32x16 acc[3];
 #pragma unroll
@@ -484,14 +517,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         const unsigned wk_ = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) SVI_X3_LOAD_A(0, j);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) SVI_X3_LOAD_W(0, i);
+        SVI_X3_LOAD_W(0, 0); SVI_X3_LOAD_W(0, 1); SVI_X3_LOAD_W(0, 2);
     }
     SVI_X3_ADVANCE();
 #pragma unroll
     for (int j = 0; j < 4; ++j) SVI_X3_STAGE_A(0, 0, j);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) SVI_X3_STAGE_W(0, 0, i);
+    SVI_X3_STAGE_W(0, 0, 0); SVI_X3_STAGE_W(0, 0, 1); SVI_X3_STAGE_W(0, 0, 2);
     {
         const int cc_ = it_cc;
         const int c_ = cc_ * 32 + a_c4 * 4;
@@ -499,8 +530,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         const unsigned wk_ = it_wk;
 #pragma unroll
         for (int j = 0; j < 4; ++j) SVI_X3_LOAD_A(1, j);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) SVI_X3_LOAD_W(1, i);
+        SVI_X3_LOAD_W(1, 0); SVI_X3_LOAD_W(1, 1); SVI_X3_LOAD_W(1, 2);
     }
     SVI_X3_ADVANCE();
     __syncthreads();
@@ -518,6 +548,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 #undef SVI_X3_LOAD_W
 #undef SVI_X3_STAGE_A
 #undef SVI_X3_STAGE_W
+#undef SVI_X3_SPLIT1
+#undef SVI_X3_MFMA
+#undef SVI_X3_STORES
+#undef SVI_X3_LOADS
 
     // ---- epilogue: lane holds pixel pp = p0 + 32 wave + l31, channels co0 + 32 n + 8 rg + 4 hi + 0..3 in acc[n][4 rg + e].
     // The 12 bias vectors and 12 residual vectors of the lane are requested in one batch (one memory round trip instead of 24
@@ -526,8 +560,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     if (pp >= P_total) return;
     if (SVI_X3_ABL(8) && acc[0][0] != 123.456f) return;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bv[12], rv[12];
+    f32x4 bv[12], rv[12], sv[12];
     const bool with_res = p.out_mode == 0 && p.res;
+    const float inv_a = H2 ? 1.0f / p.in_scale : 1.0f;                       // exact: powers of two
     const long po = pp + (long)p.t_out_off * HoWo;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -535,6 +570,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         const bool ok = co < p.Cout;
         bv[i] = (ok && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + co) : zero4;
         rv[i] = (ok && with_res) ? *reinterpret_cast<const f32x4*>(p.res + po * p.ld_res + co) : zero4;
+        if constexpr (H2) sv[i] = ok ? *reinterpret_cast<const f32x4*>(p.w2_inv + co) * inv_a : zero4;
     }
     long pq0 = 0;
     const int half = p.Cout >> 1;
@@ -550,7 +586,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         if (co >= p.Cout) continue;
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (acc[n][4 * rg + e] + bv[i][e]) + rv[i][e];
+        for (int e = 0; e < 4; ++e) {
+            float a = acc[n][4 * rg + e];
+            if constexpr (H2) a *= sv[i][e];
+            v[e] = (a + bv[i][e]) + rv[i][e];
+        }
         if (p.out_mode == 0) {
             *reinterpret_cast<f32x4*>(p.out + po * p.ld_out + co) = v;
         } else {
@@ -571,13 +611,18 @@ svi_status launch_conv(const ConvP& p, hipStream_t st) {
         p.kt * p.kh * p.kw <= 32 &&                                                   // tap bit mask
         (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 4 < 0xFFFFF000L &&               // 32-bit offsets inside the buffer window
         (long)3 * p.plane_w3 * 2 < 0xFFFFF000L) {
-        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_igemm_x3_kernel), 2 * X3_STAGE));
         dim3 grid3((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block3(512);
         ConvP pa = p;
 #ifdef SVI_ABLATIONS
         pa.abl = svi_switches().vae_abl;
 #endif
-        hipLaunchKernelGGL(conv_igemm_x3_kernel, grid3, block3, 2 * X3_STAGE, st, pa);
+        if (p.w2h && p.w2_inv && p.in_scale > 0.f && !svi_switches().vae_no_x2h && (((uintptr_t)p.w2_inv) & 15) == 0) {
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_igemm_x3_kernel<true>), 2 * X2H_STAGE));
+            hipLaunchKernelGGL(conv_igemm_x3_kernel<true>, grid3, block3, 2 * X2H_STAGE, st, pa);
+        } else {
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_igemm_x3_kernel<false>), 2 * X3_STAGE));
+            hipLaunchKernelGGL(conv_igemm_x3_kernel<false>, grid3, block3, 2 * X3_STAGE, st, pa);
+        }
         SVI_LAUNCH_CHECK();
         return SVI_OK;
     }
@@ -816,6 +861,38 @@ __global__ void pack_weight_x3_kernel(const float* __restrict__ w, bf16* __restr
     out[n + i] = m;
     out[2 * n + i] = (bf16)(r1 - (float)m);
 }
+// fp16 two-term form.  Row (output channel) maximum -> power-of-two scale 2^k with max * 2^k in [2^13, 2^14); inv[co] = 2^-k.
+__global__ __launch_bounds__(256) void weight_row_scale_kernel(const float* __restrict__ w, float* __restrict__ scale, float* __restrict__ inv, long per_row) {
+    const int co = blockIdx.x;
+    float m = 0.f;
+    for (long i = threadIdx.x; i < per_row; i += 256) m = fmaxf(m, fabsf(w[(long)co * per_row + i]));
+    m = wave_max(m);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        int e = 0;
+        if (m > 0.f && m < INFINITY) (void)frexpf(m, &e);          // m = f * 2^e, f in [0.5, 1)
+        else e = 14;
+        e = min(max(e, -100), 100);
+        scale[co] = ldexpf(1.0f, 14 - e);
+        inv[co] = ldexpf(1.0f, e - 14);
+    }
+}
+__global__ void pack_weight_x2h_kernel(const float* __restrict__ w, const float* __restrict__ scale, unsigned short* __restrict__ out, int Cout,
+                                       int Cin, int taps, int ldw3) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)taps * Cout * ldw3;
+    if (i >= n) return;
+    const int ci = (int)(i % ldw3);
+    const int co = (int)((i / ldw3) % Cout);
+    const int tap = (int)(i / ((long)ldw3 * Cout));
+    const float x = ci < Cin ? w[((long)co * Cin + ci) * taps + tap] * scale[co] : 0.f;
+    const f16 h = (f16)x;
+    out[i] = bits16(h);
+    out[n + i] = bits16((f16)(x - (float)h));
+}
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int taps, int ldw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n = (long)taps * Cout * ldw;
@@ -837,9 +914,15 @@ struct ConvW {               // one conv layer: user weight (borrowed) + packed 
     const float* b_user = nullptr;
     float* packed = nullptr;
     bf16* packed3 = nullptr;          // three bf16 planes of the packed weights (see conv_igemm_x3_kernel)
+    unsigned short* packed2h = nullptr;   // two fp16 planes of the row-scaled packed weights (conv_igemm_x3_kernel<true>)
+    float* w2_scale = nullptr;        // [2][Cout]: scale | 1 / scale
     int Cout = 0, Cin = 0, kt = 1, kh = 1, kw = 1, ldw = 0, ldw3 = 0;
 };
-struct Tens { float* p = nullptr; int T = 0, H = 0, W = 0, C = 0; long elems() const { return (long)T * H * W * C; } };
+struct Tens {
+    float* p = nullptr; int T = 0, H = 0, W = 0, C = 0;
+    float bound = 0.f;                // > 0: every |element| <= bound, guaranteed by the producer (RMS_norm [+ SiLU]); 0: unknown
+    long elems() const { return (long)T * H * W * C; }
+};
 
 }  // namespace
 
@@ -848,6 +931,7 @@ struct svi_vae {
     std::map<std::string, ConvW> convs;                 // key = layer prefix without ".weight"
     std::map<std::string, const float*> gammas;         // key = full name
     std::map<std::string, std::vector<int64_t>> gamma_shapes;
+    std::map<std::string, float> gamma_bound;           // key = full name: sqrt(C) * max|gamma| (0: unusable, see svi_vae_bind_weight)
     // workspace
     char* pool = nullptr;
     size_t pool_bytes = 0, slot_bytes = 0;
@@ -968,6 +1052,12 @@ svi_status conv_layer(svi_vae* h, const std::string& name, const Tens& in, Tens*
     if (h->dry) return SVI_OK;
     p.in = in.p; p.w = c.packed; p.ld_w = c.ldw; p.bias = c.b_user; p.out = out->p;
     p.w3 = c.packed3; p.ld_w3 = c.ldw3; p.plane_w3 = (long)c.kt * c.kh * c.kw * c.Cout * c.ldw3;
+    p.w2h = c.packed2h; p.w2_inv = c.w2_scale ? c.w2_scale + c.Cout : nullptr;
+    if (in.bound > 0.f && in.bound < 1e30f) {           // largest power of two s with bound * s <= 2^15
+        int e = 0;
+        (void)frexpf(in.bound, &e);
+        p.in_scale = ldexpf(1.0f, 15 - e);
+    }
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.Cout = c.Cout; p.ld_out = out->C;
     p.res = res ? res->p : nullptr; p.ld_res = res ? res->C : 0;
     SviProfScope _p(PROF_VAE_CONV, st);
@@ -978,6 +1068,10 @@ svi_status norm_act(svi_vae* h, const std::string& gname, const Tens& in, Tens* 
     *out = alloc_t(h, in.T, in.H, in.W, in.C);
     NEED(*out);
     if (h->dry) return SVI_OK;
+    {   // |x_c| / max(||x||, eps) <= 1, so |out_c| <= sqrt(C) |gamma_c|; SiLU never increases a magnitude
+        auto gb = h->gamma_bound.find(gname);
+        out->bound = gb == h->gamma_bound.end() ? 0.f : gb->second;
+    }
     SviProfScope _p(PROF_VAE_OTHER, st);
     return launch_rms_silu(in.p, out->p, (long)in.T * in.H * in.W, in.C, h->gammas.at(gname), do_silu, st);
 }
@@ -1223,6 +1317,8 @@ extern "C" svi_status svi_vae_destroy(svi_vae* h) {
     for (auto& kv : h->convs) {
         if (kv.second.packed) (void)hipFree(kv.second.packed);
         if (kv.second.packed3) (void)hipFree(kv.second.packed3);
+        if (kv.second.packed2h) (void)hipFree(kv.second.packed2h);
+        if (kv.second.w2_scale) (void)hipFree(kv.second.w2_scale);
     }
     if (h->pool) (void)hipFree(h->pool);
     if (h->consts) (void)hipFree(h->consts);
@@ -1248,6 +1344,15 @@ extern "C" svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const vo
     if (g != h->gammas.end()) {
         if (!shape_ok(h->gamma_shapes[key])) { svi_set_error("shape mismatch for '%s'", name); return SVI_ERR_INVALID; }
         g->second = reinterpret_cast<const float*>(dev_ptr);
+        {   // the static bound the fp16 two-term convolution relies on; a gain vector with a dead or wildly smaller channel (its
+            // activations would sit in fp16's subnormals after the common scale) keeps the three-term kernel for its consumers
+            std::vector<float> host((size_t)shape[0]);
+            SVI_CHECK_HIP(hipMemcpy(host.data(), dev_ptr, host.size() * 4, hipMemcpyDeviceToHost));
+            float mx = 0.f, mn = INFINITY;
+            for (float v : host) { mx = fmaxf(mx, fabsf(v)); mn = fminf(mn, fabsf(v)); }
+            const bool ok = mx > 0.f && mx < 1e30f && mn >= mx * (1.0f / 256.0f);
+            h->gamma_bound[key] = ok ? sqrtf((float)shape[0]) * mx * 1.0001f : 0.f;
+        }
         return SVI_OK;
     }
     const size_t dot = key.rfind('.');
@@ -1278,6 +1383,13 @@ extern "C" svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const vo
             if (e3 != hipSuccess) { svi_set_error("hipMalloc(split VAE weight) failed: %s", hipGetErrorString(e3)); return SVI_ERR_OOM; }
         }
         hipLaunchKernelGGL(pack_weight_x3_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, 0, cw.w_user, cw.packed3, cw.Cout, cw.Cin, taps, cw.ldw3);
+        if (!cw.packed2h) {
+            hipError_t e2 = hipMalloc((void**)&cw.packed2h, 2 * n3 * 2);
+            if (e2 == hipSuccess) e2 = hipMalloc((void**)&cw.w2_scale, (size_t)2 * cw.Cout * 4);
+            if (e2 != hipSuccess) { svi_set_error("hipMalloc(fp16 split VAE weight) failed: %s", hipGetErrorString(e2)); return SVI_ERR_OOM; }
+        }
+        hipLaunchKernelGGL(weight_row_scale_kernel, dim3(cw.Cout), dim3(256), 0, 0, cw.w_user, cw.w2_scale, cw.w2_scale + cw.Cout, (long)cw.Cin * taps);
+        hipLaunchKernelGGL(pack_weight_x2h_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, 0, cw.w_user, cw.w2_scale, cw.packed2h, cw.Cout, cw.Cin, taps, cw.ldw3);
     }
     SVI_LAUNCH_CHECK();
     h->pack_pending = true;

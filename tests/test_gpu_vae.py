@@ -132,3 +132,47 @@ def test_tiled_blend_is_the_reference_arithmetic(vae):
     want = wvo._blend(dec, z.cpu()[None], (1, 3, 1, 56, 72), size, stride, lambda a: a * 8,
                       ((size[0] - stride[0]) * 8, (size[1] - stride[1]) * 8)).clamp(-1, 1)[0]
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("switch", ["SVI_VAE_X2H", "SVI_VAE_EXACT_FP32"])
+def test_every_convolution_family_meets_the_same_bounds(vae, golden, switch):
+    """Default: the fp16 two-term convolution wherever the producer (RMS_norm [+ SiLU]) bounds the input, the bf16 three-term one
+    elsewhere.  SVI_VAE_X2H=0 sends everything to the three-term kernel, SVI_VAE_EXACT_FP32=1 to the fp32 MFMA kernel: the three hold
+    the same parity bounds against the reference, and the default differs from the other two far below them."""
+    from svi_hip import _lib
+    v, _ = vae
+    g = golden("vae.npz")
+    z = torch.from_numpy(synth.randn(501, 1, 16, 3, 4, 6))[0].cuda()
+    vid = torch.from_numpy(np.tanh(synth.randn(503, 3, 9, 32, 48))).cuda()
+    dflt_d, dflt_e = v.decode([z], device="cuda")[0], v.encode([vid], device="cuda")[0]
+    try:
+        _lib.set_switch(switch, "0" if switch == "SVI_VAE_X2H" else "1")
+        alt_d, alt_e = v.decode([z], device="cuda")[0], v.encode([vid], device="cuda")[0]
+    finally:
+        _lib.set_switch(switch, None)
+    for out, key in ((alt_d, "decode_3f"), (alt_e, "encode_9f")):
+        r, mx, _ = errs(out, g[key])
+        assert r < 2e-5 and mx < 2e-4, (switch, key, r, mx)
+    rd, re = errs(dflt_d, alt_d)[0], errs(dflt_e, alt_e)[0]
+    report("vae_conv_families", switch=switch, decode_default_vs_alt=rd, encode_default_vs_alt=re, identical=bool(torch.equal(dflt_d, alt_d)))
+    assert rd < 5e-6 and re < 5e-6, (rd, re)
+    assert not torch.equal(dflt_d, alt_d)                 # the default really took another kernel
+
+
+def test_gain_vector_with_a_dead_channel_keeps_the_three_term_kernel(golden):
+    """The static activation bound needs gains of comparable size: a norm whose gamma has a zero channel must not send its consumer to
+    the fp16 kernel (that channel's activations would be subnormal after the common scale).  Result: still within the bounds of the
+    oracle run on the same weights."""
+    import svi_hip
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.vae_state_dict(500).items()}
+    k = "model.decoder.middle.0.residual.0.gamma"
+    sd[k][3] = 0.0
+    sd[k][7] = 1e-5
+    v = svi_hip.WanVideoVAE.from_state_dict(sd)
+    z = torch.from_numpy(synth.randn(501, 1, 16, 3, 4, 6))[0]
+    out = v.decode([z.cuda()], device="cuda")[0]
+    with torch.no_grad():
+        want = wvo.vae_decode(sd, z[None])[0]
+    r, mx, _ = errs(out, want)
+    report("vae_dead_gain_channel", rel_l2=r, max_abs=mx)
+    assert r < 2e-5 and mx < 2e-4, (r, mx)

@@ -11,6 +11,7 @@ import sys
 
 
 def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = name.replace("void ", "")
     return name if len(name) < 70 else name[:67] + "..."

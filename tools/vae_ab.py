@@ -1,26 +1,50 @@
-"""VAE decode/encode at a C1-like and the C2 size: bf16x3 split convolution vs the exact-fp32 MFMA kernel (SVI_VAE_EXACT_FP32=1
-in a separate process, the switch is read once).  python tools/vae_ab.py [c2]"""
-import os, sys, time
+"""VAE decode / encode at a C1-like and the C2 size with each convolution family, in one process (switches re-read between runs):
+    x2h    fp16 two-term convolution where the producer bounds the input, bf16 three-term elsewhere   (default)
+    x3     bf16 three-term convolution everywhere                                                      (SVI_VAE_X2H=0)
+    exact  fp32 MFMA everywhere                                                                        (SVI_VAE_EXACT_FP32=1; small size only unless `exact` is asked for)
+Reports wall time, the per-tag kernel time (svi_prof_*) and the distance of each result to the exact-fp32 one (or to x3 at C2).
+    python tools/vae_ab.py [c2] [exact] [only-default]
+"""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import svi_hip
+from svi_hip import _lib
 from svi_hip.vae import WanVideoVAE, device_vae_weights
+
 dev = torch.device("cuda")
+c2 = "c2" in sys.argv[1:]
 vae = WanVideoVAE.from_state_dict(device_vae_weights(0, dev))
 g = torch.Generator(device=dev).manual_seed(3)
-shape = (16, 21, 60, 104) if len(sys.argv) > 1 and sys.argv[1] == "c2" else (16, 5, 32, 32)
-z = torch.randn(shape, generator=g, device=dev)
-for name, fn in (("decode", lambda: vae.decode([z], device=dev)),):
-    out = fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    from svi_hip import _lib
-    _lib.prof_enable(True)
-    e0.record(); out = fn(); e1.record(); torch.cuda.synchronize()
-    print("   per-tag:", {k: round(v["ms"], 1) for k, v in _lib.prof_summary().items()})
-    _lib.prof_enable(False)
-    print(f"{'exact-fp32' if os.environ.get('SVI_VAE_EXACT_FP32') else 'bf16x3'} {name} {tuple(shape)}: {e0.elapsed_time(e1):.1f} ms, checksum {float(out.double().sum()):.6f} absmax {float(out.abs().max()):.4f}")
-    torch.save(out.cpu(), f"/tmp/vae_{name}_{'exact' if os.environ.get('SVI_VAE_EXACT_FP32') else 'x3'}.pt")
-if os.path.exists("/tmp/vae_decode_exact.pt") and os.path.exists("/tmp/vae_decode_x3.pt"):
-    a, b = torch.load("/tmp/vae_decode_exact.pt").double(), torch.load("/tmp/vae_decode_x3.pt").double()
-    print(f"x3 vs exact-fp32: rel-L2 {float((a - b).norm() / a.norm()):.3e}  max-abs {float((a - b).abs().max()):.3e}")
+z = torch.randn((16, 21, 60, 104) if c2 else (16, 5, 32, 32), generator=g, device=dev)
+vid = torch.tanh(torch.randn((3, 81, 480, 832) if c2 else (3, 17, 256, 256), generator=g, device=dev))
+MODES = [("x2h", {}), ("x3", {"SVI_VAE_X2H": "0"})]
+if not c2 or "exact" in sys.argv[1:]:
+    MODES.append(("exact", {"SVI_VAE_EXACT_FP32": "1"}))
+if "only-default" in sys.argv[1:]:             # for a kernel trace of the product path alone
+    MODES = MODES[:1]
+res = {}
+for name, env in MODES:
+    for k in ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32"):
+        _lib.set_switch(k, env.get(k))
+    for what, fn in (("decode", lambda: vae.decode([z], device=dev)[0]), ("encode", lambda: vae.encode([vid], device=dev)[0])):
+        out = fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.prof_enable(True)
+        e0.record(); out = fn(); e1.record(); torch.cuda.synchronize()
+        tags = {k: round(v["ms"], 1) for k, v in _lib.prof_summary().items() if v["ms"] > 0}
+        _lib.prof_enable(False)
+        res[(name, what)] = out.double().cpu()
+        print(f"{name:5s} {what} {tuple(out.shape)}: {e0.elapsed_time(e1):8.1f} ms   per-tag {tags}   absmax {float(out.abs().max()):.4f}", flush=True)
+        del out
+for k in ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32"):
+    _lib.set_switch(k, None)
+base = "exact" if ("exact", "decode") in res else "x3"
+for what in ("decode", "encode"):
+    a = res[(base, what)]
+    for name, _ in MODES:
+        if name == base:
+            continue
+        b = res[(name, what)]
+        print(f"{what}: {name} vs {base}: rel-L2 {float((a - b).norm() / a.norm()):.3e}  max-abs {float((a - b).abs().max()):.3e}")
