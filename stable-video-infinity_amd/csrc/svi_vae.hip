@@ -247,6 +247,18 @@ __device__ __forceinline__ void split2h(const f32x4 x, u16x4& h, u16x4& l) {
     }
 }
 
+// the same for one pair inside the pinned K step, 5 instructions: hi = f16(x s) by v_fma_mixlo/hi_f16 (multiply and conversion
+// in one), lo = f16(x s - hi) by v_fma_mix_f32 with hi entering as an f16 operand, and one packed conversion
+__device__ __forceinline__ void split2h_pair(float x0, float x1, float s, unsigned& h, unsigned& l) {
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %[h], %[x0], %[s], 0\n\t"
+        "v_fma_mixhi_f16 %[h], %[x1], %[s], 0\n\t"
+        "v_fma_mix_f32 %[r0], %[x0], %[s], -%[h] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %[r1], %[x1], %[s], -%[h] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_f16_f32 %[l], %[r0], %[r1]"
+        : [h] "=&v"(h), [l] "=v"(l), [r0] "=&v"(r0), [r1] "=&v"(r1) : [x0] "v"(x0), [x1] "v"(x1), [s] "s"(s));
+}
+
 // timing ablations (tools/vae_ab.py, SVI_VAE_ABL): compiled in only with -DSVI_ABLATIONS so that the product kernel has no
 // branches inside a K step
 #ifdef SVI_ABLATIONS
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     const int t_first = (int)(min(p0, P_total - 1) / HoWo);      // pixels are t-major: the tile's first pixel has the smallest t
     const int t_base = max(t_first * p.st - p.pt, 0);             // buffer base = that input frame (32-bit offsets from there)
     int bt[4], by[4], bx[4];
-    unsigned a_mask[4];
+    unsigned a_mask[4], base_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long pp = p0 + (tid >> 3) + 64 * j;
@@ -303,15 +315,19 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         }
         a_mask[j] = m;
         bt[j] -= t_base;
+        base_off[j] = (unsigned)(((bt[j] * p.Hi + by[j]) * p.Wi + bx[j]) * p.ld_in) * 4u;      // tap (0,0,0); only used by the two-term form
     }
     const long base_el = (long)t_base * p.Hi * p.Wi * p.ld_in;
     const long rem_bytes = ((long)p.Ti * p.Hi * p.Wi * p.ld_in - base_el) * 4;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + base_el), 0,
-                                                                           (int)(unsigned)min(rem_bytes, 0xFFFFF000L), 0x00020000);
+                                                                           (int)(unsigned)min(rem_bytes, H2 ? 0xFFE00000L : 0xFFFFF000L), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(H2 ? const_cast<void*>(p.w2h) : (void*)const_cast<bf16*>(p.w3), 0,
-                                                                          (int)(unsigned)min((long)NPL * p.plane_w3 * 2, 0xFFFFF000L), 0x00020000);
+                                                                          (int)(unsigned)min((long)NPL * p.plane_w3 * 2, H2 ? 0xFFE00000L : 0xFFFFF000L), 0x00020000);
     const float a_scale = H2 ? p.in_scale : 1.0f;
-    const unsigned OOB = 0xFFFFFFF0u;
+    // an offset no buffer window reaches.  Two-term form: low enough that adding a channel offset (< 64 KiB) cannot wrap, so a tap
+    // that does not exist needs no select per K step (launch_conv keeps the windows below it)
+    const unsigned OOB = H2 ? 0xFFF00000u : 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);   // zero records: every load reads zeros
     unsigned woff[NWV];                              // byte offset of this thread's weight chunks at tap 0, channel chunk 0
     int wch[NWV];
 #pragma unroll
@@ -334,8 +350,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         /* tap_off[j]: byte offset of this pixel's input position for the tap being requested (OOB if it does not exist),      \
            recomputed only when the tap changes (SVI_X3_ADVANCE); per step just the channel offset is added */                 \
         const unsigned off_ = tap_off[j] + (unsigned)c_ * 4u;                                                                    \
-        const bool ok_ = cin_ & (tap_off[j] != OOB);                                                                             \
-        ra[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok_ ? off_ : OOB, 0, 0));              \
+        if constexpr (H2) {   /* Cin % 32 == 0: c_ < Cin in every real step; a step past the end reads through rs_none */         \
+            ra[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wvalid_ ? rs_in : rs_none, off_, 0, 0));  \
+        } else {                                                                                                                 \
+            const bool ok_ = cin_ & (tap_off[j] != OOB);                                                                         \
+            ra[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok_ ? off_ : OOB, 0, 0));          \
+        }                                                                                                                        \
     } while (0)
 #define SVI_X3_LOAD_W(S, i)                                                                                                      \
     do {                                                                                                                         \
@@ -370,10 +390,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
         }                                                                                                                        \
     } while (0)
 #define SVI_X3_TAP_BASES()                                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                              \
-        const int yi_ = (by[j] + it_tb) >> ups_sh, xi_ = (bx[j] + it_tc) >> ups_sh;                                              \
-        const unsigned o_ = (unsigned)((((bt[j] + it_ta) * p.Hi + yi_) * p.Wi + xi_) * p.ld_in) * 4u;                             \
-        tap_off[j] = ((a_mask[j] >> it_tap) & 1u) ? o_ : OOB;                                                                    \
+    if constexpr (H2) {   /* no upsampled read here (launch_conv): a tap moves every pixel by the same (scalar) byte distance */ \
+        const unsigned d_ = (unsigned)(((it_ta * p.Hi + it_tb) * p.Wi + it_tc) * p.ld_in) * 4u;                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) tap_off[j] = ((a_mask[j] >> it_tap) & 1u) ? base_off[j] + d_ : OOB;        \
+    } else {                                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                          \
+            const int yi_ = (by[j] + it_tb) >> ups_sh, xi_ = (bx[j] + it_tc) >> ups_sh;                                          \
+            const unsigned o_ = (unsigned)((((bt[j] + it_ta) * p.Hi + yi_) * p.Wi + xi_) * p.ld_in) * 4u;                        \
+            tap_off[j] = ((a_mask[j] >> it_tap) & 1u) ? o_ : OOB;                                                                \
+        }                                                                                                                        \
     }
 #define SVI_X3_ADVANCE()                                                                                                         \
     do {                                                                                                                         \
@@ -395,9 +420,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 #define SVI_X3_SPLIT1(S, j, e)                                                                                                   \
     do {                                                                                                                         \
         if constexpr (H2) {                                                                                                      \
-            const float x_ = ra[S][j][e] * a_scale;                                                                              \
-            const f16 hh_ = (f16)x_;                                                                                             \
-            hq_[e] = bits16(hh_); mq_[e] = bits16((f16)(x_ - (float)hh_));                                                       \
+            /* hi = f16(x s), lo = f16(x s - hi): one v_fma_mixlo/hi_f16 and one v_fma_mix_f32 (hi enters as an f16 operand) */  \
+            const float x_ = ra[S][j][e];                                                                                        \
+            const f16 hh_ = (f16)(x_ * a_scale);                                                                                 \
+            hq_[e] = bits16(hh_); mq_[e] = bits16((f16)__builtin_fmaf(x_, a_scale, -(float)hh_));                                \
         } else {                                                                                                                 \
             const float x_ = ra[S][j][e];                                                                                        \
             const bf16 hh_ = (bf16)x_;                                                                                           \
@@ -418,9 +444,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
             if (s_ < 4) {                                                                                                        \
                 char* As_ = smem + (SBUF) * STAGE;                                                                               \
                 const int off_ = x3_off((tid >> 3) + 64 * s_, a_c4 >> 1) + (a_c4 & 1) * 8;                                       \
-                *reinterpret_cast<u16x4*>(As_ + off_) = hq_;                                                                     \
-                *reinterpret_cast<u16x4*>(As_ + X3_A_PLANE + off_) = mq_;                                                        \
-                if constexpr (!H2) *reinterpret_cast<u16x4*>(As_ + 2 * X3_A_PLANE + off_) = lq_;                                 \
+                if constexpr (H2) {                                                                                              \
+                    *reinterpret_cast<u32x2*>(As_ + off_) = u32x2{hp_[0], hp_[1]};                                               \
+                    *reinterpret_cast<u32x2*>(As_ + X3_A_PLANE + off_) = u32x2{lp_[0], lp_[1]};                                  \
+                } else {                                                                                                         \
+                    *reinterpret_cast<u16x4*>(As_ + off_) = hq_;                                                                 \
+                    *reinterpret_cast<u16x4*>(As_ + X3_A_PLANE + off_) = mq_;                                                    \
+                    *reinterpret_cast<u16x4*>(As_ + 2 * X3_A_PLANE + off_) = lq_;                                                \
+                }                                                                                                                \
             } else if (s_ == 4) { SVI_X3_STAGE_W(SS, SBUF, 0); SVI_X3_STAGE_W(SS, SBUF, 1); }                                    \
             else SVI_X3_STAGE_W(SS, SBUF, 2);                                                                                    \
         }                                                                                                                        \
@@ -453,6 +484,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
             const int ks = s_ / 3, n = s_ % 3, sn = s_ + 1, ksn = sn / 3, nn = sn % 3;                                           \
             const int wc = s_ & 1, wn = wc ^ 1;                                                                                  \
             u16x4 hq_, mq_, lq_;                                                                                                 \
+            unsigned hp_[2], lp_[2];                                                                                             \
             if constexpr (H2) SVI_X3_MFMA(1, 0);   /* wl ah */                                                                   \
             else SVI_X3_MFMA(1, 1);                /* wm am */                                                                   \
             SVI_SB();                                                                                                            \
@@ -464,13 +496,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
                         af_[1][pl] = *reinterpret_cast<const bf16x8*>(As_c + pl * X3_A_PLANE + x3_off(32 * wave + l31, 2 + hi)); \
                 }                                                                                                                \
             }                                                                                                                    \
-            if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 0);                                                                                \
-            if constexpr (H2) { if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 1); }                                                          \
+            if constexpr (H2) { if (s_ < 4) split2h_pair(ra[SS][s_ < 4 ? s_ : 0][0], ra[SS][s_ < 4 ? s_ : 0][1], a_scale, hp_[0], lp_[0]); }\
+            else { if (s_ < 4) SVI_X3_SPLIT1(SS, s_, 0); }                                                                       \
             SVI_SB();                                                                                                            \
             if constexpr (H2) {                                                                                                  \
                 SVI_X3_MFMA(0, 1);                 /* wh al */                                                                   \
                 SVI_SB();                                                                                                        \
-                if (s_ < 4) { SVI_X3_SPLIT1(SS, s_, 2); SVI_X3_SPLIT1(SS, s_, 3); }                                              \
+                if (s_ < 4) split2h_pair(ra[SS][s_ < 4 ? s_ : 0][2], ra[SS][s_ < 4 ? s_ : 0][3], a_scale, hp_[1], lp_[1]);       \
                 SVI_X3_STORES(SS, SBUF);                                                                                                 \
                 SVI_SB();                                                                                                        \
             } else {                                                                                                             \
@@ -616,7 +648,8 @@ svi_status launch_conv(const ConvP& p, hipStream_t st) {
 #ifdef SVI_ABLATIONS
         pa.abl = svi_switches().vae_abl;
 #endif
-        if (p.w2h && p.w2_inv && p.in_scale > 0.f && !svi_switches().vae_no_x2h && (((uintptr_t)p.w2_inv) & 15) == 0) {
+        if (p.w2h && p.w2_inv && p.in_scale > 0.f && !svi_switches().vae_no_x2h && (((uintptr_t)p.w2_inv) & 15) == 0 && p.Cin % 32 == 0 && !p.ups &&
+            (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 4 < 0xFFE00000L && (long)2 * p.plane_w3 * 2 < 0xFFE00000L) {
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_igemm_x3_kernel<true>), 2 * X2H_STAGE));
             hipLaunchKernelGGL(conv_igemm_x3_kernel<true>, grid3, block3, 2 * X2H_STAGE, st, pa);
         } else {
