@@ -669,6 +669,7 @@ def gen_t5():
 
     run(synth.T5_TINY, synth.T5_SEED, synth.T5_TINY_CASES)
     run(synth.T5_XXL_BLOCK, synth.T5_SEED + 1, [synth.T5_XXL_CASE], synth.T5_XXL_ROWS)
+    run(synth.T5_DEEP, synth.T5_SEED + 2, [synth.T5_DEEP_CASE])
     np.savez(os.path.join(OUT, "t5_encoder.npz"), **out)
 
 
@@ -707,6 +708,7 @@ def gen_clip():
 
     run(synth.CLIP_TINY, synth.CLIP_SEED, synth.CLIP_TINY_CASES)
     run(synth.CLIP_H_BLOCK, synth.CLIP_SEED + 1, [synth.CLIP_H_CASE], synth.CLIP_H_ROWS)
+    run(synth.CLIP_DEEP, synth.CLIP_SEED + 2, [synth.CLIP_DEEP_CASE])
     np.savez(os.path.join(OUT, "clip_encoder.npz"), **out)
 
 

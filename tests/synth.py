@@ -300,6 +300,8 @@ def audio_windows(seed: int, frames: int):
 # ----------------------------------------------------------------------------------- prompt-side encoders (golden/t5_*.npz, clip_*.npz)
 T5_TINY = dict(vocab=200, dim=128, dim_attn=128, dim_ffn=256, num_heads=2, num_layers=2, num_buckets=32, shared_pos=False)
 T5_XXL_BLOCK = dict(vocab=512, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=1, num_buckets=32, shared_pos=False)   # text_encoder:211-220 widths
+T5_DEEP = dict(vocab=200, dim=128, dim_attn=128, dim_ffn=256, num_heads=2, num_layers=24, num_buckets=32, shared_pos=False)      # the real depth at the tiny width
+T5_DEEP_CASE = ("deep", 48, 31, 907)
 T5_SEED = 900
 T5_TINY_CASES = [("short", 24, 13, 901), ("long", 160, 160, 902), ("one", 16, 1, 903)]      # (name, L, valid tokens, seed)
 T5_XXL_CASE = ("xxl", 64, 40, 905)
@@ -353,6 +355,8 @@ def t5_ids(seed: int, L: int, valid: int, vocab: int):
 
 CLIP_TINY = dict(image_size=28, patch_size=14, dim=160, mlp_ratio=4, num_heads=2, num_layers=3)
 CLIP_H_BLOCK = dict(image_size=224, patch_size=14, dim=1280, mlp_ratio=4, num_heads=16, num_layers=2)     # image_encoder:826-834 widths, 2 of 32 blocks
+CLIP_DEEP = dict(image_size=28, patch_size=14, dim=160, mlp_ratio=4, num_heads=2, num_layers=32)          # the real depth (31 blocks used) at the tiny width
+CLIP_DEEP_CASE = ("deep", (1, 3, 36, 44), 957)
 CLIP_SEED = 950
 CLIP_TINY_CASES = [("down", (1, 3, 40, 56), 951), ("up", (1, 3, 20, 24), 952), ("batch2", (2, 3, 28, 28), 953)]      # (name, image shape, seed)
 CLIP_H_CASE = ("h14", (1, 3, 480, 832), 955)

@@ -65,3 +65,30 @@ def test_clip_h14_block_vs_reference(golden):
     with torch.no_grad():
         o = eo.clip_encode_image(sd, torch.from_numpy(synth.clip_image(seed, *shape)), synth.CLIP_H_BLOCK).numpy()
     assert rel_l2(o[:, synth.CLIP_H_ROWS], g[name]) < 2e-6
+
+
+def test_t5_real_depth_vs_reference(golden):
+    """24 blocks (the depth of umT5-XXL) at the tiny width: what the bf16 rounding points accumulate to."""
+    g = golden("t5_encoder.npz")
+    cfg = synth.T5_DEEP
+    name, L, valid, seed = synth.T5_DEEP_CASE
+    sd = _t(synth.t5_state_dict(synth.T5_SEED + 2, **cfg))
+    ids, _ = synth.t5_ids(seed, L, valid, cfg["vocab"])
+    with torch.no_grad():
+        o32 = eo.t5_encode(sd, torch.from_numpy(ids[0]), valid, cfg).numpy()
+        o16 = eo.t5_encode(sd, torch.from_numpy(ids[0]), valid, cfg, "bf16").numpy()
+    assert rel_l2(o32, g["deep_fp32"]) < 5e-6
+    # bf16 noise grows with depth: the reference's own bf16 module is 3.0e-2 from its fp32 run here; the restatement is as close to the
+    # fp32 run (2.9e-2) and as far from the bf16 run as two independent bf16 evaluations are (3.0e-2 <= sqrt(2) x the gap)
+    gap = rel_l2(g["deep_bf16"], g["deep_fp32"])
+    assert gap < 4e-2 and rel_l2(o16, g["deep_fp32"]) < 1.2 * gap and rel_l2(o16, g["deep_bf16"]) < 1.5 * gap
+
+
+def test_clip_real_depth_vs_reference(golden):
+    """32 blocks, 31 used (ViT-H/14's depth) at the tiny width."""
+    g = golden("clip_encoder.npz")
+    name, shape, seed = synth.CLIP_DEEP_CASE
+    sd = _t(synth.clip_state_dict(synth.CLIP_SEED + 2, **synth.CLIP_DEEP))
+    with torch.no_grad():
+        o = eo.clip_encode_image(sd, torch.from_numpy(synth.clip_image(seed, *shape)), synth.CLIP_DEEP).numpy()
+    assert rel_l2(o, g[name]) < 5e-6

@@ -95,3 +95,63 @@ def test_vae_parameter_inventory_is_the_reference_state_dict(ref):
     sd = {k: tuple(t.shape) for k, t in v.state_dict().items()}
     assert sd == dict(vae_param_shapes())
     assert sd == dict(synth.vae_param_shapes())
+
+
+def test_text_encoder_weight_table_accepts_the_reference_state_dict(ref):
+    """WanTextEncoder() with its default constructor arguments = umT5-XXL as the Wan pipelines load it (wan_video_text_encoder.py:211-220):
+    every key of its state dict binds (bf16), nothing the C side needs is missing, and the synthetic inventory of the parity tests is the
+    same table."""
+    import importlib
+    from svi_hip import _lib as L
+    te = importlib.import_module("diffsynth.models.wan_video_text_encoder")
+    with torch.device("meta"):
+        m = te.WanTextEncoder()
+    sd = m.state_dict()
+    cfg = dict(vocab=256384, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=24, num_buckets=32, shared_pos=False)
+    assert (m.dim, m.dim_attn, m.dim_ffn, m.num_heads, m.num_layers, m.num_buckets, m.shared_pos) == tuple(cfg[k] for k in
+                                                                                                         ("dim", "dim_attn", "dim_ffn", "num_heads", "num_layers", "num_buckets", "shared_pos"))
+    c = L.T5Config(cfg["vocab"], cfg["dim"], cfg["dim_attn"], cfg["dim_ffn"], cfg["num_heads"], cfg["num_layers"], cfg["num_buckets"], 128, 0)
+    h = C.c_void_p()
+    L.check(L.lib().svi_t5_create(C.byref(c), C.byref(h)), "svi_t5_create")
+    try:
+        assert L.lib().svi_t5_check_bound(h) == 2
+        _bind_all(L.lib().svi_t5_bind_weight, h, sd, L.SVI_BF16)
+        L.check(L.lib().svi_t5_check_bound(h), "svi_t5_check_bound")
+        bad = (C.c_int64 * 2)(4096, 4097)
+        assert L.lib().svi_t5_bind_weight(h, b"blocks.0.attn.q.weight", C.c_void_p(0x10000), L.SVI_BF16, bad, 2) == 1
+        ok = (C.c_int64 * 2)(32, 64)
+        assert L.lib().svi_t5_bind_weight(h, b"pos_embedding.embedding.weight", C.c_void_p(0x10000), L.SVI_BF16, ok, 2) == 1    # shared_pos is off
+        assert L.lib().svi_t5_bind_weight(h, b"blocks.0.attn.q.weight", C.c_void_p(0x10000), L.SVI_F32, (C.c_int64 * 2)(4096, 4096), 2) == 1
+    finally:
+        L.lib().svi_t5_destroy(h)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == dict(synth.t5_param_shapes(**cfg))
+    # T5RelativeEmbedding.max_dist default = the C side's
+    assert m.blocks[0].pos_embedding.max_dist == 128
+
+
+def test_image_encoder_weight_table_accepts_the_reference_state_dict(ref):
+    """The visual tower exactly as clip_xlm_roberta_vit_h_14 configures it (wan_video_image_encoder.py:822-849, XLMRobertaCLIP :686-701) — the
+    module WanImageEncoder holds as self.model.visual: all of its keys bind (fp32; post_norm / head / the last block are accepted and unused),
+    and check_bound passes."""
+    import importlib
+    from svi_hip import _lib as L
+    ie = importlib.import_module("diffsynth.models.wan_video_image_encoder")
+    with torch.device("meta"):
+        vis = ie.VisionTransformer(image_size=224, patch_size=14, dim=1280, mlp_ratio=4, out_dim=1024, num_heads=16, num_layers=32, pool_type="token",
+                                   pre_norm=True, post_norm=False, activation="gelu", attn_dropout=0.0, proj_dropout=0.0, embedding_dropout=0.0, norm_eps=1e-5)
+    sd = vis.state_dict()
+    c = L.ClipConfig(224, 14, 1280, 4, 16, 32, 31, 1e-5)
+    h = C.c_void_p()
+    L.check(L.lib().svi_clip_create(C.byref(c), C.byref(h)), "svi_clip_create")
+    try:
+        assert L.lib().svi_clip_check_bound(h) == 2
+        _bind_all(L.lib().svi_clip_bind_weight, h, sd, L.SVI_F32)
+        L.check(L.lib().svi_clip_check_bound(h), "svi_clip_check_bound")
+        tok, dim = C.c_int32(), C.c_int32()
+        L.check(L.lib().svi_clip_tokens(h, C.byref(tok), C.byref(dim)), "svi_clip_tokens")
+        assert (tok.value, dim.value) == (257, 1280)
+        assert L.lib().svi_clip_bind_weight(h, b"transformer.32.norm1.weight", C.c_void_p(0x10000), L.SVI_F32, (C.c_int64 * 1)(1280), 1) == 1
+        assert L.lib().svi_clip_bind_weight(h, b"patch_embedding.bias", C.c_void_p(0x10000), L.SVI_F32, (C.c_int64 * 1)(1280), 1) == 1   # pre_norm: no bias
+    finally:
+        L.lib().svi_clip_destroy(h)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == dict(synth.clip_param_shapes(image_size=224, patch_size=14, dim=1280, mlp_ratio=4, num_heads=16, num_layers=32))
