@@ -5,8 +5,8 @@
 
 The reference builds, per clip,  y = cat(mask[4, T', h, w], VAE.encode([motion frames ‖ padding])[16, T', h, w])  and hands
 it to the DiT as 20 extra input channels (svi_video.py:346-350; models/wan_video_dit.py patch embedding in_dim = 36).
-What is NOT here is outside SURVEY §8's path: PIL resizing / normalisation (`preprocess_image`) and the CLIP image encoder
-(`clip_context`); callers pass frames already as tensors in [-1, 1].  The reference flips the whole VAE to fp32 and back
+PIL resizing / normalisation (`preprocess_image`) stays with the caller: frames arrive as tensors in [-1, 1].  The CLIP tokens of the
+first frame (`clip_context`, :317) come from svi_hip.WanImageEncoder when one is passed.  The reference flips the whole VAE to fp32 and back
 around this call (:303-309, :359-362); the HIP VAE is fp32-resident, so nothing moves.
 """
 from __future__ import annotations
@@ -59,8 +59,10 @@ def condition_video(first_frames: torch.Tensor, random_ref_frame: Optional[torch
 
 def image_condition(vae, first_frames: Union[torch.Tensor, Sequence[torch.Tensor]], random_ref_frame: Optional[torch.Tensor],
                     num_frames: int, ref_pad_cfg: bool = False, ref_pad_num: int = 0, out_dtype=torch.bfloat16,
-                    tiled: bool = False, tile_size=(34, 34), tile_stride=(18, 16)) -> torch.Tensor:
-    """y [1, 20, T', H/8, W/8] exactly as encode_images_adaptive returns it (mask ‖ VAE latent, cast to the DiT dtype)."""
+                    tiled: bool = False, tile_size=(34, 34), tile_stride=(18, 16), image_encoder=None):
+    """y [1, 20, T', H/8, W/8] exactly as encode_images_adaptive returns it (mask ‖ VAE latent, cast to the DiT dtype).
+    With `image_encoder` (svi_hip.WanImageEncoder): the call's full result {"clip_feature": ..., "y": ...} (:317, :355-364) — the CLIP
+    tokens of the FIRST motion frame, computed in fp32 and cast to the DiT dtype."""
     if not isinstance(first_frames, torch.Tensor):
         first_frames = torch.stack([f.reshape(3, *f.shape[-2:]) for f in first_frames])
     first_frames = first_frames.to(device="cuda", dtype=torch.float32)
@@ -68,4 +70,7 @@ def image_condition(vae, first_frames: Union[torch.Tensor, Sequence[torch.Tensor
     video = condition_video(first_frames, random_ref_frame, num_frames, ref_pad_num)
     lat = vae.encode([video], device="cuda", tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)[0]
     msk = condition_mask(num_frames, H, W, n, ref_pad_cfg, device=lat.device)
-    return torch.concat([msk, lat]).unsqueeze(0).to(out_dtype)
+    y = torch.concat([msk, lat]).unsqueeze(0).to(out_dtype)
+    if image_encoder is None:
+        return y
+    return {"clip_feature": image_encoder.encode_image([first_frames[:1]]).to(out_dtype), "y": y}

@@ -75,7 +75,12 @@ class StreamLoop:
         for k in range(start_clip, num_clips):
             first = u8_to_video(motion)                                          # preprocess_image of every motion frame
             y = image_condition(self.vae, first, ref, self.num_frames, self.ref_pad_cfg, self.ref_pad_num)
-            cf = self.clip_encoder(first[:1]) if self.clip_encoder is not None else clip_feature
+            if self.clip_encoder is None:
+                cf = clip_feature
+            elif hasattr(self.clip_encoder, "encode_image"):                      # svi_hip.WanImageEncoder: clip_context of svi_video.py:317, :355
+                cf = self.clip_encoder.encode_image([first[:1]]).to(torch.bfloat16)
+            else:
+                cf = self.clip_encoder(first[:1])
             ctx_pos, ctx_neg = prompts[clip_prompt_index(k, len(prompts), prompt_repeat_times, use_first_prompt_only)]
             seed = clip_seed(k, self.seed_times)
             lat = generate_noise((1, 16, tlat, H // 8, W // 8), seed=seed, device="cpu", dtype=torch.float32).to("cuda", torch.bfloat16)

@@ -227,7 +227,8 @@ def gen_teacache(dit_mod, fm):
 
 def gen_image_condition(vae_mod):
     """SVIVideoPipeline.encode_images_adaptive (pipelines/svi_video.py:291-364) run on a stand-in `self` that carries the
-    reference VAE (seeded weights), BasePipeline.preprocess_image and a CLIP stub: pins row a22 (y = mask | VAE latent)."""
+    reference VAE (seeded weights), BasePipeline.preprocess_image and the reference's image encoder at a tiny configuration: pins row a22
+    (y = mask | VAE latent) and the clip_feature the same call returns."""
     from PIL import Image
     ns = {"torch": torch, "np": np}
     encode_images_adaptive = _reference_method("diffsynth/pipelines/svi_video.py", "SVIVideoPipeline", "encode_images_adaptive", ns)
@@ -235,13 +236,27 @@ def gen_image_condition(vae_mod):
     v = vae_mod.WanVideoVAE()
     v.load_state_dict({k: t(a) for k, a in synth.vae_state_dict(500).items()}, strict=True)
 
+    # the image encoder: the reference's own VisionTransformer (tiny configuration, seeded weights) behind the reference's own
+    # WanImageEncoder.encode_image (compiled out of the source file; torchvision's Normalize stated as in gen_clip)
+    import torch.nn.functional as F
+    ie = importlib.import_module("diffsynth.models.wan_video_image_encoder")
+    ccfg = synth.CLIP_TINY
+    vis = ie.VisionTransformer(image_size=ccfg["image_size"], patch_size=ccfg["patch_size"], dim=ccfg["dim"], mlp_ratio=ccfg["mlp_ratio"], out_dim=64,
+                               num_heads=ccfg["num_heads"], num_layers=ccfg["num_layers"], pool_type="token", pre_norm=True, post_norm=False,
+                               activation="gelu", norm_eps=1e-5).eval()
+    vis.load_state_dict({k: t(a) for k, a in synth.clip_state_dict(synth.CLIP_SEED, **ccfg).items()}, strict=True)
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+
     class Clip(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.model = torch.nn.Module()
+            self.model.visual = vis
+            self.model.image_size = ccfg["image_size"]
+            self.transforms = types.SimpleNamespace(transforms=[lambda x: x.sub_(mean).div_(std)])
 
-        def encode_image(self, images):
-            return torch.zeros(1, 257, 1280)
+    Clip.encode_image = _reference_method("diffsynth/models/wan_video_image_encoder.py", "WanImageEncoder", "encode_image", {"torch": torch, "F": F})
 
     class Self:
         torch_dtype = torch.bfloat16
@@ -258,7 +273,9 @@ def gen_image_condition(vae_mod):
             ref = Image.fromarray(synth.condition_frames(650 + i, 1, H, W)[0])
             r = encode_images_adaptive(me, frames, ref, T, H, W, use_first_aug=False, ref_pad_cfg=cfg, ref_pad_num=pad)
             assert r["y"].dtype == torch.bfloat16 and tuple(r["y"].shape) == (1, 20, 3, 4, 6)
+            assert r["clip_feature"].dtype == torch.bfloat16 and tuple(r["clip_feature"].shape) == (1, 5, ccfg["dim"])
             out[name] = r["y"].float().numpy()
+            out["clip_" + name] = r["clip_feature"].float().numpy()
     np.savez(os.path.join(OUT, "image_condition.npz"), **out)
 
 

@@ -83,6 +83,37 @@ def test_image_condition_matches_reference_golden(golden, i):
     assert float(diff.max()) <= 2 ** -7 * float(want.abs().max()) and float((diff > 0).float().mean()) < 0.01, (float(diff.max()), float((diff > 0).float().mean()))
 
 
+def _bf16_close(got, want):
+    diff = (got - want).abs()
+    return float(diff.max()) <= 2 ** -7 * float(want.abs().max()) and float((diff > 0).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("i", range(len(synth.IMAGE_CONDITION_CASES)))
+def test_oracle_clip_feature_is_pinned_to_reference(golden, i):
+    """The other half of encode_images_adaptive's result: clip_feature = bf16(encode_image([first frame])) (svi_video.py:317, :355)."""
+    from oracle import encoders_oracle as eo
+    name, n, cfg, pad, ff, ref = _golden_case(i)
+    sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(synth.CLIP_SEED, **synth.CLIP_TINY).items()}
+    with torch.no_grad():
+        got = eo.clip_encode_image(sd, ff[:1], synth.CLIP_TINY).to(torch.bfloat16).float()
+    want = torch.from_numpy(golden("image_condition.npz")["clip_" + name])
+    assert got.shape == want.shape and _bf16_close(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(synth.IMAGE_CONDITION_CASES)))
+def test_image_condition_with_image_encoder_matches_reference_golden(golden, i):
+    import svi_hip
+    name, n, cfg, pad, ff, ref = _golden_case(i)
+    v = svi_hip.WanVideoVAE.from_state_dict({k: torch.from_numpy(a) for k, a in synth.vae_state_dict(500).items()})
+    enc = svi_hip.WanImageEncoder.from_state_dict({k: torch.from_numpy(a) for k, a in synth.clip_state_dict(synth.CLIP_SEED, **synth.CLIP_TINY).items()}, num_heads=2)
+    r = svi_hip.image_condition(v, ff.cuda(), ref.cuda(), 9, cfg, pad, image_encoder=enc)
+    g = golden("image_condition.npz")
+    assert set(r) == {"clip_feature", "y"} and r["clip_feature"].dtype == torch.bfloat16
+    assert _bf16_close(r["clip_feature"].float().cpu(), torch.from_numpy(g["clip_" + name]))
+    assert torch.equal(r["y"], svi_hip.image_condition(v, ff.cuda(), ref.cuda(), 9, cfg, pad))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_cond,ref_pad_cfg,ref_pad_num", [(1, False, 0), (2, True, 1), (1, False, -1)])
 def test_image_condition_matches_oracle(n_cond, ref_pad_cfg, ref_pad_num):
