@@ -179,3 +179,26 @@ def test_clip_real_depth(hip, golden):
     r, mx, scale = errs(out, g[name])
     report("clip_deep", rel=r, max_abs=mx, out_absmax=scale)
     assert r < 2e-5 and mx < 2e-4 * max(1.0, scale), (r, mx, scale)
+
+
+def test_encoder_checkpoints_from_files(hip, t5_tiny, clip_tiny, tmp_path):
+    """svi_hip.checkpoint.load_text_encoder / load_image_encoder: the .pth state dicts the Wan encoders ship as (the open-clip file carries
+    "visual." keys and a text tower) and .safetensors."""
+    from safetensors.torch import save_file
+    from svi_hip import checkpoint
+    m, sd = t5_tiny
+    torch.save({k: v.to(torch.bfloat16) for k, v in sd.items()}, str(tmp_path / "t5.pth"))
+    ids, mask = synth.t5_ids(921, 24, 9, synth.T5_TINY["vocab"])
+    a = checkpoint.load_text_encoder(str(tmp_path / "t5.pth"))
+    assert torch.equal(a(torch.from_numpy(ids), torch.from_numpy(mask)), m(torch.from_numpy(ids), torch.from_numpy(mask)))
+    e, csd = clip_tiny
+    torch.save({**{"visual." + k: v for k, v in csd.items()}, "textual.token_embedding.weight": torch.zeros(4, 4), "log_scale": torch.zeros(())},
+               str(tmp_path / "clip.pth"))
+    save_file({"model.visual." + k: v.contiguous() for k, v in csd.items()}, str(tmp_path / "clip.safetensors"))
+    img = torch.from_numpy(synth.clip_image(922, 1, 3, 30, 30))
+    want = e.encode_image([img])
+    from svi_hip.encoders import WanImageEncoder
+    for path in ("clip.pth", "clip.safetensors"):
+        sdl = checkpoint._load_any(str(tmp_path / path), "cuda")
+        b = WanImageEncoder.from_state_dict(sdl, num_heads=2)
+        assert torch.equal(b.encode_image([img]), want)

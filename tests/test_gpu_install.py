@@ -221,6 +221,9 @@ def test_checkpoint_and_lora_file_on_the_device(tmp_path):
     ctx = torch.from_numpy(synth.text_context(seed + 2, 20, c["text_dim"], 13)).cuda()
     t = torch.tensor([637.5])
     assert torch.equal(m.forward(x, t, ctx), ref.forward(x, t, ctx))
+    auto = checkpoint.load_dit([str(tmp_path / "m1.safetensors"), str(tmp_path / "m2.safetensors")])       # constructor arguments read off the shapes
+    assert checkpoint.infer_dit_config(sd) == dict(cfg, patch_size=tuple(c["patch_size"]), has_image_input=False)
+    assert torch.equal(auto.forward(x, t, ctx), ref.forward(x, t, ctx))
     r = 8
     targets = ["blocks.0.self_attn.q.weight", "blocks.1.ffn.0.weight"]
     lsd, patched = {}, dict(sd)

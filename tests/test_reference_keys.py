@@ -155,3 +155,45 @@ def test_image_encoder_weight_table_accepts_the_reference_state_dict(ref):
     finally:
         L.lib().svi_clip_destroy(h)
     assert {k: tuple(v.shape) for k, v in sd.items()} == dict(synth.clip_param_shapes(image_size=224, patch_size=14, dim=1280, mlp_ratio=4, num_heads=16, num_layers=32))
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_read_off_the_shapes_equals_the_reference_table(ref, name):
+    """The reference looks WanModel's constructor arguments up by an md5 of the key names (wan_video_dit.py:655-714); svi_hip.checkpoint
+    reads them off the tensor shapes.  For every table entry: build the reference model from the entry, infer from its state dict, get
+    the entry back."""
+    from svi_hip.checkpoint import infer_dit_config
+    dit_mod, _, _ = ref
+    cfg = CONFIGS[name]
+    with torch.device("meta"):
+        sd = dit_mod.WanModel(**cfg).state_dict()
+    got = infer_dit_config(sd)
+    want = dict(cfg)
+    want.setdefault("enable_multitalk", False)
+    got.setdefault("enable_multitalk", False)
+    assert got == want
+
+
+def test_config_tables_of_the_reference_converter(ref):
+    """...and the tables themselves: every `config = {...}` literal of WanModelStateDictConverter.from_civitai / from_diffusers that
+    describes a Wan2.1 model is reproduced (compiled out of the reference source, not retyped)."""
+    import ast
+    import inspect
+    from svi_hip.checkpoint import infer_dit_config
+    dit_mod, _, _ = ref
+    src = open(os.path.join(REF, "diffsynth/models/wan_video_dit.py")).read()
+    tables = []
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Assign) and isinstance(node.value, ast.Dict) and getattr(node.targets[0], "id", "") == "config" and node.value.keys:
+            tables.append(ast.literal_eval(node.value))
+    assert len(tables) >= 4
+    tables = [t for t in tables if "has_image_input" in t]       # the diffusers-style entry lacks a required argument: WanModel(**it) raises in the reference too
+    assert len(tables) >= 4
+    for t in tables:
+        accepted = set(inspect.signature(dit_mod.WanModel.__init__).parameters)          # the diffusers-style table carries keys the class ignores
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in t.items() if k in accepted}
+        with torch.device("meta"):
+            sd = dit_mod.WanModel(**kw).state_dict()
+        got = infer_dit_config(sd)
+        for k, v in kw.items():
+            assert got.get(k, False) == v, (k, got.get(k), v)
