@@ -442,6 +442,7 @@ extern "C" svi_status svi_t5_forward(svi_t5* h, const int64_t* ids, int32_t L, i
         g.A = A; g.lda = K; g.W = Wm; g.ldw = K; g.C = Cm; g.ldc = Nn; g.M = R; g.N = Nn; g.K = K;
         g.epi = res ? SVI_EPI_BIAS_GATE_RES : SVI_EPI_BIAS;               // res: bf16(res + bf16(acc)), the module output rounded first (t5:137-138)
         g.res = res; g.ldres = Nn;
+        g.skinny = 1;                                                      // taken when R <= 128 (a prompt's valid tokens), see svi_gemm.hip
         return svi_launch_gemm(g, st);
     };
     auto norm = [&](const bf16* in, bf16* o, const bf16* w) {

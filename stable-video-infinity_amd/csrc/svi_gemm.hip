@@ -1013,6 +1013,81 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256q_kernel(SviGemmArgs g
 #undef SVI_KSTEPQ
 }
 
+// -------------------------------------------------------------------------------------------------
+// Skinny-M kernel (SviGemmArgs.skinny, M <= 128): the text encoder's projections have 10^1..10^2 rows against 4096..10240 columns —
+// the job is to stream the WEIGHTS once at HBM speed, and a 128^2 tiling offers the chip 32..80 workgroups.  Here a workgroup owns
+// 16 output columns for all rows, its waves split K, fragments go global -> register -> MFMA (v_mfma_f32_16x16x32_bf16, no
+// LDS staging: every weight element is used once), the partial sums meet in LDS.  N / 16 workgroups (256 for N = 4096) of eight
+// waves, 16 B per lane per load, eight K steps in flight per wave (64 KiB of weights per CU).  The activations (<= 128 x K) are re-read by every workgroup from L2.
+// Operand roles as in the other kernels: the weight fragment is the first MFMA operand, so a lane ends up holding 4 consecutive
+// columns of one row -> 8-byte stores.  Epilogues: bias, and bias + residual with the module output rounded first.
+// -------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4s;
+// MB: 16-row blocks (M <= 16 MB); NW: waves = K splits; UN: K steps requested together (bytes in flight per wave = UN KiB of weights)
+template <int MB, int NW, int UN>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SviGemmArgs g) {
+    __shared__ f32x4s red[NW][MB][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kq = g.K / NW, kbeg = wave * kq, kend = kbeg + kq;          // K % (32 NW) == 0: every share is a whole number of 32-steps
+    const bf16* wp = g.W + (size_t)min(n0 + r16, g.N - 1) * g.ldw + 8 * kg;
+    const bf16* ap[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) ap[b] = g.A + (size_t)min(16 * b + r16, g.M - 1) * g.lda + 8 * kg;
+    f32x4s acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    int k = kbeg;
+    for (; k + 32 * UN <= kend; k += 32 * UN) {                  // UN K steps requested together, then consumed
+        bf16x8 wf[UN], af[UN][MB];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) wf[u] = ld_bf16x8(wp + k + 32 * u);          // the HBM stream first
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int b = 0; b < MB; ++b) af[u][b] = ld_bf16x8(ap[b] + k + 32 * u);
+        __builtin_amdgcn_sched_barrier(0);                        // all requests out before the first wait (hipcc would interleave them with the MFMAs)
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int b = 0; b < MB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[u][b], acc[b], 0, 0, 0);
+    }
+    for (; k < kend; k += 32) {
+        const bf16x8 wf = ld_bf16x8(wp + k);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ld_bf16x8(ap[b] + k), acc[b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b) red[wave][b][lane] = acc[b];
+    __syncthreads();
+    for (int idx = tid; idx < MB * 64; idx += 64 * NW) {
+        const int b = idx >> 6, l = idx & 63;
+        f32x4s s = red[0][b][l];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[w][b][l];
+        const int m = 16 * b + (l & 15), n = n0 + 4 * (l >> 4);
+        if (m >= g.M || n >= g.N) continue;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y = s[e];
+            if (n + e < g.N) {
+                if (g.bias) y += (float)g.bias[n + e];
+                y = rbf(y);
+                if (g.epi == SVI_EPI_BIAS_GATE_RES) {
+                    if (g.gate) y = rbf(g.gate[n + e] * y);
+                    y += (float)g.res[(size_t)m * g.ldres + n + e];
+                }
+            }
+            o[e] = (bf16)y;
+        }
+        if (n + 4 <= g.N) *reinterpret_cast<bf16x4*>(g.C + (size_t)m * g.ldc + n) = o;
+        else
+            for (int e = 0; e < 4 && n + e < g.N; ++e) g.C[(size_t)m * g.ldc + n + e] = o[e];
+    }
+}
+
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     SVI_REQUIRE(g.M >= 0 && g.N >= 0 && g.K > 0, "gemm: bad sizes M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0 || g.N == 0) return SVI_OK;
@@ -1025,6 +1100,22 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     if (g.epi == SVI_EPI_BIAS_GATE_RES) {
         SVI_REQUIRE(g.res != nullptr && g.ldres % 8 == 0 && ((uintptr_t)g.res % 16) == 0,
                     "gemm: gate/residual epilogue needs an aligned residual");
+    }
+    if (g.skinny && g.M <= 128 && g.K % 128 == 0 && !g.bias_along_m && (g.epi == SVI_EPI_BIAS || g.epi == SVI_EPI_BIAS_GATE_RES) && g.ldc % 4 == 0) {
+        dim3 grid((g.N + 15) / 16);
+        const bool wide = g.K % 256 == 0;                 // eight K shares when they come out whole
+#define SVI_SKINNY(MB, UN)                                                                                                        \
+        do {                                                                                                                     \
+            if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<MB, 8, UN>), grid, dim3(512), 0, st, g);                              \
+            else hipLaunchKernelGGL((gemm_skinny_kernel<MB, 4, UN>), grid, dim3(256), 0, st, g);                                   \
+        } while (0)
+        if (g.M <= 16) SVI_SKINNY(1, 8);
+        else if (g.M <= 32) SVI_SKINNY(2, 8);
+        else if (g.M <= 64) SVI_SKINNY(4, 8);
+        else SVI_SKINNY(8, 4);
+#undef SVI_SKINNY
+        SVI_LAUNCH_CHECK();
+        return SVI_OK;
     }
     // 256^2 LDS-DMA kernel when the problem fills at least half the chip with 256^2 tiles (and K tiles are whole)
     {
