@@ -292,9 +292,11 @@ extern "C" svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, i
                                     int32_t N, int32_t K, const void* bias, int32_t bias_along_m, int32_t epilogue,
                                     const float* gate, const void* res, int32_t ldres, svi_stream stream) {
     SVI_REQUIRE(A && W && C, "svi_gemm_bf16: null argument");
-    SviGemmArgs g{reinterpret_cast<const bf16*>(A), lda, reinterpret_cast<const bf16*>(W), ldw, reinterpret_cast<bf16*>(C), ldc,
-                  M, N, K, reinterpret_cast<const bf16*>(bias), bias_along_m, epilogue, gate,
-                  reinterpret_cast<const bf16*>(res), ldres};
+    SviGemmArgs g{};
+    g.A = reinterpret_cast<const bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const bf16*>(W); g.ldw = ldw;
+    g.C = reinterpret_cast<bf16*>(C); g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = reinterpret_cast<const bf16*>(bias); g.bias_along_m = bias_along_m; g.epi = epilogue; g.gate = gate;
+    g.res = reinterpret_cast<const bf16*>(res); g.ldres = ldres;
     return svi_launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
 }
 

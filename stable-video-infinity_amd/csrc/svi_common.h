@@ -140,8 +140,7 @@ struct SviGemmArgs {
     const bf16* res; int ldres;
     int sel_m, sel_n;           // > 0: choose the kernel as for a problem with this many rows / columns (stacked samples keep the per-sample choice,
                                 // so every row sees the same kernel — and the same bits — as in a per-sample launch); 0: by M / N
-    int skinny;                 // != 0: rows <= 128 against a large weight matrix (the text encoder): the weight-streaming kernel.  LAST member:
-                                // svi_dit.hip / svi_api.hip initialise this aggregate positionally
+    int skinny;                 // != 0: rows <= 128 against a large weight matrix (the text encoder): the weight-streaming kernel
 };
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
 

@@ -359,13 +359,19 @@ static svi_status ensure_rope(svi_dit* h, int f, int hh, int ww) {
 // launch computes every row with the kernel — and the bits — a per-sample launch would.
 static svi_status linear(const bf16* A, int lda, const Lin& l, bf16* C, int ldc, int M, int N, int K, int epi,
                          hipStream_t st, const float* gate = nullptr, const bf16* res = nullptr, int ldres = 0, int nb = 1) {
-    SviGemmArgs g{A, lda, l.w, K, C, ldc, M, N, K, l.b, 0, epi, gate, res, ldres, nb > 1 ? M / nb : 0, 0};
+    SviGemmArgs g{};
+    g.A = A; g.lda = lda; g.W = l.w; g.ldw = K; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = l.b; g.epi = epi; g.gate = gate; g.res = res; g.ldres = ldres;
+    g.sel_m = nb > 1 ? M / nb : 0;
     return svi_launch_gemm(g, st);
 }
 // V^T[D, n_tok] = Wv · X^T + bv (bias along rows): same GEMM with the operands swapped.
 static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16* CT, int ldct, int n_tok, int N, int K,
                                     hipStream_t st, int nb = 1) {
-    SviGemmArgs g{l.w, K, Xin, ldx, CT, ldct, N, n_tok, K, l.b, 1, SVI_EPI_BIAS, nullptr, nullptr, 0, 0, nb > 1 ? n_tok / nb : 0};
+    SviGemmArgs g{};
+    g.A = l.w; g.lda = K; g.W = Xin; g.ldw = ldx; g.C = CT; g.ldc = ldct; g.M = N; g.N = n_tok; g.K = K;
+    g.bias = l.b; g.bias_along_m = 1; g.epi = SVI_EPI_BIAS;
+    g.sel_n = nb > 1 ? n_tok / nb : 0;
     return svi_launch_gemm(g, st);
 }
 
