@@ -303,7 +303,7 @@ T5_XXL_BLOCK = dict(vocab=512, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads
 T5_DEEP = dict(vocab=200, dim=128, dim_attn=128, dim_ffn=256, num_heads=2, num_layers=24, num_buckets=32, shared_pos=False)      # the real depth at the tiny width
 T5_DEEP_CASE = ("deep", 48, 31, 907)
 T5_SEED = 900
-T5_TINY_CASES = [("short", 24, 13, 901), ("long", 160, 160, 902), ("one", 16, 1, 903)]      # (name, L, valid tokens, seed)
+T5_TINY_CASES = [("short", 24, 13, 901), ("long", 160, 160, 902), ("one", 16, 1, 903), ("mid", 100, 77, 904)]      # (name, L, valid tokens, seed)
 T5_XXL_CASE = ("xxl", 64, 40, 905)
 T5_XXL_ROWS = [0, 1, 7, 19, 38, 39, 40, 63]
 
