@@ -45,6 +45,12 @@ WORKLOADS = {
     "c4": dict(lat=(21, 60, 104), lc=512, steps_per_clip=50, model="WAN_14B_I2V",
                desc="Wan2.1-I2V-14B 81f@832x480 50-step CFG5 single clip per GPU (SVI's own base model; DiT only, y/clip_feature synthetic)"),
     "c1": dict(lat=(5, 32, 32), lc=512, steps_per_clip=10, desc="Wan2.1-T2V-1.3B 17f@256x256 10-step CFG5 (reference CPU-runnable case)"),
+    # BASELINE configs[4] names "Wan2.2-5B fp8 MFMA path, skeleton-conditioned (test_svi_dance.py)".  The reference contains neither a
+    # Wan2.2-5B model nor fp8 arithmetic; what test_svi_dance.py runs is SVIDanceVideoPipeline = Wan2.1-I2V-14B + the pose
+    # embedder, optionally with FP8 weight STORAGE.  That workload, as the reference has it:
+    "c5": dict(lat=(21, 60, 104), lc=512, steps_per_clip=50, model="WAN_14B_I2V", pose=True, fp8_storage=True,
+               desc="skeleton-conditioned clip as test_svi_dance.py runs it: Wan2.1-I2V-14B + dwpose embedder (add_condition on the conditional branch), "
+                    "FP8 weight storage (exact cast at bind, bf16 arithmetic), 81f@832x480 50-step CFG5; no Wan2.2-5B / fp8-MFMA exists in the reference"),
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
@@ -174,7 +180,8 @@ def main() -> None:
     D, F, NL, heads = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"], cfg["dim"] // 128
     dit = svi_hip.WanDiT(eps=1e-6, num_heads=heads, **cfg)
     weights = device_weights(cfg, 0, dev)
-    if args.fp8_storage:
+    if args.fp8_storage or wl.get("fp8_storage"):
+        args.fp8_storage = True
         weights = {k: v.to(torch.float8_e4m3fn) for k, v in weights.items()}
     dit.bind(weights)
     pair, units, sp_group, sp = None, world, None, False
@@ -206,6 +213,21 @@ def main() -> None:
         yy[:, :4] = 0
         yy[:, :4, 0] = 1
         cond = dict(y=yy.to(torch.bfloat16), clip_feature=torch.randn((1, 257, 1280), generator=gen, device=dev).to(torch.bfloat16))
+
+    pose_ms = None
+    if wl.get("pose"):      # dance variant (svi_video_dance.py:527-530): pose video -> dwpose_embedding -> add_condition, once per clip
+        from svi_hip.pose import PoseEmbedder
+        pe = PoseEmbedder.from_state_dict({k: torch.from_numpy(v) for k, v in synth.pose_state_dict(7, 16, D).items()})
+        pose_video = (torch.rand((3, 4 * (T - 1) + 1, 8 * H, 8 * W), generator=gen, device=dev) * 255.0) * (torch.rand((3, 4 * (T - 1) + 1, 8 * H, 8 * W), generator=gen, device=dev) < 0.3)
+        pe(pose_video)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        cond["add_condition"] = pe(pose_video)
+        e1.record()
+        torch.cuda.synchronize()
+        pose_ms = e0.elapsed_time(e1)
+        del pose_video
 
     def one_step(i: int) -> None:
         j = i % spc
@@ -277,7 +299,7 @@ def main() -> None:
         finite = red[1].item() == 0.0
     ms_per_step = elapsed * 1000.0 / args.steps
     clip_s_dit = spc * ms_per_step / 1000.0
-    clip_s = clip_s_dit + ((vae_ms or 0.0) + (enc_ms or 0.0)) / 1000.0
+    clip_s = clip_s_dit + ((vae_ms or 0.0) + (enc_ms or 0.0) + (pose_ms or 0.0)) / 1000.0
     frames = float(T)
     value = units * frames / clip_s
     L = (T // 1) * (H // 2) * (W // 2)
@@ -313,16 +335,20 @@ def main() -> None:
                 "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4)}
     line = {
         "metric": {"c2": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step", "c1": "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",
-                   "c4": "denoised latent frames/sec, Wan2.1-I2V-14B 81f@832x480 50-step"}[args.workload],
+                   "c4": "denoised latent frames/sec, Wan2.1-I2V-14B 81f@832x480 50-step",
+                   "c5": "denoised latent frames/sec, Wan2.1-I2V-14B + pose embedder (dance) 81f@832x480 50-step, FP8 weight storage"}[args.workload],
         "value": round(value, 5), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.seq_parallel else "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
-        "config": {"workload": wl["desc"], "step": f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
+        "config": {"workload": wl["desc"], "step": (f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; the pose condition enters the conditional branch only, so the two "
+                                                    "forwards share nothing) + CFG + Euler") if wl.get("pose") else
+                   f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
                    "steps_per_clip": spc, "tokens": L, "clips_per_gpu": round(units / world, 4),
                    "parallelism": (f"one clip: {'cfg-pair x ' if pair else ''}sequence-parallel over {world} ranks" if args.seq_parallel else
                                    f"cfg-pair x{units} clips" if pair else f"clip-per-rank x{world}"),
                    "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
                    "vae_condition_encode_ms": None if enc_ms is None else round(enc_ms, 2),
+                   "pose_embedder_ms": None if pose_ms is None else round(pose_ms, 2),
                    "value_includes_vae_decode": vae_ms is not None,
                    "dit_only_value": round(units * frames / clip_s_dit, 5),
                    "dit_tflops": round(2 * flops_forward / (ms_per_step * 1e-3) / 1e12, 1),
