@@ -9,7 +9,10 @@
 """
 import math
 
+import numpy as np
 import torch
+
+import synth
 from hypothesis import given, settings
 from hypothesis import strategies as st
 
@@ -152,3 +155,37 @@ def test_nearest_timestep_lookup(steps, i):
     for noisy in (t, t.to(torch.bfloat16).float() if steps <= 30 else t, t + 1e-3):
         want = float((sch.sigmas[i + 1] if i + 1 < steps else 0.0) - sch.sigmas[i])
         assert math.isclose(sch.step_delta(noisy), want, abs_tol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------- prompt-side encoders, checkpoints
+@settings(max_examples=60, deadline=None)
+@given(st.sampled_from([8, 16, 32, 64]), st.sampled_from([32, 64, 128, 256]), st.integers(1, 300))
+def test_relative_bucket_table_of_the_library_equals_the_oracle_for_any_configuration(num_buckets, max_dist, length):
+    """svi_t5_relative_buckets (host code of libsvi_hip) against the restatement of T5RelativeEmbedding._relative_position_bucket that is
+    pinned to the reference's own table at (32, 128, 512): same buckets for every offset, monotone in |offset|, mirrored with the sign bit."""
+    from oracle import encoders_oracle as eo
+    from svi_hip import encoders
+    if max_dist <= num_buckets // 4:
+        return
+    got = np.array(encoders.relative_position_buckets(num_buckets, max_dist, length), np.int32)
+    want = eo.relative_position_buckets(num_buckets, max_dist, length)
+    assert np.array_equal(got, want)
+    zero = length - 1
+    assert got[zero] == 0 and got.max() <= num_buckets - 1
+    neg, pos = got[:zero][::-1], got[zero + 1:]
+    assert np.array_equal(pos, neg + num_buckets // 2) and np.all(np.diff(pos) >= 0)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 6), st.sampled_from([16, 36]), st.integers(1, 5), st.integers(1, 4), st.booleans(), st.booleans())
+def test_dit_configuration_is_recovered_from_shapes(heads, in_dim, layers, ffn_mult, image, talk):
+    """svi_hip.checkpoint.infer_dit_config on the key -> shape table of any WanModel configuration (the table is the reference's own:
+    tests/test_reference_keys.py checks synth.dit_param_shapes against WanModel.state_dict())."""
+    from svi_hip.checkpoint import infer_dit_config
+    cfg = dict(dim=128 * heads, in_dim=in_dim, ffn_dim=256 * ffn_mult, out_dim=16, text_dim=64, freq_dim=256, patch_size=(1, 2, 2), num_layers=layers,
+               has_image_input=image)
+    if talk:
+        cfg["enable_multitalk"] = True
+    got = infer_dit_config(synth.dit_param_shapes(**cfg))
+    want = dict(cfg, num_heads=heads, eps=1e-6)
+    assert got == want
