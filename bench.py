@@ -4,6 +4,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks (it re-executes itself under
+torch.distributed.run on 127.0.0.1, one rank per GPU, RCCL); it refuses — one line on stderr, non-zero exit — when fewer than N GPUs
+are visible or fewer than N ranks join, and never falls back to one rank.  `n_gpus` on the JSON line is the number of ranks that
+completed an RCCL all-reduce, `config.ranks` lists each rank's device and PCI bus id, `config.rccl` the library version.
+
 Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): Wan2.1-T2V-1.3B architecture, random-init bf16 weights,
 one 81-frame 832x480 clip = latents [1,16,21,60,104] -> 32760 tokens, text context [1,512,4096] (pos/neg), CFG 5.0,
 flow-match shift 5, 50 scheduler steps per clip.  A bench "step" is ONE scheduler step of the clip's denoise loop:
@@ -126,14 +131,63 @@ def cpu_baseline(max_threads: int = 32, timeout_s: int = 300) -> dict:
     clip_s = dt * 30 * 100 + vt * 81.0 / 5.0
     rel = ""
     try:
+        # the reference's own modules timed beside the oracle's restatement on one host (tools/ref_vs_oracle_block.py, build container):
+        # applied here to say what the REFERENCE would take on this box's cores, next to the port's measured figure
         rv = json.load(open(os.path.join(ROOT, "profiles", "r2_cpu_reference_vs_port.json")))
+        rb, rvae = rv["port_over_reference_block"], rv["port_over_reference_vae"]
+        base["reference_over_port"] = {"dit_block_speed": round(rb, 4), "vae_decode_speed": round(rvae, 4),
+                                       "source": "profiles/r2_cpu_reference_vs_port.json"}
+        base["value_reference_estimate"] = 21.0 / (dt / rb * 30 * 100 + vt / rvae * 81.0 / 5.0)
         rel = (f"; on the build container ({rv['threads']} threads) the reference's own DiTBlock took {rv['reference_block_s']:.1f}s against the oracle's "
-               f"{rv['oracle_block_s']:.1f}s and its VAE decode {rv['reference_vae_decode_2_latent_frames_s']:.1f}s against {rv['oracle_vae_decode_2_latent_frames_s']:.1f}s")
+               f"{rv['oracle_block_s']:.1f}s and its VAE decode {rv['reference_vae_decode_2_latent_frames_s']:.1f}s against {rv['oracle_vae_decode_2_latent_frames_s']:.1f}s "
+               f"(value_reference_estimate applies those ratios to this box's port timings)")
     except Exception:
         pass
     return dict(base, value=21.0 / clip_s,
                 sample=f"1 DiTBlock forward (fp32 oracle, oracle/wan_dit_oracle.py) at L=32760 took {dt:.1f}s and the VAE decode of 2 latent frames "
                        f"(5 frames 480x832, oracle/wan_vae_oracle.py) {vt:.1f}s on {threads} threads; extrapolated x30 blocks x100 forwards + decode x81/5 per clip{rel}")
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int, selftest: bool) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (torch.distributed.run on 127.0.0.1, one
+    process per GPU) and hand its exit code on.  Refuses instead of shrinking: N visible GPUs or nothing."""
+    import subprocess
+    if not selftest:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {have}: refusing to run fewer ranks than asked for", file=sys.stderr, flush=True)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def join_ranks(dist, dev, want: int, backend: str) -> list:
+    """Every rank adds a one over the process group: the sum is the number of ranks that really joined.  Returns each rank's
+    (rank, device, pci bus id) — or exits non-zero with a one-line reason when fewer than `want` arrived."""
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    joined = int(one.item())
+    if joined != want or dist.get_world_size() != want:
+        print(f"bench.py: {joined} of {want} ranks joined the {backend} group (world size {dist.get_world_size()}): refusing to report a {want}-GPU line",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
+    me = {"rank": dist.get_rank(), "device": str(dev)}
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        me["pci_bus_id"] = getattr(pr, "pci_bus_id", None)
+        me["name"] = pr.name
+    everyone = [None] * want
+    dist.all_gather_object(everyone, me)
+    return everyone
 
 
 def main() -> None:
@@ -153,22 +207,49 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true", help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)): for the "
                     "launch-bound regime (--workload c1); per-kernel event timing is off under capture, so `roofline` is null")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launcher-selftest", action="store_true", help="only start the ranks, join them over gloo on the CPU and print who joined "
+                    "(tests/test_bench_launcher.py: the launch path without GPUs)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker()
         return
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, args.launcher_selftest))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if args.launcher_selftest:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        who = join_ranks(dist, torch.device("cpu"), args.gpus, "gloo")
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": len(who), "ranks": who, "backend": "gloo"}), flush=True)
+        dist.destroy_process_group()
+        return
     local = int(os.environ.get("SVI_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))      # SVI_BENCH_DEVICE: pin every rank to one device (a probe only)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU {local} ({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible)", file=sys.stderr, flush=True)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
+    dist, who = None, [{"rank": 0, "device": str(dev), "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
+                        "name": torch.cuda.get_device_properties(dev).name}]
+    rccl = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        who = join_ranks(dist, dev, args.gpus, "nccl (RCCL)")
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
 
     import synth
     import svi_hip
@@ -304,8 +385,19 @@ def main() -> None:
     value = units * frames / clip_s
     L = (T // 1) * (H // 2) * (W // 2)
     lc = wl["lc"]
+    img_tok = 257 if cfg["has_image_input"] else 0
+    # the algorithmic work of one reference forward (what the reference executes; the number BASELINE.md quotes) ...
     flops_forward = NL * (12 * L * D ** 2 + 4 * L * L * D + 4 * lc * D ** 2 + 4 * L * lc * D + 4 * L * D * F
-                          + (4 * 257 * D ** 2 + 4 * L * 257 * D if cfg["has_image_input"] else 0))
+                          + (4 * img_tok * D ** 2 + 4 * L * img_tok * D if img_tok else 0))
+    # ... and what a bench step actually executes: the prompt-side projections (text embedding, cross-attention K / V of every block)
+    # are loop constants served by the context cache, and block 0's self-attention third of the second CFG forward is shared
+    # (forward_cfg_pair; not when the pose condition makes the branches differ).  dit_tflops is computed from THIS.
+    per_fwd = NL * (8 * L * D ** 2 + 4 * L * L * D + 4 * L * D ** 2 + 4 * L * lc * D + 4 * L * img_tok * D + 4 * L * D * F) \
+        + 2 * L * (cfg["in_dim"] * 4) * D + 2 * L * D * 64
+    shared = 0 if (wl.get("pose") or pair or sp) else (8 * L * D ** 2 + 4 * L * L * D)
+    flops_step = 2 * per_fwd - shared
+    if pair:
+        flops_step = per_fwd                 # a rank of a CFG pair runs one branch
     fl = prof.get("flash_self", {"count": 0, "ms": 0.0})
     roof = None
     if fl["count"]:
@@ -333,11 +425,52 @@ def main() -> None:
                           "at once unless a row's exponentials left the optimistic range)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4)}
+    # ---- every kernel family of the step against the roofline that bounds it (per rank; ms from HIP events on the launch stream) ----
+    PEAK_HBM_TBS = 8.0
+    shard = dist.get_world_size(sp_group) if sp else 1
+
+    def fam(tag, work_per_launch, bound, what, total_fn=None):
+        rec = prof.get(tag)
+        if not rec or not rec["count"]:
+            return None
+        ms = rec["ms"] / args.steps
+        n = rec["count"] / args.steps
+        total = total_fn(n) if total_fn else work_per_launch * n
+        if bound == "mfma":
+            ach, peak, unit = total / (ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = total / (ms * 1e-3) / 1e12, PEAK_HBM_TBS, "TB/s"
+        return {"bound": bound, "what": what, "launches_per_step": round(n, 2), "algorithmic_per_step": total, "ms_per_step": round(ms, 3),
+                "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}
+    Ls = L // shard if sp else L
+    roof_all = {
+        "flash_self": fam("flash_self", 4.0 * L * L * D / shard, "mfma", "4 L^2 D FLOP per launch (QK^T + PV, all heads)"),
+        "flash_cross": fam("flash_cross", 4.0 * Ls * lc * D, "mfma", "4 L Lc D FLOP per launch (text context; the 257-token image branch is untagged)"),
+        "gemm_qkv": fam("gemm_qkv", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch (q, k, v^T projections)"),
+        "gemm_attn_out": fam("gemm_attn_out", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch, gate + residual epilogue"),
+        "gemm_cross": fam("gemm_cross", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch (cross-attention q and o; cached prompt K / V excluded)"),
+        "gemm_ffn1": fam("gemm_ffn1", 2.0 * Ls * D * F, "mfma", "2 L D F FLOP per launch, GELU-tanh epilogue"),
+        "gemm_ffn2": fam("gemm_ffn2", 2.0 * Ls * D * F, "mfma", "2 L D F FLOP per launch, gate + residual epilogue"),
+        "ln_modulate": fam("ln_modulate", 4.0 * Ls * D, "hbm", "2 L D bf16 read + written per launch"),
+        # q|k launch: [L, 2D] read + written; cross-attention q launch: [L, D] read + written -> mean of the two launch kinds per block
+        # two launch kinds under one tag: the cross-attention q launch ([L, D] read + written, once per block and forward) and the q|k launch
+        # ([L, 2D] read + written: every other launch of the tag)
+        "rmsnorm_rope": fam("rmsnorm_rope", None, "hbm", "q|k launches: 8 L D bytes read + written, cross-attention q launches: 4 L D",
+                            total_fn=lambda n: 4.0 * Ls * D * min(n, NL * (1 if pair else 2)) + 8.0 * Ls * D * max(0.0, n - NL * (1 if pair else 2))),
+    }
+    if vae_ms is not None and (T, H, W) == (21, 60, 104):
+        vflop = 2.754e14                      # SURVEY 8d, measured by flop counter: fp32 FLOP of one 81f@480x832 decode
+        roof_all["vae_decode"] = {"bound": "mfma", "what": "2.754e14 fp32 FLOP per decode, executed as 3 f16 MFMA partial products per product where the input is "
+                                  "bounded (two-term split) — algorithmic figure below is the f16-MFMA-equivalent 3 x 2.754e14", "launches_per_step": None,
+                                  "algorithmic_per_step": 3 * vflop, "ms_per_step": round(vae_ms, 2), "achieved": round(3 * vflop / (vae_ms * 1e-3) / 1e12, 1),
+                                  "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s (f16 MFMA equivalent)", "frac": round(3 * vflop / (vae_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                  "fp32_equivalent_tflops": round(vflop / (vae_ms * 1e-3) / 1e12, 1)}
+    roof_all = {k: v for k, v in roof_all.items() if v is not None}
     line = {
         "metric": {"c2": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step", "c1": "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",
                    "c4": "denoised latent frames/sec, Wan2.1-I2V-14B 81f@832x480 50-step",
                    "c5": "denoised latent frames/sec, Wan2.1-I2V-14B + pose embedder (dance) 81f@832x480 50-step, FP8 weight storage"}[args.workload],
-        "value": round(value, 5), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 5), "unit": "latent frames/s", "n_gpus": len(who), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.seq_parallel else "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
         "config": {"workload": wl["desc"], "step": (f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; the pose condition enters the conditional branch only, so the two "
@@ -351,10 +484,13 @@ def main() -> None:
                    "pose_embedder_ms": None if pose_ms is None else round(pose_ms, 2),
                    "value_includes_vae_decode": vae_ms is not None,
                    "dit_only_value": round(units * frames / clip_s_dit, 5),
-                   "dit_tflops": round(2 * flops_forward / (ms_per_step * 1e-3) / 1e12, 1),
+                   "dit_tflops": round(flops_step / (dist.get_world_size(sp_group) if sp else 1) / (ms_per_step * 1e-3) / 1e12, 1),
+                   "flop_per_step_executed": flops_step, "flop_per_forward_reference": flops_forward,
+                   "ranks": who, "rccl": rccl,
                    "hip_graph": bool(args.graph), "weights": "float8_e4m3fn storage, cast to bf16 at bind (reference FP8 mode)" if args.fp8_storage else "bf16",
                    "outputs_finite": finite},
         "roofline": roof,
+        "roofline_all": roof_all,
         "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
     }
     if rank == 0:

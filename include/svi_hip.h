@@ -18,10 +18,13 @@
  *   - Errors: integer status, never abort/throw across the ABI; message via svi_last_error()
  *     (thread-local).  There is NO CPU fallback: with no usable GPU every compute call fails.
  *   - Activations are bf16 (row-major, innermost dim contiguous) unless stated; accumulation fp32.
- *   - Handles are not thread-safe; one handle per device.  The operator-level seams (svi_attention_fwd,
- *     svi_layernorm_modulate, svi_rmsnorm_rope) share one process-wide scratch buffer: call them from one thread
- *     and on one stream at a time (stream order is what protects the scratch between consecutive calls).
- *     The event profiler (svi_prof_*) is process-wide and single-threaded as well.
+ *   - Handles are not thread-safe; one handle per device, driven from one host thread at a time.  What the library owns
+ *     outside the handles — the attention kernels' per-workgroup flag words, the scratch of the operator-level seams
+ *     (svi_attention_fwd, svi_layernorm_modulate, svi_rmsnorm_rope), the per-kernel LDS attributes, the event profiler's
+ *     records — is keyed by (device, stream) and guarded by one mutex: two handles on two streams, or two host threads
+ *     driving two streams, do not share a buffer (work on ONE stream is ordered, which is what protects a buffer between
+ *     consecutive calls).  A stream that is being captured must have seen each call once before the capture (buffers are
+ *     created on first use; creating one under capture is refused with a message).
  */
 #ifndef SVI_HIP_H
 #define SVI_HIP_H
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 4
+#define SVI_HIP_ABI_VERSION 5
 
 typedef enum {
     SVI_OK = 0,
@@ -177,6 +180,10 @@ svi_status svi_dit_sp_tea(svi_dit* h, int32_t mode, void* residual, svi_stream s
 svi_status svi_dit_sp_head(svi_dit* h, void* head_rows_out, svi_stream stream);
 svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void* out, int32_t T, int32_t H, int32_t W, svi_stream stream);
 int32_t svi_dit_head_ld(svi_dit* h);
+/* Moves whenever device state that a captured hipGraph of this handle's forwards may have baked in stops being valid (workspace
+ * growth, a context-cache entry filled or evicted, svi_dit_context_cache, a weight re-bound).  Read it right after a capture;
+ * replay only while it is unchanged (svi_hip.DenoiseLoop(graph=True) does). */
+int64_t svi_dit_generation(svi_dit* h);
 svi_status svi_attention_vt_fwd(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vt, int32_t ldvt, void* out,
                                 int32_t ldo, int32_t s_q, int32_t s_kv, int32_t n, int32_t q_prescaled, svi_stream stream);
 
@@ -192,6 +199,11 @@ svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_inout, const
  * unmasked softmax(q k^T / sqrt(d)) v, d must be 128.  out may not alias the inputs. */
 svi_status svi_attention_fwd(const void* q, const void* k, const void* v, void* out, int32_t b,
                              int32_t s_q, int32_t s_kv, int32_t n, int32_t d, svi_stream stream);
+/* Diagnostics for the long-sequence attention (keys >= 2048): one call = an optimistic pass that fixes each row's reference maximum
+ * after the first key tile + a second pass in which the complete kernel recomputes exactly the workgroups whose row sums left the
+ * range the fixed reference covers.  Reports, for the LAST such call enqueued on `stream`, how many workgroups were recomputed and
+ * how many the launch had (drains the stream; tests use it to prove that adversarial operands take the second pass). */
+svi_status svi_attention_last_flagged(svi_stream stream, int32_t* flagged_out, int32_t* workgroups_out);
 
 /* nn.LayerNorm(eps) [+ affine w,b] [+ modulate(x, shift, scale)] over rows of x[rows, dim]
  * (models/wan_video_dit.py:150-151,331-333,358,372).  w,b,shift,scale are bf16 [dim] or NULL. */
@@ -305,7 +317,10 @@ svi_status svi_pose_forward(svi_pose* h, const float* pose, void* out, int32_t F
  *   keys = positions < n_valid.  Query rows < `rows` (n_valid <= rows <= L) are computed, the rest of out bf16 [L, dim] is zero:
  *   rows = L reproduces text_encoder(ids, mask); rows = n_valid reproduces encode_prompt (it zeroes rows >= n_valid, :110-111).
  *   svi_t5_relative_buckets: host-only; T5RelativeEmbedding._relative_position_bucket (:175-194, bidirectional) for
- *   rel = key - query in -(len-1) .. len-1, out[rel + len - 1]. */
+ *   rel = key - query in -(len-1) .. len-1, out[rel + len - 1], in the host's fp32 arithmetic (what the module computes on a CPU).
+ *   svi_t5_device_buckets: the table svi_t5_forward actually uses — the same function evaluated on the device in the arithmetic
+ *   the module's tensor ops perform THERE (scalar division = multiplication by the fp32 reciprocal, device logf): the two can differ
+ *   where the log ratio is an exact integer (|rel| = 16, 32, 64).  Copied to the host for inspection. */
 typedef struct svi_t5_config {
     int32_t vocab, dim, dim_attn, dim_ffn, num_heads, num_layers, num_buckets, max_dist, shared_pos;
 } svi_t5_config;
@@ -316,6 +331,7 @@ svi_status svi_t5_bind_weight(svi_t5* h, const char* name, const void* dev_ptr, 
 svi_status svi_t5_check_bound(svi_t5* h);
 svi_status svi_t5_forward(svi_t5* h, const int64_t* ids, int32_t L, int32_t n_valid, int32_t rows, void* out, svi_stream stream);
 svi_status svi_t5_relative_buckets(int32_t num_buckets, int32_t max_dist, int32_t len, int32_t* out);
+svi_status svi_t5_device_buckets(svi_t5* h, int32_t len, int32_t* out);
 
 /* WanImageEncoder.encode_image (models/wan_video_image_encoder.py:864-880): bicubic resize to image_size^2 (align_corners=False),
  * v*0.5+0.5, CLIP mean/std normalisation, then VisionTransformer.forward(use_31_block=True) (:456-478): bias-free patch embedding,

@@ -2,6 +2,9 @@
 // (the seams the reference exposes: flash_attention, LayerNorm+modulate, RMSNorm+RoPE, Linear, CFG step).
 #include <stdlib.h>
 #include <string.h>
+#include <deque>
+#include <mutex>
+#include <vector>
 
 #include "svi_common.h"
 
@@ -34,6 +37,7 @@ static SviSwitches parse_switches() {
     s.vae_exact_fp32 = getenv("SVI_VAE_EXACT_FP32") != nullptr;
     s.flash_two_pass = env_int("SVI_FLASH_TWO_PASS", 0, 1);
     s.vae_no_x2h = env_int("SVI_VAE_X2H", 0, 1) == 0;
+    { const char* v = getenv("SVI_T5_BUCKETS"); s.t5_host_buckets = v && strcmp(v, "host") == 0; }
 #ifdef SVI_ABLATIONS
     s.flash_abl = env_int("SVI_FLASH_ABL", 0, 0);
     s.gemm_epi_abl = env_int("SVI_GEMM_EPI_ABL", 0, 0);
@@ -69,16 +73,58 @@ svi_status svi_claim_device(int* handle_device) {
     return SVI_OK;
 }
 
+// Process-wide tables (LDS attributes, per-stream buffers, profiler records) are shared by every handle and every host thread:
+// one mutex guards them.  Handles themselves stay single-threaded (one handle per device, driven from one thread at a time).
+static std::mutex& table_mutex() {
+    static std::mutex m;
+    return m;
+}
+
 svi_status svi_ensure_lds(const void* kernel, int bytes) {
     struct Seen { int dev; const void* fn; };
-    static Seen seen[256];
-    static int n_seen = 0;
+    static std::vector<Seen> seen;
     const int dev = svi_current_device();
     if (dev < 0) return SVI_ERR_HIP;
-    for (int i = 0; i < n_seen; ++i)
-        if (seen[i].dev == dev && seen[i].fn == kernel) return SVI_OK;
+    std::lock_guard<std::mutex> lock(table_mutex());
+    for (const Seen& s : seen)
+        if (s.dev == dev && s.fn == kernel) return SVI_OK;
     SVI_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    if (n_seen < 256) seen[n_seen++] = Seen{dev, kernel};
+    seen.push_back(Seen{dev, kernel});
+    return SVI_OK;
+}
+
+// Device buffers owned by the library outside any handle (the attention kernels' flag words, the operator seams' scratch) are
+// keyed by (device, stream, kind): work enqueued on one stream is ordered, so a buffer is only ever used by one launch sequence
+// at a time; two streams (or two host threads driving two streams) get buffers of their own and cannot clear or overwrite each
+// other's.  Growing a buffer frees the old one (hipFree drains the device first) — never in steady state.
+svi_status svi_stream_buffer(int kind, hipStream_t st, size_t bytes, void** out, long** user_out) {
+    struct Slot { int dev, kind; hipStream_t st; void* p; size_t bytes; long user; };
+    static std::deque<Slot> slots;          // deque: a slot's address (its host-side `user` word) stays valid as the table grows
+    const int dev = svi_current_device();
+    if (dev < 0) return SVI_ERR_HIP;
+    std::lock_guard<std::mutex> lock(table_mutex());
+    Slot* s = nullptr;
+    for (Slot& c : slots)
+        if (c.dev == dev && c.kind == kind && c.st == st) { s = &c; break; }
+    if (!s) {
+        slots.push_back(Slot{dev, kind, st, nullptr, 0, 0});
+        s = &slots.back();
+    }
+    if (s->bytes < bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            svi_set_error("a library buffer (kind %d, %zu B) would have to be allocated while its stream is being captured: run the call once on "
+                          "the capture stream before capturing", kind, bytes);
+            return SVI_ERR_INVALID;
+        }
+        (void)hipGetLastError();
+        if (s->p) { SVI_CHECK_HIP(hipFree(s->p)); s->p = nullptr; s->bytes = 0; }
+        hipError_t e = hipMalloc(&s->p, bytes);
+        if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B, buffer kind %d) failed: %s", bytes, kind, hipGetErrorString(e)); return SVI_ERR_OOM; }
+        s->bytes = bytes;
+    }
+    *out = s->p;
+    if (user_out) *user_out = &s->user;
     return SVI_OK;
 }
 extern "C" int32_t svi_abi_version(void) { return SVI_HIP_ABI_VERSION; }
@@ -88,14 +134,14 @@ extern "C" int32_t svi_device_count(void) {
     return n;
 }
 
-// ---- event profiler ------------------------------------------------------------------------------
-#include <vector>
+// ---- event profiler (one recorder per process, guarded by the table mutex; tags are paired per (tag, stream)) ------------------
 bool g_svi_prof_on = false;
 namespace {
 struct ProfRec { int tag; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
-hipEvent_t g_prof_open[PROF_NTAGS];
+struct ProfOpen { int tag; hipStream_t st; hipEvent_t e; };
+std::vector<ProfOpen> g_prof_open;
 const char* kProfNames[PROF_NTAGS] = {"ln_modulate", "gemm_qkv", "rmsnorm_rope", "flash_self", "gemm_attn_out",
                                       "gemm_cross", "flash_cross", "gemm_ffn1", "gemm_ffn2", "embed", "head",
                                       "vae_conv", "vae_other"};
@@ -107,23 +153,34 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 void svi_prof_begin_impl(int tag, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(table_mutex());
     hipEvent_t e = prof_event();
     (void)hipEventRecord(e, st);
-    g_prof_open[tag] = e;
+    g_prof_open.push_back(ProfOpen{tag, st, e});
 }
 void svi_prof_end_impl(int tag, hipStream_t st) {
-    hipEvent_t e = prof_event();
-    (void)hipEventRecord(e, st);
-    g_prof_recs.push_back(ProfRec{tag, g_prof_open[tag], e});
+    std::lock_guard<std::mutex> lock(table_mutex());
+    for (size_t i = g_prof_open.size(); i-- > 0;) {
+        if (g_prof_open[i].tag != tag || g_prof_open[i].st != st) continue;
+        hipEvent_t e = prof_event();
+        (void)hipEventRecord(e, st);
+        g_prof_recs.push_back(ProfRec{tag, g_prof_open[i].e, e});
+        g_prof_open.erase(g_prof_open.begin() + (long)i);
+        return;
+    }
 }
 extern "C" svi_status svi_prof_enable(int32_t on) {
+    std::lock_guard<std::mutex> lock(table_mutex());
     for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
     g_prof_recs.clear();
+    for (auto& o : g_prof_open) g_prof_pool.push_back(o.e);
+    g_prof_open.clear();
     g_svi_prof_on = on != 0;
     return SVI_OK;
 }
 extern "C" svi_status svi_prof_summary(char* buf, int64_t buflen) {
     SVI_REQUIRE(buf && buflen > 64, "svi_prof_summary: buffer too small");
+    std::lock_guard<std::mutex> lock(table_mutex());
     double ms[PROF_NTAGS] = {0};
     long cnt[PROF_NTAGS] = {0};
     for (auto& r : g_prof_recs) {
@@ -145,26 +202,12 @@ extern "C" svi_status svi_prof_summary(char* buf, int64_t buflen) {
     return SVI_OK;
 }
 
-// ---- scratch owned by the operator seams (grown on demand, never in steady state) ----------------
+// ---- scratch owned by the operator seams (grown on demand, never in steady state; one per device and stream) ----------------
 namespace {
-struct Scratch {
-    char* p = nullptr;
-    size_t bytes = 0;
-};
-Scratch g_scratch[16];          // one per device: the seams may be used under any current device
-
-svi_status scratch_reserve(size_t bytes, char** out) {
-    const int dev = svi_current_device();
-    if (dev < 0) return SVI_ERR_HIP;
-    SVI_REQUIRE(dev < 16, "device index %d beyond the scratch table", dev);
-    Scratch& sc = g_scratch[dev];
-    if (sc.bytes < bytes) {
-        if (sc.p) { SVI_CHECK_HIP(hipFree(sc.p)); sc.p = nullptr; sc.bytes = 0; }
-        hipError_t e = hipMalloc((void**)&sc.p, bytes);
-        if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B scratch) failed: %s", bytes, hipGetErrorString(e)); return SVI_ERR_OOM; }
-        sc.bytes = bytes;
-    }
-    *out = sc.p;
+svi_status scratch_reserve(size_t bytes, hipStream_t st, char** out, int kind = SVI_BUF_SEAM_SCRATCH) {
+    void* p = nullptr;
+    SVI_TRY(svi_stream_buffer(kind, st, bytes, &p, nullptr));
+    *out = reinterpret_cast<char*>(p);
     return SVI_OK;
 }
 
@@ -185,7 +228,7 @@ extern "C" svi_status svi_attention_fwd(const void* q, const void* k, const void
     const int D = n * d;
     const int ldvt = ((s_kv + 7) / 8) * 8;
     char* scr = nullptr;
-    SVI_TRY(scratch_reserve((size_t)D * ldvt * 2, &scr));
+    SVI_TRY(scratch_reserve((size_t)D * ldvt * 2, st, &scr));
     bf16* vt = reinterpret_cast<bf16*>(scr);
     if (ldvt != s_kv) SVI_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)D * ldvt * 2, st));
     for (int i = 0; i < b; ++i) {
@@ -237,7 +280,7 @@ extern "C" svi_status svi_layernorm_modulate(const void* x, void* out, int32_t r
     const float *fs = nullptr, *fc = nullptr;
     if (shift) {
         char* scr = nullptr;
-        SVI_TRY(scratch_reserve((size_t)2 * dim * 4, &scr));
+        SVI_TRY(scratch_reserve((size_t)2 * dim * 4, st, &scr, SVI_BUF_SEAM_SMALL));
         float* f = reinterpret_cast<float*>(scr);
         hipLaunchKernelGGL(f32_prepare_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, reinterpret_cast<const bf16*>(shift), f, dim, 0);
         hipLaunchKernelGGL(f32_prepare_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, reinterpret_cast<const bf16*>(scale), f + dim, dim, 1);
@@ -271,7 +314,7 @@ extern "C" svi_status svi_rmsnorm_rope(void* x, int32_t ld, int32_t rows, int32_
                 host[o++] = make_float2((float)cos(ang), (float)sin(ang));
             }
     char* scr = nullptr;
-    svi_status s = scratch_reserve(cnt * sizeof(float2), &scr);
+    svi_status s = scratch_reserve(cnt * sizeof(float2), st, &scr, SVI_BUF_SEAM_SMALL);
     if (s != SVI_OK) { free(host); return s; }
     // the scratch may still be read by work enqueued earlier (a previous call's table): drain the stream before rewriting it,
     // and the device after, since `st` need not be ordered after the null stream the copy runs on (operator seam, not the hot path)

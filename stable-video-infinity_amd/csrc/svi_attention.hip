@@ -875,19 +875,39 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     });
 }
 
-// One flag word per workgroup of the optimistic attention pass, per device (allocated once; launches on one stream are ordered, which
-// is the library's threading contract for everything process-wide).
+// One flag word per workgroup of the optimistic attention pass, in a buffer of its own per (device, stream): launches on one stream
+// are ordered, so pass 1 (clears and raises), pass 2 (reads) and the next call's pass 1 never overlap; launches on another stream
+// (another handle, another host thread) use other words and cannot clear these between the two passes.
 #define SVI_FLASH_MAX_FLAGS 65536
-static svi_status flash_flags(int** out) {
-    static int* buf[16] = {nullptr};
-    const int dev = svi_current_device();
-    if (dev < 0) return SVI_ERR_HIP;
-    SVI_REQUIRE(dev < 16, "device index %d beyond the flag table", dev);
-    if (!buf[dev]) {
-        hipError_t e = hipMalloc((void**)&buf[dev], SVI_FLASH_MAX_FLAGS * sizeof(int));
-        if (e != hipSuccess) { svi_set_error("hipMalloc(attention flags) failed: %s", hipGetErrorString(e)); return SVI_ERR_OOM; }
-    }
-    *out = buf[dev];
+static svi_status flash_flags(hipStream_t st, long nwg, int** out) {
+    void* p = nullptr;
+    long* last_nwg = nullptr;
+    SVI_TRY(svi_stream_buffer(SVI_BUF_FLASH_FLAGS, st, SVI_FLASH_MAX_FLAGS * sizeof(int), &p, &last_nwg));
+    *last_nwg = nwg;
+    *out = reinterpret_cast<int*>(p);
+    return SVI_OK;
+}
+// Test / diagnostics hook: how many workgroups of the LAST two-pass attention launch on `stream` raised their flag in the optimistic
+// pass (and were therefore recomputed by the complete kernel), and how many workgroups that launch had.  Drains the stream.
+extern "C" svi_status svi_attention_last_flagged(svi_stream stream, int32_t* flagged_out, int32_t* workgroups_out) {
+    SVI_REQUIRE(flagged_out && workgroups_out, "svi_attention_last_flagged: null argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    void* p = nullptr;
+    long* last_nwg = nullptr;
+    SVI_TRY(svi_stream_buffer(SVI_BUF_FLASH_FLAGS, st, SVI_FLASH_MAX_FLAGS * sizeof(int), &p, &last_nwg));
+    const long n = *last_nwg;
+    *workgroups_out = (int32_t)n;
+    *flagged_out = 0;
+    if (n <= 0) return SVI_OK;
+    int* host = (int*)malloc((size_t)n * sizeof(int));
+    if (!host) { svi_set_error("out of host memory"); return SVI_ERR_OOM; }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(host, p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(host); svi_set_error("svi_attention_last_flagged: %s", hipGetErrorString(e)); return SVI_ERR_HIP; }
+    int c = 0;
+    for (long i = 0; i < n; ++i) c += host[i] != 0;
+    free(host);
+    *flagged_out = c;
     return SVI_OK;
 }
 
@@ -913,7 +933,7 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
 #ifdef SVI_ABLATIONS
         if (sw.flash_abl) two_pass = false;
 #endif
-        if (two_pass) SVI_TRY(flash_flags(&flags));
+        if (two_pass) SVI_TRY(flash_flags(st, nwg, &flags));
         kern_t kern;
         if (two_pass)
             kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false, 1> : flash_fwd2_kernel<1, 0, false, 1>)

@@ -66,6 +66,8 @@ struct SviSwitches {
     int vae_no_x2h = 0;          // SVI_VAE_X2H = 0 : the three-term bf16 convolution also where the two-term fp16 form applies (same parity bounds)
     int flash_two_pass = 1;      // SVI_FLASH_TWO_PASS = 0 : the long-sequence attention as ONE complete pass (tracked maximum) instead of the
                                  // optimistic pass + flagged second pass (same result within the attention tolerance; bit-identical on benign operands)
+    int t5_host_buckets = 0;     // SVI_T5_BUCKETS = host : the text encoder's relative-position bucket table in the HOST's fp32 arithmetic (what the
+                                 // reference module computes on a CPU — the arithmetic the committed fixtures were made with) instead of the device's
 #ifdef SVI_ABLATIONS
     int flash_abl = 0, gemm_epi_abl = 0, vae_abl = 0, flash_assume_prescaled = 0;
 #endif
@@ -74,6 +76,10 @@ const SviSwitches& svi_switches();
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: raise it once per (device, kernel).
 svi_status svi_ensure_lds(const void* kernel, int bytes);
+// Library-owned device buffers outside any handle, one per (device, stream, kind); see svi_api.hip.  `user_out`: a host-side word
+// that lives with the buffer (only the thread driving that stream touches it).
+enum SviBufKind { SVI_BUF_FLASH_FLAGS = 0, SVI_BUF_SEAM_SCRATCH = 1, SVI_BUF_SEAM_SMALL = 2 };
+svi_status svi_stream_buffer(int kind, hipStream_t st, size_t bytes, void** out, long** user_out);
 // The device current on this thread, or -1 (message set).
 int svi_current_device();
 // Handles belong to ONE device (workspace, packed weights, LDS attributes live there): the first compute call claims the device

@@ -44,7 +44,8 @@ struct BlockW {
 struct Slot { const bf16** ptr; std::vector<int64_t> shape; };
 
 struct Workspace {
-    int L = 0, Lc = 0;
+    int L = 0, Lc = 0;              // the problem the pointers below are laid out for
+    int capL = 0, capLc = 0;        // what the allocation holds (grow only)
     char* base = nullptr;
     size_t bytes = 0;
     bf16 *X, *X2, *Hb, *QK, *VT, *Fb, *CTX, *CTXH, *CK, *CVT, *CKi, *CVTi, *A2, *PATCH, *HO, *IMG0, *IMG1, *IMGD;
@@ -87,6 +88,9 @@ struct svi_dit {
     int rf = 0, rh = 0, rw = 0;
     float2* rope_dev = nullptr;
     SviRope rope{};
+    // bumped whenever a device pointer a captured hipGraph may have baked in stops being valid (workspace / context-entry
+    // (re)allocation, context-cache reset, re-bind): svi_dit_generation
+    unsigned long long generation = 0;
     // context cache
     bool ctx_cache_on = false;
     CtxEntry ctx_entries[4];
@@ -266,6 +270,7 @@ extern "C" svi_status svi_dit_bind_weight(svi_dit* h, const char* name, const vo
     SVI_REQUIRE(((uintptr_t)dev_ptr % 16) == 0, "parameter '%s' is not 16-byte aligned", name);
     *it->second.ptr = reinterpret_cast<const bf16*>(dev_ptr);
     for (auto& e : h->ctx_entries) e.filled = false;      // cached projections were made with the old weights
+    ++h->generation;
     return SVI_OK;
 }
 
@@ -273,6 +278,7 @@ extern "C" svi_status svi_dit_context_cache(svi_dit* h, int32_t enable) {
     SVI_REQUIRE(h, "null handle");
     h->ctx_cache_on = enable != 0;
     for (auto& e : h->ctx_entries) e.filled = false;
+    ++h->generation;
     return SVI_OK;
 }
 
@@ -288,34 +294,61 @@ extern "C" svi_status svi_dit_check_bound(svi_dit* h) {
 // ------------------------------------------------------------------------------------------------
 static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 
-static svi_status ensure_workspace(svi_dit* h, int L, int Lc) {
+// The allocation only grows: a problem that fits (tokens and context length both within what is held) is laid out inside the
+// buffer that is there — mixing the stacked CFG pair (2 L rows) with plain forwards (L rows) on one handle, or prompts of two
+// lengths, re-lays the pointers and re-zeroes the V^T pads on the stream, and neither frees nor allocates (legal under stream
+// capture; an allocation is not, and is refused there with a message).
+static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     Workspace& w = h->ws;
     if (w.base && w.L == L && w.Lc == Lc) return SVI_OK;
     const svi_dit_config& c = h->cfg;
     const size_t D = c.dim, F = c.ffn_dim;
     const int img = c.has_image_input ? 257 : 0;
-    const size_t Lctx = (size_t)Lc + img;
-    const int ldvt = ((L + 7) / 8) * 8, ldcvt = ((Lc + 7) / 8) * 8;
     const int kpatch = c.in_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho = (size_t)c.out_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho_ld = (ho + 7) / 8 * 8;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-    const size_t oX = take((size_t)L * D * 2), oX2 = take((size_t)L * D * 2), oH = take((size_t)L * D * 2), oQK = take((size_t)L * 2 * D * 2);
-    const size_t oVT = take(D * ldvt * 2), oF = take((size_t)L * F * 2);
-    const size_t oCTX = take(Lctx * D * 2), oCTXH = take((size_t)Lc * D * 2), oCK = take(Lctx * D * 2);
-    const size_t oCVT = take(D * ldcvt * 2), oCKi = take((size_t)264 * D * 2), oCVTi = take(D * 264 * 2);
-    const size_t oA2 = take(img ? (size_t)L * D * 2 : 256);
-    const size_t oP = take((size_t)L * kpatch * 2), oHO = take((size_t)L * ho_ld * 2);
-    const size_t oI0 = take((size_t)264 * 1280 * 2), oI1 = take((size_t)264 * 1280 * 2), oID = take((size_t)264 * D * 2);
-    const size_t oe = take(c.freq_dim * 2), oh1 = take(D * 2), ot = take(D * 2), ost = take(D * 2), otm = take(6 * D * 2);
-    const size_t omodf = take((size_t)c.num_layers * 6 * D * 4), oheadf = take(2 * D * 4);
-    if (w.base) { SVI_CHECK_HIP(hipFree(w.base)); w.base = nullptr; }
-    hipError_t e = hipMalloc((void**)&w.base, off);
-    if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B workspace) failed: %s", off, hipGetErrorString(e)); return SVI_ERR_OOM; }
-    SVI_CHECK_HIP(hipMemset(w.base, 0, off));           // V^T pad columns must read as zeros
-    SVI_CHECK_HIP(hipDeviceSynchronize());              // the caller's stream need not be ordered after the null stream
-    w.bytes = off; w.L = L; w.Lc = Lc; w.ldvt = ldvt; w.ldcvt = ldcvt; w.kpatch = kpatch;
+    size_t oX, oX2, oH, oQK, oVT, oF, oCTX, oCTXH, oCK, oCVT, oCKi, oCVTi, oA2, oP, oHO, oI0, oI1, oID, oe, oh1, ot, ost, otm, omodf, oheadf;
+    auto layout = [&](int l, int lc) -> size_t {
+        const size_t Lctx = (size_t)lc + img;
+        const int ldvt = ((l + 7) / 8) * 8, ldcvt = ((lc + 7) / 8) * 8;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+        oX = take((size_t)l * D * 2); oX2 = take((size_t)l * D * 2); oH = take((size_t)l * D * 2); oQK = take((size_t)l * 2 * D * 2);
+        oVT = take(D * ldvt * 2); oF = take((size_t)l * F * 2);
+        oCTX = take(Lctx * D * 2); oCTXH = take((size_t)lc * D * 2); oCK = take(Lctx * D * 2);
+        oCVT = take(D * ldcvt * 2); oCKi = take((size_t)264 * D * 2); oCVTi = take(D * 264 * 2);
+        oA2 = take(img ? (size_t)l * D * 2 : 256);
+        oP = take((size_t)l * kpatch * 2); oHO = take((size_t)l * ho_ld * 2);
+        oI0 = take((size_t)264 * 1280 * 2); oI1 = take((size_t)264 * 1280 * 2); oID = take((size_t)264 * D * 2);
+        oe = take(c.freq_dim * 2); oh1 = take(D * 2); ot = take(D * 2); ost = take(D * 2); otm = take(6 * D * 2);
+        omodf = take((size_t)c.num_layers * 6 * D * 4); oheadf = take(2 * D * 4);
+        return off;
+    };
+    const size_t need = layout(L, Lc);
+    if (!w.base || need > w.bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            svi_set_error("the DiT workspace must grow (%zu B) while the stream is being captured: run this problem size once before the capture", need);
+            return SVI_ERR_INVALID;
+        }
+        (void)hipGetLastError();
+        const int gl = L > w.capL ? L : w.capL, glc = Lc > w.capLc ? Lc : w.capLc;
+        size_t bytes = layout(gl, glc);
+        if (bytes < need) bytes = need;
+        if (w.base) { SVI_CHECK_HIP(hipFree(w.base)); w.base = nullptr; w.bytes = 0; }
+        hipError_t e = hipMalloc((void**)&w.base, bytes);
+        if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B workspace) failed: %s", bytes, hipGetErrorString(e)); return SVI_ERR_OOM; }
+        w.bytes = bytes; w.capL = gl; w.capLc = glc;
+        (void)layout(L, Lc);
+    }
+    ++h->generation;                    // the pointers move (also inside an unchanged allocation): a captured graph of the old layout is stale
+    // V^T pad columns (keys past the last one, up to the next multiple of 8) must read as zeros: the V^T regions are cleared whenever
+    // the layout moves (stream-ordered; the scratch rows around them are rewritten by every forward before they are read)
+    const int ldvt = ((L + 7) / 8) * 8, ldcvt = ((Lc + 7) / 8) * 8;
+    SVI_CHECK_HIP(hipMemsetAsync(w.base + oVT, 0, al(D * ldvt * 2), st));
+    SVI_CHECK_HIP(hipMemsetAsync(w.base + oCVT, 0, al(D * ldcvt * 2), st));
+    SVI_CHECK_HIP(hipMemsetAsync(w.base + oCVTi, 0, al(D * 264 * 2), st));
+    w.L = L; w.Lc = Lc; w.ldvt = ldvt; w.ldcvt = ldcvt; w.kpatch = kpatch;
     auto P = [&](size_t o) { return reinterpret_cast<bf16*>(w.base + o); };
     w.X = P(oX); w.X2 = P(oX2); w.Hb = P(oH); w.QK = P(oQK); w.VT = P(oVT); w.Fb = P(oF); w.CTX = P(oCTX); w.CTXH = P(oCTXH);
     w.CK = P(oCK); w.CVT = P(oCVT); w.CKi = P(oCKi); w.CVTi = P(oCVTi); w.A2 = P(oA2); w.PATCH = P(oP); w.HO = P(oHO);
@@ -611,6 +644,7 @@ static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* cli
                 }
             }
             ce->key_ctx = context; ce->key_clip = clip; ce->Lc = Lc; ce->filled = true;
+            ++h->generation;                                    // an entry was (re)filled: pointers / contents a captured graph relies on moved
         }
         ce->stamp = ++h->ctx_clock;
     }
@@ -686,7 +720,7 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
     const int D = c.dim;
     const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
     const int L = f * hh * ww;
-    SVI_TRY(ensure_workspace(h, L, Lc));
+    SVI_TRY(ensure_workspace(h, L, Lc, st));
     SVI_TRY(ensure_rope(h, f, hh, ww));
     Workspace& w = h->ws;
     SVI_TRY(stage_time(h, timestep, st));
@@ -726,7 +760,7 @@ static svi_status forward_pair(svi_dit* h, const bf16* x, const float* timestep,
     const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
     const int L = f * hh * ww;
     const bool stacked = h->ctx_cache_on && L <= SVI_PAIR_STACK_MAX && L % 8 == 0 && ctx_a != ctx_b;
-    SVI_TRY(ensure_workspace(h, stacked ? 2 * L : L, Lc));
+    SVI_TRY(ensure_workspace(h, stacked ? 2 * L : L, Lc, st));
     SVI_TRY(ensure_rope(h, f, hh, ww));
     Workspace& w = h->ws;
     SVI_TRY(stage_time(h, timestep, st));
@@ -845,7 +879,7 @@ extern "C" svi_status svi_dit_time_mod(svi_dit* h, const float* timestep, void* 
     SVI_TRY(svi_dit_check_bound(h));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int D = h->cfg.dim;
-    if (!h->ws.base) SVI_TRY(ensure_workspace(h, 256, 8));            // the time path only needs the small scratch rows
+    if (!h->ws.base) SVI_TRY(ensure_workspace(h, 256, 8, st));            // the time path only needs the small scratch rows
     for (int b = 0; b < B; ++b) {
         SVI_TRY(stage_time(h, timestep + b, st));
         SVI_CHECK_HIP(hipMemcpyAsync(reinterpret_cast<bf16*>(t_mod_out) + (size_t)b * 6 * D, h->ws.tmod, (size_t)6 * D * 2,
@@ -906,7 +940,7 @@ extern "C" svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* t
     SVI_REQUIRE(row0 >= 0 && nrows > 0 && row0 + nrows <= L, "svi_dit_sp_begin: rows [%d, %d) outside the %d-token sequence", row0, row0 + nrows, L);
     SVI_TRY(svi_dit_check_bound(h));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    SVI_TRY(ensure_workspace(h, nrows, Lc));
+    SVI_TRY(ensure_workspace(h, nrows, Lc, st));
     SVI_TRY(ensure_rope(h, f, hh, ww));
     SVI_TRY(stage_time(h, timestep, st));
     CtxUse cu{};
@@ -980,6 +1014,11 @@ extern "C" svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void
 
 extern "C" int32_t svi_dit_head_ld(svi_dit* h) { return h ? head_ld(h->cfg) : 0; }
 
+// A counter that moves whenever device state a captured hipGraph of this handle's forwards may have baked in stops being valid:
+// the workspace was (re)allocated, a context-cache entry was filled / evicted, the cache was reset, a weight was re-bound.
+// A replay is only legal while the value equals the one read right after the capture.
+extern "C" int64_t svi_dit_generation(svi_dit* h) { return h ? (int64_t)h->generation : -1; }
+
 extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_inout, const void* context,
                                             const void* t_mod, int32_t f, int32_t hh, int32_t ww, int32_t Lc,
                                             svi_stream stream) {
@@ -990,7 +1029,7 @@ extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_i
     SVI_TRY(svi_dit_check_bound(h));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int L = f * hh * ww, D = h->cfg.dim;
-    SVI_TRY(ensure_workspace(h, L, Lc));
+    SVI_TRY(ensure_workspace(h, L, Lc, st));
     SVI_TRY(ensure_rope(h, f, hh, ww));
     float* modf = h->ws.modf + (size_t)layer * 6 * D;
     SVI_TRY(mod_one(h->blocks[layer].modulation, reinterpret_cast<const bf16*>(t_mod), modf, D, 6, (1 << 1) | (1 << 4), 6, st));

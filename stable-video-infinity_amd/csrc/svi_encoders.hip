@@ -306,6 +306,7 @@ struct svi_t5 {
     std::map<std::string, Param> w;
     char* ws = nullptr; size_t ws_bytes = 0;
     int* tab = nullptr; int tab_len = 0;             // relative-position buckets for offsets -(tab_len-1) .. tab_len-1
+    int tab_host = 0;                                // built in the host's arithmetic (SVI_T5_BUCKETS=host) or the device's
 };
 
 // T5RelativeEmbedding._relative_position_bucket (t5:175-194), bidirectional, for rel = key - query, on the host in the fp32 steps of the
@@ -326,6 +327,64 @@ extern "C" svi_status svi_t5_relative_buckets(int32_t num_buckets, int32_t max_d
         }
         out[rel + len - 1] = b;
     }
+    return SVI_OK;
+}
+
+// The same table built ON THE DEVICE, in the arithmetic the reference's tensor ops perform there: the module evaluates
+// _relative_position_bucket on the embedding's device (t5:160-165), and a CUDA/HIP tensor divided by a Python scalar is multiplied
+// by the scalar's fp32 reciprocal (ATen BinaryDivTrueKernel), the logarithm is the device's logf.  At offsets where the ratio is an
+// exact integer (|rel| = 16, 32, 64 for the Wan configuration) the host's division and the device's reciprocal-multiply can fall on
+// different sides of it, which selects a different bias row — so the table a GPU forward uses is made by the GPU's arithmetic.
+__global__ void t5_bucket_kernel(int nb, int max_exact, float inv_exact, float inv_denom, float span, int len, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * len - 1) return;
+    const int rel = i - (len - 1);
+    int b = rel > 0 ? nb : 0;
+    const int a = rel < 0 ? -rel : rel;
+    if (a < max_exact) b += a;
+    else {
+        const float x = (float)a * inv_exact;              // rel_pos.float() / max_exact
+        float v = logf(x) * inv_denom;                     // torch.log(.) / math.log(max_dist / max_exact)
+        v = v * span;                                      // * (num_buckets - max_exact)
+        long large = (long)max_exact + (long)v;            // .long() truncates toward zero
+        if (large > nb - 1) large = nb - 1;
+        b += (int)large;
+    }
+    out[i] = b;
+}
+static svi_status t5_device_table(svi_t5* h, int L) {
+    const int want_host = svi_switches().t5_host_buckets;
+    if (h->tab_len >= L && h->tab_host == want_host) return SVI_OK;
+    const svi_t5_config& c = h->cfg;
+    if (h->tab) { SVI_CHECK_HIP(hipFree(h->tab)); h->tab = nullptr; h->tab_len = 0; }
+    SVI_CHECK_HIP(hipMalloc((void**)&h->tab, (size_t)(2 * L - 1) * 4));
+    h->tab_host = want_host;
+    if (want_host) {           // SVI_T5_BUCKETS=host: the CPU module's arithmetic (tests against CPU-made fixtures)
+        std::vector<int32_t> host((size_t)2 * L - 1);
+        SVI_TRY(svi_t5_relative_buckets(c.num_buckets, c.max_dist, L, host.data()));
+        SVI_CHECK_HIP(hipMemcpy(h->tab, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+        SVI_CHECK_HIP(hipDeviceSynchronize());
+        h->tab_len = L;
+        return SVI_OK;
+    }
+    const int nb = c.num_buckets / 2, max_exact = nb / 2;
+    const float inv_exact = 1.0f / (float)max_exact;
+    const float inv_denom = 1.0f / (float)log((double)c.max_dist / (double)max_exact);
+    hipLaunchKernelGGL(t5_bucket_kernel, dim3((2 * L - 1 + 255) / 256), dim3(256), 0, nullptr, nb, max_exact, inv_exact, inv_denom,
+                       (float)(nb - max_exact), L, h->tab);
+    SVI_LAUNCH_CHECK();
+    SVI_CHECK_HIP(hipDeviceSynchronize());                  // allocation-time work on the null stream: the caller's stream need not be ordered after it
+    h->tab_len = L;
+    return SVI_OK;
+}
+// The device-built table for offsets -(len-1) .. len-1 (tests compare it with the reference formula evaluated by torch on the device).
+extern "C" svi_status svi_t5_device_buckets(svi_t5* h, int32_t len, int32_t* out) {
+    SVI_REQUIRE(h && out && len > 0 && len <= 2048, "svi_t5_device_buckets: bad argument");
+    SVI_REQUIRE_DEVICE(h);
+    SVI_TRY(t5_device_table(h, len));
+    std::vector<int32_t> host((size_t)2 * h->tab_len - 1);
+    SVI_CHECK_HIP(hipMemcpy(host.data(), h->tab, host.size() * 4, hipMemcpyDeviceToHost));
+    for (int rel = -(len - 1); rel <= len - 1; ++rel) out[rel + len - 1] = host[(size_t)(rel + h->tab_len - 1)];
     return SVI_OK;
 }
 
@@ -416,14 +475,7 @@ extern "C" svi_status svi_t5_forward(svi_t5* h, const int64_t* ids, int32_t L, i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const svi_t5_config& c = h->cfg;
     const int R = rows, dim = c.dim, da = c.dim_attn, df = c.dim_ffn, D = da / c.num_heads;
-    if (h->tab_len < L) {
-        if (h->tab) { SVI_CHECK_HIP(hipFree(h->tab)); h->tab = nullptr; h->tab_len = 0; }
-        std::vector<int32_t> host(2 * L - 1);
-        SVI_TRY(svi_t5_relative_buckets(c.num_buckets, c.max_dist, L, host.data()));
-        SVI_CHECK_HIP(hipMalloc((void**)&h->tab, host.size() * 4));
-        SVI_CHECK_HIP(hipMemcpy(h->tab, host.data(), host.size() * 4, hipMemcpyHostToDevice));
-        h->tab_len = L;
-    }
+    SVI_TRY(t5_device_table(h, L));
     auto al = [](size_t n) { return (n + 255) & ~(size_t)255; };
     const size_t sx = al((size_t)R * dim * 2), sa = al((size_t)R * da * 2), sf = al((size_t)R * df * 2);
     SVI_TRY(grow(&h->ws, &h->ws_bytes, 2 * sx + 4 * sa + 2 * sf, "text encoder workspace"));

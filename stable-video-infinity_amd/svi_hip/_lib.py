@@ -54,6 +54,8 @@ SYMBOLS = [
     ("svi_dit_sp_head", _i32, [_vp, _vp, _vp]),
     ("svi_dit_unpatchify", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_dit_head_ld", _i32, [_vp]),
+    ("svi_dit_generation", _i64, [_vp]),
+    ("svi_attention_last_flagged", _i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     ("svi_attention_vt_fwd", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_set_audio", _i32, [_vp, _vp, _vp, _i32]),
     ("svi_cfg3_step", _i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
@@ -92,6 +94,7 @@ SYMBOLS = [
     ("svi_t5_check_bound", _i32, [_vp]),
     ("svi_t5_forward", _i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     ("svi_t5_relative_buckets", _i32, [_i32, _i32, _i32, C.POINTER(_i32)]),
+    ("svi_t5_device_buckets", _i32, [_vp, _i32, C.POINTER(_i32)]),
     ("svi_clip_create", _i32, [C.POINTER(ClipConfig), C.POINTER(_vp)]),
     ("svi_clip_destroy", _i32, [_vp]),
     ("svi_clip_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),

@@ -60,14 +60,16 @@ def load_dit(paths: Union[str, Sequence[str]], cfg: dict = None, device="cuda"):
 
 
 def load_vae(path: str, device="cuda"):
-    """A HIP WanVideoVAE from Wan2.1_VAE.pth-style weights saved as safetensors; keys without the "model." prefix get it
-    (WanVideoVAEStateDictConverter.from_civitai, models/wan_video_vae.py:799-808)."""
+    """A HIP WanVideoVAE from the stock Wan2.1_VAE.pth (a torch pickle, optionally wrapped in {"model_state": ...}) or the same weights
+    as .safetensors; keys without the "model." prefix get it and everything is cast to fp32, the precision SVI runs the VAE in
+    (WanVideoVAEStateDictConverter.from_civitai, models/wan_video_vae.py:797-808; svi_video.py:385-389)."""
     from .vae import WanVideoVAE
-    sd = load_safetensors(path, device=device, torch_dtype=torch.float32)
+    sd = _load_any(path, device)
     if "model_state" in sd:
         sd = sd["model_state"]
     if not any(k.startswith("model.") for k in sd):
         sd = {"model." + k: v for k, v in sd.items()}
+    sd = {k: v.to(device=device, dtype=torch.float32) for k, v in sd.items()}
     return WanVideoVAE.from_state_dict(sd)
 
 

@@ -23,6 +23,21 @@ def _version(t: torch.Tensor) -> int:
     return 0 if t.is_inference() else t._version
 
 
+def config_of_module(wan_model) -> dict:
+    """WanDiT's constructor arguments read off a reference `WanModel` instance (models/wan_video_dit.py:407-470): only attributes the
+    real class sets in its constructor — `dim`, `freq_dim`, `has_image_input`, `patch_embedding` (nn.Conv3d), `text_embedding[0]`
+    (nn.Linear), `blocks[i].{ffn_dim, num_heads, norm1}` (DiTBlock :321-336), `head.head` (Head :392-399), `enable_multitalk`.
+    tests/test_reference_keys.py runs it on the real class (meta device) for the reference converter's four constructor tables."""
+    blk = wan_model.blocks[0]
+    pe = wan_model.patch_embedding
+    kt, kh, kw = (int(k) for k in pe.kernel_size)
+    return dict(dim=int(wan_model.dim), in_dim=int(pe.in_channels), ffn_dim=int(blk.ffn_dim),
+                out_dim=int(wan_model.head.head.out_features) // (kt * kh * kw), text_dim=int(wan_model.text_embedding[0].in_features),
+                freq_dim=int(wan_model.freq_dim), eps=float(blk.norm1.eps), patch_size=(kt, kh, kw), num_heads=int(blk.num_heads),
+                num_layers=len(wan_model.blocks), has_image_input=bool(wan_model.has_image_input),
+                enable_multitalk=bool(getattr(wan_model, "enable_multitalk", False)))
+
+
 class PromptPins:
     """Bookkeeping that makes the pointer-keyed context cache of the C side (svi_dit_context_cache) safe to leave on.
 
@@ -73,6 +88,7 @@ class WanDiT:
         self._params: Dict[str, torch.Tensor] = {}
         self._fp8_sources: Dict[str, torch.Tensor] = {}        # fp8-stored parameters whose bf16 copies are bound (FP8 storage mode)
         self._param_versions = []
+        self._epoch = 0                     # host-side: moves on bind / rebind / context_cache(); part of a captured graph's key
         self._ctx_cache_on = False
         self._ctx_pins = PromptPins()
 
@@ -87,14 +103,7 @@ class WanDiT:
     @classmethod
     def from_module(cls, wan_model) -> "WanDiT":
         """Borrow the parameters of a reference `WanModel` (already on the GPU, bf16)."""
-        blk = wan_model.blocks[0]
-        pe = wan_model.patch_embedding
-        m = cls(dim=wan_model.dim, in_dim=pe.in_channels, ffn_dim=blk.ffn_dim, out_dim=wan_model.head.head.out_features
-                // (pe.kernel_size[0] * pe.kernel_size[1] * pe.kernel_size[2]),
-                text_dim=wan_model.text_embedding[0].in_features, freq_dim=wan_model.freq_dim,
-                eps=blk.norm1.eps, patch_size=tuple(pe.kernel_size), num_heads=blk.num_heads,
-                num_layers=len(wan_model.blocks), has_image_input=wan_model.has_image_input,
-                enable_multitalk=getattr(wan_model, "enable_multitalk", False))
+        m = cls(**config_of_module(wan_model))
         m.bind(dict(wan_model.state_dict()))
         return m
 
@@ -114,11 +123,21 @@ class WanDiT:
                     f"bind {name}")
             self._params[name] = t
         L.check(lib.svi_dit_check_bound(self._h), "svi_dit_check_bound")
-        self._param_versions = [(t, _version(t)) for t in self._params.values()]
+        # what weights_changed() watches: the bound bf16 tensors and, in FP8 storage mode, the e4m3 tensors they were cast from
+        self._param_versions = [(t, _version(t)) for t in self._params.values()] + [(t, _version(t)) for t in self._fp8_sources.values()]
+        self._epoch += 1
 
     def rebind(self) -> None:
-        """Re-read every parameter's address (after a LoRA merge, .to(), an offload round trip ...); drops the context cache."""
-        self.bind(dict(self._params))
+        """Re-read every parameter's address (after a LoRA merge, .to(), an offload round trip ...); drops the context cache.
+        FP8-stored parameters are cast again from their e4m3 sources (an in-place update of a source is picked up)."""
+        self.bind({**self._params, **self._fp8_sources})
+
+    def epoch(self) -> int:
+        return self._epoch
+
+    def generation(self) -> int:
+        """svi_dit_generation: moves when device state a captured hipGraph relies on stops being valid."""
+        return int(L.lib().svi_dit_generation(self._h))
 
     def weights_changed(self) -> bool:
         """True when a bound parameter was written in place since bind() (merge_lora_, load_state_dict into the same storage):
@@ -138,6 +157,7 @@ class WanDiT:
         L.check(L.lib().svi_dit_context_cache(self._h, 1 if enable else 0), "svi_dit_context_cache")
         self._ctx_cache_on = bool(enable)
         self._ctx_pins.clear()
+        self._epoch += 1
 
     def _prompt_args(self, *tensors):
         """The prompt-side inputs (context(s), clip_feature) as contiguous bf16; see context_cache()."""
@@ -150,6 +170,7 @@ class WanDiT:
                                  "across the calls (convert once, outside the step loop)")
         if self._ctx_pins.admit(tensors):
             L.check(L.lib().svi_dit_context_cache(self._h, 1), "svi_dit_context_cache")      # re-enabling drops every entry
+            self._epoch += 1
         return tensors
 
     def check_inputs(self, x, contexts, clip_feature=None, y=None, add_condition=None) -> None:

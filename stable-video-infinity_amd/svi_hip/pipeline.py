@@ -43,7 +43,7 @@ class DenoiseLoop:
         self.scheduler = scheduler or FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
         self._cond = self._uncond = None
         self.graph = graph
-        self._graph = None            # (key, torch.cuda.CUDAGraph, static timestep tensor)
+        self._graph = None            # dict(key, graph, ts, pins, generation) of the captured step, see _forwards_graphed
         if graph and (cfg_pair is not None or sequence_parallel):
             raise ValueError("graph capture covers the single-rank step only")
 
@@ -58,24 +58,44 @@ class DenoiseLoop:
         else:
             self.dit.forward(latents, timestep, ctx_pos, out=self._cond, **cond)
 
+    def drop_graph(self) -> None:
+        """Forget the captured step (a later graphed step captures again)."""
+        self._graph = None
+
     def _forwards_graphed(self, latents, timestep, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond) -> None:
-        """Replay (capture on first use) the hipGraph of this step's forwards.  The graph is tied to the addresses of everything it
-        reads and writes: latents, prompt embeddings, conditioning tensors, output buffers — a new clip (new tensors) re-captures."""
+        """Replay (capture on first use) the hipGraph of this step's forwards.
+
+        A captured graph has baked in the ADDRESSES of everything it reads and writes (latents, prompt embeddings, conditioning
+        tensors, output buffers, the DiT workspace, the context-cache entries) and a context-cache HIT (the projected prompt and every
+        block's cross-attention K / V are read, never recomputed).  So a replay is only legal while all of that still holds:
+          * the graph keeps STRONG references to every tensor it reads (their storage cannot be recycled for another prompt), and its
+            key records each one's address, shape and version counter (an in-place write makes a new key);
+          * the key carries the DiT's host-side epoch (context_cache() on / off, re-bind) and the C side's generation counter
+            (svi_dit_generation: workspace growth, a context entry filled or evicted) as read right after the capture;
+          * sample() drops the graph when the clip is done.
+        Anything else re-captures."""
         def ident(t):
-            return None if t is None else (t.data_ptr(), tuple(t.shape))
-        key = (ident(latents), ident(ctx_pos), ident(ctx_neg), float(cfg_scale), bool(split),
-               tuple(sorted((k, ident(v)) for k, v in cond.items())), ident(self._cond), self.dit.weights_changed())
-        if self._graph is None or self._graph[0] != key:
+            return None if t is None else (t.data_ptr(), tuple(t.shape), t.dtype, _version(t))
+        self.dit._refresh_if_weights_changed()          # a LoRA merge since the last step re-binds (and moves the epoch) BEFORE the key is formed
+        tensors = [latents, ctx_pos, ctx_neg, self._cond, self._uncond] + [v for _, v in sorted(cond.items()) if isinstance(v, torch.Tensor)]
+        key = (tuple(ident(t) for t in tensors), tuple(sorted(k for k, v in cond.items() if v is not None)), float(cfg_scale), bool(split),
+               self.dit.epoch())
+        stale = self._graph is None or self._graph["key"] != key or self._graph["generation"] != self.dit.generation()
+        if stale:
+            self._graph = None
+            side = torch.cuda.Stream()                   # warm-up AND capture on one stream: the library's per-stream buffers exist before the capture
+            side.wait_stream(torch.cuda.current_stream())
             ts_static = timestep.clone()
-            self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)      # warm-up outside capture: workspaces, context cache
-            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)      # workspaces, context cache, flag words
+            side.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=side):
                 self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)
-            self._graph = (key, g, ts_static)
-        _, g, ts_static = self._graph
-        ts_static.copy_(timestep)
-        g.replay()
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = dict(key=key, graph=g, ts=ts_static, pins=tensors, generation=self.dit.generation())
+        self._graph["ts"].copy_(timestep)
+        self._graph["graph"].replay()
 
     def step(self, latents: torch.Tensor, timestep: torch.Tensor, dsigma: float, ctx_pos: torch.Tensor,
              ctx_neg: Optional[torch.Tensor], cfg_scale: float, tea_cache_posi=None, tea_cache_nega=None, cond_wo_pose: bool = False,
@@ -185,6 +205,7 @@ class DenoiseLoop:
             for i, t in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
                 self.step(latents, ts_dev[i:i + 1], self.scheduler.step_delta(t), ctx_pos, ctx_neg, cfg_scale, cond_wo_pose=cond_wo_pose, **tea, **cond)
         finally:
+            self.drop_graph()                 # the graph reads this clip's tensors and cache entries: it dies with the clip
             self.dit.context_cache(False)
         return latents
 
@@ -240,11 +261,86 @@ def _hip_talk_fn(dit_module, x, timestep, context, clip_feature=None, y=None, te
                                    use_controlnet=use_controlnet)
 
 
-def install(pipe, vae: bool = True, encoders: bool = True):
+def _step_delta_of(scheduler, timestep) -> float:
+    """sigma_next - sigma of `scheduler.step(., timestep, .)` for the reference's own FlowMatchScheduler object
+    (schedulers/flow_match.py:52-62): the scalar its tensor update multiplies the model output by."""
+    if hasattr(scheduler, "step_delta"):
+        return scheduler.step_delta(timestep)
+    t = timestep.cpu() if isinstance(timestep, torch.Tensor) else timestep
+    i = int(torch.argmin((scheduler.timesteps - t).abs()))
+    if i + 1 >= len(scheduler.timesteps):
+        nxt = 1.0 if (scheduler.inverse_timesteps or scheduler.reverse_sigmas) else 0.0
+    else:
+        nxt = scheduler.sigmas[i + 1]
+    return float(nxt - scheduler.sigmas[i])
+
+
+def _hip_sample_with_regular_video(self, latents, prompt_emb_posi, prompt_emb_nega, image_emb, extra_input, tea_cache_posi, tea_cache_nega,
+                                   usp_kwargs, use_controlnet, cfg_scale, progress_bar_cmd):
+    """SVIVideoPipeline._sample_with_regular_video (pipelines/svi_video.py:392-421) with the reference's exact signature, bound onto the
+    pipeline by install(): the step loop of the clip on svi_hip.DenoiseLoop — both forwards of a step in one C call (block 0's
+    self-attention shared), CFG combine + Euler update in one fused kernel with the reference's bf16 rounding points — i.e. the path
+    bench.py times.  Bit-identical to the reference-style loop over the swapped model_fn_wan_video (tests/test_gpu_install.py).
+    Anything this loop does not cover (sequence parallelism through usp_kwargs, controlnet, extra inputs, non-bf16 latents) goes to the
+    pipeline's original sampler, which still reaches the HIP forward through the swapped module-level model_fn_wan_video."""
+    hip = getattr(self, "_svi_hip_dit", None)
+    plain = (hip is not None and not extra_input and not use_controlnet and not (usp_kwargs or {}).get("use_unified_sequence_parallel")
+             and set(prompt_emb_posi) == {"context"} and set(prompt_emb_nega) == {"context"} and set(image_emb) <= {"clip_feature", "y"}
+             and latents.is_cuda and latents.dtype == torch.bfloat16)
+    if not plain:
+        return self._svi_hip_original_sampler(latents, prompt_emb_posi, prompt_emb_nega, image_emb, extra_input, tea_cache_posi,
+                                              tea_cache_nega, usp_kwargs, use_controlnet, cfg_scale, progress_bar_cmd)
+    loop = self._svi_hip_loop
+    if not hip._ctx_cache_on:
+        hip.context_cache(True)
+    ctx_p = _stable_bf16(hip, prompt_emb_posi["context"])
+    ctx_n = _stable_bf16(hip, prompt_emb_nega["context"])
+    cond = {}
+    if image_emb.get("clip_feature") is not None:
+        cond["clip_feature"] = _stable_bf16(hip, image_emb["clip_feature"])
+    if image_emb.get("y") is not None:
+        cond["y"] = _stable_bf16(hip, image_emb["y"])
+    tea = {}
+    if (tea_cache_posi or {}).get("tea_cache") is not None:
+        tea = dict(tea_cache_posi=tea_cache_posi["tea_cache"], tea_cache_nega=(tea_cache_nega or {}).get("tea_cache"))
+    scale = float(cfg_scale["text"])
+    lat = latents.contiguous().clone()               # the reference's loop leaves its input tensor untouched
+    ts_dev = self.scheduler.timesteps.to(device=lat.device, dtype=torch.float32)
+    for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
+        loop.step(lat, ts_dev[progress_id:progress_id + 1], _step_delta_of(self.scheduler, self.scheduler.timesteps[progress_id]),
+                  ctx_p, ctx_n, scale, **tea, **cond)
+    return lat
+
+
+def _route_dit(pipe, hip, sampler: bool = True) -> None:
+    """The swaps of install() that concern the DiT, with the reference's own idioms: the module-level `model_fn_wan_video` (and the talk
+    pipeline's `model_fn_wan_talk_video`) of the pipeline's defining module are replaced — every call statement of that module looks the
+    name up in the module globals at call time (svi_video.py:401-408) — and, with `sampler`, `_sample_with_regular_video` is rebound on
+    the instance with types.MethodType (as svi_video.py:269-271 rebinds `forward` for USP)."""
+    dit_module = pipe.dit
+    _INSTALLED[id(dit_module)] = hip
+    pipe._svi_hip_dit = hip
+    mod = sys.modules[type(pipe).__module__]
+    if not hasattr(mod, "_svi_hip_original_model_fn"):
+        mod._svi_hip_original_model_fn = getattr(mod, "model_fn_wan_video", None)
+    mod.model_fn_wan_video = _hip_model_fn
+    if hasattr(mod, "model_fn_wan_talk_video"):        # the talk pipeline's own entry point (pipelines/svi_video_talk.py:83)
+        if not hasattr(mod, "_svi_hip_original_talk_fn"):
+            mod._svi_hip_original_talk_fn = mod.model_fn_wan_talk_video
+        mod.model_fn_wan_talk_video = _hip_talk_fn
+    if sampler and hasattr(type(pipe), "_sample_with_regular_video"):
+        pipe._svi_hip_original_sampler = types.MethodType(type(pipe)._sample_with_regular_video, pipe)
+        pipe._svi_hip_loop = DenoiseLoop(hip, scheduler=getattr(pipe, "scheduler", None))
+        pipe._sample_with_regular_video = types.MethodType(_hip_sample_with_regular_video, pipe)
+
+
+def install(pipe, vae: bool = True, encoders: bool = True, sampler: bool = True):
     """Route `pipe`'s hot path (SVIVideoPipeline / WanVideoPipeline of the reference) through libsvi_hip.
 
     * `model_fn_wan_video` in the pipeline's defining module is replaced by the HIP-backed function
       (every call site in that module — the cond/uncond forwards of the sampler — picks it up);
+    * with `sampler`: `pipe._sample_with_regular_video` (svi_video.py:392-421) is rebound to the DenoiseLoop-backed sampler of the same
+      signature — one C call for the two forwards of a step, fused CFG + Euler kernel: the loop bench.py times;
     * `pipe.vae.encode/decode` are rebound to the HIP VAE (same signatures), when `vae` is true;
     * `pipe.dit` stays the reference nn.Module: weights are borrowed, so call `install` again (or
       `pipe._svi_hip_dit.rebind()`) after `load_lora_v2`, `.to()` or any offload that moves storage.
@@ -258,16 +354,7 @@ def install(pipe, vae: bool = True, encoders: bool = True):
     if not p.is_cuda or p.dtype != torch.bfloat16:
         raise RuntimeError("install(): move the DiT to the GPU in bf16 first (pipe.dit.to('cuda', torch.bfloat16))")
     hip = WanDiT.from_module(dit_module)
-    _INSTALLED[id(dit_module)] = hip
-    pipe._svi_hip_dit = hip
-    mod = sys.modules[type(pipe).__module__]
-    if not hasattr(mod, "_svi_hip_original_model_fn"):
-        mod._svi_hip_original_model_fn = getattr(mod, "model_fn_wan_video", None)
-    mod.model_fn_wan_video = _hip_model_fn
-    if hasattr(mod, "model_fn_wan_talk_video"):        # the talk pipeline's own entry point (pipelines/svi_video_talk.py:83)
-        if not hasattr(mod, "_svi_hip_original_talk_fn"):
-            mod._svi_hip_original_talk_fn = mod.model_fn_wan_talk_video
-        mod.model_fn_wan_talk_video = _hip_talk_fn
+    _route_dit(pipe, hip, sampler=sampler)
     if vae and getattr(pipe, "vae", None) is not None:
         from .vae import WanVideoVAE
         hv = WanVideoVAE.from_module(pipe.vae)

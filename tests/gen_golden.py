@@ -331,6 +331,71 @@ def gen_c1_e2e(dit_mod, vae_mod, fm):
              video_absmean=np.array(float(video.abs().mean())))
 
 
+def gen_dit_depth(dit_mod, fm):
+    """The headline kernels at depth against the reference itself: the full 30-layer Wan2.1-T2V-1.3B architecture
+    (the C1 fixture's seeded weights) on a (5,30,52) token grid = 7800 tokens — past the 2048-key threshold, so the HIP path takes the
+    long-sequence attention kernel and the 256^2 GEMM in every block — through WanModel.forward (fp32 and, the way the pipelines run
+    it, bf16) and a 2-step CFG-5 flow-match loop (svi_video.py:392-421).  fp32 results whole, bf16 results as 16-bit patterns."""
+    import time
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    f, h, w = synth.DEPTH_GRID
+    t0 = time.time()
+    m = build_ref_dit(dit_mod, cfg, seed)
+    print(f"depth: reference WanModel 1.3B built in {time.time() - t0:.0f} s")
+    noise = torch.randn((1, 16, f, 2 * h, 2 * w), generator=torch.Generator("cpu").manual_seed(1), dtype=torch.float32)
+    pos = t(synth.text_context(seed + 1, 512, cfg["text_dim"], 64))
+    neg = t(synth.text_context(seed + 2, 512, cfg["text_dim"], 64))
+
+    def loop(model, lat, pos, neg):
+        s = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        s.set_timesteps(synth.DEPTH_STEPS, shift=5.0)
+        first = None
+        with torch.no_grad():
+            for i, ts in enumerate(s.timesteps):
+                tt = ts.unsqueeze(0)
+                c = model(lat, tt, pos)
+                if first is None:
+                    first = c
+                u = model(lat, tt, neg)
+                lat = s.step(u + 5.0 * (c - u), s.timesteps[i], lat)
+        return first, lat
+
+    t0 = time.time()
+    f32, l32 = loop(m, noise, pos, neg)
+    print(f"depth: fp32 loop {time.time() - t0:.0f} s")
+    t0 = time.time()
+    mb = m.to(torch.bfloat16)
+    f16, l16 = loop(mb, noise.to(torch.bfloat16), pos.to(torch.bfloat16), neg.to(torch.bfloat16))
+    print(f"depth: bf16 loop {time.time() - t0:.0f} s")
+    np.savez(os.path.join(OUT, "dit_depth.npz"), fwd_fp32=f32[0].numpy(), lat_fp32=l32[0].numpy(),
+             fwd_bf16_bits=synth.bf16_bits(f16[0].float().numpy()), lat_bf16_bits=synth.bf16_bits(l16[0].float().numpy()))
+
+
+def gen_c4_blocks(dit_mod):
+    """BASELINE configs[3]'s model end to end at a depth the host affords: WanModel with the Wan2.1-I2V-14B constructor table
+    (wan_video_dit.py:699-712: dim 5120, 40 heads, ffn 13824, in_dim 36, image branch) cut to 4 of its 40 blocks, on the (3,20,36) grid =
+    2160 tokens: the in_dim-36 patchify of x | y, img_emb on 257 CLIP tokens, four full blocks, head, unpatchify; fp32 and bf16."""
+    import time
+    cfg = dict(synth.WAN_14B_I2V, num_layers=synth.C4_LAYERS)
+    seed = synth.C4_SEED
+    f, h, w = synth.B14_GRID
+    t0 = time.time()
+    m = build_ref_dit(dit_mod, cfg, seed)
+    print(f"c4: reference WanModel (14B-I2V widths, {synth.C4_LAYERS} blocks) built in {time.time() - t0:.0f} s")
+    x = t(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w))
+    ctx = t(synth.text_context(seed + 2, 512, cfg["text_dim"], 64))
+    clip = t(synth.randn(seed + 3, 1, 257, 1280))
+    y = t(synth.randn(seed + 4, 1, 20, f, 2 * h, 2 * w))
+    ts = torch.tensor([757.5758], dtype=torch.float32)
+    with torch.no_grad():
+        t0 = time.time()
+        o32 = m(x, ts, ctx, clip_feature=clip, y=y)
+        print(f"c4: fp32 forward {time.time() - t0:.0f} s")
+        mb = m.to(torch.bfloat16)
+        o16 = mb(x.to(torch.bfloat16), ts, ctx.to(torch.bfloat16), clip_feature=clip.to(torch.bfloat16), y=y.to(torch.bfloat16))
+    np.savez(os.path.join(OUT, "dit_c4_4blocks.npz"), out_fp32=o32[0].numpy(), out_bf16_bits=synth.bf16_bits(o16[0].float().numpy()))
+
+
 def gen_vae_c2(vae_mod):
     """The VAE at BASELINE config 2's spatial size (latent 60x104 <-> 480x832 px): the reference's decode of 2 latent frames
     (-> 5 frames) and encode of 5 frames (-> 2 latent frames).  The decoded video is stored on a stride-7 pixel lattice
@@ -754,6 +819,8 @@ def main(argv=None):
         "t5_encoder": gen_t5,
         "clip_encoder": gen_clip,
         "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),
+        "dit_c4_4blocks": lambda: gen_c4_blocks(dit_mod),
+        "dit_depth": lambda: gen_dit_depth(dit_mod, fm),
     }
     names = list(argv if argv is not None else sys.argv[1:]) or list(jobs)
     for n in names:

@@ -228,6 +228,21 @@ C2_VIDEO_STRIDE = 7                          # golden/vae_c2.npz
 B14_SEED, B14_GRID = 950, (3, 20, 36)        # golden/dit_block_14b.npz: one 14B-I2V block on 2160 tokens
 
 
+DEPTH_GRID, DEPTH_STEPS = (5, 30, 52), 2     # golden/dit_depth.npz: the 30-layer 1.3B model (C1_SEED weights) on 7800 tokens (>= 2048: the long-sequence
+                                             # attention kernel and the 256^2 GEMM), one forward + a 2-step CFG loop
+C4_SEED, C4_LAYERS = 960, 4                  # golden/dit_c4_4blocks.npz: 4 of the 40 blocks of Wan2.1-I2V-14B end to end (in_dim-36 patchify, img_emb, head) on B14_GRID
+
+
+def bf16_bits(a) -> np.ndarray:
+    """fp32 array holding bf16-representable values -> their 16-bit patterns (fixtures store bf16 results at half the size)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return (a.view(np.uint32) >> 16).astype(np.uint16)
+
+
+def bf16_from_bits(b) -> np.ndarray:
+    return (np.asarray(b, dtype=np.uint32) << 16).view(np.float32)
+
+
 def B14_ROWS(L: int):
     return list(range(0, L, 67))
 

@@ -1,0 +1,243 @@
+"""-m gpu: the headline kernels at DEPTH against the reference itself, and the instances of the two-pass attention that no other test
+drives through their second pass.
+
+  dit_depth.npz       30-layer Wan2.1-T2V-1.3B on 7800 tokens (>= 2048 keys: flash_fwd2 optimistic + flagged pass, 256^2 GEMM in every
+                      projection): WanModel.forward fp32 / bf16 and a 2-step CFG-5 loop, made by the reference (tests/gen_golden.py).
+                      Bounds as for every whole forward (test_gpu_dit.py): rel-L2 <= 2e-2 vs the reference's bf16 run,
+                      <= max(2e-2, 2 x the reference's own bf16-vs-fp32 gap) vs its fp32 run; loop <= 5e-2.
+  dit_c4_4blocks.npz  4 of the 40 blocks of Wan2.1-I2V-14B end to end (in_dim-36 patchify, img_emb, head) on 2160 tokens.
+  second pass         svi_dit_block_forward / the sequence-parallel gather mode with self_attn.norm_q / norm_k gains scaled so that
+                      late keys outgrow a row's tile-0 maximum by > 64 log2 units: the optimistic pass raises its flags
+                      (svi_attention_last_flagged > 0), the complete kernel recomputes those workgroups, and the result meets the
+                      block tolerance against the CPU oracle and agrees with the single complete pass (SVI_FLASH_TWO_PASS=0).
+  two streams         two attention calls on two streams, one with adversarial operands: each keeps its own flag words.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import rel_l2
+from gpu_util import bf16r, dev, errs, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import svi_hip
+    return svi_hip
+
+
+def last_flagged():
+    from svi_hip import _lib as L
+    a, b = C.c_int32(), C.c_int32()
+    L.check(L.lib().svi_attention_last_flagged(L.current_stream(), C.byref(a), C.byref(b)), "svi_attention_last_flagged")
+    return a.value, b.value
+
+
+# ------------------------------------------------------------------------------------------------------------------ depth
+def test_1_3b_forward_and_loop_at_7800_tokens_vs_reference(hip, golden):
+    g = golden("dit_depth.npz")
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    f, h, w = synth.DEPTH_GRID
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **cfg).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=synth.num_heads_of(cfg), **cfg)
+    del sd
+    noise = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=1, device="cpu", dtype=torch.float32)
+    pos = dev(torch.from_numpy(synth.text_context(seed + 1, 512, cfg["text_dim"], 64)))
+    neg = dev(torch.from_numpy(synth.text_context(seed + 2, 512, cfg["text_dim"], 64)))
+    sch = hip.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(synth.DEPTH_STEPS, shift=5.0)
+    fwd = m.forward(dev(noise), sch.timesteps[:1], pos)
+    flagged, nwg = last_flagged()                      # the last self-attention of the forward: benign operands, nothing to recompute
+    assert nwg == ((f * h * w + 255) // 256) * 12 and flagged == 0, (flagged, nwg)
+    ref16, lat16 = synth.bf16_from_bits(g["fwd_bf16_bits"]), synth.bf16_from_bits(g["lat_bf16_bits"])
+    gap = rel_l2(ref16, g["fwd_fp32"])
+    r32, r16 = errs(fwd[0], g["fwd_fp32"])[0], errs(fwd[0], ref16)[0]
+    lat = hip.DenoiseLoop(m).sample(dev(noise), pos, neg, num_inference_steps=synth.DEPTH_STEPS, cfg_scale=5.0, sigma_shift=5.0)
+    l32, l16 = errs(lat[0], g["lat_fp32"])[0], errs(lat[0], lat16)[0]
+    report("dit_depth", fwd_vs_ref_fp32=r32, fwd_vs_ref_bf16=r16, ref_bf16_vs_fp32=gap, loop_vs_ref_fp32=l32, loop_vs_ref_bf16=l16,
+           ref_loop_bf16_vs_fp32=rel_l2(lat16, g["lat_fp32"]), tokens=f * h * w)
+    assert r16 < 2e-2 and r32 < max(2e-2, 2 * gap), (r32, r16, gap)
+    assert l32 < 5e-2, (l32, l16)
+
+
+def test_14b_i2v_four_blocks_end_to_end_vs_reference(hip, golden):
+    g = golden("dit_c4_4blocks.npz")
+    cfg = dict(synth.WAN_14B_I2V, num_layers=synth.C4_LAYERS)
+    seed = synth.C4_SEED
+    f, h, w = synth.B14_GRID
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **cfg).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=40, **cfg)
+    del sd
+    x = dev(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w))
+    ctx = dev(synth.text_context(seed + 2, 512, cfg["text_dim"], 64))
+    clip = dev(synth.randn(seed + 3, 1, 257, 1280))
+    y = dev(synth.randn(seed + 4, 1, 20, f, 2 * h, 2 * w))
+    out = m.forward(x, torch.tensor([757.5758]), ctx, clip_feature=clip, y=y)
+    ref16 = synth.bf16_from_bits(g["out_bf16_bits"])
+    gap = rel_l2(ref16, g["out_fp32"])
+    r32, r16 = errs(out[0], g["out_fp32"])[0], errs(out[0], ref16)[0]
+    report("dit_c4_4blocks", vs_ref_fp32=r32, vs_ref_bf16=r16, ref_bf16_vs_fp32=gap)
+    assert r16 < 2e-2 and r32 < max(2e-2, 2 * gap), (r32, r16, gap)
+
+
+# ------------------------------------------------------------------------------------------------------------------ second pass
+SEAM = dict(dim=256, in_dim=16, ffn_dim=512, out_dim=16, text_dim=64, freq_dim=256, patch_size=(1, 2, 2), num_layers=1, has_image_input=False)
+
+
+def seam_state_dict(seed, gain):
+    """Synthetic weights whose self-attention q / k RMSNorm gains are `gain` x the usual ones: pre-scaled scores then have a standard
+    deviation of about 1.44 gain^2 log2 units, so a row's maximum over all keys exceeds its maximum over the first 64 by ~1.7 sigma."""
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **SEAM).items()}
+    for k in ("blocks.0.self_attn.norm_q.weight", "blocks.0.self_attn.norm_k.weight"):
+        sd[k] = sd[k] * gain
+    return sd
+
+
+def robust_rows(sdb, bx, btm, grid, cfg, min_gap=8.0):
+    """Rows whose self-attention is numerically well-posed in every head: the best key leads the runner-up by more than `min_gap`
+    log2 units.  With gains this large a softmax row is nearly one-hot, and where two keys tie within a bf16 rounding of q or k
+    (the kernel folds the softmax scale into q's single rounding, the oracle rounds q first) two correct implementations pick
+    different mixtures; the value check is made on the rows where the answer does not hinge on that."""
+    from oracle import wan_dit_oracle as wdo
+    rnd = wdo._rounder("bf16")
+    rope = wdo.rope_table_3d(128, grid)
+    mod = rnd(sdb["blocks.0.modulation"] + btm)
+    h = wdo.modulated_norm(bx, mod[:, 0:1], mod[:, 1:2], cfg.eps, rnd)
+    p = "blocks.0.self_attn."
+    q = rnd(wdo.apply_rope(wdo.rms_norm_full(rnd(wdo.linear(h, sdb[p + "q.weight"], sdb[p + "q.bias"])), sdb[p + "norm_q.weight"], cfg.eps, rnd), rope, cfg.num_heads))
+    k = rnd(wdo.apply_rope(wdo.rms_norm_full(rnd(wdo.linear(h, sdb[p + "k.weight"], sdb[p + "k.bias"])), sdb[p + "norm_k.weight"], cfg.eps, rnd), rope, cfg.num_heads))
+    Lt = q.shape[1]
+    qh = q.reshape(Lt, cfg.num_heads, 128).permute(1, 0, 2)
+    kh = k.reshape(Lt, cfg.num_heads, 128).permute(1, 0, 2)
+    sc = torch.matmul(qh, kh.transpose(1, 2)) * (1.4426950408889634 / 128 ** 0.5)          # [H, L, L] in log2 units
+    top = sc.topk(2, dim=-1).values
+    first64 = sc[:, :, :64].amax(dim=-1)
+    return ((top[..., 0] - top[..., 1]).amin(dim=0) > min_gap), float((top[..., 0] - first64).max())
+
+
+@pytest.mark.parametrize("gain,expect_flags", [(7.0, True), (1.5, False)])
+def test_block_forward_takes_the_second_pass_on_the_dit_seam(hip, gain, expect_flags):
+    """flash_fwd2_kernel<0, 0, false, 1 / 2> (q pre-scaled, Lq == Lk: the instance that runs 59 times per headline step)."""
+    from oracle import wan_dit_oracle as wdo
+    from svi_hip import _lib as L
+    from test_oracle_dit import make_cfg
+    grid, seed, nt = (4, 24, 24), 1200, 32
+    f, h, w = grid
+    Lt = f * h * w
+    assert Lt == 2304
+    sd = seam_state_dict(seed, gain)
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=2, **SEAM)
+    bx = torch.from_numpy(synth.randn(seed + 5, 1, Lt, SEAM["dim"]))
+    bctx = torch.from_numpy(synth.randn(seed + 6, 1, nt, SEAM["dim"]))
+    btm = torch.from_numpy(0.5 * synth.randn(seed + 7, 1, 6, SEAM["dim"]))
+    got = m.block_forward(0, dev(bx), dev(bctx), dev(btm), grid)
+    # the cross-attention that follows has 32 keys (short-sequence kernel): the flag words still describe the self-attention
+    flagged, nwg = last_flagged()
+    assert nwg == (Lt // 256) * 2
+    assert (flagged > 0) == expect_flags, (flagged, nwg, gain)
+    L.set_switch("SVI_FLASH_TWO_PASS", 0)
+    try:
+        single = m.block_forward(0, dev(bx), dev(bctx), dev(btm), grid)
+    finally:
+        L.set_switch("SVI_FLASH_TWO_PASS", None)
+    sdb = {k: bf16r(v) for k, v in sd.items()}
+    cfg = make_cfg(SEAM)
+    with torch.no_grad():
+        want = wdo.dit_block(sdb, "blocks.0.", bf16r(bx), bf16r(bctx), bf16r(btm), wdo.rope_table_3d(128, grid), cfg, "bf16")
+        rows, outgrowth = robust_rows(sdb, bf16r(bx), bf16r(btm), grid, cfg)
+    assert (outgrowth > 64.0) == expect_flags, outgrowth          # the operands are what the test says they are
+    r_all, mx, _ = errs(got, want)
+    r_rob = errs(got[0, rows], want[0, rows])[0]
+    rs = errs(got, single)[0]
+    report("dit_seam_second_pass", gain=gain, flagged=flagged, workgroups=nwg, vs_oracle_all_rows=r_all, vs_oracle_well_posed_rows=r_rob,
+           well_posed_fraction=float(rows.float().mean()), max_outgrowth_log2=outgrowth, max_abs=mx, two_pass_vs_single_pass=rs)
+    assert torch.isfinite(got.float()).all()
+    assert int(rows.sum()) >= 256 and r_rob < 6e-3, (r_rob, int(rows.sum()))
+    if not expect_flags:
+        assert r_all < 6e-3, r_all
+    assert rs < 2e-3, rs
+    if expect_flags and flagged == nwg:
+        # every workgroup was recomputed by the complete kernel: the bits of the single complete pass
+        assert torch.equal(got, single)
+
+
+def test_gather_mode_takes_the_second_pass(hip):
+    """flash_fwd2_kernel<1, 0, false, 1 / 2> (q pre-scaled, Lq != Lk): a sequence-parallel rank in gather mode attends with its 256
+    query rows to all 2048 keys."""
+    from svi_hip import _lib as L
+    from svi_hip import sequence_parallel as sp
+    c = dict(dim=512, in_dim=16, ffn_dim=1024, out_dim=16, text_dim=64, freq_dim=256, patch_size=(1, 2, 2), num_layers=2, has_image_input=False)
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(900, **c).items()}
+    for k in ("blocks.1.self_attn.norm_q.weight", "blocks.1.self_attn.norm_k.weight"):      # the LAST block: its launch is the one the flag words describe,
+        sd[k] = sd[k] * 7.0                                                                    # and block 0 stays benign (bit-identical across the two schedules)
+    sdd = {k: v.to("cuda", torch.bfloat16).contiguous() for k, v in sd.items()}
+    ms = []
+    for _ in range(9):
+        m = hip.WanDiT(eps=1e-6, num_heads=4, **c)
+        m.bind(sdd)
+        ms.append(m)
+    f, h, w = 4, 16, 32
+    x = dev(synth.randn(901, 1, 16, f, 2 * h, 2 * w))
+    ctx = dev(synth.text_context(902, 24, 64, 17))
+    t = torch.tensor([712.5])
+    want = ms[-1].forward(x, t, ctx)
+    f0, n0 = last_flagged()
+    got = sp.forward_local(ms[:8], x, t, ctx, mode="gather")
+    f1, n1 = last_flagged()
+    assert n0 == (2048 // 256) * 4 and f0 > 0, (f0, n0)               # the single-rank forward: Lq == Lk instance
+    assert n1 == 1 * 4 and f1 > 0, (f1, n1)                           # the last shard's launch: 256 rows x 4 heads, Lq != Lk
+    L.set_switch("SVI_FLASH_TWO_PASS", 0)
+    try:
+        single = sp.forward_local(ms[:8], x, t, ctx, mode="gather")
+    finally:
+        L.set_switch("SVI_FLASH_TWO_PASS", None)
+    r_full, r_single = errs(got, want)[0], errs(got, single)[0]
+    report("gather_second_pass", flagged_full=f0, flagged_shard=f1, vs_single_rank=r_full, two_pass_vs_single_pass=r_single)
+    assert torch.isfinite(got.float()).all() and r_full < 3e-3 and r_single < 3e-3, (r_full, r_single)
+
+
+# ------------------------------------------------------------------------------------------------------------------ two streams
+def test_two_streams_keep_their_own_flag_words(hip):
+    """Two long-sequence attention calls on two streams, enqueued back to back so that they overlap on the device: stream A's operands
+    hold a late giant key (every workgroup must take the second pass), stream B's are benign.  With one flag buffer per device B's
+    optimistic pass would clear A's flags between A's two passes and A would keep an overflowed result."""
+    from svi_hip import _lib as L
+    n, d, Lq = 2, 128, 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    def operands(adversarial):
+        q = torch.randn((1, Lq, n * d), generator=g, device="cuda")
+        k = torch.randn((1, Lq, n * d), generator=g, device="cuda")
+        v = torch.randn((1, Lq, n * d), generator=g, device="cuda")
+        if adversarial:            # a late giant key every row projects on: raw score 3 * 2 * 128 = 768 -> 98 log2 units, ~90 above any tile-0 maximum
+            k[:, 3000] = 3.0
+            q = q + 2.0
+        return [a.to(torch.bfloat16).contiguous() for a in (q, k, v)]
+    qa, ka, va = operands(True)
+    qb, kb, vb = operands(False)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    oa, ob = torch.empty_like(qa), torch.empty_like(qb)
+    torch.cuda.synchronize()
+    for _ in range(3):                                   # repeated: the interleaving on the device varies
+        with torch.cuda.stream(sa):
+            L.check(L.lib().svi_attention_fwd(qa.data_ptr(), ka.data_ptr(), va.data_ptr(), oa.data_ptr(), 1, Lq, Lq, n, d, sa.cuda_stream))
+        with torch.cuda.stream(sb):
+            L.check(L.lib().svi_attention_fwd(qb.data_ptr(), kb.data_ptr(), vb.data_ptr(), ob.data_ptr(), 1, Lq, Lq, n, d, sb.cuda_stream))
+    torch.cuda.synchronize()
+    fa, fb = C.c_int32(), C.c_int32()
+    na, nb = C.c_int32(), C.c_int32()
+    L.check(L.lib().svi_attention_last_flagged(sa.cuda_stream, C.byref(fa), C.byref(na)))
+    L.check(L.lib().svi_attention_last_flagged(sb.cuda_stream, C.byref(fb), C.byref(nb)))
+    assert na.value == nb.value == (Lq // 256) * n
+    assert fa.value > 0 and fb.value == 0, (fa.value, fb.value)
+
+    def sdpa64(q, k, v):
+        qh, kh, vh = (a.double().view(1, Lq, n, d).transpose(1, 2) for a in (q, k, v))
+        return torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(1, Lq, n * d)
+    ra, rb = errs(oa, sdpa64(qa, ka, va))[0], errs(ob, sdpa64(qb, kb, vb))[0]
+    report("two_streams", flagged_a=fa.value, flagged_b=fb.value, rel_a=ra, rel_b=rb)
+    assert torch.isfinite(oa.float()).all() and ra < 6e-3 and rb < 6e-3, (ra, rb)

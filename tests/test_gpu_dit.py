@@ -223,4 +223,54 @@ def test_graph_replay_is_bit_identical(hip, name):
         loop = hip.DenoiseLoop(m, graph=True)
         got = loop.sample(dev(lat), cp, cn, num_inference_steps=5, cfg_scale=5.0, **kw)
         assert torch.equal(got, want)
-        assert loop._graph is not None
+        assert loop._graph is None                  # the graph reads the clip's tensors and cache entries: it dies with the clip
+
+
+def test_graph_never_replays_against_stale_state(hip):
+    """What a captured step has baked in (addresses of latents / prompts / outputs, a context-cache hit, workspace and cache-entry
+    pointers) must still hold at every replay.  One DenoiseLoop(graph=True) object is kept across clips whose tensors are freed and
+    re-created (the caching allocator hands the new prompt the old prompt's address), across a context-cache reset, an interleaved
+    eager forward of another size on the same handle (workspace re-layout) and an in-place prompt edit: every result equals the
+    eager loop's bits."""
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    f, h, w = grid
+    m, _ = build(hip, c, seed)
+    _, ctx, _ = inputs(c, grid, nt, nv, seed)
+    loop = hip.DenoiseLoop(m, graph=True)
+    eager = hip.DenoiseLoop(m)
+    seen = set()
+    for clip in range(3):
+        lat = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=20 + clip, device="cpu", dtype=torch.float32)
+        cp, cn = dev(np.asarray(ctx) * (1.0 + 0.5 * clip)), dev(-np.asarray(ctx))
+        seen.add(cp.data_ptr())
+        got = loop.sample(dev(lat), cp, cn, num_inference_steps=3, cfg_scale=5.0)
+        want = eager.sample(dev(lat), cp, cn, num_inference_steps=3, cfg_scale=5.0)
+        assert torch.equal(got, want), clip
+        del cp, cn, got, want
+    # step-level: the caller keeps the loop and its tensors, other things move underneath
+    m.context_cache(True)
+    try:
+        lat0 = dev(hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=31, device="cpu", dtype=torch.float32))
+        cp, cn = dev(np.asarray(ctx)), dev(-np.asarray(ctx))
+        t = torch.tensor([ts], device="cuda")
+
+        def both(tag):
+            a, b = lat0.clone(), lat0.clone()
+            for _ in range(2):
+                loop.step(a, t, -0.03, cp, cn, 5.0)
+                eager.step(b, t, -0.03, cp, cn, 5.0)
+            assert torch.equal(a, b), tag
+        both("first capture")
+        gen0 = m.generation()
+        big = dev(synth.randn(77, 1, 16, 2 * f, 2 * h, 2 * w))
+        m.forward(big, t, cp)                                     # another problem size on the same handle: the workspace is laid out anew
+        assert m.generation() != gen0
+        both("after a workspace re-layout")
+        m.context_cache(False)
+        m.context_cache(True)                                     # every cached projection is gone: a replay would read dead entries
+        both("after a context-cache reset")
+        cp.mul_(0.5)                                              # in-place prompt edit: same address, new contents
+        both("after an in-place prompt edit")
+    finally:
+        loop.drop_graph()
+        m.context_cache(False)

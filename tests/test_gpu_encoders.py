@@ -26,6 +26,55 @@ def _t(d):
     return {k: torch.from_numpy(v) for k, v in d.items()}
 
 
+@pytest.fixture(autouse=True)
+def cpu_bucket_arithmetic():
+    """The committed text-encoder fixtures (and the CPU oracle) were made by the reference module on a CPU, i.e. with the relative-position
+    bucket table in the HOST's fp32 arithmetic; the product builds the table on the device, in the arithmetic the module's tensor ops
+    perform there (test_t5_bucket_table_is_the_device_arithmetic).  Value checks against CPU-made fixtures select the CPU table."""
+    from svi_hip import _lib as L
+    L.set_switch("SVI_T5_BUCKETS", "host")
+    yield
+    L.set_switch("SVI_T5_BUCKETS", None)
+
+
+def test_t5_bucket_table_is_the_device_arithmetic(hip, t5_tiny, golden):
+    """T5RelativeEmbedding._relative_position_bucket (text_encoder:175-194) runs on the embedding's device (:160-165).  The table
+    svi_t5_forward uses is built on the GPU with the arithmetic torch performs there; here the formula is evaluated by torch on the GPU
+    (the reference's statement, restated as the checker) for 512 positions and must give the same table.  Where the host's arithmetic
+    (the CPU fixture `buckets_512`) differs from the device's is reported — and a forward on either table stays inside the fixture bounds."""
+    import ctypes as C
+    import math
+    from svi_hip import _lib as L
+    from svi_hip.encoders import relative_position_buckets
+    m, sd = t5_tiny
+    L.set_switch("SVI_T5_BUCKETS", None)
+    n = 512
+    out = (C.c_int32 * (2 * n - 1))()
+    L.check(L.lib().svi_t5_device_buckets(m._h, n, out), "svi_t5_device_buckets")
+    dev_tab = np.asarray(list(out), dtype=np.int64)
+    rel_pos = torch.arange(-(n - 1), n, device="cuda")
+    num_buckets, max_dist = 32 // 2, 128
+    rel_buckets = (rel_pos > 0).long() * num_buckets
+    a = torch.abs(rel_pos)
+    max_exact = num_buckets // 2
+    large = max_exact + (torch.log(a.float() / max_exact) / math.log(max_dist / max_exact) * (num_buckets - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    want = (rel_buckets + torch.where(a < max_exact, a, large)).cpu().numpy()
+    host_tab = np.asarray(relative_position_buckets(32, 128, n), dtype=np.int64)
+    g = golden("t5_encoder.npz")
+    assert np.array_equal(host_tab, g["buckets_512"])                       # the host entry point = the module on a CPU (fixture)
+    diff = np.nonzero(dev_tab != host_tab)[0] - (n - 1)
+    report("t5_bucket_table", device_equals_torch_on_device=bool(np.array_equal(dev_tab, want)), offsets_where_host_and_device_differ=[int(d) for d in diff])
+    assert np.array_equal(dev_tab, want)
+    # a forward on the device table: still inside the bounds against the CPU-made fixture (three of 1023 offsets pick the neighbouring bias row)
+    name, Lp, valid, seed = synth.T5_TINY_CASES[1]
+    ids, mask = synth.t5_ids(seed, Lp, valid, synth.T5_TINY["vocab"])
+    full = m(torch.from_numpy(ids), torch.from_numpy(mask))
+    r32, r16 = errs(full[0], g[f"{name}_fp32"])[0], errs(full[0], g[f"{name}_bf16"])[0]
+    report("t5_tiny_long_device_table", vs_ref_fp32=r32, vs_ref_bf16=r16)
+    assert r32 < 1.2e-2 and r16 < 6e-3, (r32, r16)
+
+
 @pytest.fixture(scope="module")
 def t5_tiny(hip):
     sd = _t(synth.t5_state_dict(synth.T5_SEED, **synth.T5_TINY))

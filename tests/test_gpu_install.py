@@ -240,3 +240,91 @@ def test_checkpoint_and_lora_file_on_the_device(tmp_path):
     rel = float((got.float() - want.float()).norm() / want.float().norm())
     assert rel < 2e-3, rel            # the merge differs from torch.mm only in fp32 summation order on bf16 ties
     assert not torch.equal(got, ref.forward(x, t, ctx))
+
+
+def test_load_vae_reads_the_stock_pth_checkpoint(tmp_path, golden):
+    """Wan2.1_VAE.pth as the reference ships it: a torch pickle of the bare VideoVAE_ state dict (no "model." prefix), optionally wrapped
+    in {"model_state": ...} (WanVideoVAEStateDictConverter.from_civitai, wan_video_vae.py:802-808).  Both forms, and the same weights as
+    safetensors, load through svi_hip.checkpoint.load_vae and decode to the reference's golden output."""
+    from safetensors.torch import save_file
+    from svi_hip import checkpoint
+    g = golden("vae.npz")
+    vsd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()}
+    bare = {k[len("model."):]: v for k, v in vsd.items()}
+    torch.save(bare, str(tmp_path / "Wan2.1_VAE.pth"))
+    torch.save({"model_state": bare}, str(tmp_path / "wrapped.pth"))
+    save_file({k: v.contiguous() for k, v in vsd.items()}, str(tmp_path / "vae.safetensors"))
+    import svi_hip
+    ref = svi_hip.WanVideoVAE.from_state_dict(vsd)
+    z = torch.from_numpy(synth.randn(41, 16, 2, 8, 8)).cuda()
+    want = ref.decode([z], device="cuda")[0]
+    for name in ("Wan2.1_VAE.pth", "wrapped.pth", "vae.safetensors"):
+        v = checkpoint.load_vae(str(tmp_path / name))
+        assert torch.equal(v.decode([z], device="cuda")[0], want), name
+
+
+REAL_SAMPLER_SRC = '''
+def model_fn_wan_video(dit, x, timestep, context, clip_feature=None, y=None, **kwargs):
+    raise AssertionError("the PyTorch model_fn was called: install() did not take effect")
+
+
+class SVIVideoPipeline:
+    def __init__(self, dit, scheduler):
+        self.dit, self.vae, self.scheduler, self.device = dit, None, scheduler, "cuda"
+
+    # signature and body follow pipelines/svi_video.py:392-421 (the call statements are the reference's; tests/test_reference_keys.py
+    # runs install()'s routing on the reference's OWN source, compiled with ast, on the build box)
+    def _sample_with_regular_video(self, latents, prompt_emb_posi, prompt_emb_nega, image_emb, extra_input, tea_cache_posi, tea_cache_nega, usp_kwargs, use_controlnet, cfg_scale, progress_bar_cmd):
+        for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
+            timestep = timestep.unsqueeze(0).to(device=self.device)
+            if cfg_scale['text'] != 1.0:
+                noise_pred_cond = model_fn_wan_video(self.dit, latents, timestep=timestep, **prompt_emb_posi, **image_emb, **extra_input, **tea_cache_posi, **usp_kwargs, use_controlnet=use_controlnet)
+                noise_pred_uncond = model_fn_wan_video(self.dit, latents, timestep=timestep, **prompt_emb_nega, **image_emb, **extra_input, **tea_cache_nega, **usp_kwargs, use_controlnet=use_controlnet)
+                noise_pred = noise_pred_uncond + cfg_scale['text'] * (noise_pred_cond - noise_pred_uncond)
+            else:
+                noise_pred = model_fn_wan_video(self.dit, latents, timestep=timestep, **prompt_emb_posi, **image_emb, **extra_input, **tea_cache_posi, **usp_kwargs, use_controlnet=use_controlnet)
+            latents = self.scheduler.step(noise_pred, self.scheduler.timesteps[progress_id], latents)
+        return latents
+'''
+
+
+@pytest.mark.parametrize("name,scale", [("tiny_t2v", 5.0), ("tiny_i2v", 5.0), ("tiny_t2v", 1.0)])
+def test_install_sampler_is_the_denoise_loop_and_keeps_the_reference_bits(name, scale):
+    """install(sampler=True) rebinds `_sample_with_regular_video` to the DenoiseLoop-backed sampler (both forwards of a step in one C
+    call, fused CFG + Euler kernel — what bench.py times).  It must give the bits of the reference-style loop (two swapped
+    model_fn_wan_video calls, torch's bf16 CFG arithmetic, the scheduler's tensor update) that install(sampler=False) leaves in place."""
+    import svi_hip
+    c, grid, nt, nv, ts, seed = CASES[name]
+    modname = "svi_video_double2"
+    mod = types.ModuleType(modname)
+    sys.modules[modname] = mod
+    try:
+        exec(compile(REAL_SAMPLER_SRC, modname + ".py", "exec"), mod.__dict__)
+        mod.SVIVideoPipeline.__module__ = modname
+        dit, sd = wan_model_double(c, seed)
+        sch = svi_hip.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        sch.set_timesteps(4, shift=5.0)
+        x, ctx, kw = inputs(c, grid, nt, nv, seed)
+        lat = dev(x)
+        posi, nega = {"context": dev(ctx)}, {"context": dev(-np.asarray(ctx))}
+        img = {k: dev(v) for k, v in kw.items()}
+        args = (posi, nega, img, {}, {"tea_cache": None}, {"tea_cache": None}, {}, False, {"text": scale}, lambda it: it)
+        slow_pipe = mod.SVIVideoPipeline(dit, sch)
+        svi_hip.install(slow_pipe, vae=False, sampler=False)
+        before = lat.clone()
+        slow = slow_pipe._sample_with_regular_video(lat, *args)
+        fast_pipe = mod.SVIVideoPipeline(dit, sch)
+        svi_hip.install(fast_pipe, vae=False)
+        assert fast_pipe._sample_with_regular_video.__func__ is svi_hip.pipeline._hip_sample_with_regular_video
+        fast = fast_pipe._sample_with_regular_video(lat, *args)
+        assert torch.equal(lat, before)                      # the caller's latents are left alone, as by the reference's loop
+        assert fast.dtype == slow.dtype == torch.bfloat16 and torch.isfinite(fast.float()).all()
+        assert torch.equal(fast, slow)
+        # TeaCache objects are honoured by the fast sampler too (svi_video.py:500-501): same skip pattern, same bits as the slow path
+        tp, tn = svi_hip.TeaCache(4, 0.2, "Wan2.1-T2V-1.3B"), svi_hip.TeaCache(4, 0.2, "Wan2.1-T2V-1.3B")
+        sp, sn = svi_hip.TeaCache(4, 0.2, "Wan2.1-T2V-1.3B"), svi_hip.TeaCache(4, 0.2, "Wan2.1-T2V-1.3B")
+        a_t = (posi, nega, img, {}, {"tea_cache": tp}, {"tea_cache": tn}, {}, False, {"text": scale}, lambda it: it)
+        a_s = (posi, nega, img, {}, {"tea_cache": sp}, {"tea_cache": sn}, {}, False, {"text": scale}, lambda it: it)
+        assert torch.equal(fast_pipe._sample_with_regular_video(lat, *a_t), slow_pipe._sample_with_regular_video(lat, *a_s))
+    finally:
+        del sys.modules[modname]

@@ -197,3 +197,123 @@ def test_config_tables_of_the_reference_converter(ref):
         got = infer_dit_config(sd)
         for k, v in kw.items():
             assert got.get(k, False) == v, (k, got.get(k), v)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# install() against the real classes: what WanDiT.from_module reads off a WanModel INSTANCE, and the swaps
+# install() makes, exercised on the reference's own sampler source.
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_of_module_reads_the_real_wan_model(ref, name):
+    """svi_hip.dit.config_of_module on the real WanModel (meta device) for the converter's constructor tables: every attribute it
+    reads exists on the real class, and the constructor arguments come back."""
+    from svi_hip.dit import config_of_module
+    dit_mod, _, _ = ref
+    cfg = CONFIGS[name]
+    with torch.device("meta"):
+        m = dit_mod.WanModel(**cfg)
+    got = config_of_module(m)
+    want = dict(cfg, patch_size=tuple(cfg["patch_size"]))
+    want.setdefault("enable_multitalk", False)
+    assert got == want
+
+
+def _compiled_sampler_module(name="svi_video_compiled"):
+    """A module object holding the reference's OWN `_sample_with_regular_video` source (compiled out of pipelines/svi_video.py with ast,
+    nothing retyped) inside a class named as in the reference, plus a module-level `model_fn_wan_video` that must never run."""
+    import ast
+    import sys
+    import types
+    src = open(os.path.join(REF, "diffsynth/pipelines/svi_video.py")).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "SVIVideoPipeline")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "_sample_with_regular_video")
+    call = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__call__")
+    new_cls = ast.ClassDef(name="SVIVideoPipeline", bases=[], keywords=[], body=[fn], decorator_list=[])
+    mod_ast = ast.Module(body=[new_cls], type_ignores=[])
+    ast.fix_missing_locations(mod_ast)
+    mod = types.ModuleType(name)
+    sys.modules[name] = mod
+
+    def never(*a, **k):
+        raise AssertionError("the PyTorch model_fn_wan_video ran: the swap did not take effect")
+    mod.model_fn_wan_video = never
+    exec(compile(mod_ast, name + ".py", "exec"), mod.__dict__)
+    mod.SVIVideoPipeline.__module__ = name
+    return mod, fn, call
+
+
+def test_hip_sampler_has_the_reference_signature_and_call_form(ref):
+    """The sampler install() binds takes exactly the parameters of SVIVideoPipeline._sample_with_regular_video (svi_video.py:392), in
+    order — and __call__ hands them over positionally in that order (svi_video.py:506-509)."""
+    import ast
+    import inspect
+    from svi_hip.pipeline import _hip_sample_with_regular_video
+    _, fn, call = _compiled_sampler_module("svi_video_sig")
+    ref_params = [a.arg for a in fn.args.args]
+    assert list(inspect.signature(_hip_sample_with_regular_video).parameters) == ref_params
+    stmt = next(n for n in ast.walk(call) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute) and n.func.attr == "_sample_with_regular_video")
+    assert [a.id for a in stmt.args] == ref_params[1:] and not stmt.keywords
+
+
+def test_install_routing_through_the_real_sampler_source(ref):
+    """_route_dit (the DiT half of install()) on a pipeline whose class and module are the reference's own sampler source: the real call
+    statements (`model_fn_wan_video(self.dit, latents, timestep=timestep, **prompt_emb_posi, **image_emb, **extra_input, **tea_cache_posi,
+    **usp_kwargs, use_controlnet=use_controlnet)`, svi_video.py:401-408) reach the HIP twin's forward with the right tensors, twice per
+    step, and the reference's own CFG / scheduler arithmetic runs around them; the sampler rebind keeps the original reachable."""
+    import gen_golden
+    from svi_hip import pipeline
+    from svi_hip.dit import PromptPins
+    dit_mod, _, fm = ref
+    mod, _, _ = _compiled_sampler_module("svi_video_route")
+    calls = []
+
+    class FakeHip:                       # records what reaches WanDiT.forward; no GPU on this box
+        _ctx_cache_on = False
+        dim, patch_size = 8, (1, 2, 2)
+
+        def context_cache(self, on):
+            self._ctx_cache_on = bool(on)
+
+        def forward(self, x, timestep, context, clip_feature=None, y=None, add_condition=None, **kw):
+            calls.append(dict(x=x, timestep=timestep, context=context, clip_feature=clip_feature, y=y, add_condition=add_condition))
+            return x * 0.5 + context.float().mean().to(x.dtype)
+
+    with torch.device("meta"):
+        real_dit = dit_mod.WanModel(**CONFIGS["1.3B-T2V"])
+    pipe = mod.SVIVideoPipeline.__new__(mod.SVIVideoPipeline)
+    pipe.dit, pipe.device = real_dit, "cpu"
+    pipe.scheduler = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+    pipe.scheduler.set_timesteps(3, shift=5.0)
+    hip = FakeHip()
+    pipeline._route_dit(pipe, hip, sampler=False)
+    assert mod.model_fn_wan_video is pipeline._hip_model_fn and pipeline._INSTALLED[id(real_dit)] is hip
+    lat = torch.randn(1, 16, 2, 4, 4).to(torch.bfloat16)
+    pos, neg = torch.randn(1, 6, 8).to(torch.bfloat16), torch.randn(1, 6, 8).to(torch.bfloat16)
+    out = pipe._sample_with_regular_video(lat, {"context": pos}, {"context": neg}, {}, {}, {"tea_cache": None}, {"tea_cache": None}, {},
+                                          False, {"text": 5.0}, lambda x: x)
+    assert len(calls) == 6 and out.shape == lat.shape and out.dtype == torch.bfloat16
+    assert all(c["context"] is (pos if i % 2 == 0 else neg) for i, c in enumerate(calls))           # cond first, then uncond, every step
+    assert [float(c["timestep"]) for c in calls[::2]] == [float(t) for t in pipe.scheduler.timesteps]
+    assert calls[0]["x"] is lat and calls[2]["x"] is not lat                                          # the loop re-creates latents; step 0 sees the caller's
+    # the same arithmetic by hand: CFG combine and the scheduler's step around the recorded forwards
+    want = lat
+    for i, t in enumerate(pipe.scheduler.timesteps):
+        c = want * 0.5 + pos.float().mean().to(want.dtype)
+        u = want * 0.5 + neg.float().mean().to(want.dtype)
+        want = pipe.scheduler.step(u + 5.0 * (c - u), pipe.scheduler.timesteps[i], want)
+    assert torch.equal(out, want)
+    # with the sampler rebind: the instance attribute is ours, the class's own stays reachable for what the fast loop does not cover
+    pipeline._route_dit(pipe, hip, sampler=True)
+    assert pipe._sample_with_regular_video.__func__ is pipeline._hip_sample_with_regular_video
+    assert pipe._svi_hip_original_sampler.__func__ is mod.SVIVideoPipeline._sample_with_regular_video
+    del calls[:]
+    out2 = pipe._sample_with_regular_video(lat, {"context": pos}, {"context": neg}, {}, {}, {"tea_cache": None}, {"tea_cache": None}, {},
+                                           False, {"text": 5.0}, lambda x: x)       # CPU latents: not the fast loop's case -> the original sampler
+    assert torch.equal(out2, want) and len(calls) == 6
+    # the scalar the fused Euler kernel is handed equals what the reference scheduler multiplies by
+    for i, t in enumerate(pipe.scheduler.timesteps):
+        nxt = pipe.scheduler.sigmas[i + 1] if i + 1 < len(pipe.scheduler.sigmas) else 0.0
+        assert pipeline._step_delta_of(pipe.scheduler, t) == float(nxt - pipe.scheduler.sigmas[i])
+    import sys
+    for n in ("svi_video_route", "svi_video_sig"):
+        sys.modules.pop(n, None)
