@@ -48,9 +48,13 @@ template <int TAG>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restrict__ Q, int ldq,
                                                            const bf16* __restrict__ K, int ldk,
                                                            const bf16* __restrict__ VT, int ldvt,
-                                                           bf16* __restrict__ O, int ldo, int Lq, int Lk,
-                                                           float scale_log2e) {
+                                                           bf16* __restrict__ O, int ldo, int Lq, int Lk_full,
+                                                           float scale_log2e, const int* __restrict__ key_tail) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // key_tail = {n, m}: keys n-1 .. Lk_full-1 are identical (the caller's statement), so the softmax over all Lk_full keys equals the
+    // softmax over keys 0 .. n-1 with key n-1 counted m times, i.e. with log2(m) added to its score in the exponent's units
+    const int Lk = key_tail ? min(max(key_tail[0], 1), Lk_full) : Lk_full;
+    const float tail_bias = (key_tail && key_tail[1] > 1) ? __builtin_amdgcn_logf((float)key_tail[1]) / scale_log2e : 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int head = blockIdx.y;
@@ -135,8 +139,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kb + 32 * tt + 16 * (r >> 3) + (r & 7) >= Lk) s[tt][r] = -INFINITY;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + 32 * tt + 16 * (r >> 3) + (r & 7);
+                    if (key >= Lk) s[tt][r] = -INFINITY;
+                    else if (key == Lk - 1) s[tt][r] += tail_bias;
+                }
         }
         // ---- online softmax (per query = per (l & 31); the other 32 keys live in lane ^ 32) -----------
         float m8[8];
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
         store_tile(cur ^ 1);
         __syncthreads();
     }
-    if (Lk & (KB - 1)) tile(ntiles - 1, (ntiles - 1) & 1, std::true_type{});
+    if ((Lk & (KB - 1)) || key_tail) tile(ntiles - 1, (ntiles - 1) & 1, std::true_type{});      // the counted key lives in the last tile
     else tile(ntiles - 1, (ntiles - 1) & 1, std::false_type{});
 
     // ---- normalise and store: lane holds O[q_row][32 d + (r&3) + 8 (r>>2) + 4 hi] --------------------
@@ -912,7 +919,7 @@ extern "C" svi_status svi_attention_last_flagged(svi_stream stream, int32_t* fla
 }
 
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt, bf16* O,
-                            int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st) {
+                            int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st, const int* key_tail) {
     SVI_REQUIRE(Lq > 0 && Lk > 0 && num_heads > 0, "attention: bad sizes Lq=%d Lk=%d heads=%d", Lq, Lk, num_heads);
     SVI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: leading dims must be multiples of 8");
     SVI_REQUIRE(ldvt >= ((Lk + 7) / 8) * 8, "attention: V^T leading dim %d < keys rounded up to 8", ldvt);
@@ -983,9 +990,9 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     dim3 grid((Lq + QB - 1) / QB, num_heads), block(256);
     const float v1_scale = q_prescaled ? 1.0f : scale_log2e;
     if (Lq == Lk)
-        hipLaunchKernelGGL(flash_fwd_kernel<0>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, v1_scale);
+        hipLaunchKernelGGL(flash_fwd_kernel<0>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, v1_scale, key_tail);
     else
-        hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, v1_scale);
+        hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, v1_scale, key_tail);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }

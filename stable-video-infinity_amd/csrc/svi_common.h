@@ -66,6 +66,8 @@ struct SviSwitches {
     int vae_no_x2h = 0;          // SVI_VAE_X2H = 0 : the three-term bf16 convolution also where the two-term fp16 form applies (same parity bounds)
     int flash_two_pass = 1;      // SVI_FLASH_TWO_PASS = 0 : the long-sequence attention as ONE complete pass (tracked maximum) instead of the
                                  // optimistic pass + flagged second pass (same result within the attention tolerance; bit-identical on benign operands)
+    int cross_dedup = 1;         // SVI_CROSS_DEDUP = 0 : cross-attention walks every context row even where the prompt embedding's trailing rows are
+                                 // identical (the prompter's zero padding); default: m identical keys = one key counted m times (same softmax)
     int t5_host_buckets = 0;     // SVI_T5_BUCKETS = host : the text encoder's relative-position bucket table in the HOST's fp32 arithmetic (what the
                                  // reference module computes on a CPU — the arithmetic the committed fixtures were made with) instead of the device's
 #ifdef SVI_ABLATIONS
@@ -155,8 +157,9 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
 // q_prescaled != 0: Q already carries softmax_scale * log2(e) = 1.4426950408889634 / sqrt(128)  (SVI_QK_SCALE_LOG2E).
 #define SVI_QK_SCALE_LOG2E 0.12751743f
 // (svi_launch_flash: q/k token-major with row strides, V TRANSPOSED [heads*128, ldvt])
+// key_tail (device, optional; short key axes only): {n, m} — attend to keys 0 .. n-1 and count key n-1 m times (keys n-1 .. Lk-1 are identical)
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt,
-                            bf16* O, int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st);
+                            bf16* O, int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st, const int* key_tail = nullptr);
 
 svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int rows, int dim, float eps,
                              const bf16* w, const bf16* b, const float* shift, const float* scale1p,

@@ -51,6 +51,7 @@ struct Workspace {
     bf16 *X, *X2, *Hb, *QK, *VT, *Fb, *CTX, *CTXH, *CK, *CVT, *CKi, *CVTi, *A2, *PATCH, *HO, *IMG0, *IMG1, *IMGD;
     bf16 *e, *h1, *t, *st, *tmod;
     float *modf, *headf;
+    int* tail = nullptr;            // identical-suffix summary of the text context when no cache entry holds it
     int ldvt = 0, ldcvt = 0, ldcvti = 264, kpatch = 0;
 };
 
@@ -67,11 +68,12 @@ struct CtxEntry {
     char* base = nullptr;
     bf16* CTX = nullptr;
     std::vector<bf16*> CK, CVT, CKi, CVTi;
+    int* tail = nullptr;            // {effective key count, multiplicity of the last effective key}: see ctx_tail_*_kernel
     bool filled = false;
     unsigned long long stamp = 0;
 };
 
-struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; };
+struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; const int* tail; };
 
 struct svi_dit {
     svi_dit_config cfg;
@@ -307,7 +309,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     const int kpatch = c.in_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho = (size_t)c.out_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho_ld = (ho + 7) / 8 * 8;
-    size_t oX, oX2, oH, oQK, oVT, oF, oCTX, oCTXH, oCK, oCVT, oCKi, oCVTi, oA2, oP, oHO, oI0, oI1, oID, oe, oh1, ot, ost, otm, omodf, oheadf;
+    size_t oX, oX2, oH, oQK, oVT, oF, oCTX, oCTXH, oCK, oCVT, oCKi, oCVTi, oA2, oP, oHO, oI0, oI1, oID, oe, oh1, ot, ost, otm, omodf, oheadf, otail;
     auto layout = [&](int l, int lc) -> size_t {
         const size_t Lctx = (size_t)lc + img;
         const int ldvt = ((l + 7) / 8) * 8, ldcvt = ((lc + 7) / 8) * 8;
@@ -322,6 +324,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
         oI0 = take((size_t)264 * 1280 * 2); oI1 = take((size_t)264 * 1280 * 2); oID = take((size_t)264 * D * 2);
         oe = take(c.freq_dim * 2); oh1 = take(D * 2); ot = take(D * 2); ost = take(D * 2); otm = take(6 * D * 2);
         omodf = take((size_t)c.num_layers * 6 * D * 4); oheadf = take(2 * D * 4);
+        otail = take((size_t)(lc + 8) * 4);
         return off;
     };
     const size_t need = layout(L, Lc);
@@ -355,6 +358,43 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     w.IMG0 = P(oI0); w.IMG1 = P(oI1); w.IMGD = P(oID); w.e = P(oe); w.h1 = P(oh1); w.t = P(ot); w.st = P(ost); w.tmod = P(otm);
     w.modf = reinterpret_cast<float*>(w.base + omodf);
     w.headf = reinterpret_cast<float*>(w.base + oheadf);
+    w.tail = reinterpret_cast<int*>(w.base + otail);
+    return SVI_OK;
+}
+
+// ---- identical trailing rows of the text context -----------------------------------------------------------------------------
+// The prompter zero-fills the rows of a prompt embedding past the prompt's own tokens (prompters/wan_prompter.py:107-108: 512 positions,
+// a few dozen of them real), and cross-attention attends to all 512 without a mask (dit:266-303).  Every kernel between the embedding
+// and the cross-attention K / V is row-local (text_embedding MLP, K / V projections, RMSNorm; no RoPE on the context), so identical
+// input rows give identical K rows and identical V rows, and m identical keys are ONE key whose probability counts m times:
+//   softmax over {s_0 .. s_{n-1}, s_n x m}  ==  softmax with the last score raised by ln m.
+// ctx_tail finds the identical suffix of the INPUT rows (bitwise comparison with the last row — nothing is assumed about zeros) and
+// leaves {n + 1, m} on the device; the cross-attention launch reads it there (no host round trip) and walks n + 1 keys instead of Lc.
+// Per step at BASELINE configs[1]: 60 launches over 512 keys -> 60 launches over 65 / 33 keys.  SVI_CROSS_DEDUP=0 attends to every row.
+__global__ void ctx_tail_rows_kernel(const bf16* __restrict__ ctx, int Lc, int dim, int* __restrict__ eq) {
+    const int r = blockIdx.x;
+    const u32x4* a = reinterpret_cast<const u32x4*>(ctx + (size_t)r * dim);
+    const u32x4* b = reinterpret_cast<const u32x4*>(ctx + (size_t)(Lc - 1) * dim);
+    int same = 1;
+    for (int i = threadIdx.x; i < dim / 8; i += blockDim.x) {
+        const u32x4 x = a[i], y = b[i];
+        same &= (x[0] == y[0]) & (x[1] == y[1]) & (x[2] == y[2]) & (x[3] == y[3]);
+    }
+    same = __syncthreads_and(same);
+    if (threadIdx.x == 0) eq[r] = same;
+}
+__global__ void ctx_tail_scan_kernel(const int* __restrict__ eq, int Lc, int* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int s = Lc - 1;                                  // rows s .. Lc-1 are identical to the last row
+    while (s > 0 && eq[s - 1]) --s;
+    out[0] = s + 1;                                  // effective key count: keys 0 .. s
+    out[1] = Lc - s;                                 // key s stands for this many identical keys
+}
+// tail: int[2 + Lc] (the summary, then the per-row scratch)
+static svi_status stage_ctx_tail(const bf16* context, int Lc, int text_dim, int* tail, hipStream_t st) {
+    hipLaunchKernelGGL(ctx_tail_rows_kernel, dim3(Lc), dim3(256), 0, st, context, Lc, text_dim, tail + 2);
+    hipLaunchKernelGGL(ctx_tail_scan_kernel, dim3(1), dim3(64), 0, st, tail + 2, Lc, tail);
+    SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
 
@@ -481,7 +521,7 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
             { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(kv.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, 1.0f, st)); }
             { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, kv.CVT, w.ldcvt, Lc, D, D, st)); }
         }
-        { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb + ro * D, D, L, Lc, H, 1, st)); }
+        { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb + ro * D, D, L, Lc, H, 1, st, kv.tail)); }
         if (img) {
             if (kv.compute) {
                 SVI_TRY(linear(CTX, D, b.ca.k_img, kv.CKi, D, img, D, D, SVI_EPI_BIAS, st));
@@ -628,7 +668,7 @@ static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* cli
             ce = lru;
             const size_t Dd = c.dim, Lctx = (size_t)Lc + img, nl = c.num_layers;
             const size_t per_layer = al(Lctx * Dd * 2) + al(Dd * w.ldcvt * 2) + (img ? al((size_t)264 * Dd * 2) + al(Dd * 264 * 2) : 0);
-            const size_t need = al(Lctx * Dd * 2) + nl * per_layer;
+            const size_t need = al(Lctx * Dd * 2) + nl * per_layer + al((size_t)(Lc + 8) * 4);
             if (!ce->base || ce->Lc != Lc || ce->CK.size() != nl) {
                 if (ce->base) { SVI_CHECK_HIP(hipFree(ce->base)); ce->base = nullptr; }
                 hipError_t e2 = hipMalloc((void**)&ce->base, need);
@@ -642,6 +682,7 @@ static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* cli
                     ce->CK[l] = take(Lctx * Dd * 2); ce->CVT[l] = take(Dd * w.ldcvt * 2);
                     if (img) { ce->CKi[l] = take((size_t)264 * Dd * 2); ce->CVTi[l] = take(Dd * 264 * 2); }
                 }
+                ce->tail = reinterpret_cast<int*>(take((size_t)(Lc + 8) * 4));
             }
             ce->key_ctx = context; ce->key_clip = clip; ce->Lc = Lc; ce->filled = true;
             ++h->generation;                                    // an entry was (re)filled: pointers / contents a captured graph relies on moved
@@ -650,6 +691,7 @@ static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* cli
     }
     bf16* CTXp = ce ? ce->CTX : w.CTX;
     if (ctx_compute) {
+        SVI_TRY(stage_ctx_tail(context, Lc, c.text_dim, ce ? ce->tail : w.tail, st));
         SVI_TRY(linear(context, c.text_dim, h->text0, w.CTXH, D, Lc, D, c.text_dim, SVI_EPI_BIAS_GELU_TANH, st));
         SVI_TRY(linear(w.CTXH, D, h->text2, CTXp + (size_t)img * D, D, Lc, D, D, SVI_EPI_BIAS, st));
         if (img) {
@@ -683,7 +725,8 @@ static svi_status stage_embed(svi_dit* h, const bf16* x, const bf16* y, const bf
 
 static CtxKV kv_of(svi_dit* h, const CtxUse& u, int l) {
     Workspace& w = h->ws;
-    return CtxKV{u.ce ? u.ce->CK[l] : w.CK, u.ce ? u.ce->CVT[l] : w.CVT, u.ce ? u.ce->CKi[l] : w.CKi, u.ce ? u.ce->CVTi[l] : w.CVTi, u.compute};
+    const int* tail = svi_switches().cross_dedup ? (u.ce ? u.ce->tail : w.tail) : nullptr;
+    return CtxKV{u.ce ? u.ce->CK[l] : w.CK, u.ce ? u.ce->CVT[l] : w.CVT, u.ce ? u.ce->CKi[l] : w.CKi, u.ce ? u.ce->CVTi[l] : w.CVTi, u.compute, tail};
 }
 
 // head (dit:401-404): LN + modulation + Linear(dim -> out_dim * patch volume) on the rows in X -> HO [L, ho_ld]
@@ -1033,6 +1076,6 @@ extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_i
     SVI_TRY(ensure_rope(h, f, hh, ww));
     float* modf = h->ws.modf + (size_t)layer * 6 * D;
     SVI_TRY(mod_one(h->blocks[layer].modulation, reinterpret_cast<const bf16*>(t_mod), modf, D, 6, (1 << 1) | (1 << 4), 6, st));
-    CtxKV kv{h->ws.CK, h->ws.CVT, h->ws.CKi, h->ws.CVTi, true};
+    CtxKV kv{h->ws.CK, h->ws.CVT, h->ws.CKi, h->ws.CVTi, true, nullptr};      // the context arrives projected: no statement about its input rows
     return run_block(h, layer, reinterpret_cast<bf16*>(x_inout), reinterpret_cast<const bf16*>(context), modf, L, Lc, kv, st);
 }

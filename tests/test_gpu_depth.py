@@ -152,13 +152,15 @@ def test_block_forward_takes_the_second_pass_on_the_dit_seam(hip, gain, expect_f
         rows, outgrowth = robust_rows(sdb, bf16r(bx), bf16r(btm), grid, cfg)
     assert (outgrowth > 64.0) == expect_flags, outgrowth          # the operands are what the test says they are
     r_all, mx, _ = errs(got, want)
-    r_rob = errs(got[0, rows], want[0, rows])[0]
+    r_rob = errs(got[0, rows], want[0, rows])[0] if int(rows.sum()) else float("nan")     # benign gains: hardly any row is that peaked
     rs = errs(got, single)[0]
     report("dit_seam_second_pass", gain=gain, flagged=flagged, workgroups=nwg, vs_oracle_all_rows=r_all, vs_oracle_well_posed_rows=r_rob,
            well_posed_fraction=float(rows.float().mean()), max_outgrowth_log2=outgrowth, max_abs=mx, two_pass_vs_single_pass=rs)
     assert torch.isfinite(got.float()).all()
-    assert int(rows.sum()) >= 256 and r_rob < 6e-3, (r_rob, int(rows.sum()))
-    if not expect_flags:
+    if expect_flags:
+        assert int(rows.sum()) >= 256 and r_rob < 6e-3, (r_rob, int(rows.sum()))
+        assert r_all < 2e-2, r_all          # all rows, including the ones where two keys tie within a rounding of q or k (measured 3.7e-3)
+    else:
         assert r_all < 6e-3, r_all
     assert rs < 2e-3, rs
     if expect_flags and flagged == nwg:

@@ -274,3 +274,38 @@ def test_graph_never_replays_against_stale_state(hip):
     finally:
         loop.drop_graph()
         m.context_cache(False)
+
+
+@pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
+def test_identical_trailing_context_rows_count_as_one_key(hip, name):
+    """The prompter zero-fills a prompt embedding past the prompt's tokens and cross-attention attends to all rows without a mask:
+    identical input rows -> identical K / V rows -> one key counted m times (csrc/svi_dit.hip ctx_tail_*).  (i) with a zero-padded
+    context the forward with the shortcut equals the forward that walks every row (SVI_CROSS_DEDUP=0) to bf16 noise — and both meet
+    the reference's golden output, which attends to all rows; (ii) a context without identical trailing rows gives the same BITS either
+    way; (iii) rows identical to the last one in the MIDDLE of the context are not merged (only a suffix is)."""
+    from svi_hip import _lib as L
+    c, grid, nt, nv, ts, seed = CASES[name]
+    g = np.load(f"{__import__('conftest').GOLDEN}/dit_{name}.npz")
+    m, _ = build(hip, c, seed)
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    kw = {k: dev(v) for k, v in kw.items()}
+    assert nv < nt and not np.asarray(ctx)[0, nv:].any()
+    t = torch.tensor([ts])
+
+    def fwd(context, dedup):
+        L.set_switch("SVI_CROSS_DEDUP", 1 if dedup else 0)
+        try:
+            return m.forward(dev(x), t, dev(context), **kw).clone()
+        finally:
+            L.set_switch("SVI_CROSS_DEDUP", None)
+    a, b = fwd(ctx, True), fwd(ctx, False)
+    r = errs(a, b)[0]
+    ra, rb = errs(a, g["out_bf16"])[0], errs(b, g["out_bf16"])[0]
+    report("cross_dedup", case=name, dedup_vs_all_rows=r, dedup_vs_ref_bf16=ra, all_rows_vs_ref_bf16=rb, padded_rows=nt - nv)
+    assert r < 2e-3 and ra < 2e-2 and rb < 2e-2, (r, ra, rb)
+    full = np.asarray(ctx).copy()
+    full[0, nv:] = synth.randn(seed + 40, nt - nv, full.shape[-1])             # no two rows alike
+    assert torch.equal(fwd(full, True), fwd(full, False))
+    mid = full.copy()
+    mid[0, 2] = mid[0, -1]                                                     # a twin of the last row far from the end
+    assert torch.equal(fwd(mid, True), fwd(mid, False))
