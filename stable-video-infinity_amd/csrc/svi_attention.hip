@@ -247,6 +247,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
 // =================================================================================================
 #define QB2 256
 #define SVI_RESCALE_THR 8.0f
+#ifndef SVI_FLASH_BALANCED
+#define SVI_FLASH_BALANCED 1
+#endif
 
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float r;
@@ -404,9 +407,15 @@ __device__ __forceinline__ void pv_stmt(int& tok, u32x4 vf, u32x4 vf2, u32x4 p, 
     const u32x4 rs = d.rs;
     const int vo = d.vo, so = d.so, m0v = d.m0v;
     float t1;
-    static_assert(FILL != SVI_F_E2 && !(DMA && FILL != SVI_F_NONE), "unsupported PV statement");
+    static_assert(FILL != SVI_F_E2 && !(AMAX && DMA && FILL != SVI_F_NONE), "unsupported PV statement");
     if constexpr (!AMAX) {          // no row-maximum piece (the optimistic kernel, or a bare statement): the other fillers as below
-        if constexpr (DMA) {
+        if constexpr (DMA && FILL == SVI_F_EA) {
+            if constexpr (MULC) asm volatile(SVI_DMA_M0 SVI_MEXP0 SVI_PVM SVI_ADD0 SVI_DMA SVI_END : SVI_PV_OUT, [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_PV_IN, [x0] "v"(x0), [c] "s"(c), SVI_DMA_IN);
+            else asm volatile(SVI_DMA_M0 SVI_EXP0 SVI_PVM SVI_ADD0 SVI_DMA SVI_END : SVI_PV_OUT, [t0] "=&v"(t0), [a0] "+v"(sum0) : SVI_PV_IN, [x0] "v"(x0), SVI_DMA_IN);
+        } else if constexpr (DMA && FILL == SVI_F_EB) {
+            if constexpr (MULC) asm volatile(SVI_DMA_M0 SVI_MEXP1 SVI_PVM SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_PV_OUT, [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_PV_IN, [x1] "v"(x1), [t0] "v"(t0), [c] "s"(c), SVI_DMA_IN);
+            else asm volatile(SVI_DMA_M0 SVI_EXP1 SVI_PVM SVI_ADD1 SVI_CVT SVI_DMA SVI_END : SVI_PV_OUT, [t1] "=&v"(t1), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_PV_IN, [x1] "v"(x1), [t0] "v"(t0), SVI_DMA_IN);
+        } else if constexpr (DMA) {
             asm volatile(SVI_DMA_M0 SVI_PVM SVI_DMA SVI_END : SVI_PV_OUT : SVI_PV_IN, SVI_DMA_IN);
         } else if constexpr (FILL == SVI_F_NONE) {
             asm(SVI_PVM SVI_END : SVI_PV_OUT : SVI_PV_IN);
@@ -499,6 +508,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                                                             bf16* __restrict__ O, int ldo, int Lq, int Lk,
                                                             float scale_log2e, int* __restrict__ flags) {
     constexpr bool OPT = MODE == 1;
+    // BAL (optimistic kernel only): one score per MFMA statement everywhere.  The optimistic pass never waits for a row maximum, so the
+    // exponentials of tile t can start as soon as S(t) is complete: its 32 score pairs per lane are spread as
+    //   4 pairs (key block 0, row group 0)             on statements 24..31 of phase 2 of tile t     (from sn; the only statements without B work before)
+    //   16 pairs (kb 0 g 1, kb 1 g 0, kb 1 g 1, kb 2 g 0) on the 32 statements of phase 1 of tile t+1
+    //   12 pairs (kb 2 g 1, kb 3 g 0, kb 3 g 1)         on statements 0..23 of phase 2 of tile t+1    (each before the PV statement that reads its word)
+    // instead of 20 pairs on phase 1 (8 of its statements carrying a whole pair: 2 v_exp + 2 v_add + pack in one 32-cycle MFMA shadow,
+    // more than fits) and 12 on phase 2.  Row sums run in four accumulators per lane over the whole key axis (no per-tile fold).
+    constexpr bool BAL = OPT && ABL == 0 && (SVI_FLASH_BALANCED != 0);
     const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x;
     if constexpr (MODE == 2) {
         if (flags[wg_linear] == 0) return;          // uniform: the whole workgroup leaves before any barrier
@@ -605,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     for (int c = 0; c < 4; ++c) vaddr[c] = lds0 + VST0 + v_off(l31, 2 * c + hi);
     f32x16 sA[2][2], sB[2][2];                   // score tiles: even tiles live in sA, odd tiles in sB
     u32x4 kf[4], vf[4];                          // fragment rings; kf[0..2] / vf[0..2] are filled one phase ahead
-    float ps[2][2];
+    float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float ma[2], mb[2];                          // per-lane running maxima of the tile in phase 2 (two chains per row group)
 
     // ---- B bookkeeping.  The 64 scores of a lane in a tile (per row group g: tb in {0,1}, 16 scores each) form 32 pairs
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         constexpr int ks = decltype(ks_c)::value * KT_BYTES, vs = decltype(vs_c)::value * VT_BYTES;
         constexpr int vd = VST0 + decltype(vd_c)::value * VT_BYTES;
         const int so_v = t * KB * 2;
-        ps[0][0] = ps[0][1] = ps[1][0] = ps[1][1] = 0.f;
+        if constexpr (!BAL) ps[0][0] = ps[0][1] = ps[1][0] = ps[1][1] = 0.f;
         static_for<0, 16>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int tt = f >> 3, kk = f & 7, f3 = (f + 3) & 15;
@@ -634,18 +651,29 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 // the register whose next use must stay behind this MFMA: the address of the fragment read that follows
                 int& pin = *((f + 3 < 16) ? &kaddr[f3 & 7] : &vaddr[0]);
                 constexpr bool dma = ((k & 7) == 4) && !(ABL & 8);
-                constexpr bool whole = (k & 3) == 3;
-                constexpr int si = k - ((k + 1) >> 2);              // index among the 24 single-score statements
-                constexpr int pi = whole ? (k >> 2) : 8 + (si >> 1); // pair handled (or started / finished) here
-                constexpr int pg = pi & 1, tb = pi >> 4, w = (pi >> 1) & 7, r0 = 2 * w;
-                constexpr int fill = !WITH_B ? SVI_F_NONE : whole ? SVI_F_E2 : (si & 1) ? SVI_F_EB : SVI_F_EA;
                 const SviDma d = {v_rs, voff0, so_v + ((k >> 3) & 3) * vstep, piece0 + vd + 4096 * ((k >> 3) & 3)};
                 unsigned wd = 0;
-                // even fragments wait for themselves and their successor at once (none to wait for behind fragment 15)
-                qk_stmt<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin, cneg[g], so[pg][tb][r0],
-                                                                                so[pg][tb][r0 + 1], scale_log2e, tcar, ps[pg][0], ps[pg][1], wd,
-                                                                                dma ? d : no_dma);
-                if constexpr (fill == SVI_F_E2 || fill == SVI_F_EB) pw[pg][tb][w >> 2][w & 3] = wd;
+                if constexpr (BAL) {
+                    // pair k >> 1 of this phase: groups of four words — kb 0 g 1 | kb 1 g 0 | kb 1 g 1 | kb 2 g 0
+                    constexpr int q1 = k >> 1, grp = q1 >> 2, w4 = q1 & 3;
+                    constexpr int pg = (grp == 0 || grp == 2) ? 1 : 0, tb = grp == 3 ? 1 : 0, psb = (grp == 1 || grp == 2) ? 1 : 0, r0 = 2 * (4 * psb + w4);
+                    constexpr int fill = !WITH_B ? SVI_F_NONE : (k & 1) ? SVI_F_EB : SVI_F_EA;
+                    qk_stmt<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin, cneg[g], so[pg][tb][r0],
+                                                                                    so[pg][tb][r0 + 1], scale_log2e, tcar, ps[pg][0], ps[pg][1], wd,
+                                                                                    dma ? d : no_dma);
+                    if constexpr (fill == SVI_F_EB) pw[pg][tb][psb][w4] = wd;
+                } else {
+                    constexpr bool whole = (k & 3) == 3;
+                    constexpr int si = k - ((k + 1) >> 2);              // index among the 24 single-score statements
+                    constexpr int pi = whole ? (k >> 2) : 8 + (si >> 1); // pair handled (or started / finished) here
+                    constexpr int pg = pi & 1, tb = pi >> 4, w = (pi >> 1) & 7, r0 = 2 * w;
+                    constexpr int fill = !WITH_B ? SVI_F_NONE : whole ? SVI_F_E2 : (si & 1) ? SVI_F_EB : SVI_F_EA;
+                    // even fragments wait for themselves and their successor at once (none to wait for behind fragment 15)
+                    qk_stmt<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin, cneg[g], so[pg][tb][r0],
+                                                                                    so[pg][tb][r0 + 1], scale_log2e, tcar, ps[pg][0], ps[pg][1], wd,
+                                                                                    dma ? d : no_dma);
+                    if constexpr (fill == SVI_F_E2 || fill == SVI_F_EB) pw[pg][tb][w >> 2][w & 3] = wd;
+                }
                 if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
                     kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ks + ((f + 3) >> 3) * 32 * 256);
                 if constexpr (g == 0 && f + 3 >= 16)                 // f = 13, 14, 15: V^T fragments 0, 1, 2 of phase 2
@@ -690,21 +718,36 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 if constexpr (WITH_PV) {
                     int& pin = *((f + 3 < 16) ? &vaddr[f3 >> 2] : &kaddr[nf]);
                     constexpr bool dma = (j >= 24) && !(j & 1) && !(ABL & 8);
+                    const SviDma d = {k_rs, koff0, so_k + ((j >> 1) & 3) * kstep, piece0 + kd + 4096 * ((j >> 1) & 3)};
+                    unsigned wd = 0;
+                    if constexpr (BAL) {
+                        // statements 0..23: pairs of tile t-1 in the order the PV statements need their words — kb 2 g 1 | kb 3 g 0 | kb 3 g 1;
+                        // statements 24..31: the first four pairs of THIS tile (kb 0, g 0; from sn) into the words PV statements 0..6 are done with
+                        constexpr bool own = j >= 24;
+                        constexpr int q = own ? (j - 24) >> 1 : j >> 1, grp = q >> 2, w4 = q & 3;
+                        // (psb: the PAIR's half of its key block — not the fragment's `sb` of the enclosing scope, which names this statement's P operand)
+                        constexpr int pg = own ? 0 : (grp == 1 ? 0 : 1), tb = own ? 0 : 1, psb = own ? 0 : (grp == 0 ? 0 : 1), r0 = 2 * (4 * psb + w4);
+                        constexpr int fill = !WITH_B ? SVI_F_NONE : (j & 1) ? SVI_F_EB : SVI_F_EA;
+                        pv_stmt<SVI_OREG0 + (g * 4 + d4) * 16, false, fill, dma, MULC>(
+                            tok, vf[f & 3], vf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pw[g][tt][sb], pin, mch, 0.f, 0.f,
+                            own ? sn[pg][tb][r0] : so[pg][tb][r0], own ? sn[pg][tb][r0 + 1] : so[pg][tb][r0 + 1],
+                            scale_log2e, tcar, ps[pg][0], ps[pg][1], wd, dma ? d : no_dma);
+                        if constexpr (fill == SVI_F_EB) pw[pg][tb][psb][w4] = wd;
+                    } else {
                     constexpr int pi = 20 + (j >> 1);                // pairs 20..31 on statements 0..23
                     constexpr int pg = pi & 1, w = (pi >> 1) & 7, r0 = 2 * w;          // tb = 1
                     constexpr int fill = (!WITH_B || j >= 24) ? SVI_F_NONE : (j & 1) ? SVI_F_EB : SVI_F_EA;
                     constexpr bool amax = !((ABL & 2) || (ABL & 32) || (ABL & 1024) || OPT);
                     constexpr bool rest = amax || (ABL & 1024) || OPT;   // optimistic mode / ABL 1024: only the row-maximum pieces are left out
-                    const SviDma d = {k_rs, koff0, so_k + ((j >> 1) & 3) * kstep, piece0 + kd + 4096 * ((j >> 1) & 3)};
-                    unsigned wd = 0;
                     pv_stmt<SVI_OREG0 + (g * 4 + d4) * 16, amax, rest ? fill : SVI_F_NONE, rest && dma, MULC>(
                         tok, vf[f & 3], vf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pw[g][tt][sb], pin, mch, sn[ga][ta][ra], sn[ga][ta][ra + 1], so[pg][1][r0], so[pg][1][r0 + 1],
                         scale_log2e, tcar, ps[pg][0], ps[pg][1], wd, dma ? d : no_dma);
                     if constexpr (rest && fill == SVI_F_EB) pw[pg][1][w >> 2][w & 3] = wd;
+                    }
                     if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
                         vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
                     if constexpr (g == 0 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
-                    if constexpr (WITH_B && j == 23) {               // all 32 pairs of tile t-1 are done: fold the row sums
+                    if constexpr (WITH_B && j == 23 && !BAL) {       // all 32 pairs of tile t-1 are done: fold the row sums
                         l_run[0] = l_run[0] * alpha[0] + (ps[0][0] + ps[0][1]);
                         l_run[1] = l_run[1] * alpha[1] + (ps[1][0] + ps[1][1]);
                         alpha[0] = alpha[1] = 1.0f;
@@ -799,6 +842,16 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         const float d0[2] = {row_max(0), row_max(1)};                  // first reference = the row maxima of tile 0 (any sign)
         commit(sA, d0);
         alpha[0] = alpha[1] = 1.0f;                                    // O and l are still 0
+        if constexpr (BAL) {      // the four pairs a later tile handles on statements 24..31 of its own phase 2 (kb 0, g 0), for tile 0
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const float p0 = __builtin_amdgcn_exp2f(sA[0][0][2 * w4] * cs);
+                const float p1 = __builtin_amdgcn_exp2f(sA[0][0][2 * w4 + 1] * cs);
+                ps[0][0] += p0;
+                ps[0][1] += p1;
+                pw[0][0][0][w4] = pack_bf16x2(p0, p1);
+            }
+        }
     }
     __syncthreads();                                                   // K stage 0 may be overwritten from tile 1 on
 
@@ -835,12 +888,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
+                    if (BAL && g == 0 && tt == 0 && r < 8) continue;      // already done (and summed) on statements 24..31 of the last phase 2
                     const float p0 = __builtin_amdgcn_exp2f(sB[g][tt][r] * cs);
                     const float p1 = __builtin_amdgcn_exp2f(sB[g][tt][r + 1] * cs);
                     psd[g] += p0 + p1;
                     pw[g][tt][r >> 3][(r & 7) >> 1] = pack_bf16x2(p0, p1);
                 }
-            l_run[g] = l_run[g] * alpha[g] + psd[g];
+            if constexpr (BAL) l_run[g] = (ps[g][0] + ps[g][1]) + psd[g];      // four running sums per lane over the whole key axis
+            else l_run[g] = l_run[g] * alpha[g] + psd[g];
         }
         asm("s_nop 1" : "+v"(tok), "+v"(pw[0][0][0]), "+v"(pw[0][0][1]), "+v"(pw[0][1][0]), "+v"(pw[0][1][1]));
         asm("s_nop 1" : "+v"(tok), "+v"(pw[1][0][0]), "+v"(pw[1][0][1]), "+v"(pw[1][1][0]), "+v"(pw[1][1][1]));
