@@ -250,6 +250,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
 #ifndef SVI_FLASH_BALANCED
 #define SVI_FLASH_BALANCED 1
 #endif
+#ifndef SVI_FLASH_DMA_SPLIT
+#define SVI_FLASH_DMA_SPLIT 0     // 1: a statement that issues an LDS-DMA piece hands its fragment read to the next statement (balanced kernel only).
+                                  // Measured (same box, interleaved, profiles/r3e_attn_split_ab.txt): 5.025 ms against 4.981 ms without — the read
+                                  // one statement later costs more than the lighter DMA statement returns.  Kept as a recorded negative result.
+#endif
 
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float r;
@@ -516,6 +521,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     // instead of 20 pairs on phase 1 (8 of its statements carrying a whole pair: 2 v_exp + 2 v_add + pack in one 32-cycle MFMA shadow,
     // more than fits) and 12 on phase 2.  Row sums run in four accumulators per lane over the whole key axis (no per-tile fold).
     constexpr bool BAL = OPT && ABL == 0 && (SVI_FLASH_BALANCED != 0);
+    // rg(f, dma): the row-group statement (0 or 1) of fragment f behind which that fragment's look-ahead LDS read is issued: normally g = 0;
+    // where the g = 0 statement also issues an LDS-DMA piece (s_mov m0 + buffer_load ... lds on top of its score), the g = 1 statement
+    constexpr bool SPLIT = BAL && (SVI_FLASH_DMA_SPLIT != 0);
     const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x;
     if constexpr (MODE == 2) {
         if (flags[wg_linear] == 0) return;          // uniform: the whole workgroup leaves before any barrier
@@ -674,9 +682,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                                                                                     dma ? d : no_dma);
                     if constexpr (fill == SVI_F_E2 || fill == SVI_F_EB) pw[pg][tb][w >> 2][w & 3] = wd;
                 }
-                if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
+                constexpr int rg1 = (SPLIT && ((2 * f) & 7) == 4 && !(ABL & 8)) ? 1 : 0;       // this fragment's g = 0 statement carries a DMA piece
+                if constexpr (g == rg1 && f + 3 < 16 && !(ABL & 4))
                     kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ks + ((f + 3) >> 3) * 32 * 256);
-                if constexpr (g == 0 && f + 3 >= 16)                 // f = 13, 14, 15: V^T fragments 0, 1, 2 of phase 2
+                if constexpr (g == rg1 && f + 3 >= 16)               // f = 13, 14, 15: V^T fragments 0, 1, 2 of phase 2
                     vf[f >= 13 ? f - 13 : 0] = *(lds_u32x4_t)(vaddr[0] + vs + (f >= 13 ? f - 13 : 0) * 32 * 128);
             });
         });
@@ -744,9 +753,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                         scale_log2e, tcar, ps[pg][0], ps[pg][1], wd, dma ? d : no_dma);
                     if constexpr (rest && fill == SVI_F_EB) pw[pg][1][w >> 2][w & 3] = wd;
                     }
-                    if constexpr (g == 0 && f + 3 < 16 && !(ABL & 4))
+                    constexpr int rg2 = (SPLIT && f >= 12 && !(ABL & 8)) ? 1 : 0;               // statements 24, 26, 28, 30 carry the K pieces
+                    if constexpr (g == rg2 && f + 3 < 16 && !(ABL & 4))
                         vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
-                    if constexpr (g == 0 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
+                    if constexpr (g == rg2 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
                     if constexpr (WITH_B && j == 23 && !BAL) {       // all 32 pairs of tile t-1 are done: fold the row sums
                         l_run[0] = l_run[0] * alpha[0] + (ps[0][0] + ps[0][1]);
                         l_run[1] = l_run[1] * alpha[1] + (ps[1][0] + ps[1][1]);
