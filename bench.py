@@ -204,6 +204,9 @@ def main() -> None:
                     "spread Ulysses-style over the ranks (K / V all-gather fallback when the heads do not divide); with --cfg-pair: 2 CFG branches x N/2 sequence shards")
     ap.add_argument("--fp8-storage", action="store_true", help="the reference's FP8 mode (test_svi.py:337): parameters stored as float8_e4m3fn; the exact "
                     "cast to bf16 happens once at bind time, arithmetic stays bf16 (a separate line, never the headline)")
+    ap.add_argument("--fp8-mfma", action="store_true", help="opt-in MX-fp8 MLP (north_star 'bf16/fp8 MFMA'): FP8 weight storage + both MLP GEMMs of every block on "
+                    "v_mfma_scale_f32_32x32x64_f8f6f4 with per-32-element activation scales.  Arithmetic the reference never performs (it computes in bf16): "
+                    "a separately toleranced line (tests/test_gpu_mx8.py), never the headline")
     ap.add_argument("--graph", action="store_true", help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)): for the "
                     "launch-bound regime (--workload c1); per-kernel event timing is off under capture, so `roofline` is null")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -261,10 +264,12 @@ def main() -> None:
     D, F, NL, heads = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"], cfg["dim"] // 128
     dit = svi_hip.WanDiT(eps=1e-6, num_heads=heads, **cfg)
     weights = device_weights(cfg, 0, dev)
-    if args.fp8_storage or wl.get("fp8_storage"):
+    if args.fp8_storage or wl.get("fp8_storage") or args.fp8_mfma:
         args.fp8_storage = True
         weights = {k: v.to(torch.float8_e4m3fn) for k, v in weights.items()}
     dit.bind(weights)
+    if args.fp8_mfma:
+        dit.ffn_fp8_mfma(True)
     pair, units, sp_group, sp = None, world, None, False
     if args.seq_parallel and dist is not None:
         sp, units = True, 1
@@ -472,7 +477,7 @@ def main() -> None:
                    "c5": "denoised latent frames/sec, Wan2.1-I2V-14B + pose embedder (dance) 81f@832x480 50-step, FP8 weight storage"}[args.workload],
         "value": round(value, 5), "unit": "latent frames/s", "n_gpus": len(who), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.seq_parallel else "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
+        "dtype": "bf16 (MLP GEMMs: MX fp8 e4m3, opt-in)" if args.fp8_mfma else "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
         "config": {"workload": wl["desc"], "step": (f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; the pose condition enters the conditional branch only, so the two "
                                                     "forwards share nothing) + CFG + Euler") if wl.get("pose") else
                    f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
@@ -487,7 +492,9 @@ def main() -> None:
                    "dit_tflops": round(flops_step / (dist.get_world_size(sp_group) if sp else 1) / (ms_per_step * 1e-3) / 1e12, 1),
                    "flop_per_step_executed": flops_step, "flop_per_forward_reference": flops_forward,
                    "ranks": who, "rccl": rccl,
-                   "hip_graph": bool(args.graph), "weights": "float8_e4m3fn storage, cast to bf16 at bind (reference FP8 mode)" if args.fp8_storage else "bf16",
+                   "hip_graph": bool(args.graph), "weights": ("float8_e4m3fn storage; MLP GEMMs on the MX block-scaled fp8 matrix path (activations e4m3 with one E8M0 scale per 32 elements), everything else "
+                               "bf16 — NOT the reference's arithmetic, opt-in, separately toleranced") if args.fp8_mfma else
+                   "float8_e4m3fn storage, cast to bf16 at bind (reference FP8 mode)" if args.fp8_storage else "bf16",
                    "outputs_finite": finite},
         "roofline": roof,
         "roofline_all": roof_all,

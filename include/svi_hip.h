@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 5
+#define SVI_HIP_ABI_VERSION 6
 
 typedef enum {
     SVI_OK = 0,
@@ -224,6 +224,23 @@ svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw,
                          int32_t M, int32_t N, int32_t K, const void* bias, int32_t bias_along_m,
                          int32_t epilogue, const float* gate, const void* res, int32_t ldres,
                          svi_stream stream);
+
+/* ---- MX-fp8 (opt-in; north_star "bf16/fp8 MFMA").  The reference computes in bf16 and only STORES weights as float8_e4m3fn
+ * (test_svi.py:337, vram_management/layers.py:65-71): what follows is arithmetic it never performs — own tolerance, own bench line.
+ *   svi_mx8_quantize   x bf16 [rows, ldx] -> q e4m3 [rows, ldq] (OCP e4m3fn, round-to-nearest-even, saturating) with one E8M0 scale per
+ *                      32 consecutive K elements (OCP MX: 2^(floor(log2 amax) - 8)); scales as dwords [K/128][sc_rows], byte b of dword
+ *                      [kt][m] = block 4 kt + b of row m; K % 128 == 0, sc_rows >= rows.
+ *   svi_gemm_mx8       C[M,N] = epilogue(A8[M,K] · W8[N,K]^T) on v_mfma_scale_f32_32x32x64_f8f6f4: A8 with the scales above (sc_rows a
+ *                      multiple of 256 covering M), W8 e4m3 with unit scales (the reference's stored bytes); bias / epilogue / gate / res
+ *                      as svi_gemm_bf16; lda / ldw in bytes, multiples of 16.
+ *   svi_dit_bind_ffn_fp8 / svi_dit_ffn_mx8   hand blocks.<layer>.ffn.<0|2>.weight over as stored e4m3 bytes [out, in] and route both MLP
+ *                      GEMMs of every block through svi_gemm_mx8 (activations quantised in front of each). */
+svi_status svi_mx8_quantize(const void* x, int32_t ldx, int32_t rows, int32_t K, void* q, int32_t ldq, void* scales, int32_t sc_rows, svi_stream stream);
+svi_status svi_gemm_mx8(const void* A8, int32_t lda, const void* a_scales, int32_t sc_rows, const void* W8, int32_t ldw, void* C, int32_t ldc,
+                        int32_t M, int32_t N, int32_t K, const void* bias, int32_t epilogue, const float* gate, const void* res, int32_t ldres,
+                        svi_stream stream);
+svi_status svi_dit_bind_ffn_fp8(svi_dit* h, int32_t layer, int32_t which, const void* e4m3_weight);
+svi_status svi_dit_ffn_mx8(svi_dit* h, int32_t enable);
 
 /* Classifier-free-guidance combine + FlowMatchScheduler.step, fused (pipelines/svi_video.py:410,420;
  * schedulers/flow_match.py:53-64):  lat += (uncond + s*(cond-uncond)) * (sigma_next - sigma), bf16,

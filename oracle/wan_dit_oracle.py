@@ -232,7 +232,7 @@ def audio_cross_attention(sd: Dict[str, Tensor], prefix: str, x: Tensor, audio: 
 
 
 def dit_block(sd: Dict[str, Tensor], prefix: str, x: Tensor, context: Tensor, t_mod: Tensor, rope: Tensor,
-              cfg: DiTConfig, rounding: Optional[str] = None, audio: Optional[Tensor] = None, frames: int = 0) -> Tensor:
+              cfg: DiTConfig, rounding: Optional[str] = None, audio: Optional[Tensor] = None, frames: int = 0, mlp_linear=None) -> Tensor:
     """One DiTBlock (dit:354-374).  x [B,L,D], context [B,Lc,D] (already text-embedded),
     t_mod [B,6,D], rope complex128 [L, dh/2]; audio [f, 32, 768] (talk variant) or None."""
     rnd = _rounder(rounding)
@@ -245,8 +245,9 @@ def dit_block(sd: Dict[str, Tensor], prefix: str, x: Tensor, context: Tensor, t_
     if audio is not None:
         x = rnd(x + audio_cross_attention(sd, prefix, x, audio, frames, cfg, rnd))                     # dit:364-366
     h = modulated_norm(x, sh_m, sc_m, cfg.eps, rnd)
-    u = rnd(gelu_tanh(rnd(linear(h, sd[prefix + "ffn.0.weight"], sd[prefix + "ffn.0.bias"]))))
-    x = rnd(x + rnd(g_m * rnd(linear(u, sd[prefix + "ffn.2.weight"], sd[prefix + "ffn.2.bias"]))))
+    lin = mlp_linear or linear          # the opt-in MX-fp8 MLP of the HIP path is checked with oracle/mx8_oracle.mx8_linear here
+    u = rnd(gelu_tanh(rnd(lin(h, sd[prefix + "ffn.0.weight"], sd[prefix + "ffn.0.bias"]))))
+    x = rnd(x + rnd(g_m * rnd(lin(u, sd[prefix + "ffn.2.weight"], sd[prefix + "ffn.2.bias"]))))
     return x
 
 

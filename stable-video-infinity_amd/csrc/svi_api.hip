@@ -344,6 +344,24 @@ extern "C" svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, i
     return svi_launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
 }
 
+// MX-fp8 operator seams (opt-in path; see csrc/svi_gemm.hip): quantise bf16 activations, and the block-scaled GEMM itself.
+extern "C" svi_status svi_mx8_quantize(const void* x, int32_t ldx, int32_t rows, int32_t K, void* q, int32_t ldq, void* scales, int32_t sc_rows,
+                                       svi_stream stream) {
+    SVI_REQUIRE(x && q && scales, "svi_mx8_quantize: null argument");
+    return svi_launch_mx8_quantize(reinterpret_cast<const bf16*>(x), ldx, rows, K, reinterpret_cast<unsigned char*>(q), ldq, reinterpret_cast<unsigned*>(scales), sc_rows,
+                                   reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" svi_status svi_gemm_mx8(const void* A8, int32_t lda, const void* a_scales, int32_t sc_rows, const void* W8, int32_t ldw, void* C, int32_t ldc,
+                                   int32_t M, int32_t N, int32_t K, const void* bias, int32_t epilogue, const float* gate, const void* res, int32_t ldres,
+                                   svi_stream stream) {
+    SVI_REQUIRE(A8 && a_scales && W8 && C, "svi_gemm_mx8: null argument");
+    SviGemmArgs g{};
+    g.A = reinterpret_cast<const bf16*>(A8); g.lda = lda; g.W = reinterpret_cast<const bf16*>(W8); g.ldw = ldw;
+    g.C = reinterpret_cast<bf16*>(C); g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = reinterpret_cast<const bf16*>(bias); g.epi = epilogue; g.gate = gate; g.res = reinterpret_cast<const bf16*>(res); g.ldres = ldres;
+    return svi_launch_gemm_mx8(g, reinterpret_cast<const unsigned*>(a_scales), sc_rows, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" svi_status svi_cfg_step(void* latents, const void* cond, const void* uncond, int64_t n, float cfg_scale,
                                    float dsigma, svi_stream stream) {
     SVI_REQUIRE(latents && cond, "svi_cfg_step: null argument");

@@ -36,6 +36,7 @@ struct BlockW {
     const bf16* norm3_w = nullptr;
     const bf16* norm3_b = nullptr;
     Lin ffn0, ffn2;
+    const unsigned char *ffn0_8 = nullptr, *ffn2_8 = nullptr;      // the same weights as stored e4m3 bytes (FP8 storage mode), for the opt-in MX-fp8 MLP
     // talk variant (enable_multitalk): audio cross-attention (models/attention.py:283-371) and its pre-norm (dit:351)
     Lin aud_q, aud_kv, aud_proj;
     const bf16* normx_w = nullptr;
@@ -52,6 +53,9 @@ struct Workspace {
     bf16 *e, *h1, *t, *st, *tmod;
     float *modf, *headf;
     int* tail = nullptr;            // identical-suffix summary of the text context when no cache entry holds it
+    unsigned char* Q8 = nullptr;    // MX-fp8 MLP: e4m3 activations [L, max(D, F)] and their block scales [F/128][sc_rows]
+    unsigned* S8 = nullptr;
+    int sc_rows = 0;
     int ldvt = 0, ldcvt = 0, ldcvti = 264, kpatch = 0;
 };
 
@@ -93,6 +97,7 @@ struct svi_dit {
     // bumped whenever a device pointer a captured hipGraph may have baked in stops being valid (workspace / context-entry
     // (re)allocation, context-cache reset, re-bind): svi_dit_generation
     unsigned long long generation = 0;
+    bool ffn_mx8 = false;             // opt-in: the MLP GEMMs on the block-scaled fp8 matrix path (svi_dit_ffn_mx8)
     // context cache
     bool ctx_cache_on = false;
     CtxEntry ctx_entries[4];
@@ -276,6 +281,29 @@ extern "C" svi_status svi_dit_bind_weight(svi_dit* h, const char* name, const vo
     return SVI_OK;
 }
 
+// Opt-in MX-fp8 MLP (north_star "bf16/fp8 MFMA"; the reference has no fp8 arithmetic, only e4m3 weight STORAGE: test_svi.py:337,
+// vram_management/layers.py:65-71).  svi_dit_bind_ffn_fp8 hands over the stored e4m3 bytes of blocks.<layer>.ffn.<0|2>.weight — the
+// very values whose bf16 casts are bound as the ordinary weights — and svi_dit_ffn_mx8(h, 1) routes both MLP GEMMs of every block
+// through csrc/svi_gemm.hip's block-scaled fp8 kernel (activations quantised per row and 32-element block).  Arithmetic the reference
+// never performs: separately toleranced (tests/test_gpu_mx8.py), a separate bench line, never the default.
+extern "C" svi_status svi_dit_bind_ffn_fp8(svi_dit* h, int32_t layer, int32_t which, const void* e4m3_weight) {
+    SVI_REQUIRE(h && e4m3_weight && layer >= 0 && layer < h->cfg.num_layers && (which == 0 || which == 2), "svi_dit_bind_ffn_fp8: bad argument");
+    SVI_REQUIRE(((uintptr_t)e4m3_weight % 16) == 0, "svi_dit_bind_ffn_fp8: the weight is not 16-byte aligned");
+    (which == 0 ? h->blocks[layer].ffn0_8 : h->blocks[layer].ffn2_8) = reinterpret_cast<const unsigned char*>(e4m3_weight);
+    return SVI_OK;
+}
+extern "C" svi_status svi_dit_ffn_mx8(svi_dit* h, int32_t enable) {
+    SVI_REQUIRE(h, "null handle");
+    if (enable) {
+        SVI_REQUIRE(h->cfg.dim % 128 == 0 && h->cfg.ffn_dim % 128 == 0, "svi_dit_ffn_mx8: dim and ffn_dim must be multiples of 128");
+        for (int l = 0; l < h->cfg.num_layers; ++l)
+            if (!h->blocks[l].ffn0_8 || !h->blocks[l].ffn2_8) { svi_set_error("svi_dit_ffn_mx8: blocks.%d.ffn weights were not bound as e4m3 (svi_dit_bind_ffn_fp8)", l); return SVI_ERR_UNBOUND; }
+    }
+    h->ffn_mx8 = enable != 0;
+    ++h->generation;
+    return SVI_OK;
+}
+
 extern "C" svi_status svi_dit_context_cache(svi_dit* h, int32_t enable) {
     SVI_REQUIRE(h, "null handle");
     h->ctx_cache_on = enable != 0;
@@ -302,14 +330,15 @@ static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 // capture; an allocation is not, and is refused there with a message).
 static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     Workspace& w = h->ws;
-    if (w.base && w.L == L && w.Lc == Lc) return SVI_OK;
+    if (w.base && w.L == L && w.Lc == Lc && (w.Q8 != nullptr) == h->ffn_mx8) return SVI_OK;
     const svi_dit_config& c = h->cfg;
     const size_t D = c.dim, F = c.ffn_dim;
     const int img = c.has_image_input ? 257 : 0;
     const int kpatch = c.in_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho = (size_t)c.out_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho_ld = (ho + 7) / 8 * 8;
-    size_t oX, oX2, oH, oQK, oVT, oF, oCTX, oCTXH, oCK, oCVT, oCKi, oCVTi, oA2, oP, oHO, oI0, oI1, oID, oe, oh1, ot, ost, otm, omodf, oheadf, otail;
+    size_t oX, oX2, oH, oQK, oVT, oF, oCTX, oCTXH, oCK, oCVT, oCKi, oCVTi, oA2, oP, oHO, oI0, oI1, oID, oe, oh1, ot, ost, otm, omodf, oheadf, otail, oQ8 = 0, oS8 = 0;
+    const bool mx8 = h->ffn_mx8;
     auto layout = [&](int l, int lc) -> size_t {
         const size_t Lctx = (size_t)lc + img;
         const int ldvt = ((l + 7) / 8) * 8, ldcvt = ((lc + 7) / 8) * 8;
@@ -325,6 +354,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
         oe = take(c.freq_dim * 2); oh1 = take(D * 2); ot = take(D * 2); ost = take(D * 2); otm = take(6 * D * 2);
         omodf = take((size_t)c.num_layers * 6 * D * 4); oheadf = take(2 * D * 4);
         otail = take((size_t)(lc + 8) * 4);
+        if (mx8) { oQ8 = take((size_t)l * F); oS8 = take((size_t)(F / 128) * (size_t)(((l + 255) / 256) * 256) * 4); }
         return off;
     };
     const size_t need = layout(L, Lc);
@@ -359,6 +389,9 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     w.modf = reinterpret_cast<float*>(w.base + omodf);
     w.headf = reinterpret_cast<float*>(w.base + oheadf);
     w.tail = reinterpret_cast<int*>(w.base + otail);
+    w.Q8 = mx8 ? reinterpret_cast<unsigned char*>(w.base + oQ8) : nullptr;
+    w.S8 = mx8 ? reinterpret_cast<unsigned*>(w.base + oS8) : nullptr;
+    w.sc_rows = ((L + 255) / 256) * 256;
     return SVI_OK;
 }
 
@@ -537,6 +570,21 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
     if (audio_frames > 0) SVI_TRY(block_audio(h, layer, X, L, audio_frames, st));
     // --- MLP: x += gate_mlp * W2 gelu_tanh(W1 modulate(norm2 x))                  dit:372-373,334-335
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, R, D, c.eps, nullptr, nullptr, sh_m, sc_m, st)); }
+    if (h->ffn_mx8) {          // opt-in MX-fp8 MLP: both GEMMs on v_mfma_scale_f32_32x32x64_f8f6f4, activations quantised per 32-element K block
+        auto mx = [&](const unsigned char* A8, int K, const unsigned char* W8, const bf16* bias, bf16* C, int ldc, int N, int epi, const float* gate, const bf16* res) {
+            SviGemmArgs g{};
+            g.A = reinterpret_cast<const bf16*>(A8); g.lda = K; g.W = reinterpret_cast<const bf16*>(W8); g.ldw = K; g.C = C; g.ldc = ldc; g.M = R; g.N = N; g.K = K;
+            g.bias = bias; g.epi = epi; g.gate = gate; g.res = res; g.ldres = ldc;
+            return svi_launch_gemm_mx8(g, w.S8, w.sc_rows, st);
+        };
+        { SviProfScope _p(PROF_GEMM_FFN1, st);
+          SVI_TRY(svi_launch_mx8_quantize(w.Hb, D, R, D, w.Q8, D, w.S8, w.sc_rows, st));
+          SVI_TRY(mx(w.Q8, D, b.ffn0_8, b.ffn0.b, w.Fb, F, F, SVI_EPI_BIAS_GELU_TANH, nullptr, nullptr)); }
+        { SviProfScope _p(PROF_GEMM_FFN2, st);
+          SVI_TRY(svi_launch_mx8_quantize(w.Fb, F, R, F, w.Q8, F, w.S8, w.sc_rows, st));
+          SVI_TRY(mx(w.Q8, F, b.ffn2_8, b.ffn2.b, X, D, D, SVI_EPI_BIAS_GATE_RES, g_m, X)); }
+        return SVI_OK;
+    }
     { SviProfScope _p(PROF_GEMM_FFN1, st); SVI_TRY(linear(w.Hb, D, b.ffn0, w.Fb, F, R, F, D, SVI_EPI_BIAS_GELU_TANH, st, nullptr, nullptr, 0, nb)); }
     { SviProfScope _p(PROF_GEMM_FFN2, st); SVI_TRY(linear(w.Fb, F, b.ffn2, X, D, R, D, F, SVI_EPI_BIAS_GATE_RES, st, g_m, X, D, nb)); }
     return SVI_OK;

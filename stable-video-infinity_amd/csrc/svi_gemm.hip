@@ -1088,6 +1088,191 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SviGemmArgs g) {
     }
 }
 
+// =================================================================================================
+// MX-fp8 path (opt-in; never the default): C[M,N] = epi(A8[M,K] · W8[N,K]^T) on v_mfma_scale_f32_32x32x64_f8f6f4 — OCP e4m3
+// elements with one E8M0 power-of-two scale per 32 consecutive K elements, dequantised inside the matrix pipe at twice the bf16
+// rate (MI355X_MICROARCH.md: MX K=128 ~4.6 PFLOP/s).  north_star names "bf16/fp8 MFMA" GEMMs; the reference itself only STORES
+// weights as e4m3 (test_svi.py:337, vram_management/layers.py:65-71) and computes in bf16, so this is arithmetic the reference never
+// performs: its own tolerance, its own bench line, never the headline.
+//   weights      the reference's e4m3 storage bytes as they are, unit scales (2^0): exactly the values its FP8 mode multiplies with
+//   activations  quantised per row and 32-element K block (mx8_quantize_kernel): E = max(exponent(amax) - 8, 0) biased by 127
+//                (OCP MX: shared scale 2^(floor(log2 amax) - emax), emax(e4m3) = 8), element = e4m3_rne_sat(x * 2^-(E-127))
+//   scale layout [K / 128][rows_padded] dwords: byte b of dword [kt][m] scales K block 4 kt + b of row m — a k-tile's scales for a 256-row
+//                tile are one contiguous KiB = ONE LDS-DMA piece
+// Same 256 x 256 tile, LDS image (128-byte rows, source-side XOR swizzle), XCD band order and epilogue as the bf16 kernels; a K tile is
+// 128 elements = the same 128 bytes per row, fed to 2 x 8 MFMAs of 64 cycles instead of 4 x 8 of 32.
+// Operand layout of the scaled MFMA (verified against a host model by tests/test_gpu_mx8.py): lane l supplies row (l & 31) and the 32
+// consecutive K elements [32 (l >> 5), +32) of the 64-wide step as 8 VGPRs, and the E8M0 scale of exactly that block in the byte of
+// its scale VGPR that op_sel names.
+// =================================================================================================
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+#define MX8_SC_OFF (4 * T_STAGE)                 // two 1 KiB scale slabs behind the four operand stages
+static_assert(MX8_SC_OFF + 2048 <= LDS256_BYTES, "scale slabs must fit the 256^2 kernels' LDS allocation");
+
+struct SviMx8Args {
+    SviGemmArgs g;                 // A = e4m3 activations [M, lda bytes], W = e4m3 weights [N, ldw bytes]; C / bias / epilogue as for bf16
+    const unsigned* a_scales;      // [K / 128][sc_rows]
+    int sc_rows;
+};
+
+// x bf16 [rows, ldx] -> q e4m3 [rows, ldq] + scales [K/128][sc_rows].  One lane per 8 elements, four lanes per 32-block, sixteen per dword of scales.
+__global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16* __restrict__ x, int ldx, int rows, int K, unsigned char* __restrict__ q, int ldq,
+                                                           unsigned* __restrict__ scales, int sc_rows) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = K >> 3;
+    const long total = (long)rows * per_row;
+    const bool live = idx < total;
+    const int row = live ? (int)(idx / per_row) : 0, c8 = live ? (int)(idx - (long)row * per_row) : 0;
+    float v[8];
+    float amax = 0.f;
+    if (live) {
+        const bf16x8 t = ld_bf16x8(x + (size_t)row * ldx + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = (float)t[e]; amax = fmaxf(amax, fabsf(v[e])); }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);            // biased exponent of the block maximum (0 for zero / subnormal)
+    const int E = max(eb - 8, 0);                                           // E8M0 code of the shared scale 2^(E - 127)
+    const float inv = __uint_as_float((unsigned)(254 - E) << 23);           // 2^(127 - E), exact
+    unsigned w[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(v[4 * h2 + e] * inv, -448.f), 448.f);      // saturate to the e4m3 range, then round to nearest even
+        unsigned pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], pk, true);
+        w[h2] = pk;
+    }
+    if (live) *reinterpret_cast<u32x2*>(q + (size_t)row * ldq + c8 * 8) = u32x2{w[0], w[1]};
+    // the four block codes of a 128-element group -> one dword, written by the group's first lane
+    const int lane = threadIdx.x & 63;
+    const unsigned e0 = (unsigned)E;
+    const unsigned e1 = (unsigned)__shfl(E, (lane & ~15) + 4), e2 = (unsigned)__shfl(E, (lane & ~15) + 8), e3 = (unsigned)__shfl(E, (lane & ~15) + 12);
+    if (live && (lane & 15) == 0) scales[(size_t)(c8 >> 4) * sc_rows + row] = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+}
+
+__device__ __forceinline__ i32x8 mx8_frag(int base, int s, int hi, int row) {      // 32 consecutive K bytes of `row` for step s, lane half hi
+    const u32x4 lo = *(lds_u32x4_t)(base + lds_tile_off(row, 4 * s + 2 * hi));
+    const u32x4 up = *(lds_u32x4_t)(base + lds_tile_off(row, 4 * s + 2 * hi + 1));
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_mx8_nt_256_kernel(SviMx8Args a, int tiles_m, int tiles_n, int GM) {
+    const SviGemmArgs& g = a.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    const int group = swz / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = swz - group * GM * tiles_n;
+    const int tile_n = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n * gm);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+    const unsigned char* A8 = reinterpret_cast<const unsigned char*>(g.A);
+    const unsigned char* W8 = reinterpret_cast<const unsigned char*>(g.W);
+    unsigned a_off[4], w_off[4];         // byte offsets of this lane's source chunk at k = 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 16;
+        w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 16;
+    }
+    const int nk = g.K / 128;
+    auto stage = [&](int kt, int buf) {
+        char* As = smem + buf * 2 * T_STAGE;
+        char* Ws = As + T_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(A8 + (size_t)kt * 128 + a_off[j]), (lptr_t)(As + (j * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(W8 + (size_t)kt * 128 + w_off[j]), (lptr_t)(Ws + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+        if (wave == 0)        // the k-tile's scale dwords of rows m0 .. m0+255: one KiB, lane-linear (the scale table is padded to whole tiles)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.a_scales + (size_t)kt * a.sc_rows + m0 + lane * 4), (lptr_t)(smem + MX8_SC_OFF + buf * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][4];                       // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const int abase = lds0 + cur * 2 * T_STAGE, wbase = abase + T_STAGE, sbase = lds0 + MX8_SC_OFF + cur * 1024;
+        int xs[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            xs[mi] = (int)((*(const __attribute__((address_space(3))) unsigned*)(sbase + (wm * 128 + mi * 32 + l31) * 4)) >> (8 * hi));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            i32x8 xa[4], wb[2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) xa[mi] = mx8_frag(abase, s, hi, wm * 128 + mi * 32 + l31);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) wb[ni] = mx8_frag(wbase, s, hi, wn * 64 + ni * 32 + l31);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    if (s == 0) acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 0, xs[mi]);
+                    else acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 2, xs[mi]);
+                }
+        }
+        __syncthreads();                    // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
+    }
+    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
+}
+
+svi_status svi_launch_mx8_quantize(const bf16* x, int ldx, int rows, int K, unsigned char* q, int ldq, unsigned* scales, int sc_rows, hipStream_t st) {
+    SVI_REQUIRE(rows > 0 && K > 0 && K % 128 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K, "mx8 quantize: K=%d must be a multiple of 128 (ldx %d, ldq %d)", K, ldx, ldq);
+    SVI_REQUIRE(sc_rows >= rows && ((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0, "mx8 quantize: bad scale rows / alignment");
+    const long total = (long)rows * (K / 8);
+    hipLaunchKernelGGL(mx8_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, ldx, rows, K, q, ldq, scales, sc_rows);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+// sc_rows: row count of the scale table, a multiple of 256 (whole tiles: the scale slab of a tile is fetched unconditionally)
+svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, int sc_rows, hipStream_t st) {
+    SVI_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 128 == 0, "mx8 gemm: K=%d must be a multiple of 128", g.K);
+    SVI_REQUIRE(g.lda % 16 == 0 && g.ldw % 16 == 0 && g.ldc % 8 == 0 && g.lda >= g.K && g.ldw >= g.K && g.ldc >= g.N, "mx8 gemm: bad leading dims");
+    SVI_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)a_scales % 16) == 0, "mx8 gemm: operands must be 16-byte aligned");
+    SVI_REQUIRE(sc_rows % 256 == 0 && sc_rows >= ((g.M + 255) / 256) * 256, "mx8 gemm: the scale table must cover whole 256-row tiles (sc_rows %d, M %d)", sc_rows, g.M);
+    SVI_REQUIRE(g.epi >= 0 && g.epi <= SVI_EPI_BIAS_RELU, "mx8 gemm: unknown epilogue %d", g.epi);
+    SVI_REQUIRE((long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31), "mx8 gemm: operand beyond 2 GiB");
+    if (g.epi == SVI_EPI_BIAS_GATE_RES) SVI_REQUIRE(g.res != nullptr && g.ldres % 8 == 0 && ((uintptr_t)g.res % 16) == 0, "mx8 gemm: gate/residual epilogue needs an aligned residual");
+    const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
+    const int gm_rows = svi_switches().gemm_gm ? svi_switches().gemm_gm : (tn >= 16 ? 5 : 2);
+    SviMx8Args a{g, a_scales, sc_rows};
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_mx8_nt_256_kernel), LDS256_BYTES));
+    hipLaunchKernelGGL(gemm_mx8_nt_256_kernel, dim3(tm * tn), dim3(512), LDS256_BYTES, st, a, tm, tn, gm_rows);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     SVI_REQUIRE(g.M >= 0 && g.N >= 0 && g.K > 0, "gemm: bad sizes M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0 || g.N == 0) return SVI_OK;

@@ -692,42 +692,54 @@ svi_status svi_launch_gemm_f32(const float* A, int lda, const float* W, int ldw,
 
 namespace {
 // ---- RMS_norm over channels (+SiLU):  x / max(||x||_2, 1e-12) * sqrt(C) * gamma   (vae:55-70, 207-209) ----
-// One 32-lane half-wave per pixel; lane owns channels lane + 32 i.
+// Eight lanes per pixel, 16 bytes per lane and access: lane q of a pixel owns channels 4 q + 32 i .. + 3, so every wave instruction moves
+// eight whole 128-byte segments (was: 32 lanes per pixel with 4-byte accesses, 3.4 TB/s on the 12.4 GB layers).  C % 4 == 0.
 template <int MAXI>
 __global__ __launch_bounds__(256) void rms_silu_kernel(const float* __restrict__ in, float* __restrict__ out, long pixels,
                                                        int C, const float* __restrict__ gamma, int do_silu) {
-    const long px = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int l = threadIdx.x & 31;
-    if (px >= pixels) return;
+    const long px = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int q = threadIdx.x & 7;
+    if (px >= pixels) return;                   // whole 8-lane groups leave together: the shuffles below stay inside a group
     const float* ip = in + px * C;
-    float v[MAXI];
+    f32x4 v[MAXI];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int c = l + 32 * i;
-        v[i] = c < C ? ip[c] : 0.f;
-        ss += v[i] * v[i];
+        const int c = 4 * q + 32 * i;
+        if (c < C) v[i] = *reinterpret_cast<const f32x4*>(ip + c);
+        else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ss += v[i][0] * v[i][0];
+        ss += v[i][1] * v[i][1];
+        ss += v[i][2] * v[i][2];
+        ss += v[i][3] * v[i][3];
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    for (int o = 4; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float denom = fmaxf(sqrtf(ss), 1e-12f);
     const float scale = sqrtf((float)C);
     float* op = out + px * C;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int c = l + 32 * i;
+        const int c = 4 * q + 32 * i;
         if (c < C) {
-            float y = v[i] / denom * scale * gamma[c];
-            if (do_silu) y = y / (1.0f + expf(-y));
-            op[c] = y;
+            const float g[4] = {gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]};      // borrowed parameter: no alignment promise beyond 4 bytes
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[i][e] / denom * scale * g[e];
+                if (do_silu) t = t / (1.0f + expf(-t));
+                y[e] = t;
+            }
+            *reinterpret_cast<f32x4*>(op + c) = y;
         }
     }
 }
 
 svi_status launch_rms_silu(const float* in, float* out, long pixels, int C, const float* gamma, int do_silu, hipStream_t st) {
-    SVI_REQUIRE(C <= 384, "vae rms norm: C=%d > 384", C);
+    SVI_REQUIRE(C <= 384 && C % 4 == 0, "vae rms norm: C=%d (need a multiple of 4, at most 384)", C);
+    SVI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "vae rms norm: activations must be 16-byte aligned");
     if (pixels <= 0) return SVI_OK;
-    dim3 grid((unsigned)((pixels + 7) / 8)), block(256);
+    dim3 grid((unsigned)((pixels + 31) / 32)), block(256);
     if (C <= 96) hipLaunchKernelGGL(rms_silu_kernel<3>, grid, block, 0, st, in, out, pixels, C, gamma, do_silu);
     else if (C <= 192) hipLaunchKernelGGL(rms_silu_kernel<6>, grid, block, 0, st, in, out, pixels, C, gamma, do_silu);
     else hipLaunchKernelGGL(rms_silu_kernel<12>, grid, block, 0, st, in, out, pixels, C, gamma, do_silu);

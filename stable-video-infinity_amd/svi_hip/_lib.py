@@ -69,6 +69,10 @@ SYMBOLS = [
     ("svi_rmsnorm_rope", _i32, [_vp, _i32, _i32, _i32, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_gemm_bf16", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     ("svi_cfg_step", _i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
+    ("svi_mx8_quantize", _i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
+    ("svi_gemm_mx8", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
+    ("svi_dit_bind_ffn_fp8", _i32, [_vp, _i32, _i32, _vp]),
+    ("svi_dit_ffn_mx8", _i32, [_vp, _i32]),
     ("svi_fp8_e4m3_to_bf16", _i32, [_vp, _vp, _i64, _vp]),
     ("svi_prof_enable", _i32, [_i32]),
     ("svi_prof_summary", _i32, [C.c_char_p, _i64]),

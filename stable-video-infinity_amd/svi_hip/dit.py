@@ -89,6 +89,7 @@ class WanDiT:
         self._fp8_sources: Dict[str, torch.Tensor] = {}        # fp8-stored parameters whose bf16 copies are bound (FP8 storage mode)
         self._param_versions = []
         self._epoch = 0                     # host-side: moves on bind / rebind / context_cache(); part of a captured graph's key
+        self._ffn_mx8 = False               # opt-in MX-fp8 MLP (ffn_fp8_mfma)
         self._ctx_cache_on = False
         self._ctx_pins = PromptPins()
 
@@ -126,11 +127,32 @@ class WanDiT:
         # what weights_changed() watches: the bound bf16 tensors and, in FP8 storage mode, the e4m3 tensors they were cast from
         self._param_versions = [(t, _version(t)) for t in self._params.values()] + [(t, _version(t)) for t in self._fp8_sources.values()]
         self._epoch += 1
+        if self._ffn_mx8:
+            self.ffn_fp8_mfma(True)         # the e4m3 tensors may have moved with the re-bind
 
     def rebind(self) -> None:
         """Re-read every parameter's address (after a LoRA merge, .to(), an offload round trip ...); drops the context cache.
         FP8-stored parameters are cast again from their e4m3 sources (an in-place update of a source is picked up)."""
         self.bind({**self._params, **self._fp8_sources})
+
+    def ffn_fp8_mfma(self, enable: bool = True) -> None:
+        """Opt-in: run both MLP GEMMs of every block on the MX block-scaled fp8 matrix path (svi_gemm_mx8; ~2x the bf16 MFMA rate).
+        Needs the FP8 weight STORAGE mode (parameters bound as float8_e4m3fn, the reference's test_svi.py:337 mode): the stored e4m3
+        bytes of ffn.0 / ffn.2 are used as they are (unit scales), activations are quantised per row and 32-element block in front of
+        each GEMM.  The reference performs no fp8 arithmetic — this mode has its own tolerance (tests/test_gpu_mx8.py) and bench line
+        (bench.py --fp8-mfma) and is never a default."""
+        lib = L.lib()
+        if enable:
+            for l in range(self.num_layers):
+                for which in (0, 2):
+                    name = f"blocks.{l}.ffn.{which}.weight"
+                    t = self._fp8_sources.get(name)
+                    if t is None:
+                        raise RuntimeError(f"ffn_fp8_mfma needs {name} bound as float8_e4m3fn (FP8 weight storage mode)")
+                    L.check(lib.svi_dit_bind_ffn_fp8(self._h, l, which, t.data_ptr()), f"svi_dit_bind_ffn_fp8 {name}")
+        L.check(lib.svi_dit_ffn_mx8(self._h, 1 if enable else 0), "svi_dit_ffn_mx8")
+        self._ffn_mx8 = bool(enable)
+        self._epoch += 1
 
     def epoch(self) -> int:
         return self._epoch
