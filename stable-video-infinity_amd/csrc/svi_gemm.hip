@@ -1101,9 +1101,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SviGemmArgs g) {
 //                tile are one contiguous KiB = ONE LDS-DMA piece
 // Same 256 x 256 tile, LDS image (128-byte rows, source-side XOR swizzle), XCD band order and epilogue as the bf16 kernels; a K tile is
 // 128 elements = the same 128 bytes per row, fed to 2 x 8 MFMAs of 64 cycles instead of 4 x 8 of 32.
-// Operand layout of the scaled MFMA (verified against a host model by tests/test_gpu_mx8.py): lane l supplies row (l & 31) and the 32
-// consecutive K elements [32 (l >> 5), +32) of the 64-wide step as 8 VGPRs, and the E8M0 scale of exactly that block in the byte of
-// its scale VGPR that op_sel names.
+// Operand layout of the scaled MFMA, measured (tools/mx8_layout_probe.py) and pinned by tests/test_gpu_mx8.py: within a 64-wide K step lane l
+// (row l & 31, half hi = l >> 5) supplies K elements [16 hi, +16) in its first four VGPRs and [32 + 16 hi, +16) in its last four — two
+// K = 32 halves, each spread over both lane halves — while the E8M0 scale of the FIRST 32-element block is taken from the hi = 0 lanes and that
+// of the SECOND block from the hi = 1 lanes (the byte of the scale VGPR that op_sel names).  So a lane's two 16-byte LDS reads are chunks
+// 4 s + hi and 4 s + 2 + hi of the 128-byte row, and lane half hi carries the scale of block 2 s + hi.
 // =================================================================================================
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 #define MX8_SC_OFF (4 * T_STAGE)                 // two 1 KiB scale slabs behind the four operand stages
@@ -1157,9 +1159,9 @@ __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16* __restric
     if (live && (lane & 15) == 0) scales[(size_t)(c8 >> 4) * sc_rows + row] = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
 }
 
-__device__ __forceinline__ i32x8 mx8_frag(int base, int s, int hi, int row) {      // 32 consecutive K bytes of `row` for step s, lane half hi
-    const u32x4 lo = *(lds_u32x4_t)(base + lds_tile_off(row, 4 * s + 2 * hi));
-    const u32x4 up = *(lds_u32x4_t)(base + lds_tile_off(row, 4 * s + 2 * hi + 1));
+__device__ __forceinline__ i32x8 mx8_frag(int base, int s, int hi, int row) {      // K bytes [16 hi, +16) and [32 + 16 hi, +16) of step s of `row`
+    const u32x4 lo = *(lds_u32x4_t)(base + lds_tile_off(row, 4 * s + hi));
+    const u32x4 up = *(lds_u32x4_t)(base + lds_tile_off(row, 4 * s + 2 + hi));
     return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
 }
 
