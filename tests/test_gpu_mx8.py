@@ -139,3 +139,26 @@ def test_forward_with_the_fp8_mlp_stays_within_the_stated_distance(hip):
     with pytest.raises(RuntimeError, match="float8_e4m3fn"):                         # bf16-stored weights: refused, not silently quantised
         sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
         hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=2, **c).ffn_fp8_mfma(True)
+
+
+def test_c1_end_to_end_with_the_fp8_mlp(hip, golden):
+    """BASELINE config 1 (30-layer 1.3B, 17 f 256x256, 10 steps, CFG 5) with the weights in the reference's FP8 storage mode: the loop with
+    the MX-fp8 MLP against the SAME loop in bf16 arithmetic (the reference's FP8 mode), and both against the reference's fp32 run on the
+    unrounded weights (c1_e2e.npz) — which shows how the fp8-MFMA step compares with what e4m3 weight storage alone already costs.
+    Stated tolerance of the opt-in mode: latents within rel-L2 5e-2 of the bf16-arithmetic loop after the 10 steps."""
+    g = golden("c1_e2e.npz")
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    sd8 = fp8_state_dict(cfg, seed)
+    m = hip.WanDiT.from_state_dict(sd8, eps=1e-6, num_heads=synth.num_heads_of(cfg), **cfg)
+    del sd8
+    noise = hip.generate_noise((1, 16, 5, 32, 32), seed=0, device="cpu", dtype=torch.float32)
+    pos = dev(torch.from_numpy(synth.text_context(seed + 1, 512, cfg["text_dim"], 64)))
+    neg = dev(torch.from_numpy(synth.text_context(seed + 2, 512, cfg["text_dim"], 64)))
+    loop = hip.DenoiseLoop(m)
+    base = loop.sample(dev(noise), pos, neg, num_inference_steps=10, cfg_scale=5.0, sigma_shift=5.0)
+    m.ffn_fp8_mfma(True)
+    got = loop.sample(dev(noise), pos, neg, num_inference_steps=10, cfg_scale=5.0, sigma_shift=5.0)
+    r = errs(got, base)[0]
+    r_ref_mx, r_ref_16 = errs(got[0], g["latents_fp32"])[0], errs(base[0], g["latents_fp32"])[0]
+    report("c1_e2e_mx8", mx8_vs_bf16_arithmetic=r, mx8_vs_ref_fp32=r_ref_mx, fp8_storage_bf16_arithmetic_vs_ref_fp32=r_ref_16)
+    assert torch.isfinite(got.float()).all() and r < 5e-2, (r, r_ref_mx, r_ref_16)
