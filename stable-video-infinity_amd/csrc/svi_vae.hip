@@ -52,6 +52,7 @@ struct ConvP {
     const float* res; int ld_res;                    // optional residual, same pixel indexing as out (mode 0)
     int act_silu;                                    // conv_igemm_kernel, mode 0: out = silu(conv + bias)  (pose embedder)
     bf16* out_bf16;                                  // conv_igemm_kernel, mode 0: store bf16 [pixel][ld_out] here instead of fp32 `out`
+    const unsigned short* in_h; const unsigned short* in_l;      // conv_dma2h_kernel: the input as two fp16 planes [pixel][ld_in] of x * in_scale (hi | lo)
 };
 
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 // convolutions and to_qkv — 94 % of the decoder's FLOP — have a static bound (Tens::bound).  The scales are undone in the epilogue
 // by one exact multiplication.  Convolutions whose input has no such bound (conv_in, shortcuts, resample / time convolutions,
 // attention proj) stay on the three-term bf16 kernel.  SVI_VAE_X2H=0 sends everything to the three-term kernel (A/B).
+typedef __attribute__((address_space(3))) void* lptr_t;
 typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
@@ -633,6 +635,209 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 }
 
 
+// =================================================================================================
+// Two-term fp16 convolution, operands staged by LDS-DMA (round 3).  Same arithmetic as conv_igemm_x3_kernel<true> — the same products in
+// the same order into the same accumulators, so the same bits — but the activation split is no longer done by every consumer tile
+// for every tap: the PRODUCER (rms_silu_planes_kernel: RMS_norm + SiLU) writes its output once as the two fp16 words hi = f16(x s),
+// lo = f16(x s - hi) in two channels-last planes (the same bytes as one fp32 tensor), and this kernel only moves bytes:
+//   * a K step (one tap, 32 input channels) of a pixel is 64 contiguous bytes per plane = one LDS row; four lanes fetch it with one
+//     buffer_load_dwordx4 ... lds each, 16 pixel rows per wave instruction, the bank swizzle on the SOURCE chunk (rule 21); a tap that
+//     does not exist (border, causal padding, the hidden frame) is an offset beyond the descriptor's range: the DMA writes zeros;
+//   * wave w stages exactly the 32 pixel rows it multiplies (4 instructions per step), so activations need no workgroup barrier —
+//     only the 12 KiB of weights (12 instructions shared by the 8 waves) do;
+//   * no staging registers, no conversions, no ds_write: per K step a wave issues 18 MFMAs, 16 ds_read_b128 and 5-6 DMA instructions
+//     (the x3 kernel: 18 MFMAs against ~185 VALU / LDS instructions of splitting and storing).
+// LDS: two stages x (2 planes x [256 px][64 B] + 2 planes x [96 co][64 B]) = 88 KiB.
+// =================================================================================================
+__global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
+    constexpr int STAGE = X2H_STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long HoWo = (long)p.Ho * p.Wo;
+    const long P_total = (long)p.To * HoWo;
+    const long p0 = (long)p.t_begin * HoWo + (long)blockIdx.x * X3_PIX;
+    const int co0 = blockIdx.y * X3_CO;
+    const int nchunk = p.Cin >> 5;
+    const int khw = p.kh * p.kw, ntaps = p.kt * khw;
+    const int nk = ntaps * nchunk;
+
+    // ---- activation DMA: lane (r4 = lane >> 2, c = lane & 3) of wave w moves chunk c of pixel rows 32 w + r4 and 32 w + 16 + r4, both planes
+    const int t_first = (int)(min(p0, P_total - 1) / HoWo);
+    const int t_base = max(t_first * p.st - p.pt, 0);
+    unsigned a_mask[2], base_off[2];
+    int src_chunk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 32 * wave + 16 * j + (lane >> 2);
+        const long pp = p0 + row;
+        const bool pix = pp < P_total;
+        const long q = pix ? pp : 0;
+        const int at = (int)(q / HoWo);
+        const int rem = (int)(q - (long)at * HoWo);
+        const int ay = rem / p.Wo, ax = rem - ay * p.Wo;
+        const int bt = at * p.st - p.pt, by = ay * p.sh - p.ph, bx = ax * p.sw - p.pw;
+        unsigned m = 0;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int ta = tap / khw, tb = (tap / p.kw) % p.kh, tc = tap % p.kw;
+            const int ti = bt + ta, yi = by + tb, xi = bx + tc;
+            bool ok = pix && ti >= 0 && ti < p.Ti && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi;
+            if (p.zero_frame0 && ti == 0) ok = false;
+            if (ok) m |= 1u << tap;
+        }
+        a_mask[j] = m;
+        src_chunk[j] = (lane & 3) ^ ((row >> 2) & 3);                  // LDS slot (row, lane & 3) holds source chunk (lane & 3) ^ swizzle(row)
+        base_off[j] = (unsigned)((((bt - t_base) * p.Hi + by) * p.Wi + bx) * p.ld_in) * 2u + (unsigned)src_chunk[j] * 16u;
+    }
+    const long base_el = (long)t_base * p.Hi * p.Wi * p.ld_in;
+    const long rem_bytes = ((long)p.Ti * p.Hi * p.Wi * p.ld_in - base_el) * 2;
+    const int win = (int)(unsigned)min(rem_bytes, 0xFFE00000L);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.in_h + base_el), 0, win, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.in_l + base_el), 0, win, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2h), 0, (int)(unsigned)min((long)2 * p.plane_w3 * 2, 0xFFE00000L), 0x00020000);
+    const unsigned OOB = 0xFFF00000u;
+    // ---- weight DMA: 2 planes x 96 rows x 64 B = 12 wave instructions of 16 rows; wave w issues instruction w, waves 0..3 also 8 + w
+    unsigned w_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave + 8 * i;                                    // 0..11 (i = 1 only for waves 0..3)
+        const int pl = q / 6, row = (q % 6) * 16 + (lane >> 2);
+        const int ch = (lane & 3) ^ ((row >> 2) & 3);
+        const bool ok = q < 12 && co0 + row < p.Cout;
+        w_off[i] = ok ? (unsigned)((pl * p.plane_w3 + (long)(co0 + row) * p.ld_w3 + ch * 8) * 2) : OOB;
+    }
+    int it_tap = 0, it_cc = 0, it_ta = 0, it_tb = 0, it_tc = 0;
+    unsigned it_wk = 0;                                                // byte offset of (tap, channel chunk) inside a weight plane
+    unsigned tap_off[2];
+    auto tap_bases = [&]() {
+        const unsigned d = (unsigned)(((it_ta * p.Hi + it_tb) * p.Wi + it_tc) * p.ld_in) * 2u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tap_off[j] = ((a_mask[j] >> it_tap) & 1u) ? base_off[j] + d : OOB;
+    };
+    auto advance = [&]() {
+        it_wk += 64u;
+        if (++it_cc == nchunk) {
+            it_cc = 0; ++it_tap;
+            it_wk = (unsigned)((long)it_tap * p.Cout * p.ld_w3 * 2);
+            if (++it_tc == p.kw) { it_tc = 0; if (++it_tb == p.kh) { it_tb = 0; ++it_ta; } }
+            tap_bases();
+        }
+    };
+    // request K step (the iterator's position) into stage `buf`; a step past the end requests nothing
+    auto request = [&](int buf, bool valid) {
+        if (!valid) return;
+        char* As = smem + buf * STAGE;
+        char* Ws = As + 2 * X3_A_PLANE;
+        const unsigned coff = (unsigned)it_cc * 64u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned off = tap_off[j] == OOB ? OOB : tap_off[j] + coff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lptr_t)(As + (32 * wave + 16 * j) * 64), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lptr_t)(As + X3_A_PLANE + (32 * wave + 16 * j) * 64), 16, off, 0, 0, 0);
+        }
+        {
+            const int q = wave, pl = q / 6, r16 = q % 6;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + pl * X3_W_PLANE + r16 * 16 * 64), 16, w_off[0] == OOB ? OOB : w_off[0] + it_wk, 0, 0, 0);
+        }
+        if (wave < 4) {
+            const int q = wave + 8, pl = q / 6, r16 = q % 6;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + pl * X3_W_PLANE + r16 * 16 * 64), 16, w_off[1] == OOB ? OOB : w_off[1] + it_wk, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    tap_bases();
+    request(0, true);
+    advance();
+    __syncthreads();                     // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+    for (int k = 0; k < nk; ++k) {
+        const int cur = k & 1;
+        request(cur ^ 1, k + 1 < nk);    // stage cur ^ 1 was last read in step k - 1: every wave has passed the barrier behind it
+        advance();
+        const char* As = smem + cur * STAGE;
+        const char* Ws = As + 2 * X3_A_PLANE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah = *reinterpret_cast<const f16x8*>(As + x3_off(32 * wave + l31, 2 * ks + hi));
+            f16x8 al = *reinterpret_cast<const f16x8*>(As + X3_A_PLANE + x3_off(32 * wave + l31, 2 * ks + hi));
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(Ws + x3_off(32 * n + l31, 2 * ks + hi));
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(Ws + X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, acc[n], 0, 0, 0);        // the order of conv_igemm_x3_kernel<true>: wl ah, wh al, wh ah
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc[n], 0, 0, 0);
+            }
+        }
+        __syncthreads();                 // step k + 1 landed (vmcnt(0)) and every wave is done reading stage cur
+    }
+
+    // ---- epilogue: as conv_igemm_x3_kernel<true>
+    const long pp = p0 + 32 * wave + l31;
+    if (pp >= P_total) return;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv[12], rv[12], sv[12];
+    const bool with_res = p.out_mode == 0 && p.res;
+    const float inv_a = 1.0f / p.in_scale;
+    const long po = pp + (long)p.t_out_off * HoWo;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int co = co0 + 32 * (i >> 2) + 8 * (i & 3) + 4 * hi;
+        const bool ok = co < p.Cout;
+        bv[i] = (ok && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + co) : zero4;
+        rv[i] = (ok && with_res) ? *reinterpret_cast<const f32x4*>(p.res + po * p.ld_res + co) : zero4;
+        sv[i] = ok ? *reinterpret_cast<const f32x4*>(p.w2_inv + co) * inv_a : zero4;
+    }
+    long pq0 = 0;
+    const int half = p.Cout >> 1;
+    if (p.out_mode != 0) {
+        const int t = (int)(pp / HoWo);
+        const long sp = pp - (long)t * HoWo;
+        pq0 = (long)(1 + 2 * (t - 1)) * HoWo + sp;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int n = i >> 2, rg = i & 3;
+        const int co = co0 + 32 * n + 8 * rg + 4 * hi;
+        if (co >= p.Cout) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (acc[n][4 * rg + e] * sv[i][e] + bv[i][e]) + rv[i][e];
+        if (p.out_mode == 0) {
+            *reinterpret_cast<f32x4*>(p.out + po * p.ld_out + co) = v;
+        } else {
+            const int j = co >= half ? 1 : 0;
+            *reinterpret_cast<f32x4*>(p.out + (pq0 + (long)j * HoWo) * p.ld_out + (co - j * half)) = v;
+        }
+    }
+}
+
+// Can a convolution take its input as the producer's two fp16 planes (conv_dma2h_kernel)?  Decided BEFORE the producer runs.
+bool conv_planes_ok(const ConvP& p) {
+    return p.w2h && p.w2_inv && p.in_scale > 0.f && !svi_switches().vae_no_x2h && !svi_switches().vae_exact_fp32 && svi_switches().vae_dma &&
+           (((uintptr_t)p.w2_inv) & 15) == 0 && p.Cin % 32 == 0 && p.ld_in == p.Cin && !p.ups && p.Cout >= 64 && p.Cout % 4 == 0 &&
+           p.kt * p.kh * p.kw <= 32 && !p.act_silu && !p.out_bf16 && (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) &&
+           (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 2 < 0xFFE00000L && (long)2 * p.plane_w3 * 2 < 0xFFE00000L;
+}
+
+svi_status launch_conv_planes(const ConvP& p, hipStream_t st) {
+    SVI_REQUIRE(conv_planes_ok(p) && p.in_h && p.in_l, "conv: this layer cannot take fp16 input planes");
+    SVI_REQUIRE(p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) && (((uintptr_t)p.bias | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0, "conv: output / residual alignment");
+    const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
+    if (pixels <= 0) return SVI_OK;
+    dim3 grid((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block(512);
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel), 2 * X2H_STAGE));
+    hipLaunchKernelGGL(conv_dma2h_kernel, grid, block, 2 * X2H_STAGE, st, p);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
 svi_status launch_conv(const ConvP& p, hipStream_t st) {
     SVI_REQUIRE(p.Cin % 4 == 0 && p.ld_in % 4 == 0 && p.ld_w % 4 == 0, "conv: Cin/ld must be multiples of 4 (Cin=%d)", p.Cin);
     const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
@@ -743,6 +948,65 @@ svi_status launch_rms_silu(const float* in, float* out, long pixels, int C, cons
     if (C <= 96) hipLaunchKernelGGL(rms_silu_kernel<3>, grid, block, 0, st, in, out, pixels, C, gamma, do_silu);
     else if (C <= 192) hipLaunchKernelGGL(rms_silu_kernel<6>, grid, block, 0, st, in, out, pixels, C, gamma, do_silu);
     else hipLaunchKernelGGL(rms_silu_kernel<12>, grid, block, 0, st, in, out, pixels, C, gamma, do_silu);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+// The same RMS_norm (+ SiLU), written as the two fp16 words the two-term convolution multiplies: hi = f16(y s), lo = f16(y s - hi) with the
+// power-of-two scale s the bound of y allows (|y| s <= 2^15) — exactly the split conv_igemm_x3_kernel<true> performs on the fly, done ONCE by
+// the producer.  Planes are channels-last [pixel][C] fp16; together they are as large as the fp32 tensor they replace.
+template <int MAXI>
+__global__ __launch_bounds__(256) void rms_silu_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ out_h, unsigned short* __restrict__ out_l,
+                                                              long pixels, int C, const float* __restrict__ gamma, int do_silu, float s) {
+    const long px = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int q = threadIdx.x & 7;
+    if (px >= pixels) return;
+    const float* ip = in + px * C;
+    f32x4 v[MAXI];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = 4 * q + 32 * i;
+        if (c < C) v[i] = *reinterpret_cast<const f32x4*>(ip + c);
+        else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ss += v[i][0] * v[i][0];
+        ss += v[i][1] * v[i][1];
+        ss += v[i][2] * v[i][2];
+        ss += v[i][3] * v[i][3];
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f);
+    const float scale = sqrtf((float)C);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = 4 * q + 32 * i;
+        if (c < C) {
+            const float g[4] = {gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]};
+            u16x4 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[i][e] / denom * scale * g[e];
+                if (do_silu) t = t / (1.0f + expf(-t));
+                const f16 hw = (f16)(t * s);
+                hh[e] = bits16(hw);
+                ll[e] = bits16((f16)__builtin_fmaf(t, s, -(float)hw));
+            }
+            *reinterpret_cast<u16x4*>(out_h + px * C + c) = hh;
+            *reinterpret_cast<u16x4*>(out_l + px * C + c) = ll;
+        }
+    }
+}
+
+svi_status launch_rms_silu_planes(const float* in, unsigned short* out_h, unsigned short* out_l, long pixels, int C, const float* gamma, int do_silu, float s,
+                                  hipStream_t st) {
+    SVI_REQUIRE(C <= 384 && C % 4 == 0 && s > 0.f, "vae rms norm (planes): C=%d", C);
+    SVI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out_h % 8) == 0 && ((uintptr_t)out_l % 8) == 0, "vae rms norm (planes): alignment");
+    if (pixels <= 0) return SVI_OK;
+    dim3 grid((unsigned)((pixels + 31) / 32)), block(256);
+    if (C <= 96) hipLaunchKernelGGL(rms_silu_planes_kernel<3>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
+    else if (C <= 192) hipLaunchKernelGGL(rms_silu_planes_kernel<6>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
+    else hipLaunchKernelGGL(rms_silu_planes_kernel<12>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
@@ -966,6 +1230,7 @@ struct ConvW {               // one conv layer: user weight (borrowed) + packed 
 struct Tens {
     float* p = nullptr; int T = 0, H = 0, W = 0, C = 0;
     float bound = 0.f;                // > 0: every |element| <= bound, guaranteed by the producer (RMS_norm [+ SiLU]); 0: unknown
+    float plane_scale = 0.f;          // > 0: the slot holds two fp16 planes [pixel][C] (hi at p, lo behind it) of value * plane_scale instead of fp32
     long elems() const { return (long)T * H * W * C; }
 };
 
@@ -1080,36 +1345,65 @@ void free_t(svi_vae* h, Tens& t) {
 }
 #define NEED(t) do { if (!h->dry && !(t).p) { svi_set_error("VAE tensor pool exhausted"); return SVI_ERR_OOM; } } while (0)
 
-svi_status conv_layer(svi_vae* h, const std::string& name, const Tens& in, Tens* out, hipStream_t st, int stride_t = 1,
-                      bool causal_pad = true, int sh = 1, int ups = 0, int zero_frame0 = 0, const Tens* res = nullptr,
-                      bool down_pad = false) {
-    const ConvW& c = h->convs.at(name);
+static float scale_of_bound(float bound) {          // largest power of two s with bound * s <= 2^15 (0: no usable bound)
+    if (!(bound > 0.f && bound < 1e30f)) return 0.f;
+    int e = 0;
+    (void)frexpf(bound, &e);
+    return ldexpf(1.0f, 15 - e);
+}
+
+// The parts of a convolution's launch parameters that do not depend on where tensors live: geometry, weights, input scale.
+static ConvP conv_params(const ConvW& c, const Tens& in, int stride_t, bool causal_pad, int sh, int ups, int zero_frame0, bool down_pad, int* To_, int* Ho_, int* Wo_) {
     ConvP p{};
     p.Ti = in.T; p.Hi = in.H; p.Wi = in.W; p.Cin = (c.Cin + 3) / 4 * 4; p.ld_in = in.C;
     p.kt = c.kt; p.kh = c.kh; p.kw = c.kw; p.st = stride_t; p.sh = sh; p.sw = sh;
     p.pt = causal_pad ? c.kt - 1 : 0; p.ph = down_pad ? 0 : c.kh / 2; p.pw = down_pad ? 0 : c.kw / 2;
     p.ups = ups; p.zero_frame0 = zero_frame0;
     const int Hv = ups ? 2 * in.H : in.H, Wv = ups ? 2 * in.W : in.W;
-    const int To = causal_pad ? in.T : (in.T - c.kt) / stride_t + 1;
-    const int Ho = down_pad ? Hv / 2 : Hv, Wo = down_pad ? Wv / 2 : Wv;
+    *To_ = causal_pad ? in.T : (in.T - c.kt) / stride_t + 1;
+    *Ho_ = down_pad ? Hv / 2 : Hv; *Wo_ = down_pad ? Wv / 2 : Wv;
+    p.w = c.packed; p.ld_w = c.ldw; p.bias = c.b_user;
+    p.w3 = c.packed3; p.ld_w3 = c.ldw3; p.plane_w3 = (long)c.kt * c.kh * c.kw * c.Cout * c.ldw3;
+    p.w2h = c.packed2h; p.w2_inv = c.w2_scale ? c.w2_scale + c.Cout : nullptr;
+    p.in_scale = scale_of_bound(in.bound);
+    p.To = *To_; p.Ho = *Ho_; p.Wo = *Wo_; p.Cout = c.Cout;
+    return p;
+}
+
+// Would `name`, fed by RMS_norm `gname` of a tensor shaped like `x`, take its input as fp16 planes?  (stride 1, causal, same-size: the residual-block convolutions)
+static float planes_scale_for(svi_vae* h, const std::string& name, const std::string& gname, const Tens& x) {
+    if (h->dry) return 0.f;
+    auto gb = h->gamma_bound.find(gname);
+    Tens like = x;
+    like.bound = gb == h->gamma_bound.end() ? 0.f : gb->second;
+    int To, Ho, Wo;
+    ConvP p = conv_params(h->convs.at(name), like, 1, true, 1, 0, 0, false, &To, &Ho, &Wo);
+    return conv_planes_ok(p) ? p.in_scale : 0.f;
+}
+
+svi_status conv_layer(svi_vae* h, const std::string& name, const Tens& in, Tens* out, hipStream_t st, int stride_t = 1,
+                      bool causal_pad = true, int sh = 1, int ups = 0, int zero_frame0 = 0, const Tens* res = nullptr,
+                      bool down_pad = false) {
+    const ConvW& c = h->convs.at(name);
+    int To, Ho, Wo;
+    ConvP p = conv_params(c, in, stride_t, causal_pad, sh, ups, zero_frame0, down_pad, &To, &Ho, &Wo);
     *out = alloc_t(h, To, Ho, Wo, c.Cout < 4 ? 4 : c.Cout);
     NEED(*out);
     if (h->dry) return SVI_OK;
-    p.in = in.p; p.w = c.packed; p.ld_w = c.ldw; p.bias = c.b_user; p.out = out->p;
-    p.w3 = c.packed3; p.ld_w3 = c.ldw3; p.plane_w3 = (long)c.kt * c.kh * c.kw * c.Cout * c.ldw3;
-    p.w2h = c.packed2h; p.w2_inv = c.w2_scale ? c.w2_scale + c.Cout : nullptr;
-    if (in.bound > 0.f && in.bound < 1e30f) {           // largest power of two s with bound * s <= 2^15
-        int e = 0;
-        (void)frexpf(in.bound, &e);
-        p.in_scale = ldexpf(1.0f, 15 - e);
-    }
-    p.To = To; p.Ho = Ho; p.Wo = Wo; p.Cout = c.Cout; p.ld_out = out->C;
+    p.in = in.p; p.out = out->p; p.ld_out = out->C;
     p.res = res ? res->p : nullptr; p.ld_res = res ? res->C : 0;
     SviProfScope _p(PROF_VAE_CONV, st);
+    if (in.plane_scale > 0.f) {          // the producer wrote fp16 planes for this layer (planes_scale_for said it would take them)
+        SVI_REQUIRE(in.plane_scale == p.in_scale, "conv %s: input planes carry scale %g, the layer expects %g", name.c_str(), in.plane_scale, p.in_scale);
+        p.in = nullptr;
+        p.in_h = reinterpret_cast<const unsigned short*>(in.p);
+        p.in_l = p.in_h + in.elems();
+        return launch_conv_planes(p, st);
+    }
     return launch_conv(p, st);
 }
 
-svi_status norm_act(svi_vae* h, const std::string& gname, const Tens& in, Tens* out, int do_silu, hipStream_t st) {
+svi_status norm_act(svi_vae* h, const std::string& gname, const Tens& in, Tens* out, int do_silu, hipStream_t st, float plane_scale = 0.f) {
     *out = alloc_t(h, in.T, in.H, in.W, in.C);
     NEED(*out);
     if (h->dry) return SVI_OK;
@@ -1118,6 +1412,11 @@ svi_status norm_act(svi_vae* h, const std::string& gname, const Tens& in, Tens* 
         out->bound = gb == h->gamma_bound.end() ? 0.f : gb->second;
     }
     SviProfScope _p(PROF_VAE_OTHER, st);
+    if (plane_scale > 0.f) {             // the only consumer is a convolution that multiplies fp16 word pairs: write those instead of fp32
+        out->plane_scale = plane_scale;
+        unsigned short* ph = reinterpret_cast<unsigned short*>(out->p);
+        return launch_rms_silu_planes(in.p, ph, ph + in.elems(), (long)in.T * in.H * in.W, in.C, h->gammas.at(gname), do_silu, plane_scale, st);
+    }
     return launch_rms_silu(in.p, out->p, (long)in.T * in.H * in.W, in.C, h->gammas.at(gname), do_silu, st);
 }
 
@@ -1126,10 +1425,10 @@ svi_status res_block(svi_vae* h, const std::string& p, Tens* x, hipStream_t st) 
     Tens n, hmid, out, skip;
     const bool has_sc = h->convs.count(p + "shortcut") > 0;
     if (has_sc) SVI_TRY(conv_layer(h, p + "shortcut", *x, &skip, st));
-    SVI_TRY(norm_act(h, p + "residual.0.gamma", *x, &n, 1, st));
+    SVI_TRY(norm_act(h, p + "residual.0.gamma", *x, &n, 1, st, planes_scale_for(h, p + "residual.2", p + "residual.0.gamma", *x)));
     SVI_TRY(conv_layer(h, p + "residual.2", n, &hmid, st));
     free_t(h, n);
-    SVI_TRY(norm_act(h, p + "residual.3.gamma", hmid, &n, 1, st));
+    SVI_TRY(norm_act(h, p + "residual.3.gamma", hmid, &n, 1, st, planes_scale_for(h, p + "residual.6", p + "residual.3.gamma", hmid)));
     free_t(h, hmid);
     SVI_TRY(conv_layer(h, p + "residual.6", n, &out, st, 1, true, 1, 0, 0, has_sc ? &skip : x));
     free_t(h, n);

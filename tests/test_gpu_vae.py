@@ -176,3 +176,23 @@ def test_gain_vector_with_a_dead_channel_keeps_the_three_term_kernel(golden):
     r, mx, _ = errs(out, want)
     report("vae_dead_gain_channel", rel_l2=r, max_abs=mx)
     assert r < 2e-5 and mx < 2e-4, (r, mx)
+
+
+@pytest.mark.parametrize("shape", [(16, 3, 12, 20), (16, 2, 30, 52)])
+def test_plane_fed_convolutions_give_the_same_bits(vae, shape):
+    """Residual-block convolutions fed by the producing RMS_norm's fp16 word pairs through LDS-DMA (conv_dma2h_kernel, the default) against
+    the same convolutions splitting their fp32 input on the fly (SVI_VAE_DMA=0, conv_igemm_x3_kernel<true>): the same products in the same
+    order into the same accumulators — decode and encode must agree bit for bit (borders, causal padding, the hidden first frame of the
+    upsampling time convolutions, ragged pixel tiles included)."""
+    from svi_hip import _lib as L
+    v, _ = vae
+    z = torch.from_numpy(synth.randn(611, *shape)).cuda()
+    vid = torch.from_numpy(np.tanh(synth.randn(612, 3, 4 * (shape[1] - 1) + 1, 8 * shape[2], 8 * shape[3]))).cuda()
+    a_dec, a_enc = v.decode([z], device="cuda")[0], v.encode([vid], device="cuda")[0]
+    L.set_switch("SVI_VAE_DMA", 0)
+    try:
+        b_dec, b_enc = v.decode([z], device="cuda")[0], v.encode([vid], device="cuda")[0]
+    finally:
+        L.set_switch("SVI_VAE_DMA", None)
+    assert torch.isfinite(a_dec).all() and torch.isfinite(a_enc).all()
+    assert torch.equal(a_dec, b_dec) and torch.equal(a_enc, b_enc)
