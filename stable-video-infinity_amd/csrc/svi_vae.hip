@@ -636,21 +636,30 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 
 
 // =================================================================================================
-// Two-term fp16 convolution, operands staged by LDS-DMA (round 3).  Same arithmetic as conv_igemm_x3_kernel<true> — the same products in
-// the same order into the same accumulators, so the same bits — but the activation split is no longer done by every consumer tile
-// for every tap: the PRODUCER (rms_silu_planes_kernel: RMS_norm + SiLU) writes its output once as the two fp16 words hi = f16(x s),
-// lo = f16(x s - hi) in two channels-last planes (the same bytes as one fp32 tensor), and this kernel only moves bytes:
-//   * a K step (one tap, 32 input channels) of a pixel is 64 contiguous bytes per plane = one LDS row; four lanes fetch it with one
-//     buffer_load_dwordx4 ... lds each, 16 pixel rows per wave instruction, the bank swizzle on the SOURCE chunk (rule 21); a tap that
-//     does not exist (border, causal padding, the hidden frame) is an offset beyond the descriptor's range: the DMA writes zeros;
-//   * wave w stages exactly the 32 pixel rows it multiplies (4 instructions per step), so activations need no workgroup barrier —
-//     only the 12 KiB of weights (12 instructions shared by the 8 waves) do;
-//   * no staging registers, no conversions, no ds_write: per K step a wave issues 18 MFMAs, 16 ds_read_b128 and 5-6 DMA instructions
-//     (the x3 kernel: 18 MFMAs against ~185 VALU / LDS instructions of splitting and storing).
-// LDS: two stages x (2 planes x [256 px][64 B] + 2 planes x [96 co][64 B]) = 88 KiB.
+// Two-term fp16 convolution on the producer's fp16 word pairs, staged by LDS-DMA, with the three x-taps of a kernel row served from
+// ONE staged strip (round 3).
+//
+// What bounds conv_igemm_x3_kernel<true> is neither the matrix pipe nor LDS: every (tap, 32-channel) K step re-fetches the tile's
+// 256 pixel rows, so a 3x3x3 convolution pulls each input element 27 times through the CU's vector-memory path — 44 KiB per step and
+// CU every ~1.6 us = ~7 TB/s chip-wide, which is the L2 -> CU fill rate this part sustains (MI355X_MICROARCH.md, ldsdma-fill: 6.4-6.8 TB/s).
+// Removing the staging arithmetic alone (the producer writes hi = f16(x s), lo = f16(x s - hi) once, this kernel only moves bytes) bought
+// 4 %; a three-stage DMA ring nothing.  So the bytes had to go:
+//   * a K step is (frame tap, row tap, 32 channels); its activation strip is the tile's 256 consecutive pixels PLUS one pixel on either
+//     side (272 LDS rows of 64 B per plane), fetched once and read three times: x-tap tc of output pixel i is LDS row i + tc.  Where
+//     pixel i + tc - 1 is not the x-neighbour of pixel i (image border: the strip continues into the next image row) the lane's
+//     fragment is replaced by zeros — the padding the convolution asks for;
+//   * the weights of the three x-taps ride along (3 x 12 KiB): 70 DMA instructions per step and workgroup for 54 MFMAs per wave,
+//     against 3 x 44 = 132 instructions for the same MFMAs before: 1.9 x fewer bytes through the fill path;
+//   * a tap whose (frame, row) does not exist for a pixel is an offset beyond the descriptor's range: the DMA writes zeros.
+// Summation order differs from the x3 kernels (x-taps innermost), so results agree to rounding, not bit for bit; the parity bounds are
+// the VAE's (rel-L2 2e-5 / max-abs 2e-4 against the reference).  Layers: 3x3 spatial taps, stride 1, 'same' padding — every
+// residual-block convolution.  LDS: two stages x (2 x [272][64 B] + 3 taps x 2 x [96][64 B]) = 140 KiB.
 // =================================================================================================
+#define D2_ROWS 272
+#define D2_A_PLANE (D2_ROWS * 64)
+#define D2_STAGE (2 * D2_A_PLANE + 6 * X3_W_PLANE)
+#define D2_SLOTS 9                                   // DMA instructions per wave and step: 34 activation + 36 weight pieces over 8 waves
 __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
-    constexpr int STAGE = X2H_STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -660,35 +669,42 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
     const long p0 = (long)p.t_begin * HoWo + (long)blockIdx.x * X3_PIX;
     const int co0 = blockIdx.y * X3_CO;
     const int nchunk = p.Cin >> 5;
-    const int khw = p.kh * p.kw, ntaps = p.kt * khw;
-    const int nk = ntaps * nchunk;
+    const int nrow = p.kt * p.kh;                    // (frame tap, row tap) pairs
+    const int nk = nrow * nchunk;
 
-    // ---- activation DMA: lane (r4 = lane >> 2, c = lane & 3) of wave w moves chunk c of pixel rows 32 w + r4 and 32 w + 16 + r4, both planes
-    const int t_first = (int)(min(p0, P_total - 1) / HoWo);
+    const int t_first = (int)(max(min(p0 - 1, P_total - 1), 0L) / HoWo);
     const int t_base = max(t_first * p.st - p.pt, 0);
-    unsigned a_mask[2], base_off[2];
-    int src_chunk[2];
+    // ---- per-slot DMA bookkeeping: slot i of wave w is piece q = w + 8 i (q < 34: activation strip, else weights)
+    unsigned s_off[D2_SLOTS], s_mask[D2_SLOTS];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 32 * wave + 16 * j + (lane >> 2);
-        const long pp = p0 + row;
-        const bool pix = pp < P_total;
-        const long q = pix ? pp : 0;
-        const int at = (int)(q / HoWo);
-        const int rem = (int)(q - (long)at * HoWo);
-        const int ay = rem / p.Wo, ax = rem - ay * p.Wo;
-        const int bt = at * p.st - p.pt, by = ay * p.sh - p.ph, bx = ax * p.sw - p.pw;
-        unsigned m = 0;
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int ta = tap / khw, tb = (tap / p.kw) % p.kh, tc = tap % p.kw;
-            const int ti = bt + ta, yi = by + tb, xi = bx + tc;
-            bool ok = pix && ti >= 0 && ti < p.Ti && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi;
-            if (p.zero_frame0 && ti == 0) ok = false;
-            if (ok) m |= 1u << tap;
+    for (int i = 0; i < D2_SLOTS; ++i) {
+        const int q = wave + 8 * i;
+        s_off[i] = 0xFFF00000u; s_mask[i] = 0;
+        if (q < 34) {
+            const int r16 = q % 17, row = r16 * 16 + (lane >> 2);
+            const long pp = p0 - 1 + row;
+            const bool pix = pp >= 0 && pp < P_total;
+            const long qq = pix ? pp : 0;
+            const int at = (int)(qq / HoWo);
+            const int rem = (int)(qq - (long)at * HoWo);
+            const int ay = rem / p.Wo, ax = rem - ay * p.Wo;
+            const int bt = at * p.st - p.pt, by = ay - p.ph;
+            unsigned m = 0;
+            for (int rt = 0; rt < nrow; ++rt) {
+                const int ta = rt / p.kh, tb = rt - ta * p.kh;
+                const int ti = bt + ta, yi = by + tb;
+                bool ok = pix && ti >= 0 && ti < p.Ti && yi >= 0 && yi < p.Hi;
+                if (p.zero_frame0 && ti == 0) ok = false;
+                if (ok) m |= 1u << rt;
+            }
+            s_mask[i] = m;
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            s_off[i] = (unsigned)((((bt - t_base) * p.Hi + by) * p.Wi + ax) * p.ld_in) * 2u + (unsigned)chunk * 16u;
+        } else if (q < 70) {
+            const int w = q - 34, tc = w / 12, pl = (w % 12) / 6, row = (w % 6) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            if (co0 + row < p.Cout) s_off[i] = (unsigned)((pl * p.plane_w3 + ((long)tc * p.Cout + co0 + row) * p.ld_w3 + chunk * 8) * 2);
         }
-        a_mask[j] = m;
-        src_chunk[j] = (lane & 3) ^ ((row >> 2) & 3);                  // LDS slot (row, lane & 3) holds source chunk (lane & 3) ^ swizzle(row)
-        base_off[j] = (unsigned)((((bt - t_base) * p.Hi + by) * p.Wi + bx) * p.ld_in) * 2u + (unsigned)src_chunk[j] * 16u;
     }
     const long base_el = (long)t_base * p.Hi * p.Wi * p.ld_in;
     const long rem_bytes = ((long)p.Ti * p.Hi * p.Wi * p.ld_in - base_el) * 2;
@@ -697,52 +713,39 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
     const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.in_l + base_el), 0, win, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2h), 0, (int)(unsigned)min((long)2 * p.plane_w3 * 2, 0xFFE00000L), 0x00020000);
     const unsigned OOB = 0xFFF00000u;
-    // ---- weight DMA: 2 planes x 96 rows x 64 B = 12 wave instructions of 16 rows; wave w issues instruction w, waves 0..3 also 8 + w
-    unsigned w_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = wave + 8 * i;                                    // 0..11 (i = 1 only for waves 0..3)
-        const int pl = q / 6, row = (q % 6) * 16 + (lane >> 2);
-        const int ch = (lane & 3) ^ ((row >> 2) & 3);
-        const bool ok = q < 12 && co0 + row < p.Cout;
-        w_off[i] = ok ? (unsigned)((pl * p.plane_w3 + (long)(co0 + row) * p.ld_w3 + ch * 8) * 2) : OOB;
+    // this lane's output pixel and whether its left / right x-neighbour exists
+    bool left_ok, right_ok;
+    {
+        const long pp = min(p0 + 32 * wave + l31, P_total - 1);
+        const int ax = (int)(pp % p.Wo);
+        left_ok = ax > 0; right_ok = ax < p.Wo - 1;
     }
-    int it_tap = 0, it_cc = 0, it_ta = 0, it_tb = 0, it_tc = 0;
-    unsigned it_wk = 0;                                                // byte offset of (tap, channel chunk) inside a weight plane
-    unsigned tap_off[2];
-    auto tap_bases = [&]() {
-        const unsigned d = (unsigned)(((it_ta * p.Hi + it_tb) * p.Wi + it_tc) * p.ld_in) * 2u;
+
+    int it_rt = 0, it_cc = 0, it_ta = 0, it_tb = 0;
+    auto request = [&](int buf) {                    // K step (it_rt, it_cc) -> stage buf
+        char* As = smem + buf * D2_STAGE;
+        char* Ws = As + 2 * D2_A_PLANE;
+        const unsigned d_act = (unsigned)(((it_ta * p.Hi + it_tb) * p.Wi) * p.ld_in) * 2u + (unsigned)it_cc * 64u;
+        const unsigned d_w = (unsigned)((long)it_rt * p.kw * p.Cout * p.ld_w3 * 2) + (unsigned)it_cc * 64u;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) tap_off[j] = ((a_mask[j] >> it_tap) & 1u) ? base_off[j] + d : OOB;
+        for (int i = 0; i < D2_SLOTS; ++i) {
+            const int q = wave + 8 * i;
+            if (q < 34) {
+                const int pl = q / 17, r16 = q % 17;
+                const unsigned off = ((s_mask[i] >> it_rt) & 1u) ? s_off[i] + d_act : OOB;
+                if (pl == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lptr_t)(As + r16 * 1024), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lptr_t)(As + D2_A_PLANE + r16 * 1024), 16, off, 0, 0, 0);
+            } else if (q < 70) {
+                const int w = q - 34, tc = w / 12, pl = (w % 12) / 6, r16 = w % 6;
+                const unsigned off = s_off[i] == OOB ? OOB : s_off[i] + d_w;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + (tc * 2 + pl) * X3_W_PLANE + r16 * 1024), 16, off, 0, 0, 0);
+            }
+        }
     };
     auto advance = [&]() {
-        it_wk += 64u;
         if (++it_cc == nchunk) {
-            it_cc = 0; ++it_tap;
-            it_wk = (unsigned)((long)it_tap * p.Cout * p.ld_w3 * 2);
-            if (++it_tc == p.kw) { it_tc = 0; if (++it_tb == p.kh) { it_tb = 0; ++it_ta; } }
-            tap_bases();
-        }
-    };
-    // request K step (the iterator's position) into stage `buf`; a step past the end requests nothing
-    auto request = [&](int buf, bool valid) {
-        if (!valid) return;
-        char* As = smem + buf * STAGE;
-        char* Ws = As + 2 * X3_A_PLANE;
-        const unsigned coff = (unsigned)it_cc * 64u;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned off = tap_off[j] == OOB ? OOB : tap_off[j] + coff;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lptr_t)(As + (32 * wave + 16 * j) * 64), 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lptr_t)(As + X3_A_PLANE + (32 * wave + 16 * j) * 64), 16, off, 0, 0, 0);
-        }
-        {
-            const int q = wave, pl = q / 6, r16 = q % 6;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + pl * X3_W_PLANE + r16 * 16 * 64), 16, w_off[0] == OOB ? OOB : w_off[0] + it_wk, 0, 0, 0);
-        }
-        if (wave < 4) {
-            const int q = wave + 8, pl = q / 6, r16 = q % 6;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + pl * X3_W_PLANE + r16 * 16 * 64), 16, w_off[1] == OOB ? OOB : w_off[1] + it_wk, 0, 0, 0);
+            it_cc = 0; ++it_rt;
+            if (++it_tb == p.kh) { it_tb = 0; ++it_ta; }
         }
     };
 
@@ -752,27 +755,36 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-    tap_bases();
-    request(0, true);
+    request(0);
     advance();
     __syncthreads();                     // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+    const f16x8 zero8 = {(f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0};
     for (int k = 0; k < nk; ++k) {
         const int cur = k & 1;
-        request(cur ^ 1, k + 1 < nk);    // stage cur ^ 1 was last read in step k - 1: every wave has passed the barrier behind it
+        if (k + 1 < nk) request(cur ^ 1);            // stage cur ^ 1 was last read in step k - 1: every wave has passed the barrier behind it
         advance();
-        const char* As = smem + cur * STAGE;
-        const char* Ws = As + 2 * X3_A_PLANE;
+        const char* As = smem + cur * D2_STAGE;
+        const char* Ws = As + 2 * D2_A_PLANE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah = *reinterpret_cast<const f16x8*>(As + x3_off(32 * wave + l31, 2 * ks + hi));
-            f16x8 al = *reinterpret_cast<const f16x8*>(As + X3_A_PLANE + x3_off(32 * wave + l31, 2 * ks + hi));
+        for (int tc = 0; tc < 3; ++tc) {
+            const bool live = tc == 0 ? left_ok : tc == 2 ? right_ok : true;
 #pragma unroll
-            for (int n = 0; n < 3; ++n) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(Ws + x3_off(32 * n + l31, 2 * ks + hi));
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(Ws + X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, acc[n], 0, 0, 0);        // the order of conv_igemm_x3_kernel<true>: wl ah, wh al, wh ah
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc[n], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ah = *reinterpret_cast<const f16x8*>(As + x3_off(32 * wave + l31 + tc, 2 * ks + hi));
+                f16x8 al = *reinterpret_cast<const f16x8*>(As + D2_A_PLANE + x3_off(32 * wave + l31 + tc, 2 * ks + hi));
+                if (tc != 1) { ah = live ? ah : zero8; al = live ? al : zero8; }
+                f16x8 wh[3], wl[3];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    wh[n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
+                    wl[n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2 + 1) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
+                }
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[n], ah, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], al, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], ah, acc[n], 0, 0, 0);
             }
         }
         __syncthreads();                 // step k + 1 landed (vmcnt(0)) and every wave is done reading stage cur
@@ -822,7 +834,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
 bool conv_planes_ok(const ConvP& p) {
     return p.w2h && p.w2_inv && p.in_scale > 0.f && !svi_switches().vae_no_x2h && !svi_switches().vae_exact_fp32 && svi_switches().vae_dma &&
            (((uintptr_t)p.w2_inv) & 15) == 0 && p.Cin % 32 == 0 && p.ld_in == p.Cin && !p.ups && p.Cout >= 64 && p.Cout % 4 == 0 &&
-           p.kt * p.kh * p.kw <= 32 && !p.act_silu && !p.out_bf16 && (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) &&
+           p.kw == 3 && p.kh == 3 && p.kt * p.kh <= 32 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
+           !p.act_silu && !p.out_bf16 && (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) &&
            (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 2 < 0xFFE00000L && (long)2 * p.plane_w3 * 2 < 0xFFE00000L;
 }
 
@@ -832,8 +845,8 @@ svi_status launch_conv_planes(const ConvP& p, hipStream_t st) {
     const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
     if (pixels <= 0) return SVI_OK;
     dim3 grid((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block(512);
-    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel), 2 * X2H_STAGE));
-    hipLaunchKernelGGL(conv_dma2h_kernel, grid, block, 2 * X2H_STAGE, st, p);
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel), 2 * D2_STAGE));
+    hipLaunchKernelGGL(conv_dma2h_kernel, grid, block, 2 * D2_STAGE, st, p);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }

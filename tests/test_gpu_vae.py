@@ -178,12 +178,14 @@ def test_gain_vector_with_a_dead_channel_keeps_the_three_term_kernel(golden):
     assert r < 2e-5 and mx < 2e-4, (r, mx)
 
 
-@pytest.mark.parametrize("shape", [(16, 3, 12, 20), (16, 2, 30, 52)])
-def test_plane_fed_convolutions_give_the_same_bits(vae, shape):
-    """Residual-block convolutions fed by the producing RMS_norm's fp16 word pairs through LDS-DMA (conv_dma2h_kernel, the default) against
-    the same convolutions splitting their fp32 input on the fly (SVI_VAE_DMA=0, conv_igemm_x3_kernel<true>): the same products in the same
-    order into the same accumulators — decode and encode must agree bit for bit (borders, causal padding, the hidden first frame of the
-    upsampling time convolutions, ragged pixel tiles included)."""
+@pytest.mark.parametrize("shape", [(16, 3, 12, 20), (16, 2, 30, 52), (16, 2, 5, 3)])
+def test_plane_fed_convolutions_agree_with_the_on_the_fly_split(vae, shape):
+    """Residual-block convolutions fed by the producing RMS_norm's fp16 word pairs through LDS-DMA with the three x-taps of a kernel row
+    served from one staged strip (conv_dma2h_kernel, the default) against the same convolutions splitting their fp32 input on the fly
+    (SVI_VAE_DMA=0, conv_igemm_x3_kernel<true>): the same products, another summation order (x-taps innermost) — decode and encode agree
+    to fp32 rounding (rel-L2 <= 5e-6, max-abs <= 5e-5 on outputs of unit scale), borders, causal padding, the hidden first frame of the
+    upsampling time convolutions, ragged pixel tiles and strips that run across image rows and frames included (widths 24 .. 416 px, not
+    multiples of the 256-pixel tile)."""
     from svi_hip import _lib as L
     v, _ = vae
     z = torch.from_numpy(synth.randn(611, *shape)).cuda()
@@ -195,4 +197,7 @@ def test_plane_fed_convolutions_give_the_same_bits(vae, shape):
     finally:
         L.set_switch("SVI_VAE_DMA", None)
     assert torch.isfinite(a_dec).all() and torch.isfinite(a_enc).all()
-    assert torch.equal(a_dec, b_dec) and torch.equal(a_enc, b_enc)
+    rd, md, _ = errs(a_dec, b_dec)
+    re, me, _ = errs(a_enc, b_enc)
+    report("vae_dma_vs_on_the_fly", shape=list(shape), decode_rel=rd, decode_maxabs=md, encode_rel=re, encode_maxabs=me)
+    assert rd < 5e-6 and md < 5e-5 and re < 5e-6 and me < 5e-5, (rd, md, re, me)
