@@ -765,27 +765,32 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
         advance();
         const char* As = smem + cur * D2_STAGE;
         const char* Ws = As + 2 * D2_A_PLANE;
-#pragma unroll
-        for (int tc = 0; tc < 3; ++tc) {
+        // six sub-steps (x-tap tc, k-half ks); the eight fragment reads of sub-step s + 1 are requested before the nine MFMAs of sub-step s
+        f16x8 ah[2], al[2], wh[2][3], wl[2][3];
+        auto frags = [&](int sidx, int set) {
+            const int tc = sidx >> 1, ks = sidx & 1;
             const bool live = tc == 0 ? left_ok : tc == 2 ? right_ok : true;
+            f16x8 h_ = *reinterpret_cast<const f16x8*>(As + x3_off(32 * wave + l31 + tc, 2 * ks + hi));
+            f16x8 l_ = *reinterpret_cast<const f16x8*>(As + D2_A_PLANE + x3_off(32 * wave + l31 + tc, 2 * ks + hi));
+            if (tc != 1) { h_ = live ? h_ : zero8; l_ = live ? l_ : zero8; }
+            ah[set] = h_; al[set] = l_;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f16x8 ah = *reinterpret_cast<const f16x8*>(As + x3_off(32 * wave + l31 + tc, 2 * ks + hi));
-                f16x8 al = *reinterpret_cast<const f16x8*>(As + D2_A_PLANE + x3_off(32 * wave + l31 + tc, 2 * ks + hi));
-                if (tc != 1) { ah = live ? ah : zero8; al = live ? al : zero8; }
-                f16x8 wh[3], wl[3];
-#pragma unroll
-                for (int n = 0; n < 3; ++n) {
-                    wh[n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
-                    wl[n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2 + 1) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
-                }
-#pragma unroll
-                for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[n], ah, acc[n], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], al, acc[n], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], ah, acc[n], 0, 0, 0);
+            for (int n = 0; n < 3; ++n) {
+                wh[set][n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
+                wl[set][n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2 + 1) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
             }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int sidx = 0; sidx < 6; ++sidx) {
+            const int set = sidx & 1;
+            if (sidx + 1 < 6) frags(sidx + 1, set ^ 1);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[set][n], ah[set], acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[set][n], al[set], acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[set][n], ah[set], acc[n], 0, 0, 0);
         }
         __syncthreads();                 // step k + 1 landed (vmcnt(0)) and every wave is done reading stage cur
     }
