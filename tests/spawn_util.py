@@ -12,7 +12,7 @@ def _free_port():
     return p
 
 
-def run_ranks(worker, world, *args, attempts=2, timeout=120):
+def run_ranks(worker, world, *args, attempts=3, timeout=180):
     """Spawn `world` processes running worker(rank, world, port, *args, queue) and collect one queue item per rank.  A rendezvous
     can fail for reasons outside the code under test (the probed port taken in between, a slow fork): one retry on a new port."""
     last = None
