@@ -39,6 +39,7 @@ static SviSwitches parse_switches() {
     s.vae_no_x2h = env_int("SVI_VAE_X2H", 0, 1) == 0;
     s.cross_dedup = env_int("SVI_CROSS_DEDUP", 0, 1);
     s.vae_dma = env_int("SVI_VAE_DMA", 0, 1);
+    s.vae_up_phases = env_int("SVI_VAE_UP_PHASES", 0, 1);
     { const char* v = getenv("SVI_T5_BUCKETS"); s.t5_host_buckets = v && strcmp(v, "host") == 0; }
 #ifdef SVI_ABLATIONS
     s.flash_abl = env_int("SVI_FLASH_ABL", 0, 0);

@@ -250,6 +250,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
 #ifndef SVI_FLASH_BALANCED
 #define SVI_FLASH_BALANCED 1
 #endif
+#ifndef SVI_FLASH_SHORT_NOP
+#define SVI_FLASH_SHORT_NOP 1
+#endif
 #ifndef SVI_FLASH_DMA_SPLIT
 #define SVI_FLASH_DMA_SPLIT 0     // 1: a statement that issues an LDS-DMA piece hands its fragment read to the next statement (balanced kernel only).
                                   // Measured (same box, interleaved, profiles/r3e_attn_split_ab.txt): 5.025 ms against 4.981 ms without — the read
@@ -702,8 +705,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         constexpr bool WITH_NEXT = decltype(with_next)::value;
         constexpr int vs = decltype(vs_c)::value * VT_BYTES, kn = decltype(kn_c)::value * KT_BYTES;
         const int kd = ((t + 3) & 3) * KT_BYTES, so_k = (t + 3) * KB * ldk * 2;
-        // MFMA result (the last QK^T MFMAs) -> VALU read, and VALU-written P -> MFMA operand: wait states by hand
-        asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
+        // MFMA result (the last QK^T MFMAs) -> VALU read, and VALU-written P -> MFMA operand: wait states by hand.  In the balanced optimistic
+        // schedule nothing reads the new scores before statement 24 of this phase and the last P word written in phase 1 is first read by
+        // statement 16, so an unmasked tile needs no wait here (SVI_FLASH_SHORT_NOP=0 keeps the 16 states)
+        if constexpr (BAL && !MASKED && (SVI_FLASH_SHORT_NOP != 0)) asm("s_nop 0" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
+        else asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
         if (MASKED) {
             const int key_base = t * KB;
 #pragma unroll

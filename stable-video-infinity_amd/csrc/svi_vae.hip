@@ -53,6 +53,8 @@ struct ConvP {
     int act_silu;                                    // conv_igemm_kernel, mode 0: out = silu(conv + bias)  (pose embedder)
     bf16* out_bf16;                                  // conv_igemm_kernel, mode 0: store bf16 [pixel][ld_out] here instead of fp32 `out`
     const unsigned short* in_h; const unsigned short* in_l;      // conv_dma2h_kernel: the input as two fp16 planes [pixel][ld_in] of x * in_scale (hi | lo)
+    int up_phase;                                    // conv_igemm_x3_kernel, mode 0: 1 + 2 py + px = this launch computes output pixels (2 y + py, 2 x + px) of an image twice the size
+                                                     // of its (To, Ho, Wo) grid (one phase of a convolution behind a nearest x2 upsample, see launch_conv_up_phases); 0 = plain
 };
 
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -597,7 +599,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
     f32x4 bv[12], rv[12], sv[12];
     const bool with_res = p.out_mode == 0 && p.res;
     const float inv_a = H2 ? 1.0f / p.in_scale : 1.0f;                       // exact: powers of two
-    const long po = pp + (long)p.t_out_off * HoWo;
+    long po = pp + (long)p.t_out_off * HoWo;
+    if (!H2 && p.up_phase) {             // one phase of an upsample convolution: pixel (t, y, x) of this grid is (t, 2 y + py, 2 x + px) of the output
+        const int ph_ = p.up_phase - 1;
+        const int t = (int)(pp / HoWo);
+        const int rem = (int)(pp - (long)t * HoWo);
+        const int y = rem / p.Wo, x = rem - y * p.Wo;
+        po = ((long)(t + p.t_out_off) * (2 * p.Ho) + 2 * y + (ph_ >> 1)) * (2 * p.Wo) + 2 * x + (ph_ & 1);
+    }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int co = co0 + 32 * (i >> 2) + 8 * (i & 3) + 4 * hi;
@@ -856,22 +865,28 @@ svi_status launch_conv_planes(const ConvP& p, hipStream_t st) {
     return SVI_OK;
 }
 
+// Does conv_igemm_x3_kernel take this convolution?
+bool conv_x3_ok(const ConvP& p) {
+    const bool no_x3 = svi_switches().vae_exact_fp32 != 0;                 // A/B aid: force the exact-fp32 MFMA kernel
+    return p.w3 && !no_x3 && !p.act_silu && !p.out_bf16 && p.Cout >= 64 && p.Cout % 4 == 0 && p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) &&
+           (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) && (((uintptr_t)p.bias | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0 &&
+           p.kt * p.kh * p.kw <= 32 &&                                                   // tap bit mask
+           (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 4 < 0xFFFFF000L &&               // 32-bit offsets inside the buffer window
+           (long)3 * p.plane_w3 * 2 < 0xFFFFF000L;
+}
+
 svi_status launch_conv(const ConvP& p, hipStream_t st) {
     SVI_REQUIRE(p.Cin % 4 == 0 && p.ld_in % 4 == 0 && p.ld_w % 4 == 0, "conv: Cin/ld must be multiples of 4 (Cin=%d)", p.Cin);
+    SVI_REQUIRE(!p.up_phase || (conv_x3_ok(p) && !p.ups && p.out_mode == 0), "conv: an upsample phase runs on the three-term kernel only");
     const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
     if (pixels <= 0) return SVI_OK;
-    const bool no_x3 = svi_switches().vae_exact_fp32 != 0;                 // A/B aid: force the exact-fp32 MFMA kernel
-    if (p.w3 && !no_x3 && !p.act_silu && !p.out_bf16 && p.Cout >= 64 && p.Cout % 4 == 0 && p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) &&
-        (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) && (((uintptr_t)p.bias | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0 &&
-        p.kt * p.kh * p.kw <= 32 &&                                                   // tap bit mask
-        (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 4 < 0xFFFFF000L &&               // 32-bit offsets inside the buffer window
-        (long)3 * p.plane_w3 * 2 < 0xFFFFF000L) {
+    if (conv_x3_ok(p)) {
         dim3 grid3((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block3(512);
         ConvP pa = p;
 #ifdef SVI_ABLATIONS
         pa.abl = svi_switches().vae_abl;
 #endif
-        if (p.w2h && p.w2_inv && p.in_scale > 0.f && !svi_switches().vae_no_x2h && (((uintptr_t)p.w2_inv) & 15) == 0 && p.Cin % 32 == 0 && !p.ups &&
+        if (p.w2h && p.w2_inv && p.in_scale > 0.f && !svi_switches().vae_no_x2h && (((uintptr_t)p.w2_inv) & 15) == 0 && p.Cin % 32 == 0 && !p.ups && !p.up_phase &&
             (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 4 < 0xFFE00000L && (long)2 * p.plane_w3 * 2 < 0xFFE00000L) {
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_igemm_x3_kernel<true>), 2 * X2H_STAGE));
             hipLaunchKernelGGL(conv_igemm_x3_kernel<true>, grid3, block3, 2 * X2H_STAGE, st, pa);
@@ -891,6 +906,28 @@ svi_status launch_conv(const ConvP& p, hipStream_t st) {
     else
         hipLaunchKernelGGL(conv_igemm_kernel<1>, grid, block, 2 * (128 * 128 + 1 * 32 * 128), st, p);
     SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+// A 3x3 (spatial) convolution behind a nearest x2 upsample (Resample 'upsample2d/3d', vae:120-131), as FOUR 2x2 convolutions of the
+// small image: output pixel (2 y + py, 2 x + px) sees only two distinct input rows and two distinct input columns —
+//     py = 0: rows y-1 (kernel row 0) and y (kernel rows 1 + 2);     py = 1: rows y (kernel rows 0 + 1) and y+1 (kernel row 2)
+// (columns alike), and positions outside the small image are exactly the positions whose upsampled pixels fall into the convolution's
+// zero padding.  Summing the kernel entries that meet the same input pixel beforehand (fp32, svi_vae_set_weight) leaves 4 taps of
+// the 9: 2.25 x fewer products for the same sum, up to the rounding of the weight sums (<= 2 ulp of fp32 per entry; the three-term
+// operand split the kernel runs on is itself good to 2^-24).  p describes the SMALL grid (ups = 0, kh = kw = 2); w3_up holds the
+// four phases' weights, each in the three-plane layout with 4 taps.
+svi_status launch_conv_up_phases(ConvP p, const bf16* w3_up, hipStream_t st) {
+    p.ups = 0; p.kh = p.kw = 2;
+    p.Ho = p.Hi; p.Wo = p.Wi;
+    p.plane_w3 = (long)p.kt * 4 * p.Cout * p.ld_w3;
+    p.w2h = nullptr; p.w = nullptr;
+    for (int ph = 0; ph < 4; ++ph) {
+        p.up_phase = 1 + ph;
+        p.ph = 1 - (ph >> 1); p.pw = 1 - (ph & 1);
+        p.w3 = w3_up + (long)ph * 3 * p.plane_w3;
+        SVI_TRY(launch_conv(p, st));
+    }
     return SVI_OK;
 }
 
@@ -1188,6 +1225,33 @@ __global__ void pack_weight_x3_kernel(const float* __restrict__ w, bf16* __restr
     out[n + i] = m;
     out[2 * n + i] = (bf16)(r1 - (float)m);
 }
+// weights [Cout, Cin, 3, 3] of a convolution behind a nearest x2 upsample -> four phases x three bf16 planes [phase][plane][2x2 tap][Cout][ldw3]
+// of the summed kernels (launch_conv_up_phases).  Sums in fp32, kernel rows outer, columns inner.
+__global__ void pack_weight_up_x3_kernel(const float* __restrict__ w, bf16* __restrict__ out, int Cout, int Cin, int ldw3) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)4 * Cout * ldw3;            // one plane of one phase
+    if (i >= 4 * n) return;
+    const int ph = (int)(i / n);
+    const long r = i - (long)ph * n;
+    const int ci = (int)(r % ldw3);
+    const int co = (int)((r / ldw3) % Cout);
+    const int tap = (int)(r / ((long)ldw3 * Cout));
+    const int py = ph >> 1, px = ph & 1, a = tap >> 1, b = tap & 1;
+    // kernel rows met by tap row a of phase py: py = 0: {0} | {1, 2};  py = 1: {0, 1} | {2}
+    const int r0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), r1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int c0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), c1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    float x = 0.f;
+    if (ci < Cin)
+        for (int rr = r0; rr <= r1; ++rr)
+            for (int cc = c0; cc <= c1; ++cc) x += w[((long)co * Cin + ci) * 9 + rr * 3 + cc];
+    const bf16 h = (bf16)x;
+    const float r1f = x - (float)h;
+    const bf16 m = (bf16)r1f;
+    bf16* o = out + (long)ph * 3 * n + r;
+    o[0] = h;
+    o[n] = m;
+    o[2 * n] = (bf16)(r1f - (float)m);
+}
 // fp16 two-term form.  Row (output channel) maximum -> power-of-two scale 2^k with max * 2^k in [2^13, 2^14); inv[co] = 2^-k.
 __global__ __launch_bounds__(256) void weight_row_scale_kernel(const float* __restrict__ w, float* __restrict__ scale, float* __restrict__ inv, long per_row) {
     const int co = blockIdx.x;
@@ -1243,6 +1307,8 @@ struct ConvW {               // one conv layer: user weight (borrowed) + packed 
     bf16* packed3 = nullptr;          // three bf16 planes of the packed weights (see conv_igemm_x3_kernel)
     unsigned short* packed2h = nullptr;   // two fp16 planes of the row-scaled packed weights (conv_igemm_x3_kernel<true>)
     float* w2_scale = nullptr;        // [2][Cout]: scale | 1 / scale
+    bf16* packed3_up = nullptr;       // upsample convolutions: the four 2x2 phase kernels, three bf16 planes each (launch_conv_up_phases)
+    bool upsample = false;            // a 3x3 spatial convolution read through a nearest x2 upsample (Resample upsample2d/3d)
     int Cout = 0, Cin = 0, kt = 1, kh = 1, kw = 1, ldw = 0, ldw3 = 0;
 };
 struct Tens {
@@ -1339,6 +1405,7 @@ void declare_architecture(svi_vae* h) {
         if (i != 3) {
             const std::string p = d + "upsamples." + std::to_string(idx++) + ".";
             add_conv(h, p + "resample.1", dout / 2, dout, 1, 3, 3, true);
+            h->convs[p + "resample.1"].upsample = true;
             if (tup[i]) add_conv(h, p + "time_conv", dout * 2, dout, 3, 1, 1);
         }
     }
@@ -1417,6 +1484,11 @@ svi_status conv_layer(svi_vae* h, const std::string& name, const Tens& in, Tens*
         p.in_h = reinterpret_cast<const unsigned short*>(in.p);
         p.in_l = p.in_h + in.elems();
         return launch_conv_planes(p, st);
+    }
+    if (ups && c.packed3_up && svi_switches().vae_up_phases && !res) {
+        ConvP q = p;                     // one phase's launch parameters, to ask whether the three-term kernel takes it
+        q.ups = 0; q.kh = q.kw = 2; q.Ho = q.Hi; q.Wo = q.Wi; q.plane_w3 = (long)q.kt * 4 * q.Cout * q.ld_w3;
+        if (conv_x3_ok(q)) return launch_conv_up_phases(p, c.packed3_up, st);
     }
     return launch_conv(p, st);
 }
@@ -1680,6 +1752,7 @@ extern "C" svi_status svi_vae_destroy(svi_vae* h) {
         if (kv.second.packed) (void)hipFree(kv.second.packed);
         if (kv.second.packed3) (void)hipFree(kv.second.packed3);
         if (kv.second.packed2h) (void)hipFree(kv.second.packed2h);
+        if (kv.second.packed3_up) (void)hipFree(kv.second.packed3_up);
         if (kv.second.w2_scale) (void)hipFree(kv.second.w2_scale);
     }
     if (h->pool) (void)hipFree(h->pool);
@@ -1749,6 +1822,15 @@ extern "C" svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const vo
             hipError_t e2 = hipMalloc((void**)&cw.packed2h, 2 * n3 * 2);
             if (e2 == hipSuccess) e2 = hipMalloc((void**)&cw.w2_scale, (size_t)2 * cw.Cout * 4);
             if (e2 != hipSuccess) { svi_set_error("hipMalloc(fp16 split VAE weight) failed: %s", hipGetErrorString(e2)); return SVI_ERR_OOM; }
+        }
+        if (cw.upsample && cw.kt == 1 && cw.kh == 3 && cw.kw == 3) {
+            const size_t nu = (size_t)4 * 3 * 4 * cw.Cout * cw.ldw3;
+            if (!cw.packed3_up) {
+                hipError_t eu = hipMalloc((void**)&cw.packed3_up, nu * 2);
+                if (eu != hipSuccess) { svi_set_error("hipMalloc(upsample phase weights) failed: %s", hipGetErrorString(eu)); return SVI_ERR_OOM; }
+            }
+            const size_t nt = (size_t)4 * 4 * cw.Cout * cw.ldw3;
+            hipLaunchKernelGGL(pack_weight_up_x3_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, cw.w_user, cw.packed3_up, cw.Cout, cw.Cin, cw.ldw3);
         }
         hipLaunchKernelGGL(weight_row_scale_kernel, dim3(cw.Cout), dim3(256), 0, 0, cw.w_user, cw.w2_scale, cw.w2_scale + cw.Cout, (long)cw.Cin * taps);
         hipLaunchKernelGGL(pack_weight_x2h_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, 0, cw.w_user, cw.w2_scale, cw.packed2h, cw.Cout, cw.Cin, taps, cw.ldw3);

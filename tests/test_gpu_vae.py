@@ -201,3 +201,24 @@ def test_plane_fed_convolutions_agree_with_the_on_the_fly_split(vae, shape):
     re, me, _ = errs(a_enc, b_enc)
     report("vae_dma_vs_on_the_fly", shape=list(shape), decode_rel=rd, decode_maxabs=md, encode_rel=re, encode_maxabs=me)
     assert rd < 5e-6 and md < 5e-5 and re < 5e-6 and me < 5e-5, (rd, md, re, me)
+
+
+@pytest.mark.parametrize("shape", [(16, 3, 12, 20), (16, 2, 30, 52), (16, 2, 5, 3), (16, 1, 7, 9)])
+def test_upsample_convolution_phases_agree_with_the_nine_tap_form(vae, shape):
+    """The convolution behind a nearest x2 upsample (Resample upsample2d/3d, vae:120-131) as four 2x2 convolutions of the small image with
+    pre-summed kernels (the default) against the one 3x3 convolution reading through the upsample (SVI_VAE_UP_PHASES=0): the same sum with
+    the kernel entries that meet one input pixel added beforehand — decode agrees to fp32 rounding (rel-L2 <= 5e-6, max-abs <= 5e-5), image
+    borders (where the upsampled image's zero padding is the small image's), odd sizes and single frames included."""
+    from svi_hip import _lib as L
+    v, _ = vae
+    z = torch.from_numpy(synth.randn(613, *shape)).cuda()
+    a = v.decode([z], device="cuda")[0]
+    L.set_switch("SVI_VAE_UP_PHASES", 0)
+    try:
+        b = v.decode([z], device="cuda")[0]
+    finally:
+        L.set_switch("SVI_VAE_UP_PHASES", None)
+    assert torch.isfinite(a).all()
+    r, mx, _ = errs(a, b)
+    report("vae_upsample_phases_vs_nine_taps", shape=list(shape), decode_rel=r, decode_maxabs=mx)
+    assert r < 5e-6 and mx < 5e-5, (r, mx)

@@ -3,7 +3,8 @@
     x3     bf16 three-term convolution everywhere                                                      (SVI_VAE_X2H=0)
     exact  fp32 MFMA everywhere                                                                        (SVI_VAE_EXACT_FP32=1; small size only unless `exact` is asked for)
 Reports wall time, the per-tag kernel time (svi_prof_*) and the distance of each result to the exact-fp32 one (or to x3 at C2).
-    python tools/vae_ab.py [c2] [exact] [only-default]
+    python tools/vae_ab.py [c2] [exact] [only-default | ab-up]
+ab-up: the default against SVI_VAE_UP_PHASES=0 (upsample convolutions as one nine-tap convolution reading through the upsample).
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,9 +25,12 @@ if not c2 or "exact" in sys.argv[1:]:
     MODES.append(("exact", {"SVI_VAE_EXACT_FP32": "1"}))
 if "only-default" in sys.argv[1:]:             # for a kernel trace of the product path alone
     MODES = MODES[:1]
+if "ab-up" in sys.argv[1:]:
+    MODES = [("x2h", {}), ("up9", {"SVI_VAE_UP_PHASES": "0"})]
+KEYS = ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32", "SVI_VAE_UP_PHASES")
 res = {}
 for name, env in MODES:
-    for k in ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32"):
+    for k in KEYS:
         _lib.set_switch(k, env.get(k))
     for what, fn in (("decode", lambda: vae.decode([z], device=dev)[0]), ("encode", lambda: vae.encode([vid], device=dev)[0])):
         out = fn(); torch.cuda.synchronize()
@@ -38,10 +42,10 @@ for name, env in MODES:
         res[(name, what)] = out.double().cpu()
         print(f"{name:5s} {what} {tuple(out.shape)}: {e0.elapsed_time(e1):8.1f} ms   per-tag {tags}   absmax {float(out.abs().max()):.4f}", flush=True)
         del out
-for k in ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32"):
+for k in KEYS:
     _lib.set_switch(k, None)
-base = "exact" if ("exact", "decode") in res else "x3"
-for what in ("decode", "encode"):
+base = "exact" if ("exact", "decode") in res else "x3" if ("x3", "decode") in res else MODES[-1][0]
+for what in ("decode", "encode") if len(MODES) > 1 else ():
     a = res[(base, what)]
     for name, _ in MODES:
         if name == base:
