@@ -218,6 +218,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 __device__ __forceinline__ unsigned short bits16(bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 __device__ __forceinline__ unsigned short bits16(f16 v) { return __builtin_bit_cast(unsigned short, v); }
 
@@ -667,8 +668,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 #define D2_ROWS 272
 #define D2_A_PLANE (D2_ROWS * 64)
 #define D2_STAGE (2 * D2_A_PLANE + 6 * X3_W_PLANE)
-#define D2_SLOTS 9                                   // DMA instructions per wave and step: 34 activation + 36 weight pieces over 8 waves
+// NB: 32-output-channel blocks per workgroup.  3: the residual-block convolutions (Cout = 96 per grid.y).  1: narrow heads (Cout <= 32: the
+// decoder's 96 -> 3 and the encoder's 384 -> 32 head convolutions) — a third of the weight pieces and MFMAs, output channel count not
+// necessarily a multiple of 4 (the lane that holds the last, partial group of four reads bias / scale element-wise and writes the pad
+// channels of the [pixel][ld_out] row as zeros).
+template <int NB>
 __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
+    constexpr int WP = 2 * NB;                       // 1 KiB weight pieces per (x-tap, plane): 32 NB rows of 64 B
+    constexpr int NPIECE = 34 + 6 * WP;              // per K step: 34 activation pieces + the weights of three x-taps x two planes
+    constexpr int D2_SLOTS = (NPIECE + 7) / 8;       // DMA instructions per wave and step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -709,8 +717,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
             s_mask[i] = m;
             const int chunk = (lane & 3) ^ ((row >> 2) & 3);
             s_off[i] = (unsigned)((((bt - t_base) * p.Hi + by) * p.Wi + ax) * p.ld_in) * 2u + (unsigned)chunk * 16u;
-        } else if (q < 70) {
-            const int w = q - 34, tc = w / 12, pl = (w % 12) / 6, row = (w % 6) * 16 + (lane >> 2);
+        } else if (q < NPIECE) {
+            const int w = q - 34, tc = w / (2 * WP), pl = (w % (2 * WP)) / WP, row = (w % WP) * 16 + (lane >> 2);
             const int chunk = (lane & 3) ^ ((row >> 2) & 3);
             if (co0 + row < p.Cout) s_off[i] = (unsigned)((pl * p.plane_w3 + ((long)tc * p.Cout + co0 + row) * p.ld_w3 + chunk * 8) * 2);
         }
@@ -744,8 +752,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
                 const unsigned off = ((s_mask[i] >> it_rt) & 1u) ? s_off[i] + d_act : OOB;
                 if (pl == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lptr_t)(As + r16 * 1024), 16, off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lptr_t)(As + D2_A_PLANE + r16 * 1024), 16, off, 0, 0, 0);
-            } else if (q < 70) {
-                const int w = q - 34, tc = w / 12, pl = (w % 12) / 6, r16 = w % 6;
+            } else if (q < NPIECE) {
+                const int w = q - 34, tc = w / (2 * WP), pl = (w % (2 * WP)) / WP, r16 = w % WP;
                 const unsigned off = s_off[i] == OOB ? OOB : s_off[i] + d_w;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + (tc * 2 + pl) * X3_W_PLANE + r16 * 1024), 16, off, 0, 0, 0);
             }
@@ -758,9 +766,9 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
         }
     };
 
-    f32x16 acc[3];
+    f32x16 acc[NB];
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
         const char* As = smem + cur * D2_STAGE;
         const char* Ws = As + 2 * D2_A_PLANE;
         // six sub-steps (x-tap tc, k-half ks); the eight fragment reads of sub-step s + 1 are requested before the nine MFMAs of sub-step s
-        f16x8 ah[2], al[2], wh[2][3], wl[2][3];
+        f16x8 ah[2], al[2], wh[2][NB], wl[2][NB];
         auto frags = [&](int sidx, int set) {
             const int tc = sidx >> 1, ks = sidx & 1;
             const bool live = tc == 0 ? left_ok : tc == 2 ? right_ok : true;
@@ -784,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
             if (tc != 1) { h_ = live ? h_ : zero8; l_ = live ? l_ : zero8; }
             ah[set] = h_; al[set] = l_;
 #pragma unroll
-            for (int n = 0; n < 3; ++n) {
+            for (int n = 0; n < NB; ++n) {
                 wh[set][n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
                 wl[set][n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2 + 1) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
             }
@@ -795,11 +803,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
             const int set = sidx & 1;
             if (sidx + 1 < 6) frags(sidx + 1, set ^ 1);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[set][n], ah[set], acc[n], 0, 0, 0);
+            for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[set][n], ah[set], acc[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[set][n], al[set], acc[n], 0, 0, 0);
+            for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[set][n], al[set], acc[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[set][n], ah[set], acc[n], 0, 0, 0);
+            for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[set][n], ah[set], acc[n], 0, 0, 0);
         }
         __syncthreads();                 // step k + 1 landed (vmcnt(0)) and every wave is done reading stage cur
     }
@@ -808,14 +816,24 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
     const long pp = p0 + 32 * wave + l31;
     if (pp >= P_total) return;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bv[12], rv[12], sv[12];
+    f32x4 bv[4 * NB], rv[4 * NB], sv[4 * NB];
     const bool with_res = p.out_mode == 0 && p.res;
     const float inv_a = 1.0f / p.in_scale;
     const long po = pp + (long)p.t_out_off * HoWo;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < 4 * NB; ++i) {
         const int co = co0 + 32 * (i >> 2) + 8 * (i & 3) + 4 * hi;
         const bool ok = co < p.Cout;
+        if (NB == 1 && ok && co + 4 > p.Cout) {      // the partial last group of a narrow head: element-wise, pad channels read as zeros
+            bv[i] = zero4; sv[i] = zero4; rv[i] = zero4;
+            for (int e = 0; e < 4; ++e)
+                if (co + e < p.Cout) {
+                    if (p.bias) bv[i][e] = p.bias[co + e];
+                    sv[i][e] = p.w2_inv[co + e] * inv_a;
+                    if (with_res) rv[i][e] = p.res[po * p.ld_res + co + e];
+                }
+            continue;
+        }
         bv[i] = (ok && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + co) : zero4;
         rv[i] = (ok && with_res) ? *reinterpret_cast<const f32x4*>(p.res + po * p.ld_res + co) : zero4;
         sv[i] = ok ? *reinterpret_cast<const f32x4*>(p.w2_inv + co) * inv_a : zero4;
@@ -828,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
         pq0 = (long)(1 + 2 * (t - 1)) * HoWo + sp;
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < 4 * NB; ++i) {
         const int n = i >> 2, rg = i & 3;
         const int co = co0 + 32 * n + 8 * rg + 4 * hi;
         if (co >= p.Cout) continue;
@@ -836,7 +854,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (acc[n][4 * rg + e] * sv[i][e] + bv[i][e]) + rv[i][e];
         if (p.out_mode == 0) {
-            *reinterpret_cast<f32x4*>(p.out + po * p.ld_out + co) = v;
+            *reinterpret_cast<f32x4*>(p.out + po * p.ld_out + co) = v;       // (narrow head: co + 4 <= ld_out, launch_conv_planes checks)
         } else {
             const int j = co >= half ? 1 : 0;
             *reinterpret_cast<f32x4*>(p.out + (pq0 + (long)j * HoWo) * p.ld_out + (co - j * half)) = v;
@@ -846,21 +864,33 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
 
 // Can a convolution take its input as the producer's two fp16 planes (conv_dma2h_kernel)?  Decided BEFORE the producer runs.
 bool conv_planes_ok(const ConvP& p) {
+    const bool vec_ok = (((uintptr_t)p.w2_inv | (uintptr_t)p.bias) & 15) == 0;
+    const bool wide = p.Cout >= 64 && p.Cout % 4 == 0 && vec_ok && (p.out_mode == 0 || (p.Cout / 2) % 4 == 0);
+    const bool narrow = p.Cout <= 32 && p.out_mode == 0 && (p.Cout % 4 != 0 || vec_ok);          // one 32-channel block; any channel count (conv_dma2h_kernel<1>)
     return p.w2h && p.w2_inv && p.in_scale > 0.f && !svi_switches().vae_no_x2h && !svi_switches().vae_exact_fp32 && svi_switches().vae_dma &&
-           (((uintptr_t)p.w2_inv) & 15) == 0 && p.Cin % 32 == 0 && p.ld_in == p.Cin && !p.ups && p.Cout >= 64 && p.Cout % 4 == 0 &&
+           p.Cin % 32 == 0 && p.ld_in == p.Cin && !p.ups && (wide || narrow) &&
            p.kw == 3 && p.kh == 3 && p.kt * p.kh <= 32 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
-           !p.act_silu && !p.out_bf16 && (p.out_mode == 0 || (p.Cout / 2) % 4 == 0) &&
+           !p.act_silu && !p.out_bf16 &&
            (long)(p.kt + 3) * p.Hi * p.Wi * p.ld_in * 2 < 0xFFE00000L && (long)2 * p.plane_w3 * 2 < 0xFFE00000L;
 }
 
 svi_status launch_conv_planes(const ConvP& p, hipStream_t st) {
     SVI_REQUIRE(conv_planes_ok(p) && p.in_h && p.in_l, "conv: this layer cannot take fp16 input planes");
-    SVI_REQUIRE(p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) && (((uintptr_t)p.bias | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0, "conv: output / residual alignment");
+    SVI_REQUIRE(p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) && (((uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0, "conv: output / residual alignment");
     const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
     if (pixels <= 0) return SVI_OK;
-    dim3 grid((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block(512);
-    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel), 2 * D2_STAGE));
-    hipLaunchKernelGGL(conv_dma2h_kernel, grid, block, 2 * D2_STAGE, st, p);
+    if (p.Cout <= 32) {                  // narrow head
+        SVI_REQUIRE((p.Cout + 3) / 4 * 4 <= p.ld_out && (!p.res || (p.Cout + 3) / 4 * 4 <= p.ld_res), "conv: a narrow head writes whole groups of four channels (Cout=%d, ld_out=%d)", p.Cout, p.ld_out);
+        SVI_REQUIRE(p.Cout % 4 != 0 || (((uintptr_t)p.bias | (uintptr_t)p.w2_inv) & 15) == 0, "conv: bias / scale alignment");
+        dim3 grid((unsigned)((pixels + X3_PIX - 1) / X3_PIX), 1), block(512);
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel<1>), 2 * D2_STAGE));
+        hipLaunchKernelGGL(conv_dma2h_kernel<1>, grid, block, 2 * D2_STAGE, st, p);
+    } else {
+        SVI_REQUIRE((((uintptr_t)p.bias) & 15) == 0, "conv: bias alignment");
+        dim3 grid((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block(512);
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel<3>), 2 * D2_STAGE));
+        hipLaunchKernelGGL(conv_dma2h_kernel<3>, grid, block, 2 * D2_STAGE, st, p);
+    }
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
@@ -954,6 +984,15 @@ namespace {
 // ---- RMS_norm over channels (+SiLU):  x / max(||x||_2, 1e-12) * sqrt(C) * gamma   (vae:55-70, 207-209) ----
 // Eight lanes per pixel, 16 bytes per lane and access: lane q of a pixel owns channels 4 q + 32 i .. + 3, so every wave instruction moves
 // eight whole 128-byte segments (was: 32 lanes per pixel with 4-byte accesses, 3.4 TB/s on the 12.4 GB layers).  C % 4 == 0.
+// Arithmetic per element (both kernels, one function): the pixel's factor sqrt(C) / max(||x||, eps) is formed once (IEEE division), then
+// y = x * factor * gamma and SiLU as y * rcp(1 + exp2(-y log2 e)) on the hardware's v_exp / v_rcp (1 ulp each).  (Was: two IEEE divisions
+// and an expf per element, ~40 VALU instructions against 8 bytes of traffic — the 12.4 GB layers ran at 4.4 TB/s, arithmetic-bound.)
+__device__ __forceinline__ float norm_silu_el(float x, float factor, float g, int do_silu) {
+    const float y = x * factor * g;
+    if (!do_silu) return y;
+    const float e = __builtin_amdgcn_exp2f(y * -1.4426950408889634f);
+    return y * __builtin_amdgcn_rcpf(1.0f + e);
+}
 template <int MAXI>
 __global__ __launch_bounds__(256) void rms_silu_kernel(const float* __restrict__ in, float* __restrict__ out, long pixels,
                                                        int C, const float* __restrict__ gamma, int do_silu) {
@@ -975,8 +1014,7 @@ __global__ __launch_bounds__(256) void rms_silu_kernel(const float* __restrict__
     }
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    const float denom = fmaxf(sqrtf(ss), 1e-12f);
-    const float scale = sqrtf((float)C);
+    const float factor = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
     float* op = out + px * C;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
@@ -985,11 +1023,7 @@ __global__ __launch_bounds__(256) void rms_silu_kernel(const float* __restrict__
             const float g[4] = {gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]};      // borrowed parameter: no alignment promise beyond 4 bytes
             f32x4 y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = v[i][e] / denom * scale * g[e];
-                if (do_silu) t = t / (1.0f + expf(-t));
-                y[e] = t;
-            }
+            for (int e = 0; e < 4; ++e) y[e] = norm_silu_el(v[i][e], factor, g[e], do_silu);
             *reinterpret_cast<f32x4*>(op + c) = y;
         }
     }
@@ -1010,6 +1044,7 @@ svi_status launch_rms_silu(const float* in, float* out, long pixels, int C, cons
 // The same RMS_norm (+ SiLU), written as the two fp16 words the two-term convolution multiplies: hi = f16(y s), lo = f16(y s - hi) with the
 // power-of-two scale s the bound of y allows (|y| s <= 2^15) — exactly the split conv_igemm_x3_kernel<true> performs on the fly, done ONCE by
 // the producer.  Planes are channels-last [pixel][C] fp16; together they are as large as the fp32 tensor they replace.
+// Eight lanes per pixel; lane q owns channels 8 q + 64 i .. + 7 (two 16-byte loads, ONE 16-byte store per plane).  C % 8 == 0.
 template <int MAXI>
 __global__ __launch_bounds__(256) void rms_silu_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ out_h, unsigned short* __restrict__ out_l,
                                                               long pixels, int C, const float* __restrict__ gamma, int do_silu, float s) {
@@ -1017,51 +1052,51 @@ __global__ __launch_bounds__(256) void rms_silu_planes_kernel(const float* __res
     const int q = threadIdx.x & 7;
     if (px >= pixels) return;
     const float* ip = in + px * C;
-    f32x4 v[MAXI];
+    f32x4 v[MAXI][2];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int c = 4 * q + 32 * i;
-        if (c < C) v[i] = *reinterpret_cast<const f32x4*>(ip + c);
-        else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ss += v[i][0] * v[i][0];
-        ss += v[i][1] * v[i][1];
-        ss += v[i][2] * v[i][2];
-        ss += v[i][3] * v[i][3];
+        const int c = 8 * q + 64 * i;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (c < C) v[i][hf] = *reinterpret_cast<const f32x4*>(ip + c + 4 * hf);
+            else v[i][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ss += v[i][hf][0] * v[i][hf][0];
+            ss += v[i][hf][1] * v[i][hf][1];
+            ss += v[i][hf][2] * v[i][hf][2];
+            ss += v[i][hf][3] * v[i][hf][3];
+        }
     }
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    const float denom = fmaxf(sqrtf(ss), 1e-12f);
-    const float scale = sqrtf((float)C);
+    const float factor = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int c = 4 * q + 32 * i;
+        const int c = 8 * q + 64 * i;
         if (c < C) {
-            const float g[4] = {gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]};
-            u16x4 hh, ll;
+            u16x8 hh, ll;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = v[i][e] / denom * scale * g[e];
-                if (do_silu) t = t / (1.0f + expf(-t));
+            for (int e = 0; e < 8; ++e) {
+                const float t = norm_silu_el(v[i][e >> 2][e & 3], factor, gamma[c + e], do_silu);
                 const f16 hw = (f16)(t * s);
                 hh[e] = bits16(hw);
                 ll[e] = bits16((f16)__builtin_fmaf(t, s, -(float)hw));
             }
-            *reinterpret_cast<u16x4*>(out_h + px * C + c) = hh;
-            *reinterpret_cast<u16x4*>(out_l + px * C + c) = ll;
+            *reinterpret_cast<u16x8*>(out_h + px * C + c) = hh;
+            *reinterpret_cast<u16x8*>(out_l + px * C + c) = ll;
         }
     }
 }
 
 svi_status launch_rms_silu_planes(const float* in, unsigned short* out_h, unsigned short* out_l, long pixels, int C, const float* gamma, int do_silu, float s,
                                   hipStream_t st) {
-    SVI_REQUIRE(C <= 384 && C % 4 == 0 && s > 0.f, "vae rms norm (planes): C=%d", C);
-    SVI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out_h % 8) == 0 && ((uintptr_t)out_l % 8) == 0, "vae rms norm (planes): alignment");
+    SVI_REQUIRE(C <= 384 && C % 8 == 0 && s > 0.f, "vae rms norm (planes): C=%d", C);
+    SVI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out_h % 16) == 0 && ((uintptr_t)out_l % 16) == 0, "vae rms norm (planes): alignment");
     if (pixels <= 0) return SVI_OK;
     dim3 grid((unsigned)((pixels + 31) / 32)), block(256);
-    if (C <= 96) hipLaunchKernelGGL(rms_silu_planes_kernel<3>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
-    else if (C <= 192) hipLaunchKernelGGL(rms_silu_planes_kernel<6>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
-    else hipLaunchKernelGGL(rms_silu_planes_kernel<12>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
+    if (C <= 128) hipLaunchKernelGGL(rms_silu_planes_kernel<2>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
+    else if (C <= 192) hipLaunchKernelGGL(rms_silu_planes_kernel<3>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
+    else hipLaunchKernelGGL(rms_silu_planes_kernel<6>, grid, block, 0, st, in, out_h, out_l, pixels, C, gamma, do_silu, s);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
@@ -1660,7 +1695,7 @@ svi_status decode_graph(svi_vae* h, const float* latents, float* video, int T, i
         if (i != 3) SVI_TRY(upsample_block(h, d + "upsamples." + std::to_string(idx++) + ".", &x, tup[i], st));
     }
     Tens n, rgb;
-    SVI_TRY(norm_act(h, d + "head.0.gamma", x, &n, 1, st));
+    SVI_TRY(norm_act(h, d + "head.0.gamma", x, &n, 1, st, planes_scale_for(h, d + "head.2", d + "head.0.gamma", x)));
     free_t(h, x);
     SVI_TRY(conv_layer(h, d + "head.2", n, &rgb, st));
     free_t(h, n);
@@ -1698,7 +1733,7 @@ svi_status encode_graph(svi_vae* h, const float* video, float* latents, int T, i
     SVI_TRY(attn_block(h, e + "middle.1.", &x, st));
     SVI_TRY(res_block(h, e + "middle.2.", &x, st));
     Tens n, hd, mu;
-    SVI_TRY(norm_act(h, e + "head.0.gamma", x, &n, 1, st));
+    SVI_TRY(norm_act(h, e + "head.0.gamma", x, &n, 1, st, planes_scale_for(h, e + "head.2", e + "head.0.gamma", x)));
     free_t(h, x);
     SVI_TRY(conv_layer(h, e + "head.2", n, &hd, st));
     free_t(h, n);
@@ -1810,7 +1845,8 @@ extern "C" svi_status svi_vae_bind_weight(svi_vae* h, const char* name, const vo
         if (e != hipSuccess) { svi_set_error("hipMalloc(packed VAE weight) failed: %s", hipGetErrorString(e)); return SVI_ERR_OOM; }
     }
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, cw.w_user, cw.packed, cw.Cout, cw.Cin, taps, cw.ldw);
-    if (cw.Cout >= 64) {               // layers wide enough for conv_igemm_x3_kernel also get the three-term bf16 form
+    const bool narrow_head = cw.Cout <= 32 && cw.kh == 3 && cw.kw == 3 && cw.Cin % 32 == 0;       // conv_dma2h_kernel<1> (two-term fp16 form on the producer's planes)
+    if (cw.Cout >= 64 || narrow_head) {               // layers wide enough for conv_igemm_x3_kernel get the three-term bf16 form and the two-term fp16 form
         cw.ldw3 = (cw.Cin + 31) / 32 * 32;
         const size_t n3 = (size_t)taps * cw.Cout * cw.ldw3;
         if (!cw.packed3) {
