@@ -40,6 +40,8 @@ static SviSwitches parse_switches() {
     s.cross_dedup = env_int("SVI_CROSS_DEDUP", 0, 1);
     s.vae_dma = env_int("SVI_VAE_DMA", 0, 1);
     s.vae_up_phases = env_int("SVI_VAE_UP_PHASES", 0, 1);
+    s.flash_split = env_int("SVI_FLASH_SPLIT", 0, 0);
+    if (s.flash_split > 4) s.flash_split = 4;
     { const char* v = getenv("SVI_T5_BUCKETS"); s.t5_host_buckets = v && strcmp(v, "host") == 0; }
 #ifdef SVI_ABLATIONS
     s.flash_abl = env_int("SVI_FLASH_ABL", 0, 0);
@@ -326,7 +328,7 @@ extern "C" svi_status svi_rmsnorm_rope(void* x, int32_t ld, int32_t rows, int32_
     if (e == hipSuccess) e = hipDeviceSynchronize();
     free(host);
     if (e != hipSuccess) { svi_set_error("hipMemcpy(rope table) failed: %s", hipGetErrorString(e)); return SVI_ERR_HIP; }
-    SviRope r;
+    SviRope r{};
     r.tab_f = reinterpret_cast<const float2*>(scr);
     r.tab_h = r.tab_f + (size_t)f * npf;
     r.tab_w = r.tab_h + (size_t)h * nph;

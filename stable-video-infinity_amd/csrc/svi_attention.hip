@@ -514,7 +514,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                                                             const bf16* __restrict__ K, int ldk,
                                                             const bf16* __restrict__ VT, int ldvt,
                                                             bf16* __restrict__ O, int ldo, int Lq, int Lk,
-                                                            float scale_log2e, int* __restrict__ flags) {
+                                                            float scale_log2e, int* __restrict__ flags,
+                                                            float* __restrict__ opart, float2* __restrict__ ml) {
     constexpr bool OPT = MODE == 1;
     // BAL (optimistic kernel only): one score per MFMA statement everywhere.  The optimistic pass never waits for a row maximum, so the
     // exponentials of tile t can start as soon as S(t) is complete: its 32 score pairs per lane are spread as
@@ -527,7 +528,18 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     // rg(f, dma): the row-group statement (0 or 1) of fragment f behind which that fragment's look-ahead LDS read is issued: normally g = 0;
     // where the g = 0 statement also issues an LDS-DMA piece (s_mov m0 + buffer_load ... lds on top of its score), the g = 1 statement
     constexpr bool SPLIT = BAL && (SVI_FLASH_DMA_SPLIT != 0);
-    const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x;
+    const int wg_linear = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // Split key axis (gridDim.z > 1; svi_launch_flash decides): workgroup z sees keys [k0, k1) — whole tiles — as if they were the whole
+    // problem and leaves its UNNORMALISED O (fp32), reference maximum and row sum in opart / ml; flash_combine_kernel merges the splits.
+    int vt_skip = 0;
+    if (gridDim.z > 1) {
+        const int tiles = (Lk + KB - 1) / KB, per = (tiles + (int)gridDim.z - 1) / (int)gridDim.z;
+        const int k0 = (int)blockIdx.z * per * KB, k1 = min(Lk, k0 + per * KB);
+        K += (size_t)k0 * ldk;
+        VT += k0;
+        vt_skip = k0;
+        Lk = k1 - k0;
+    }
     if constexpr (MODE == 2) {
         if (flags[wg_linear] == 0) return;          // uniform: the whole workgroup leaves before any barrier
     }
@@ -576,7 +588,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         k_rs[0] = (unsigned)kb; k_rs[1] = (unsigned)(kb >> 32) & 0xffffu;
         k_rs[2] = (unsigned)(((size_t)(Lk - 1) * ldk + (size_t)(head + 1) * DH) * 2); k_rs[3] = 0x00020000u;
         v_rs[0] = (unsigned)vb; v_rs[1] = (unsigned)(vb >> 32) & 0xffffu;
-        v_rs[2] = (unsigned)(((size_t)((head + 1) * DH - 1) * ldvt + (size_t)ldvt) * 2); v_rs[3] = 0x00020000u;
+        v_rs[2] = (unsigned)(((size_t)((head + 1) * DH - 1) * ldvt + (size_t)ldvt - (size_t)vt_skip) * 2); v_rs[3] = 0x00020000u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             k_rs[i] = __builtin_amdgcn_readfirstlane(k_rs[i]);
@@ -932,6 +944,30 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     }
     // ---- normalise and store: a[(g*4+d)*16 + r] is O[row][32 d + (r&3) + 8 (r>>2) + 4 hi] ----------------------
     asm("s_nop 15" : "+v"(tok));                // last MFMA result -> v_accvgpr_read wait states
+    if (opart) {                                // one split of the key axis: unnormalised O, reference maximum, row sum
+        const int ldp = (int)gridDim.y * DH;
+        static_for<0, 2>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[g]), __float_as_uint(l_run[g]), false, false);
+            const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            const int qr = row0 + 32 * g;
+            if (qr < Lq && hi == 0) ml[((size_t)blockIdx.z * gridDim.y + head) * Lq + qr] = make_float2(m_ref[g], l);
+            float* op = opart + ((size_t)blockIdx.z * Lq + min(qr, Lq - 1)) * ldp + head * DH + 4 * hi;
+            static_for<0, 4>([&](auto dc) {
+                constexpr int d = decltype(dc)::value;
+                static_for<0, 4>([&](auto qc) {
+                    constexpr int rg = decltype(qc)::value;
+                    f32x4 v;
+                    v[0] = o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 0>(tok);
+                    v[1] = o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 1>(tok);
+                    v[2] = o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 2>(tok);
+                    v[3] = o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 3>(tok);
+                    if (qr < Lq) *reinterpret_cast<f32x4*>(op + 32 * d + 8 * rg) = v;
+                });
+            });
+        });
+        return;
+    }
     static_for<0, 2>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[g]), __float_as_uint(l_run[g]), false, false);
@@ -951,6 +987,51 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             });
         });
     });
+}
+
+// Merge the splits of the key axis: O = sum_s w_s O_s / sum_s w_s l_s with w_s = 2^((M_s - max M) cs) — the same softmax, each split's
+// exponentials re-referenced to the common maximum.  One thread per (row, head, 4 channels).
+__global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restrict__ opart, const float2* __restrict__ ml, bf16* __restrict__ O, int ldo,
+                                                            int Lq, int H, int S, float cs) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = (int)(i & 31);
+    const long rh = i >> 5;
+    const int head = (int)(rh % H);
+    const long row = rh / H;
+    if (row >= Lq) return;
+    float m = -INFINITY;
+    float2 st[4];
+    for (int s = 0; s < S; ++s) { st[s] = ml[((size_t)s * H + head) * Lq + row]; m = fmaxf(m, st[s].x); }
+    float den = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const float w = __builtin_amdgcn_exp2f((st[s].x - m) * cs);
+        den += w * st[s].y;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(opart + ((size_t)s * Lq + row) * ((size_t)H * DH) + head * DH + 4 * c4);
+        acc += v * w;
+    }
+    const float inv = 1.0f / den;
+    bf16x4 pk;
+    pk[0] = (bf16)(acc[0] * inv); pk[1] = (bf16)(acc[1] * inv); pk[2] = (bf16)(acc[2] * inv); pk[3] = (bf16)(acc[3] * inv);
+    *reinterpret_cast<bf16x4*>(O + (size_t)row * ldo + head * DH + 4 * c4) = pk;
+}
+
+// How many pieces to cut the key axis into.  A launch is (q-blocks x heads) workgroups of equal length on `cus` compute units, one
+// workgroup per unit: its time is ceil(n / cus) rounds.  With S splits it is ceil(n S / cus) / S rounds (plus the merge): worth it when
+// the last round is poorly filled — a sequence-parallel rank's 3 heads x 128 q-blocks = 384 workgroups on 256 units take 2 rounds whole
+// and 1.5 in halves.  SVI_FLASH_SPLIT: 0 = decide here (default), 1 = never (bit-identical to the unsplit kernel), 2..4 = that many.
+static int flash_splits(long nwg, int Lk, int cus) {
+    const int want = svi_switches().flash_split;
+    const int max_by_keys = Lk / 4096;                               // every piece keeps a long key axis (prologue and merge stay small)
+    if (want == 1 || max_by_keys < 2) return 1;
+    if (want >= 2) return min(min(want, 4), max_by_keys);
+    int best = 1;
+    double best_t = (double)((nwg + cus - 1) / cus);
+    for (int S = 2; S <= min(4, max_by_keys); ++S) {
+        const double t = (double)((nwg * S + cus - 1) / cus) / S * (1.0 + 0.01 * S);     // ~1 % per piece: prologue, partial store, merge
+        if (t < best_t * 0.95) { best = S; best_t = t; }
+    }
+    return best;
 }
 
 // One flag word per workgroup of the optimistic attention pass, in a buffer of its own per (device, stream): launches on one stream
@@ -1001,10 +1082,25 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     const SviSwitches& sw = svi_switches();
     const bool v2 = sw.flash_kernel ? sw.flash_kernel == 2 : (Lk >= 2048);     // short key axes (text context) are prologue-bound: v1
     if (v2) {
-        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*);
+        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*, float*, float2*);
         const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
         dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
-        const long nwg = (long)grid2.x * grid2.y;
+        static int cus[64] = {0};                                // compute units per device
+        const int dev = svi_current_device();
+        if (dev < 0) return SVI_ERR_HIP;
+        if (dev < 64 && !cus[dev]) { int n = 0; SVI_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev)); cus[dev] = n > 0 ? n : 256; }
+        const int nsplit = flash_splits((long)grid2.x * grid2.y, Lk, dev < 64 ? cus[dev] : 256);
+        grid2.z = nsplit;
+        float* opart = nullptr;
+        float2* ml = nullptr;
+        if (nsplit > 1) {
+            const size_t o_bytes = (size_t)nsplit * Lq * num_heads * DH * 4, ml_bytes = (size_t)nsplit * num_heads * Lq * sizeof(float2);
+            void* pbuf = nullptr;
+            SVI_TRY(svi_stream_buffer(SVI_BUF_FLASH_SPLIT, st, o_bytes + ml_bytes, &pbuf, nullptr));
+            opart = reinterpret_cast<float*>(pbuf);
+            ml = reinterpret_cast<float2*>(reinterpret_cast<char*>(pbuf) + o_bytes);
+        }
+        const long nwg = (long)grid2.x * grid2.y * grid2.z;
         // optimistic pass + flagged second pass (see the kernel's MODE): needs the per-device flag words
         int* flags = nullptr;
         bool two_pass = sw.flash_two_pass != 0 && nwg <= SVI_FLASH_MAX_FLAGS;
@@ -1045,13 +1141,19 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         }
 #endif
         SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(kern), lds2));
-        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags);
+        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml);
         SVI_LAUNCH_CHECK();
         if (two_pass) {
             kern_t safe = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false, 2> : flash_fwd2_kernel<1, 0, false, 2>)
                                       : (Lq == Lk ? flash_fwd2_kernel<0, 0, true, 2> : flash_fwd2_kernel<1, 0, true, 2>);
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(safe), lds2));
-            hipLaunchKernelGGL(safe, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags);
+            hipLaunchKernelGGL(safe, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml);
+            SVI_LAUNCH_CHECK();
+        }
+        if (nsplit > 1) {
+            const long threads = (long)Lq * num_heads * 32;
+            hipLaunchKernelGGL(flash_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, opart, ml, O, ldo, Lq, num_heads, nsplit,
+                               q_prescaled ? 1.0f : scale_log2e);
             SVI_LAUNCH_CHECK();
         }
         return SVI_OK;

@@ -70,6 +70,8 @@ struct SviSwitches {
                                  // instead of four 2x2 convolutions of the small image with pre-summed kernels (4 taps; same sum up to fp32 rounding of the weights)
     int flash_two_pass = 1;      // SVI_FLASH_TWO_PASS = 0 : the long-sequence attention as ONE complete pass (tracked maximum) instead of the
                                  // optimistic pass + flagged second pass (same result within the attention tolerance; bit-identical on benign operands)
+    int flash_split = 0;         // SVI_FLASH_SPLIT = 1 : never cut the key axis of the long-sequence attention (bit-identical to the unsplit kernel); 2..4: that many
+                                 // pieces wherever the key axis allows; 0 (default): where the workgroup count fills the chip's last round poorly (svi_attention.hip)
     int cross_dedup = 1;         // SVI_CROSS_DEDUP = 0 : cross-attention walks every context row even where the prompt embedding's trailing rows are
                                  // identical (the prompter's zero padding); default: m identical keys = one key counted m times (same softmax)
     int t5_host_buckets = 0;     // SVI_T5_BUCKETS = host : the text encoder's relative-position bucket table in the HOST's fp32 arithmetic (what the
@@ -84,7 +86,7 @@ const SviSwitches& svi_switches();
 svi_status svi_ensure_lds(const void* kernel, int bytes);
 // Library-owned device buffers outside any handle, one per (device, stream, kind); see svi_api.hip.  `user_out`: a host-side word
 // that lives with the buffer (only the thread driving that stream touches it).
-enum SviBufKind { SVI_BUF_FLASH_FLAGS = 0, SVI_BUF_SEAM_SCRATCH = 1, SVI_BUF_SEAM_SMALL = 2 };
+enum SviBufKind { SVI_BUF_FLASH_FLAGS = 0, SVI_BUF_SEAM_SCRATCH = 1, SVI_BUF_SEAM_SMALL = 2, SVI_BUF_FLASH_SPLIT = 3 };
 svi_status svi_stream_buffer(int kind, hipStream_t st, size_t bytes, void** out, long** user_out);
 // The device current on this thread, or -1 (message set).
 int svi_current_device();
@@ -177,6 +179,7 @@ struct SviRope {                // device tables of (cos,sin) pairs, fp32
     int f, h, w;
     int row0;                   // token index of row 0 of the launch (sequence-parallel shards start mid-grid)
     int period;                 // > 0: rows are `rows / period` samples stacked one under the other; token = (row0 + row) % period
+    const float2* tab_tok;      // optional: [f*h*w][64] — every token's 64 pairs gathered from the axis tables (16-byte aligned); the DiT builds it once per grid
 };
 // Sequence-parallel send layout (svi_hip/sequence_parallel.py): instead of in place, operand p of the q | k launch is stored as
 // out[p][g][j][row][cg] — destination rank j = col / Dp owns head-channel block [j*Dp, (j+1)*Dp), inside it head group g = (col % Dp) / Dg,

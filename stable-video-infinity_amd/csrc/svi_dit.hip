@@ -431,6 +431,20 @@ static svi_status stage_ctx_tail(const bf16* context, int Lc, int text_dim, int*
     return SVI_OK;
 }
 
+// token -> its 64 (cos, sin) pairs, gathered once from the three axis tables: the q | k normalisation then reads 32 contiguous bytes per
+// lane and chunk instead of four 8-byte table lookups behind three integer divisions
+__global__ void rope_token_table_kernel(SviRope r, float2* __restrict__ out, int tokens) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)tokens * 64) return;
+    const int tok = (int)(i >> 6), pi = (int)(i & 63);
+    const int hw = r.h * r.w, pf = tok / hw, rem = tok - pf * hw, ph = rem / r.w, pw = rem - ph * r.w;
+    float2 cs;
+    if (pi < r.npf) cs = r.tab_f[pf * r.npf + pi];
+    else if (pi < r.npf + r.nph) cs = r.tab_h[ph * r.nph + (pi - r.npf)];
+    else cs = r.tab_w[pw * r.npw + (pi - r.npf - r.nph)];
+    out[i] = cs;
+}
+
 // precompute_freqs_cis_3d (models/wan_video_dit.py:161-175): fp64 angles, stored as fp32 (cos, sin)
 static svi_status ensure_rope(svi_dit* h, int f, int hh, int ww) {
     if (h->rope_dev && h->rf == f && h->rh == hh && h->rw == ww) return SVI_OK;
@@ -447,16 +461,23 @@ static svi_status ensure_rope(svi_dit* h, int f, int hh, int ww) {
             }
     };
     fill(f, d_f, npf); fill(hh, d_hw, nph); fill(ww, d_hw, npw);
-    if (h->rope_dev) { SVI_CHECK_HIP(hipFree(h->rope_dev)); h->rope_dev = nullptr; }
-    SVI_CHECK_HIP(hipMalloc((void**)&h->rope_dev, host.size() * sizeof(float2)));
+    if (h->rope_dev) { SVI_CHECK_HIP(hipDeviceSynchronize()); SVI_CHECK_HIP(hipFree(h->rope_dev)); h->rope_dev = nullptr; ++h->generation; }
+    const size_t n_axis = (host.size() + 1) & ~(size_t)1;            // the per-token table behind the axis tables, 16-byte aligned
+    const size_t tokens = (size_t)f * hh * ww;
+    SVI_REQUIRE(tokens * 64 < ((size_t)1 << 31), "rope: grid %dx%dx%d too large", f, hh, ww);
+    SVI_CHECK_HIP(hipMalloc((void**)&h->rope_dev, (n_axis + tokens * 64) * sizeof(float2)));
     SVI_CHECK_HIP(hipMemcpy(h->rope_dev, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
-    SVI_CHECK_HIP(hipDeviceSynchronize());
     h->rf = f; h->rh = hh; h->rw = ww;
     h->rope.tab_f = h->rope_dev;
     h->rope.tab_h = h->rope_dev + (size_t)f * npf;
     h->rope.tab_w = h->rope.tab_h + (size_t)hh * nph;
     h->rope.npf = npf; h->rope.nph = nph; h->rope.npw = npw;
     h->rope.f = f; h->rope.h = hh; h->rope.w = ww;
+    h->rope.tab_tok = nullptr;
+    hipLaunchKernelGGL(rope_token_table_kernel, dim3((unsigned)((tokens * 64 + 255) / 256)), dim3(256), 0, 0, h->rope, h->rope_dev + n_axis, (int)tokens);
+    SVI_LAUNCH_CHECK();
+    SVI_CHECK_HIP(hipDeviceSynchronize());
+    h->rope.tab_tok = h->rope_dev + n_axis;
     return SVI_OK;
 }
 

@@ -130,10 +130,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
     }
     const float rs = rsqrtf(wave_sum(ss) / (float)dim + eps);
     int pf = 0, ph = 0, pw = 0;
+    const float2* tt = nullptr;                  // this token's 64 pairs, when the caller gathered them (SviRope::tab_tok)
     if (use_rope) {
         const int hw = r.h * r.w;
         int tok = row + r.row0;
         if (r.period > 0) tok %= r.period;
+        if (r.tab_tok) tt = r.tab_tok + (size_t)tok * 64;
         pf = tok / hw;
         const int rem = tok - pf * hw;
         ph = rem / r.w;
@@ -151,11 +153,17 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
             bf16x8 o;
             if (use_rope) {
                 const int pair0 = (col & 127) >> 1;            // complex-pair index inside the head
+                f32x4 t01 = {0.f, 0.f, 0.f, 0.f}, t23 = t01;
+                if (tt) {
+                    t01 = *reinterpret_cast<const f32x4*>(tt + pair0);
+                    t23 = *reinterpret_cast<const f32x4*>(tt + pair0 + 2);
+                }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int pi = pair0 + p;
                     float2 cs;
-                    if (pi < r.npf) cs = r.tab_f[pf * r.npf + pi];
+                    if (tt) cs = p == 0 ? make_float2(t01[0], t01[1]) : p == 1 ? make_float2(t01[2], t01[3]) : p == 2 ? make_float2(t23[0], t23[1]) : make_float2(t23[2], t23[3]);
+                    else if (pi < r.npf) cs = r.tab_f[pf * r.npf + pi];
                     else if (pi < r.npf + r.nph) cs = r.tab_h[ph * r.nph + (pi - r.npf)];
                     else cs = r.tab_w[pw * r.npw + (pi - r.npf - r.nph)];
                     const float a = y[2 * p], bq = y[2 * p + 1];

@@ -117,13 +117,28 @@ def test_dit_c2_geometry_pair_cache_determinism(hip):
 @pytest.mark.parametrize("P", [2, 4])
 def test_sequence_parallel_c2_geometry(hip, P):
     """The Ulysses schedule at C2 size: shards of 16380 / 8190 rows (ragged against every tile size), 6 / 3 heads per rank, the
-    256^2 GEMM and the long-sequence attention kernel on shard-local buffers — same bits as the single-rank forward."""
-    from svi_hip import sequence_parallel as sp
+    256^2 GEMM and the long-sequence attention kernel on shard-local buffers — same bits as the single-rank forward with the attention's
+    key axis in one piece (SVI_FLASH_SPLIT=1).  By default a rank whose heads x q-blocks fill the chip's last round poorly (P = 4: 3 x 128
+    = 384 workgroups on 256 compute units) cuts the key axis in two and merges the halves: the same softmax with another rounding
+    sequence — equal to the single-rank forward to bf16 rounding (rel-L2 <= 4e-3 on the two-block output), not bit for bit."""
+    from svi_hip import sequence_parallel as sp, _lib as L
+    from gpu_util import report
     ms = _wan13b_two_blocks(hip, P + 1)
     x, ctx, t = _rnd(20, 1, 16, 21, 60, 104), _rnd(21, 1, 512, 4096), torch.tensor([991.7355])
     want = ms[-1].forward(x, t, ctx)
     got = sp.forward_local(ms[:P], x, t, ctx)
-    assert torch.equal(got, want)
+    same = bool(torch.equal(got, want))
+    r = _rel(got.float().cpu(), want.float().cpu())
+    report("sp_c2_geometry_default_vs_single_rank", P=P, identical=same, rel_l2=r)
+    assert torch.isfinite(got.float()).all() and r < 4e-3, r
+    if P == 2:
+        assert same                      # 6 x 128 = 768 workgroups: three whole rounds, nothing to split
+    L.set_switch("SVI_FLASH_SPLIT", 1)
+    try:
+        whole = sp.forward_local(ms[:P], x, t, ctx)
+    finally:
+        L.set_switch("SVI_FLASH_SPLIT", None)
+    assert torch.equal(whole, want)
 
 
 def test_dit_c2_geometry_vs_cpu_oracle(hip):
@@ -151,11 +166,19 @@ def test_dit_c2_geometry_vs_cpu_oracle(hip):
 
 def test_dit_720p_geometry(hip):
     """81 frames at 1280x720 (the I2V-720P configuration's grid, 21x45x80 = 75600 tokens) at 1.3B widths, one block: finite,
-    deterministic, and the two-rank sequence-parallel schedule reproduces it bit for bit."""
-    from svi_hip import sequence_parallel as sp
+    deterministic, and the two-rank sequence-parallel schedule reproduces it — bit for bit with the attention's key axis in one piece
+    (SVI_FLASH_SPLIT=1), to bf16 rounding by default (the schedule's head groups launch 2 heads x 296 q-blocks = 592 workgroups on 256
+    compute units at a time, which the launcher cuts into two key halves: 2.5 instead of 3 rounds)."""
+    from svi_hip import sequence_parallel as sp, _lib as L
     ms = _wan13b_two_blocks(hip, 3, layers=1)
     x, ctx, t = _rnd(30, 1, 16, 21, 90, 160), _rnd(31, 1, 512, 4096), torch.tensor([500.0])
     a = ms[-1].forward(x, t, ctx)
     assert a.shape == (1, 16, 21, 90, 160) and torch.isfinite(a.float()).all()
     assert torch.equal(a, ms[-1].forward(x, t, ctx))
-    assert torch.equal(a, sp.forward_local(ms[:2], x, t, ctx))
+    b = sp.forward_local(ms[:2], x, t, ctx)
+    assert _rel(b.float().cpu(), a.float().cpu()) < 4e-3
+    L.set_switch("SVI_FLASH_SPLIT", 1)
+    try:
+        assert torch.equal(a, sp.forward_local(ms[:2], x, t, ctx))
+    finally:
+        L.set_switch("SVI_FLASH_SPLIT", None)

@@ -213,6 +213,39 @@ def test_flash_attention_long_sequence_rescale_paths(hip, pattern):
     assert torch.isfinite(got.float()).all() and r < 6e-3, (pattern, r, mx)
 
 
+@pytest.mark.parametrize("pieces,pattern", [(2, "plain"), (3, "plain"), (2, "ragged"), (2, "late_giant"), (2, "ramp")])
+def test_flash_attention_split_key_axis(hip, pieces, pattern):
+    """The long-sequence kernel with its key axis cut into pieces that run as separate workgroups (what a sequence-parallel rank's 3 heads x
+    128 q-blocks need to fill 256 compute units evenly) and a merge of the pieces' unnormalised O, reference maxima and row sums: the
+    same softmax(QK^T/sqrt(128))V (fp64 on the same bf16 inputs, rel-L2 <= 6e-3), including a key count that is not a multiple of the
+    tile or of the piece length, q rows that end inside a workgroup, pieces whose maxima differ by hundreds of logits (the last key
+    dominating every row: the earlier pieces merge to ~0), a norm ramp along the keys (later pieces outweigh earlier ones; the optimistic
+    pass's flagged workgroups are recomputed per piece), and agreement with the unsplit kernel (SVI_FLASH_SPLIT=1) to bf16 rounding."""
+    from svi_hip import _lib as L
+    Lq, Lk, heads = (300, 8192 * pieces + 77, 2) if pattern == "ragged" else (320, 8192 * pieces, 2)
+    D = heads * 128
+    q = bf16r(torch.from_numpy(synth.randn(191, 1, Lq, D)))
+    k = bf16r(torch.from_numpy(synth.randn(192, 1, Lk, D)))
+    v = bf16r(torch.from_numpy(synth.randn(193, 1, Lk, D)))
+    if pattern == "ramp":
+        k = bf16r(k * torch.linspace(0.2, 3.0, Lk).view(1, Lk, 1))
+    elif pattern == "late_giant":
+        k[0, Lk - 1] = 2.0
+        q = bf16r(q + 1.5)
+    want = wdo.attention(q.double(), k.double(), v.double(), heads).float()
+    L.set_switch("SVI_FLASH_SPLIT", pieces)
+    try:
+        got = hip.flash_attention(dev(q), dev(k), dev(v), heads)
+        L.set_switch("SVI_FLASH_SPLIT", 1)
+        whole = hip.flash_attention(dev(q), dev(k), dev(v), heads)
+    finally:
+        L.set_switch("SVI_FLASH_SPLIT", None)
+    r, mx, _ = errs(got, want)
+    rw, mw, _ = errs(got, whole.float().cpu())
+    report("flash_attention_split", pieces=pieces, pattern=pattern, rel_l2=r, max_abs=mx, vs_unsplit_rel=rw, vs_unsplit_max=mw)
+    assert torch.isfinite(got.float()).all() and r < 6e-3 and rw < 6e-3, (pieces, pattern, r, rw)
+
+
 def test_flash_attention_batch_and_linearity_in_v(hip):
     """Size-independent property: attention is linear in V;  attn(q,k,a*v1+v2) == a*attn(q,k,v1)+attn(q,k,v2)."""
     q = dev(synth.randn(71, 2, 200, 256)); k = dev(synth.randn(72, 2, 300, 256))

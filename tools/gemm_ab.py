@@ -40,6 +40,13 @@ if len(sys.argv) > 2 and sys.argv[2] == "calib":       # calibration shapes agai
     SHAPES = {"8192^3": (8192, 8192, 8192, L.EPI_BIAS, 0), "4096^3": (4096, 4096, 4096, L.EPI_BIAS, 0),
               "ffn2 M=8192": (8192, D, F, L.EPI_BIAS, 0), "ffn2 full, bias only": (Ltok, D, F, L.EPI_BIAS, 0),
               "N=6144 K=8960": (Ltok, 6144, F, L.EPI_BIAS, 0)}
+if len(sys.argv) > 2 and sys.argv[2] == "shards":      # a sequence-parallel rank's token shard (L / P rows): where do the 256^2 tiles fill the chip poorly?
+    SHAPES = {}
+    for P in (2, 3, 4, 6):
+        M = Ltok // P
+        SHAPES[f"P={P} qkv"] = (M, D, D, L.EPI_BIAS, 0)
+        SHAPES[f"P={P} ffn1"] = (M, F, D, L.EPI_BIAS_GELU_TANH, 0)
+        SHAPES[f"P={P} ffn2"] = (M, D, F, L.EPI_BIAS_GATE_RES, 0)
 for name, (M, N, K, epi, bam) in SHAPES.items():
     x = rnd(M, K); w = rnd(N, K, scale=K ** -0.5); b = rnd(M if bam else N)
     ldc = (N + 7) // 8 * 8

@@ -1,7 +1,7 @@
 """What the sequence-parallel schedule costs besides the transport, on ONE GPU: P shards run back to back with the exchange
 simulated by device copies (svi_hip.sequence_parallel.forward_local) vs the plain forward, Wan2.1-1.3B widths, C2 geometry.
 With P ranks on P GPUs the shard work runs concurrently, so  (local time / P)  is the per-rank compute + packing time that the
-all-to-all transport is added to.   python tools/sp_overhead.py [layers]"""
+all-to-all transport is added to.   python tools/sp_overhead.py [layers] [tags]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -9,7 +9,7 @@ import torch
 import svi_hip, synth
 from svi_hip import sequence_parallel as sp
 from bench import device_weights
-layers = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+layers = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6
 dev = torch.device("cuda")
 cfg = dict(synth.WAN_1_3B); cfg["num_layers"] = layers
 sd = device_weights(cfg, 0, dev)
@@ -30,6 +30,15 @@ plain = handle()
 for m in (plain,): m.context_cache(True)
 base = timeit(lambda: plain.forward(x, t, ctx))
 print(f"plain forward, {layers} blocks: {base:.1f} ms")
+from svi_hip import _lib
+def tags(fn):
+    """per-tag kernel time of one call (svi_prof_*), ms"""
+    fn(); torch.cuda.synchronize()
+    _lib.prof_enable(True); fn(); torch.cuda.synchronize()
+    out = {k: v["ms"] for k, v in _lib.prof_summary().items() if v["ms"] > 0}
+    _lib.prof_enable(False)
+    return out
+base_tags = tags(lambda: plain.forward(x, t, ctx))
 for P in (2, 4, 6):
     hs = [handle() for _ in range(P)]
     for m in hs: m.context_cache(True)
@@ -46,4 +55,8 @@ for P in (2, 4, 6):
         per_rank = (ms - cp) / P
         print(f"P={P} G={G}: all shards back to back {ms:.1f} ms, of which simulated transport {cp:.1f} ms -> per rank compute + unpack {per_rank:.1f} ms "
               f"({per_rank / (base / P) - 1:+.1%} over an ideal 1/P split); exchange volume per block and rank {(32760 // P) * (1536 // P) * (P - 1) * 2 * 4 / 1e6:.1f} MB")
+        if "tags" in sys.argv[1:]:
+            tg = tags(lambda: sp.forward_local(hs, x, t, ctx, groups=G))
+            print("      per tag, all shards / plain: " + "  ".join(f"{k} {tg.get(k, 0.0):.2f}/{v:.2f} ({tg.get(k, 0.0) / v - 1:+.0%})" for k, v in base_tags.items())
+                  + f"  | tagged sum {sum(tg.values()):.1f}/{sum(base_tags.values()):.1f} of {ms:.1f}/{base:.1f} ms")
     del hs
