@@ -282,19 +282,23 @@ __device__ __forceinline__ void gemm256_apply(float (&y)[8], const u32x4& res, c
     }
 }
 
-template <int EPI>
-__device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* smem, int m0, int n0, int tid,
+// MI x NI: 32x32 accumulator blocks per wave along M / N (wave grid (256 / 32 MI) x (TNV / 32 NI)); TNV: tile width.  The 256^2 kernels are
+// <4, 2, 256>; the 256 x 192 kernel <2, 3, 192> (read-back threads whose column chunk lies past the tile's 192 columns sit idle).
+template <int EPI, int MI = 4, int NI = 2, int TNV = TN>
+__device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, int m0, int n0, int tid,
                                                    int wm, int wn, int l31, int hi, int abl) {
-    const bool interior = (m0 + TM <= g.M) && (n0 + TN <= g.N);
+    const bool interior = (m0 + TM <= g.M) && (n0 + TNV <= g.N);
     // gate·y + residual: the 16 residual chunks this thread will need are requested NOW (64 registers, the accumulators
     // are about to die) so that their latency runs under the LDS round trip; the column block (and so the gate values)
     // is the same for all 16 chunks of a thread.
     u32x4 resv[16];
     float gatev[8];
     const int ecc = tid & 31, er = tid >> 5, en = n0 + ecc * 8;
+    const bool active = TNV == TN || ecc * 8 < TNV;          // this thread's column chunk belongs to the tile
     const bool efull = en + 8 <= g.N;
     if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
-        if (interior) {
+        if (!active) {
+        } else if (interior) {
             const bf16* rp = g.res + (size_t)(m0 + er) * g.ldres + en;
 #pragma unroll
             for (int it = 0; it < 16; ++it) resv[it] = *reinterpret_cast<const u32x4*>(rp + (size_t)(16 * it) * g.ldres);
@@ -305,7 +309,10 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
                 if (m < g.M && efull) resv[it] = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + en);
             }
         }
-        if (g.gate && efull && (((uintptr_t)g.gate & 15) == 0)) {
+        if (!active) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gatev[e] = 0.f;
+        } else if (g.gate && efull && (((uintptr_t)g.gate & 15) == 0)) {
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(g.gate + en), g1 = *reinterpret_cast<const f32x4*>(g.gate + en + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { gatev[e] = g0[e]; gatev[4 + e] = g1[e]; }
@@ -315,15 +322,15 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
         }
     }
     // ---- part 1: y = bf16(acc + bias) -> LDS [256 m][C2_LD] bf16 ---------------------------------------------------------
-    u32x2 bnp[2][4];
-    float bmv[4];
+    u32x2 bnp[NI][4];
+    float bmv[MI];
     const bool bias_n = g.bias && !g.bias_along_m, bias_m = g.bias && g.bias_along_m;
-    const bool bias_vec = bias_n && (n0 + TN <= g.N) && (((uintptr_t)g.bias & 7) == 0);
+    const bool bias_vec = bias_n && (n0 + TNV <= g.N) && (((uintptr_t)g.bias & 7) == 0);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const int n = n0 + wn * 64 + ni * 32 + 8 * rg + 4 * hi;
+            const int n = n0 + wn * (32 * NI) + ni * 32 + 8 * rg + 4 * hi;
             if (bias_vec) {
                 bnp[ni][rg] = *reinterpret_cast<const u32x2*>(g.bias + n);
             } else {
@@ -335,19 +342,19 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
             }
         }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 128 + mi * 32 + l31;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * (32 * MI) + mi * 32 + l31;
         bmv[mi] = (bias_m && m < g.M) ? (float)g.bias[m] : 0.f;
     }
     bf16* Cs = reinterpret_cast<bf16*>(smem);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int ml = wm * 128 + mi * 32 + l31;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ml = wm * (32 * MI) + mi * 32 + l31;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int nl = wn * 64 + ni * 32 + 8 * rg + 4 * hi;
+                const int nl = wn * (32 * NI) + ni * 32 + 8 * rg + 4 * hi;
                 const unsigned b01 = bnp[ni][rg][0], b23 = bnp[ni][rg][1];
                 const float bv[4] = {__builtin_bit_cast(float, b01 << 16) + bmv[mi], __builtin_bit_cast(float, b01 & 0xffff0000u) + bmv[mi],
                                      __builtin_bit_cast(float, b23 << 16) + bmv[mi], __builtin_bit_cast(float, b23 & 0xffff0000u) + bmv[mi]};
@@ -360,6 +367,7 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
     }
     __syncthreads();
     if (abl == 3) return;
+    if (!active) return;                 // (no barrier follows)
 
     // ---- part 2: row-contiguous read-back (512 B per row), activation / gate / residual, coalesced store ---------------------
     const bool has_gate = g.gate != nullptr;
@@ -423,19 +431,20 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
     }
 }
 
-__device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* smem, int m0, int n0, int tid,
+template <int MI = 4, int NI = 2, int TNV = TN>
+__device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, int m0, int n0, int tid,
                                                  int wm, int wn, int l31, int hi, int abl = 0) {
     if (abl == 1) {
-        if (acc[0][0][0] == 123.456f) g.C[0] = (bf16)acc[1][3][5];      // keep the accumulators alive
+        if (acc[0][0][0] == 123.456f) g.C[0] = (bf16)acc[1][MI - 1][5];      // keep the accumulators alive
         return;
     }
     switch (g.epi) {        // uniform: one scalar branch per tile
-        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        default:                     gemm256_epilogue_t<SVI_EPI_BIAS>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        default:                     gemm256_epilogue_t<SVI_EPI_BIAS, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
     }
 }
 
@@ -736,6 +745,141 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g
 }
 
 
+
+// =================================================================================================
+// 256(M) x 192(N) tile on the v3 main loop: 8 waves as 4(M) x 2(N), 64 x 96 per wave = 2 x 3 MFMA tiles.
+//
+// Why: tile QUANTISATION, not throughput.  A sequence-parallel rank's shard of the C2 clip has M = L / P rows: at P = 4 its N = 1536 GEMMs
+// are 32 x 6 = 192 tiles of 256^2 on 256 compute units — a quarter of the chip idles for the whole launch; at P = 2, 64 x 6 = 384 tiles take two
+// rounds for 1.5 rounds of work.  With 192 columns the same GEMMs are 32 x 8 = 256 and 64 x 8 = 512 tiles: whole rounds of three-quarter
+// tiles.  svi_launch_gemm picks this kernel when that arithmetic says so (never on the single-rank C2 shapes: 128 x 6 = 768 tiles there).
+// Per element the K summation order and the epilogue arithmetic are the 256^2 kernel's: bit-identical results (tests/test_gpu_ops.py).
+// Per K tile a wave issues 7 LDS-DMA pieces (4 of A, 3 of W) behind its first 7 MFMAs of 24; a k-step is 6 MFMAs with 5 fragment reads.
+// LDS: the 256^2 kernels' image (a W stage uses 24 of its 32 KiB), C staged as [256][264] bf16 like theirs.
+// =================================================================================================
+#define TN3 192
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256x192_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    const int group = swz / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = swz - group * GM * tiles_n;
+    const int tile_n = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n * gm);
+    const int m0 = tile_m * TM, n0 = tile_n * TN3;
+
+    unsigned a_off[4], w_off[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 8;
+        if (j < 3) w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 8;
+    }
+    const int nk = g.K / BK;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_addr[4], w_addr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_addr[kk] = lds0 + lds_tile_off(wm * 64 + l31, 2 * kk + hi);
+        w_addr[kk] = lds0 + T_STAGE + lds_tile_off(wn * 96 + l31, 2 * kk + hi);
+    }
+    int tok = 0;
+    u32x4 xa[2][2], wb[2][3];
+
+    // one k-step: 6 MFMAs (ni = i >> 1, mi = i & 1) on fragment set KK & 1; behind MFMAs 0..4 the five fragment reads of k-step (KK+1)&3
+    // (2 of A, 3 of W); the MFMA with running index gi = G0 + i < 7 over the K tile is followed by DMA piece gi (A0 W0 A1 W1 A2 W2 A3)
+#define SVI_KSTEP3(KK, G0, READ, DMA, rso, dk, dso)                                                                             \
+    static_for8([&](auto ic) {                                                                                                  \
+        constexpr int i = decltype(ic)::value;                                                                                  \
+        if constexpr (i < 6) {                                                                                                  \
+            constexpr int ni = i >> 1, mi = i & 1, cs = (KK) & 1, ns = cs ^ 1, kn = ((KK) + 1) & 3, gi = (G0) + i;               \
+            int& pin = (i < 2) ? a_addr[kn] : w_addr[kn];                                                                       \
+            gemm_mfma_v(tok, acc[ni][mi], wb[cs][ni], xa[cs][mi], pin);                                                         \
+            if constexpr (READ) {                                                                                               \
+                if constexpr (i < 2) xa[ns][i] = *(lds_u32x4_t)(a_addr[kn] + (rso) + i * 32 * 128);                             \
+                else if constexpr (i < 5) wb[ns][i - 2] = *(lds_u32x4_t)(w_addr[kn] + (rso) + (i - 2) * 32 * 128);              \
+            }                                                                                                                   \
+            if constexpr ((DMA) && gi < 7) {                                                                                    \
+                constexpr int j = gi >> 1;                                                                                      \
+                if constexpr ((gi & 1) == 0)                                                                                    \
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.A + dk + a_off[j]), (lptr_t)(smem + dso + (j * 8 + wave) * 1024), 16, 0, 0);            \
+                else                                                                                                            \
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.W + dk + w_off[j]), (lptr_t)(smem + dso + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);  \
+            }                                                                                                                   \
+        }                                                                                                                       \
+    })
+
+    // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-steps 0..2 computed
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.A + a_off[j]), (lptr_t)(smem + (j * 8 + wave) * 1024), 16, 0, 0);
+        if (j < 3) __builtin_amdgcn_global_load_lds((gptr_t)(g.W + w_off[j]), (lptr_t)(smem + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.A + BK + a_off[j]), (lptr_t)(smem + 2 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+            if (j < 3) __builtin_amdgcn_global_load_lds((gptr_t)(g.W + BK + w_off[j]), (lptr_t)(smem + 3 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xa[0][i] = *(lds_u32x4_t)(a_addr[0] + i * 32 * 128);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wb[0][i] = *(lds_u32x4_t)(w_addr[0] + i * 32 * 128);
+    SVI_KSTEP3(0, 6, true, false, 0, -1, 0);
+    SVI_KSTEP3(1, 12, true, false, 0, -1, 0);
+    SVI_KSTEP3(2, 18, true, false, 0, -1, 0);
+
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        const int nso = ((kt + 1) & 1) * 2 * T_STAGE;          // stage of tile kt+1 (read)
+        const int dso = (kt & 1) * 2 * T_STAGE;                // stage tile kt vacates (DMA target of tile kt+2)
+        const int dk = (kt + 2) * BK;
+        __syncthreads();                                       // vmcnt(0): tile kt+1 landed; lgkmcnt(0) + barrier: tile kt fully read by all waves
+        SVI_KSTEP3(3, 0, true, true, nso, dk, dso);
+        SVI_KSTEP3(0, 6, true, true, nso, dk, dso);
+        SVI_KSTEP3(1, 12, true, true, nso, dk, dso);
+        SVI_KSTEP3(2, 18, true, true, nso, dk, dso);
+    }
+    if (kt + 1 < nk) {                                         // last tile: nothing left to fetch
+        const int nso = ((kt + 1) & 1) * 2 * T_STAGE;
+        __syncthreads();
+        SVI_KSTEP3(3, 0, true, false, nso, -1, 0);
+        SVI_KSTEP3(0, 6, true, false, nso, -1, 0);
+        SVI_KSTEP3(1, 12, true, false, nso, -1, 0);
+        SVI_KSTEP3(2, 18, true, false, nso, -1, 0);
+    }
+    SVI_KSTEP3(3, 0, false, false, 0, -1, 0);
+#undef SVI_KSTEP3
+    asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));   // MFMA result -> VALU read
+    asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[2][0]), "+v"(acc[2][1]));
+    __syncthreads();                                           // every wave is done with the operand stages: the C tile may overwrite them
+    gemm256_epilogue<2, 3, TN3>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
+}
 
 // =================================================================================================
 // Persistent variant of the v3 kernel (same tile, same main loop, same arithmetic per element): one workgroup per CU walks
@@ -1310,7 +1454,7 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
         const long t256 = (long)((selM + TM - 1) / TM) * ((selN + TN - 1) / TN);
         const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
         const SviSwitches& sw = svi_switches();
-        const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 256 : (t256 >= 128);
+        const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 192 : (t256 >= 128);
         if (want256 && g.K % BK == 0 && fits32) {
             const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
             // measured (tools/gemm_gm.py, v3 loop): N = 1536 (6 column panels): 2 is best (ffn2 1257 vs 1168-1230 TFLOP/s), flat on q/k/v;
@@ -1320,6 +1464,20 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             const int nkq = g.K / BK;
             const bool can_q = (nkq % 2 == 0) && nkq >= 4 && true;
             const int ncu = 256;
+            {   // 256 x 192 tiles where they fill the chip's rounds better (sequence-parallel shards; see the kernel's header).  A 192-wide tile is
+                // 0.75 of a 256-wide one plus ~8 % (6 MFMAs per 5 fragment reads instead of 8 per 6, the same DMA / barrier count per K tile; measured,
+                // tools/gemm_ab.py shards: N = 1536 shard GEMMs gain 4-20 %, the N = 8960 ones — already many rounds of 256-wide tiles — lose 2-10 % and stay)
+                const int tm_s = (selM + TM - 1) / TM;
+                const long r256 = ((long)tm_s * ((selN + TN - 1) / TN) + ncu - 1) / ncu, r192 = ((long)tm_s * ((selN + TN3 - 1) / TN3) + ncu - 1) / ncu;
+                const bool better = (double)r192 * 0.75 * 1.08 < (double)r256 * 0.97;
+                if (g.N >= TN3 && (sw.gemm_kernel == 192 || (sw.gemm_kernel == 0 && better))) {
+                    const int tn3 = (g.N + TN3 - 1) / TN3;
+                    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256x192_kernel), LDS256_BYTES));
+                    hipLaunchKernelGGL(gemm_bf16_nt_256x192_kernel, dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 2));
+                    SVI_LAUNCH_CHECK();
+                    return SVI_OK;
+                }
+            }
             if (can_q && sw.gemm_kernel == 258) {     // persistent variant (A/B only, see its header: bit-identical, no faster)
                 SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256q_kernel), LDS256Q_BYTES));
                 hipLaunchKernelGGL(gemm_bf16_nt_256q_kernel, dim3(std::min(tm * tn, ncu)), dim3(512), LDS256Q_BYTES, st, g, tm, tn, gm_rows);

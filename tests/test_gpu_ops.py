@@ -88,6 +88,43 @@ def test_gemm_epilogues(hip, epi):
     assert r < 4e-3, (epi, r, mx)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [
+    (8190, 1536, 1536, "bias"), (700, 1536, 1536, "gate_res"), (513, 8960, 256, "gelu_tanh"), (300, 200, 64, "bias"), (256, 192, 128, "gate_res"),
+    (1030, 1000, 192, "gelu_tanh"), (1536, 1100, 128, "transposed"), (257, 392, 8960, "gate_res")])
+def test_gemm_tile_256x192_bit_identical(hip, M, N, K, epi):
+    """The 256 x 192 tile kernel (what a sequence-parallel rank's shard GEMMs run on when 256-wide tiles fill the chip's rounds poorly)
+    against the 256^2 kernel on the same operands: per element the same K summation order and the same epilogue arithmetic, so the same
+    bits — whole tiles, ragged row and column edges (N not a multiple of 192 or 8: the read-back's idle column chunks and the
+    element-wise tail), one and many K tiles, every epilogue the DiT uses, the transposed-bias form — and against fp64 (rel-L2 <= 4e-3)."""
+    L = hip._lib
+    x = dev(synth.randn(31, M, K)); w = dev(synth.randn(32, N, K) / math.sqrt(K))
+    b = dev(synth.randn(33, M if epi == "transposed" else N))
+    gate = dev(synth.randn(34, N), torch.float32) if epi == "gate_res" else None
+    res = dev(synth.randn(35, M, N)) if epi == "gate_res" else None
+    kw = dict(epilogue={"bias": L.EPI_BIAS, "gate_res": L.EPI_BIAS_GATE_RES, "gelu_tanh": L.EPI_BIAS_GELU_TANH, "transposed": L.EPI_BIAS}[epi])
+    if epi == "gate_res":
+        kw.update(gate=gate, residual=res)
+    outs = {}
+    try:
+        for kind in (192, 257):
+            L.set_switch("SVI_GEMM_KERNEL", kind)
+            if epi == "transposed":      # C^T = W X^T with the bias along the rows of the output (the DiT's V^T projection)
+                out = torch.zeros((N, (M + 7) // 8 * 8), dtype=torch.bfloat16, device="cuda")
+                L.check(L.lib().svi_gemm_bf16(w.data_ptr(), K, x.data_ptr(), K, out.data_ptr(), out.shape[1], N, M, K, dev(synth.randn(33, N)).data_ptr(), 1,
+                                              L.EPI_BIAS, None, None, 0, L.current_stream()))
+                outs[kind] = out[:, :M].clone()
+            else:
+                outs[kind] = hip.linear(x, w, b, **kw)
+    finally:
+        L.set_switch("SVI_GEMM_KERNEL", None)
+    assert torch.equal(outs[192], outs[257])
+    if epi == "bias":
+        want = (x.double().cpu() @ w.double().cpu().t() + b.double().cpu()).float()
+        r, mx, _ = errs(outs[192], want)
+        report("gemm_tile_256x192", M=M, N=N, K=K, rel_l2=r, max_abs=mx)
+        assert r < 4e-3, r
+
+
 def test_gemm_inplace_residual(hip):
     """x += gate*(h W^T + b) with the residual aliasing the output, as the block does (dit:369,373)."""
     L = hip._lib
