@@ -487,6 +487,8 @@ template <int N>
 __device__ __forceinline__ void tile_barrier(int& tok) {
     asm volatile("s_waitcnt vmcnt(%c1)\n\ts_barrier" : "+v"(tok) : "n"(N) : "memory");
 }
+// key-axis split of a launch (see flash_splits): items [0, whole) run whole, items [whole, qblocks * heads) in `pieces` workgroups each
+struct SviFlashSplit { int whole, pieces, qblocks, heads; };
 // One PV MFMA:  a[R:R+15] += V^T-fragment x P-fragment
 template <int R>
 __device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) {
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                                                             const bf16* __restrict__ VT, int ldvt,
                                                             bf16* __restrict__ O, int ldo, int Lq, int Lk,
                                                             float scale_log2e, int* __restrict__ flags,
-                                                            float* __restrict__ opart, float2* __restrict__ ml) {
+                                                            float* __restrict__ opart, float2* __restrict__ ml, SviFlashSplit sp) {
     constexpr bool OPT = MODE == 1;
     // BAL (optimistic kernel only): one score per MFMA statement everywhere.  The optimistic pass never waits for a row maximum, so the
     // exponentials of tile t can start as soon as S(t) is complete: its 32 score pairs per lane are spread as
@@ -528,17 +530,32 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     // rg(f, dma): the row-group statement (0 or 1) of fragment f behind which that fragment's look-ahead LDS read is issued: normally g = 0;
     // where the g = 0 statement also issues an LDS-DMA piece (s_mov m0 + buffer_load ... lds on top of its score), the g = 1 statement
     constexpr bool SPLIT = BAL && (SVI_FLASH_DMA_SPLIT != 0);
-    const int wg_linear = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    // Split key axis (gridDim.z > 1; svi_launch_flash decides): workgroup z sees keys [k0, k1) — whole tiles — as if they were the whole
-    // problem and leaves its UNNORMALISED O (fp32), reference maximum and row sum in opart / ml; flash_combine_kernel merges the splits.
+    // Work items are (q-block, head) pairs, q-block fastest.  Plain launch: a 2-D grid, one workgroup per item.  Split launch (sp.pieces > 1;
+    // svi_launch_flash decides): a 1-D grid; the first sp.whole items run whole, every later item is cut along the key axis into
+    // sp.pieces workgroups: piece z sees keys [k0, k1) — whole tiles — as if they were the whole problem and leaves its UNNORMALISED O
+    // (fp32), reference maximum and row sum in opart / ml; flash_combine_kernel merges the pieces of those items.
+    const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x;
+    int qblock = blockIdx.x, head = blockIdx.y, piece = 0, num_heads = gridDim.y;
+    bool is_piece = false;
     int vt_skip = 0;
-    if (gridDim.z > 1) {
-        const int tiles = (Lk + KB - 1) / KB, per = (tiles + (int)gridDim.z - 1) / (int)gridDim.z;
-        const int k0 = (int)blockIdx.z * per * KB, k1 = min(Lk, k0 + per * KB);
-        K += (size_t)k0 * ldk;
-        VT += k0;
-        vt_skip = k0;
-        Lk = k1 - k0;
+    if (sp.pieces > 1) {
+        int item = wg_linear;
+        if (wg_linear >= sp.whole) {
+            item = sp.whole + (wg_linear - sp.whole) / sp.pieces;
+            piece = (wg_linear - sp.whole) % sp.pieces;
+            is_piece = true;
+        }
+        qblock = item % sp.qblocks;
+        head = item / sp.qblocks;
+        num_heads = sp.heads;
+        if (is_piece) {
+            const int tiles = (Lk + KB - 1) / KB, per = (tiles + sp.pieces - 1) / sp.pieces;
+            const int k0 = piece * per * KB, k1 = min(Lk, k0 + per * KB);
+            K += (size_t)k0 * ldk;
+            VT += k0;
+            vt_skip = k0;
+            Lk = k1 - k0;
+        }
     }
     if constexpr (MODE == 2) {
         if (flags[wg_linear] == 0) return;          // uniform: the whole workgroup leaves before any barrier
@@ -553,8 +570,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int head = blockIdx.y;
-    const int row0 = blockIdx.x * QB2 + wave * 64 + l31;
+    const int row0 = qblock * QB2 + wave * 64 + l31;
 
     // ---- Q fragments of both row groups -> a[192:255]; O accumulators a[64:191] = 0 ----------------------------
     static_for<0, 2>([&](auto gc) {
@@ -944,15 +960,15 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     }
     // ---- normalise and store: a[(g*4+d)*16 + r] is O[row][32 d + (r&3) + 8 (r>>2) + 4 hi] ----------------------
     asm("s_nop 15" : "+v"(tok));                // last MFMA result -> v_accvgpr_read wait states
-    if (opart) {                                // one split of the key axis: unnormalised O, reference maximum, row sum
-        const int ldp = (int)gridDim.y * DH;
+    if (is_piece) {                             // one piece of the key axis: unnormalised O, reference maximum, row sum
+        const int ldp = num_heads * DH;
         static_for<0, 2>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[g]), __float_as_uint(l_run[g]), false, false);
             const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
             const int qr = row0 + 32 * g;
-            if (qr < Lq && hi == 0) ml[((size_t)blockIdx.z * gridDim.y + head) * Lq + qr] = make_float2(m_ref[g], l);
-            float* op = opart + ((size_t)blockIdx.z * Lq + min(qr, Lq - 1)) * ldp + head * DH + 4 * hi;
+            if (qr < Lq && hi == 0) ml[((size_t)piece * num_heads + head) * Lq + qr] = make_float2(m_ref[g], l);
+            float* op = opart + ((size_t)piece * Lq + min(qr, Lq - 1)) * ldp + head * DH + 4 * hi;
             static_for<0, 4>([&](auto dc) {
                 constexpr int d = decltype(dc)::value;
                 static_for<0, 4>([&](auto qc) {
@@ -989,49 +1005,55 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     });
 }
 
-// Merge the splits of the key axis: O = sum_s w_s O_s / sum_s w_s l_s with w_s = 2^((M_s - max M) cs) — the same softmax, each split's
-// exponentials re-referenced to the common maximum.  One thread per (row, head, 4 channels).
+// Merge the pieces of the key axis for the items that were cut: O = sum_s w_s O_s / sum_s w_s l_s with w_s = 2^((M_s - max M) cs) — the same
+// softmax, each piece's exponentials re-referenced to the common maximum.  One workgroup per cut item (256 rows of one head); a thread
+// owns 4 channels of 32 rows.
 __global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restrict__ opart, const float2* __restrict__ ml, bf16* __restrict__ O, int ldo,
-                                                            int Lq, int H, int S, float cs) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int c4 = (int)(i & 31);
-    const long rh = i >> 5;
-    const int head = (int)(rh % H);
-    const long row = rh / H;
-    if (row >= Lq) return;
-    float m = -INFINITY;
-    float2 st[4];
-    for (int s = 0; s < S; ++s) { st[s] = ml[((size_t)s * H + head) * Lq + row]; m = fmaxf(m, st[s].x); }
-    float den = 0.f;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < S; ++s) {
-        const float w = __builtin_amdgcn_exp2f((st[s].x - m) * cs);
-        den += w * st[s].y;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(opart + ((size_t)s * Lq + row) * ((size_t)H * DH) + head * DH + 4 * c4);
-        acc += v * w;
+                                                            int Lq, SviFlashSplit sp, float cs) {
+    const int item = sp.whole + blockIdx.x;
+    const int qblock = item % sp.qblocks, head = item / sp.qblocks, H = sp.heads, S = sp.pieces;
+    const int c4 = threadIdx.x & 31;
+    for (int rr = threadIdx.x >> 5; rr < QB2; rr += 8) {
+        const long row = (long)qblock * QB2 + rr;
+        if (row >= Lq) break;
+        float m = -INFINITY;
+        float2 st[4];
+        for (int s = 0; s < S; ++s) { st[s] = ml[((size_t)s * H + head) * Lq + row]; m = fmaxf(m, st[s].x); }
+        float den = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            const float w = __builtin_amdgcn_exp2f((st[s].x - m) * cs);
+            den += w * st[s].y;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(opart + ((size_t)s * Lq + row) * ((size_t)H * DH) + head * DH + 4 * c4);
+            acc += v * w;
+        }
+        const float inv = 1.0f / den;
+        bf16x4 pk;
+        pk[0] = (bf16)(acc[0] * inv); pk[1] = (bf16)(acc[1] * inv); pk[2] = (bf16)(acc[2] * inv); pk[3] = (bf16)(acc[3] * inv);
+        *reinterpret_cast<bf16x4*>(O + (size_t)row * ldo + head * DH + 4 * c4) = pk;
     }
-    const float inv = 1.0f / den;
-    bf16x4 pk;
-    pk[0] = (bf16)(acc[0] * inv); pk[1] = (bf16)(acc[1] * inv); pk[2] = (bf16)(acc[2] * inv); pk[3] = (bf16)(acc[3] * inv);
-    *reinterpret_cast<bf16x4*>(O + (size_t)row * ldo + head * DH + 4 * c4) = pk;
 }
 
-// How many pieces to cut the key axis into.  A launch is (q-blocks x heads) workgroups of equal length on `cus` compute units, one
-// workgroup per unit: its time is ceil(n / cus) rounds.  With S splits it is ceil(n S / cus) / S rounds (plus the merge): worth it when
-// the last round is poorly filled — a sequence-parallel rank's 3 heads x 128 q-blocks = 384 workgroups on 256 units take 2 rounds whole
-// and 1.5 in halves.  SVI_FLASH_SPLIT: 0 = decide here (default), 1 = never (bit-identical to the unsplit kernel), 2..4 = that many.
-static int flash_splits(long nwg, int Lk, int cus) {
+// Which items to cut along the key axis, and into how many pieces.  A launch is n = q-blocks x heads items of equal length on `cus` compute
+// units, one workgroup per unit: ceil(n / cus) rounds.  When the last round is poorly filled — a sequence-parallel rank's 3 heads x 128
+// q-blocks = 384 items on 256 units: 2 rounds for 1.5 rounds of work — the items of that round (the last n mod cus) are cut into
+// S = floor(cus / (n mod cus)) <= 4 pieces each: the launch ends after floor(n / cus) + 1 / S rounds, and only the cut items pay for
+// partial results (fp32 O, maximum, sum through memory, then a merge).  SVI_FLASH_SPLIT: 0 = decide here (default), 1 = never
+// (bit-identical to the unsplit kernel), 2..4 = cut EVERY item into that many pieces (tests, A/B).
+static SviFlashSplit flash_splits(int qblocks, int heads, int Lk, int cus) {
     const int want = svi_switches().flash_split;
+    const int n = qblocks * heads;
     const int max_by_keys = Lk / 4096;                               // every piece keeps a long key axis (prologue and merge stay small)
-    if (want == 1 || max_by_keys < 2) return 1;
-    if (want >= 2) return min(min(want, 4), max_by_keys);
-    int best = 1;
-    double best_t = (double)((nwg + cus - 1) / cus);
-    for (int S = 2; S <= min(4, max_by_keys); ++S) {
-        const double t = (double)((nwg * S + cus - 1) / cus) / S * (1.0 + 0.01 * S);     // ~1 % per piece: prologue, partial store, merge
-        if (t < best_t * 0.95) { best = S; best_t = t; }
-    }
-    return best;
+    SviFlashSplit sp{n, 1, qblocks, heads};
+    if (want == 1 || max_by_keys < 2) return sp;
+    if (want >= 2) { sp.whole = 0; sp.pieces = min(min(want, 4), max_by_keys); return sp; }
+    const int rem = n % cus;
+    if (rem == 0) return sp;
+    const int S = min(min(cus / rem, 4), max_by_keys);
+    if (S < 2) return sp;
+    const double whole_t = (double)(n / cus) + 1.0, cut_t = (double)(n / cus) + (1.0 + 0.03 * S) / S;     // ~3 % per piece: prologue, partial store, merge
+    if (cut_t < whole_t * 0.95) { sp.whole = n - rem; sp.pieces = S; }
+    return sp;
 }
 
 // One flag word per workgroup of the optimistic attention pass, in a buffer of its own per (device, stream): launches on one stream
@@ -1082,25 +1104,26 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     const SviSwitches& sw = svi_switches();
     const bool v2 = sw.flash_kernel ? sw.flash_kernel == 2 : (Lk >= 2048);     // short key axes (text context) are prologue-bound: v1
     if (v2) {
-        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*, float*, float2*);
+        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*, float*, float2*, SviFlashSplit);
         const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
         dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
         static int cus[64] = {0};                                // compute units per device
         const int dev = svi_current_device();
         if (dev < 0) return SVI_ERR_HIP;
         if (dev < 64 && !cus[dev]) { int n = 0; SVI_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev)); cus[dev] = n > 0 ? n : 256; }
-        const int nsplit = flash_splits((long)grid2.x * grid2.y, Lk, dev < 64 ? cus[dev] : 256);
-        grid2.z = nsplit;
+        const SviFlashSplit sp = flash_splits((int)grid2.x, num_heads, Lk, dev < 64 ? cus[dev] : 256);
+        const int n_items = (int)grid2.x * num_heads, n_cut = n_items - sp.whole;
         float* opart = nullptr;
         float2* ml = nullptr;
-        if (nsplit > 1) {
-            const size_t o_bytes = (size_t)nsplit * Lq * num_heads * DH * 4, ml_bytes = (size_t)nsplit * num_heads * Lq * sizeof(float2);
+        if (sp.pieces > 1) {
+            grid2 = dim3((unsigned)(sp.whole + n_cut * sp.pieces), 1);
+            const size_t o_bytes = (size_t)sp.pieces * Lq * num_heads * DH * 4, ml_bytes = (size_t)sp.pieces * num_heads * Lq * sizeof(float2);
             void* pbuf = nullptr;
             SVI_TRY(svi_stream_buffer(SVI_BUF_FLASH_SPLIT, st, o_bytes + ml_bytes, &pbuf, nullptr));
             opart = reinterpret_cast<float*>(pbuf);
             ml = reinterpret_cast<float2*>(reinterpret_cast<char*>(pbuf) + o_bytes);
         }
-        const long nwg = (long)grid2.x * grid2.y * grid2.z;
+        const long nwg = (long)grid2.x * grid2.y;
         // optimistic pass + flagged second pass (see the kernel's MODE): needs the per-device flag words
         int* flags = nullptr;
         bool two_pass = sw.flash_two_pass != 0 && nwg <= SVI_FLASH_MAX_FLAGS;
@@ -1141,19 +1164,17 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         }
 #endif
         SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(kern), lds2));
-        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml);
+        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml, sp);
         SVI_LAUNCH_CHECK();
         if (two_pass) {
             kern_t safe = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false, 2> : flash_fwd2_kernel<1, 0, false, 2>)
                                       : (Lq == Lk ? flash_fwd2_kernel<0, 0, true, 2> : flash_fwd2_kernel<1, 0, true, 2>);
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(safe), lds2));
-            hipLaunchKernelGGL(safe, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml);
+            hipLaunchKernelGGL(safe, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml, sp);
             SVI_LAUNCH_CHECK();
         }
-        if (nsplit > 1) {
-            const long threads = (long)Lq * num_heads * 32;
-            hipLaunchKernelGGL(flash_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, opart, ml, O, ldo, Lq, num_heads, nsplit,
-                               q_prescaled ? 1.0f : scale_log2e);
+        if (sp.pieces > 1) {
+            hipLaunchKernelGGL(flash_combine_kernel, dim3((unsigned)n_cut), dim3(256), 0, st, opart, ml, O, ldo, Lq, sp, q_prescaled ? 1.0f : scale_log2e);
             SVI_LAUNCH_CHECK();
         }
         return SVI_OK;

@@ -283,6 +283,29 @@ def test_flash_attention_split_key_axis(hip, pieces, pattern):
     assert torch.isfinite(got.float()).all() and r < 6e-3 and rw < 6e-3, (pieces, pattern, r, rw)
 
 
+def test_flash_attention_cuts_only_the_last_round(hip):
+    """The launcher's own decision: 100 q-blocks x 3 heads = 300 work items on 256 compute units leave 44 items for a second round; those
+    (q-blocks 56..99 of the last head) are cut into 2 key pieces (8192 keys: two pieces of >= 4096) and merged, the 256 items of the first round run whole.
+    Against the single-piece kernel (SVI_FLASH_SPLIT=1, itself checked against fp64 above): rows of uncut items carry the same bits, rows
+    of cut items agree to bf16 rounding and are not all identical (the cut path really ran)."""
+    from svi_hip import _lib as L
+    Lq, Lk, heads = 25600, 8192, 3
+    q = dev(synth.randn(195, 1, Lq, heads * 128)); k = dev(synth.randn(196, 1, Lk, heads * 128)); v = dev(synth.randn(197, 1, Lk, heads * 128))
+    got = hip.flash_attention(q, k, v, heads)
+    L.set_switch("SVI_FLASH_SPLIT", 1)
+    try:
+        whole = hip.flash_attention(q, k, v, heads)
+    finally:
+        L.set_switch("SVI_FLASH_SPLIT", None)
+    g, w = got[0].float(), whole[0].float()
+    cut_rows = slice(56 * 256, Lq)
+    assert torch.equal(g[:, :256], w[:, :256]) and torch.equal(g[: 56 * 256, 256:], w[: 56 * 256, 256:])          # heads 0, 1 and the uncut q-blocks of head 2
+    cg, cw = g[cut_rows, 256:], w[cut_rows, 256:]
+    r = float((cg - cw).norm() / cw.norm())
+    report("flash_attention_last_round_cut", rel_l2=r, identical=bool(torch.equal(cg, cw)))
+    assert r < 6e-3 and not torch.equal(cg, cw), r
+
+
 def test_flash_attention_batch_and_linearity_in_v(hip):
     """Size-independent property: attention is linear in V;  attn(q,k,a*v1+v2) == a*attn(q,k,v1)+attn(q,k,v2)."""
     q = dev(synth.randn(71, 2, 200, 256)); k = dev(synth.randn(72, 2, 300, 256))
