@@ -118,12 +118,16 @@ __device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *reinterpret_cast
 // gelu_tanh(x) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi)(x + 0.044715 x^3).  1 + tanh(u) = 2 sigmoid(2u), so
 // gelu_tanh(x) = x / (1 + exp(-2u)): one v_exp + one v_rcp instead of a tanhf expansion (fp32-accurate;
 // the result is rounded to bf16 by the caller).
+// With the constants folded: 2^(-2 log2(e) u) = 2^(x (A x^2 + B)), A = -2 log2(e) k0 k1, B = -2 log2(e) k0 (one multiply fewer; every kernel
+// uses this one function, so a shard on one tile size and the whole on another round alike).
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+    const float A = -2.0f * 1.4426950408889634f * 0.7978845608028654f * 0.044715f, B = -2.0f * 1.4426950408889634f * 0.7978845608028654f;
+    const float a = x * __builtin_fmaf(x * x, A, B);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
+// Tried: two elements at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma / v_pk_add around the scalar v_exp / v_rcp) in the 256-row
+// tiles' epilogue — the same bits, and no faster (ffn1 834-860 us either way, tools/gemm_ab.py on one box): the two transcendentals per element,
+// not the five multiply-adds, are what the GELU epilogue costs.
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 #endif
