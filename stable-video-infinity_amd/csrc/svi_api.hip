@@ -153,7 +153,13 @@ const char* kProfNames[PROF_NTAGS] = {"ln_modulate", "gemm_qkv", "rmsnorm_rope",
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
+    // timing-only events: no system-scope fence when the event completes — the default event's cache writeback / invalidation between
+    // every two kernels of the block cost the step it was measuring 1-2 % (eager 437-440 ms against 431 ms replayed from a graph, which records none)
+#ifdef SVI_PROF_FENCED_EVENTS      // A/B aid (tools/build_variant.py): the default events
     (void)hipEventCreate(&e);
+    return e;
+#endif
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); (void)hipEventCreate(&e); }
     return e;
 }
 }  // namespace
