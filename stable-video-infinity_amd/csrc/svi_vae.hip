@@ -53,6 +53,7 @@ struct ConvP {
     int act_silu;                                    // conv_igemm_kernel, mode 0: out = silu(conv + bias)  (pose embedder)
     bf16* out_bf16;                                  // conv_igemm_kernel, mode 0: store bf16 [pixel][ld_out] here instead of fp32 `out`
     const unsigned short* in_h; const unsigned short* in_l;      // conv_dma2h_kernel: the input as two fp16 planes [pixel][ld_in] of x * in_scale (hi | lo)
+    int ord_T, ord_Lf, ord_G;                        // conv_dma2h_kernel: workgroup -> tile order (launch_conv_planes); ord_T = 0: tiles in pixel order
     int up_phase;                                    // conv_igemm_x3_kernel, mode 0: 1 + 2 py + px = this launch computes output pixels (2 y + py, 2 x + px) of an image twice the size
                                                      // of its (To, Ho, Wo) grid (one phase of a convolution behind a nearest x2 upsample, see launch_conv_up_phases); 0 = plain
 };
@@ -683,8 +684,28 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
     const int l31 = lane & 31, hi = lane >> 5;
     const long HoWo = (long)p.Ho * p.Wo;
     const long P_total = (long)p.To * HoWo;
-    const long p0 = (long)p.t_begin * HoWo + (long)blockIdx.x * X3_PIX;
-    const int co0 = blockIdx.y * X3_CO;
+    // Tile order.  Tiles are 256 consecutive pixels, frame-major; in pixel order the chip sweeps one frame before the next, so the two
+    // earlier frames a causal 3x3x3 convolution reads were last touched one and two whole frames ago (153 MB of planes per frame at
+    // 480 x 832 x 96: out of L2, largely out of the 256 MB MALL).  With ord_T frames of ord_Lf tiles each, workgroups walk groups of ord_G tiles
+    // (about 16 image rows) through ALL frames before moving down the image: the slab of input rows a group needs from frames t-2, t-1, t is
+    // reused while it is still close.
+    // Output-channel blocks of one pixel tile sit next to each other in the launch order (1-D grid: workgroup = tile * blocks + block), so the
+    // 2 or 4 workgroups that read the same activation strips run together instead of a whole tensor apart.
+    const int ncob = (p.Cout + NB * 32 - 1) / (NB * 32);
+    long tile = blockIdx.x / ncob;
+    const int cob = (int)(blockIdx.x - tile * ncob);
+    if (p.ord_T > 0) {
+        const long per_group = (long)p.ord_T * p.ord_G;
+        const int full = p.ord_Lf / p.ord_G;                     // whole groups; the rest of a frame forms a last, shorter group
+        const long g = tile / per_group;
+        int gl = p.ord_G;
+        long r = tile - g * per_group, gbase = g * p.ord_G;
+        if (g >= full) { gl = p.ord_Lf - full * p.ord_G; r = tile - (long)full * per_group; gbase = (long)full * p.ord_G; }
+        const int t = (int)(r / gl), j = (int)(r - (long)t * gl);
+        tile = (long)t * p.ord_Lf + gbase + j;
+    }
+    const long p0 = (long)p.t_begin * HoWo + tile * X3_PIX;
+    const int co0 = cob * NB * 32;
     const int nchunk = p.Cin >> 5;
     const int nrow = p.kt * p.kh;                    // (frame tap, row tap) pairs
     const int nk = nrow * nchunk;
@@ -879,17 +900,29 @@ svi_status launch_conv_planes(const ConvP& p, hipStream_t st) {
     SVI_REQUIRE(p.ld_out % 4 == 0 && (!p.res || p.ld_res % 4 == 0) && (((uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0, "conv: output / residual alignment");
     const long pixels = (long)(p.To - p.t_begin) * p.Ho * p.Wo;
     if (pixels <= 0) return SVI_OK;
+    ConvP q = p;
+    {   // frame-interleaved tile order (see the kernel) when frames are whole numbers of tiles and there is more than one
+        const long hw = (long)p.Ho * p.Wo;
+        const int frames = p.To - p.t_begin;
+        q.ord_T = 0;
+        if (svi_switches().vae_tile_order && p.kt > 1 && frames > 1 && hw % X3_PIX == 0) {
+            q.ord_T = frames; q.ord_Lf = (int)(hw / X3_PIX);
+            q.ord_G = (int)std::max<long>(1, std::min<long>(q.ord_Lf, (16L * p.Wo + X3_PIX - 1) / X3_PIX));
+        }
+    }
     if (p.Cout <= 32) {                  // narrow head
         SVI_REQUIRE((p.Cout + 3) / 4 * 4 <= p.ld_out && (!p.res || (p.Cout + 3) / 4 * 4 <= p.ld_res), "conv: a narrow head writes whole groups of four channels (Cout=%d, ld_out=%d)", p.Cout, p.ld_out);
         SVI_REQUIRE(p.Cout % 4 != 0 || (((uintptr_t)p.bias | (uintptr_t)p.w2_inv) & 15) == 0, "conv: bias / scale alignment");
         dim3 grid((unsigned)((pixels + X3_PIX - 1) / X3_PIX), 1), block(512);
         SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel<1>), 2 * D2_STAGE));
-        hipLaunchKernelGGL(conv_dma2h_kernel<1>, grid, block, 2 * D2_STAGE, st, p);
+        hipLaunchKernelGGL(conv_dma2h_kernel<1>, grid, block, 2 * D2_STAGE, st, q);
     } else {
         SVI_REQUIRE((((uintptr_t)p.bias) & 15) == 0, "conv: bias alignment");
-        dim3 grid((unsigned)((pixels + X3_PIX - 1) / X3_PIX), (unsigned)((p.Cout + X3_CO - 1) / X3_CO)), block(512);
+        const long nwg = ((pixels + X3_PIX - 1) / X3_PIX) * ((p.Cout + X3_CO - 1) / X3_CO);
+        SVI_REQUIRE(nwg < (1L << 31), "conv: too many workgroups");
+        dim3 grid((unsigned)nwg, 1), block(512);
         SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel<3>), 2 * D2_STAGE));
-        hipLaunchKernelGGL(conv_dma2h_kernel<3>, grid, block, 2 * D2_STAGE, st, p);
+        hipLaunchKernelGGL(conv_dma2h_kernel<3>, grid, block, 2 * D2_STAGE, st, q);
     }
     SVI_LAUNCH_CHECK();
     return SVI_OK;

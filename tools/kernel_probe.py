@@ -3,6 +3,7 @@
     python tools/kernel_probe.py attn [iters]      self-attention flash kernel, L=32760, 12 heads
     python tools/kernel_probe.py gemm_ffn1|gemm_ffn2|gemm_qkv [iters]
     python tools/kernel_probe.py ln|rms [iters]
+    python tools/kernel_probe.py vae [iters]       VAE decode of 3 latent frames at 480x832 (every decoder layer at its C2 spatial size)
 Prints achieved TFLOP/s (or TB/s) from torch.cuda.Event timing on the launch stream.
 """
 import os
@@ -69,5 +70,10 @@ elif what == "ln":
 elif what == "rms":
     x = rnd(Ltok, D); wt = rnd(D)
     timeit(lambda: svi_hip.rmsnorm_rope_(x, wt, 1e-6, grid=(21, 30, 52), num_heads=12), bytes_=2.0 * Ltok * D * 2)
+elif what == "vae":
+    from svi_hip.vae import WanVideoVAE, device_vae_weights
+    vae = WanVideoVAE.from_state_dict(device_vae_weights(0, dev))
+    z = torch.randn((16, 3, 60, 104), generator=g, device=dev)
+    timeit(lambda: vae.decode([z], device=dev)[0])
 else:
     raise SystemExit("unknown probe")

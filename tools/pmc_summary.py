@@ -13,7 +13,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         k = row.get("Kernel_Name", "")
         if sub and sub not in k:
             continue
-        k = k.split("(")[0][:60]
+        k = k.replace("(anonymous namespace)::", "").split("(")[0][:60]
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]] += 1
 for k in acc:

@@ -3,7 +3,7 @@
     x3     bf16 three-term convolution everywhere                                                      (SVI_VAE_X2H=0)
     exact  fp32 MFMA everywhere                                                                        (SVI_VAE_EXACT_FP32=1; small size only unless `exact` is asked for)
 Reports wall time, the per-tag kernel time (svi_prof_*) and the distance of each result to the exact-fp32 one (or to x3 at C2).
-    python tools/vae_ab.py [c2] [exact] [only-default | ab-up]
+    python tools/vae_ab.py [c2] [exact] [only-default | ab-up | ab-order]
 ab-up: the default against SVI_VAE_UP_PHASES=0 (upsample convolutions as one nine-tap convolution reading through the upsample).
 """
 import os, sys
@@ -27,7 +27,9 @@ if "only-default" in sys.argv[1:]:             # for a kernel trace of the produ
     MODES = MODES[:1]
 if "ab-up" in sys.argv[1:]:
     MODES = [("x2h", {}), ("up9", {"SVI_VAE_UP_PHASES": "0"})]
-KEYS = ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32", "SVI_VAE_UP_PHASES")
+if "ab-order" in sys.argv[1:]:
+    MODES = [("x2h", {}), ("pxord", {"SVI_VAE_TILE_ORDER": "0"}), ("x2h", {})]
+KEYS = ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32", "SVI_VAE_UP_PHASES", "SVI_VAE_TILE_ORDER")
 res = {}
 for name, env in MODES:
     for k in KEYS:
