@@ -207,6 +207,8 @@ def main() -> None:
     ap.add_argument("--fp8-mfma", action="store_true", help="opt-in MX-fp8 MLP (north_star 'bf16/fp8 MFMA'): FP8 weight storage + both MLP GEMMs of every block on "
                     "v_mfma_scale_f32_32x32x64_f8f6f4 with per-32-element activation scales.  Arithmetic the reference never performs (it computes in bf16): "
                     "a separately toleranced line (tests/test_gpu_mx8.py), never the headline")
+    ap.add_argument("--profile-all", action="store_true", help="bracket every tagged kernel family with HIP events inside the timed region (about 1 %% slower steps) "
+                    "instead of the dominant kernel there and the full breakdown in 4 extra steps behind it")
     ap.add_argument("--graph", action="store_true", help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)): for the "
                     "launch-bound regime (--workload c1); per-kernel event timing is off under capture, so `roofline` is null")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -330,6 +332,11 @@ def main() -> None:
     for i in range(args.warmup):
         one_step(i)
     sync()
+    # Over the timed region only the dominant kernel is bracketed by HIP events (`roofline`): every event record is a packet between two
+    # kernels of the stream it measures, and the ~1440 records of a fully instrumented C2 step cost that step about 1 % (profiles/r3m_prof_events_ab.txt).
+    # The breakdown over all kernel families (`roofline_all`, `kernel_ms_per_step`) comes from `prof_steps` fully instrumented steps run
+    # BEHIND the timed region.  --profile-all keeps every family's events inside the timed region (rounds 1-3's behaviour).
+    _lib.prof_select(None if args.profile_all else ["flash_self"])
     _lib.prof_enable(not args.graph)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -341,8 +348,18 @@ def main() -> None:
         dist.all_gather(gathered, tail)
     sync()
     elapsed = time.perf_counter() - t0
-    prof = _lib.prof_summary()
+    prof_timed = _lib.prof_summary()
     _lib.prof_enable(False)
+    _lib.prof_select(None)
+    prof, prof_steps = prof_timed, args.steps
+    if not args.graph and not args.profile_all:
+        prof_steps = max(1, min(4, args.steps))
+        _lib.prof_enable(True)
+        for i in range(prof_steps):
+            one_step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        prof = _lib.prof_summary()
+        _lib.prof_enable(False)
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -403,7 +420,7 @@ def main() -> None:
     flops_step = 2 * per_fwd - shared
     if pair:
         flops_step = per_fwd                 # a rank of a CFG pair runs one branch
-    fl = prof.get("flash_self", {"count": 0, "ms": 0.0})
+    fl = prof_timed.get("flash_self", {"count": 0, "ms": 0.0})          # the dominant kernel: events over the timed region itself
     roof = None
     if fl["count"]:
         per_launch_ms = fl["ms"] / fl["count"]
@@ -438,8 +455,8 @@ def main() -> None:
         rec = prof.get(tag)
         if not rec or not rec["count"]:
             return None
-        ms = rec["ms"] / args.steps
-        n = rec["count"] / args.steps
+        ms = rec["ms"] / prof_steps
+        n = rec["count"] / prof_steps
         total = total_fn(n) if total_fn else work_per_launch * n
         if bound == "mfma":
             ach, peak, unit = total / (ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
@@ -498,7 +515,9 @@ def main() -> None:
                    "outputs_finite": finite},
         "roofline": roof,
         "roofline_all": roof_all,
-        "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+        "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items()},
+        "kernel_ms_source": ("HIP events of every tagged kernel family inside the timed region" if (args.profile_all or args.graph) else
+                             f"{prof_steps} fully instrumented steps behind the timed region (inside it only the dominant kernel is bracketed by events; `roofline` is from those)"),
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

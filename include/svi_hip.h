@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 6
+#define SVI_HIP_ABI_VERSION 7
 
 typedef enum {
     SVI_OK = 0,
@@ -268,6 +268,10 @@ svi_status svi_fp8_e4m3_to_bf16(const void* in, void* out, int64_t n, svi_stream
  * recorded events and writes one JSON object {"tag": {"count": n, "ms": total_ms}, ...} into buf. */
 svi_status svi_prof_enable(int32_t on);
 svi_status svi_prof_summary(char* buf, int64_t buflen);
+/* Restrict recording to some tags: comma-separated names as svi_prof_summary prints them ("flash_self,gemm_ffn1"); NULL or "" = all (the
+ * default).  Every event record is a packet between two kernels of the stream it measures (~1440 per C2 step with all tags, ~1 % of the
+ * step); bench.py records the dominant kernel alone over its timed region and takes the full breakdown in a short pass behind it. */
+svi_status svi_prof_select(const char* tags);
 
 /* ------------------------------------------------------------------ VAE ------------------- */
 /* WanVideoVAE() (models/wan_video_vae.py:599-618): fixed architecture (dim 96, z 16, mult 1,2,4,4). */

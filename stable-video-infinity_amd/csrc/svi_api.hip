@@ -142,6 +142,7 @@ extern "C" int32_t svi_device_count(void) {
 
 // ---- event profiler (one recorder per process, guarded by the table mutex; tags are paired per (tag, stream)) ------------------
 bool g_svi_prof_on = false;
+unsigned g_svi_prof_mask = 0xFFFFFFFFu;
 namespace {
 struct ProfRec { int tag; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof_recs;
@@ -188,6 +189,29 @@ extern "C" svi_status svi_prof_enable(int32_t on) {
     for (auto& o : g_prof_open) g_prof_pool.push_back(o.e);
     g_prof_open.clear();
     g_svi_prof_on = on != 0;
+    return SVI_OK;
+}
+// Which tags are recorded: a comma-separated list of tag names (as svi_prof_summary prints them), or NULL / "" for all.  Every event record is
+// a packet between two kernels of the stream being measured; a caller that needs one kernel's durations over a long timed region (bench.py:
+// the dominant kernel) selects that tag there and takes the full breakdown in a shorter pass.  Takes effect for launches after the call.
+extern "C" svi_status svi_prof_select(const char* tags) {
+    unsigned mask = 0;
+    if (!tags || !*tags) mask = 0xFFFFFFFFu;
+    else {
+        const char* p = tags;
+        while (*p) {
+            const char* e = strchr(p, ',');
+            const size_t n = e ? (size_t)(e - p) : strlen(p);
+            int found = -1;
+            for (int i = 0; i < PROF_NTAGS; ++i)
+                if (strlen(kProfNames[i]) == n && strncmp(kProfNames[i], p, n) == 0) found = i;
+            if (found < 0) { svi_set_error("svi_prof_select: unknown tag '%.*s'", (int)n, p); return SVI_ERR_INVALID; }
+            mask |= 1u << found;
+            p += n + (e ? 1 : 0);
+        }
+    }
+    std::lock_guard<std::mutex> lock(table_mutex());
+    g_svi_prof_mask = mask;
     return SVI_OK;
 }
 extern "C" svi_status svi_prof_summary(char* buf, int64_t buflen) {

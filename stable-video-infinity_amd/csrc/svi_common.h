@@ -140,12 +140,13 @@ enum SviProfTag {
     PROF_GEMM_FFN1, PROF_GEMM_FFN2, PROF_EMBED, PROF_HEAD, PROF_VAE_CONV, PROF_VAE_OTHER, PROF_NTAGS
 };
 extern bool g_svi_prof_on;
+extern unsigned g_svi_prof_mask;             // bit t: tag t is recorded (svi_prof_select; all tags by default)
 void svi_prof_begin_impl(int tag, hipStream_t st);
 void svi_prof_end_impl(int tag, hipStream_t st);
 struct SviProfScope {
-    int tag; hipStream_t st;
-    SviProfScope(int t, hipStream_t s) : tag(t), st(s) { if (g_svi_prof_on) svi_prof_begin_impl(tag, st); }
-    ~SviProfScope() { if (g_svi_prof_on) svi_prof_end_impl(tag, st); }
+    int tag; hipStream_t st; bool on;
+    SviProfScope(int t, hipStream_t s) : tag(t), st(s), on(g_svi_prof_on && ((g_svi_prof_mask >> t) & 1u)) { if (on) svi_prof_begin_impl(tag, st); }
+    ~SviProfScope() { if (on) svi_prof_end_impl(tag, st); }
 };
 
 // ---- kernel launchers shared between translation units (all enqueue on `st`) ----------------

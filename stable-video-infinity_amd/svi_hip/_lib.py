@@ -76,6 +76,7 @@ SYMBOLS = [
     ("svi_fp8_e4m3_to_bf16", _i32, [_vp, _vp, _i64, _vp]),
     ("svi_prof_enable", _i32, [_i32]),
     ("svi_prof_summary", _i32, [C.c_char_p, _i64]),
+    ("svi_prof_select", _i32, [C.c_char_p]),
     ("svi_vae_create", _i32, [C.POINTER(_vp)]),
     ("svi_vae_destroy", _i32, [_vp]),
     ("svi_vae_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
@@ -156,6 +157,12 @@ def set_switch(name: str, value=None) -> None:
 
 def prof_enable(on: bool) -> None:
     check(lib().svi_prof_enable(1 if on else 0), "svi_prof_enable")
+
+
+def prof_select(tags=None) -> None:
+    """Record only these tags (an iterable of names as prof_summary reports them); None = all."""
+    arg = None if not tags else ",".join(tags).encode()
+    check(lib().svi_prof_select(arg), "svi_prof_select")
 
 
 def prof_summary() -> dict:
