@@ -74,6 +74,8 @@ struct SviSwitches {
                                  // optimistic pass + flagged second pass (same result within the attention tolerance; bit-identical on benign operands)
     int flash_split = 0;         // SVI_FLASH_SPLIT = 1 : never cut the key axis of the long-sequence attention (bit-identical to the unsplit kernel); 2..4: that many
                                  // pieces wherever the key axis allows; 0 (default): where the workgroup count fills the chip's last round poorly (svi_attention.hip)
+    int mx8_fused = 1;           // SVI_MX8_FUSED = 0 : (opt-in MX-fp8 MLP) ffn1 stores its bf16 result and a separate launch quantises it, instead of quantising in
+                                 // ffn1's epilogue (bit-identical; saves one write and one read of the [L, ffn_dim] activation)
     int cross_dedup = 1;         // SVI_CROSS_DEDUP = 0 : cross-attention walks every context row even where the prompt embedding's trailing rows are
                                  // identical (the prompter's zero padding); default: m identical keys = one key counted m times (same softmax)
     int t5_host_buckets = 0;     // SVI_T5_BUCKETS = host : the text encoder's relative-position bucket table in the HOST's fp32 arithmetic (what the
@@ -162,6 +164,9 @@ struct SviGemmArgs {
     int sel_m, sel_n;           // > 0: choose the kernel as for a problem with this many rows / columns (stacked samples keep the per-sample choice,
                                 // so every row sees the same kernel — and the same bits — as in a per-sample launch); 0: by M / N
     int skinny;                 // != 0: rows <= 128 against a large weight matrix (the text encoder): the weight-streaming kernel
+    // svi_launch_gemm_mx8 only: when q8 is set the epilogue's bf16 result is not stored but quantised in place to MX e4m3 ([M][ldq8] bytes) with its
+    // E8M0 block scales ([N/128][q8_sc_rows] dwords) — bit for bit what svi_launch_mx8_quantize makes of the stored bf16 tensor.  N % 256 == 0.
+    unsigned char* q8; int ldq8; unsigned* q8s; int q8_sc_rows;
 };
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
 // MX-fp8 (opt-in): bf16 -> e4m3 + E8M0 block scales ([K/128][sc_rows] dwords), and C = epi(A8 W8^T) with g.A / g.W e4m3, lda / ldw in bytes

@@ -598,6 +598,25 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
             g.bias = bias; g.epi = epi; g.gate = gate; g.res = res; g.ldres = ldc;
             return svi_launch_gemm_mx8(g, w.S8, w.sc_rows, st);
         };
+        if (svi_switches().mx8_fused && F % 256 == 0 && (size_t)(F / 128) * w.sc_rows * 4 + 256 <= (size_t)R * F) {
+            // ffn1 quantises its own GELU output in the epilogue: the [R, F] bf16 activation is never written or read back.  Its e4m3 bytes and block
+            // scales live where that tensor would have been (w.Fb: 2 R F bytes >= R F + R F / 32)
+            unsigned char* q8f = reinterpret_cast<unsigned char*>(w.Fb);
+            unsigned* s8f = reinterpret_cast<unsigned*>(q8f + (((size_t)R * F + 255) & ~(size_t)255));
+            { SviProfScope _p(PROF_GEMM_FFN1, st);
+              SVI_TRY(svi_launch_mx8_quantize(w.Hb, D, R, D, w.Q8, D, w.S8, w.sc_rows, st));
+              SviGemmArgs g{};
+              g.A = reinterpret_cast<const bf16*>(w.Q8); g.lda = D; g.W = reinterpret_cast<const bf16*>(b.ffn0_8); g.ldw = D; g.C = w.Fb; g.ldc = F; g.M = R; g.N = F; g.K = D;
+              g.bias = b.ffn0.b; g.epi = SVI_EPI_BIAS_GELU_TANH;
+              g.q8 = q8f; g.ldq8 = F; g.q8s = s8f; g.q8_sc_rows = w.sc_rows;
+              SVI_TRY(svi_launch_gemm_mx8(g, w.S8, w.sc_rows, st)); }
+            { SviProfScope _p(PROF_GEMM_FFN2, st);
+              SviGemmArgs g{};
+              g.A = reinterpret_cast<const bf16*>(q8f); g.lda = F; g.W = reinterpret_cast<const bf16*>(b.ffn2_8); g.ldw = F; g.C = X; g.ldc = D; g.M = R; g.N = D; g.K = F;
+              g.bias = b.ffn2.b; g.epi = SVI_EPI_BIAS_GATE_RES; g.gate = g_m; g.res = X; g.ldres = D;
+              SVI_TRY(svi_launch_gemm_mx8(g, s8f, w.sc_rows, st)); }
+            return SVI_OK;
+        }
         { SviProfScope _p(PROF_GEMM_FFN1, st);
           SVI_TRY(svi_launch_mx8_quantize(w.Hb, D, R, D, w.Q8, D, w.S8, w.sc_rows, st));
           SVI_TRY(mx(w.Q8, D, b.ffn0_8, b.ffn0.b, w.Fb, F, F, SVI_EPI_BIAS_GELU_TANH, nullptr, nullptr)); }

@@ -282,9 +282,42 @@ __device__ __forceinline__ void gemm256_apply(float (&y)[8], const u32x4& res, c
     }
 }
 
+// Eight consecutive elements of a row (a quarter of a 32-element MX block) -> e4m3 bytes + the block's E8M0 code.  Lane layout: lane & 3 = the
+// quarter inside its block, lane & 15 = the eighth inside its 128-element group (whose four codes make one dword, written by the group's first
+// lane); the 16 lanes of a group hold the same row and are all live or all dead.  Shared by mx8_quantize_kernel and the GEMM epilogue that
+// quantises its own result (SviGemmArgs::q8): the same operations, the same bits.
+__device__ __forceinline__ void mx8_quant8(const float (&v)[8], bool live, int row, int c8, unsigned char* __restrict__ q, int ldq,
+                                           unsigned* __restrict__ scales, int sc_rows) {
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);            // biased exponent of the block maximum (0 for zero / subnormal)
+    const int E = max(eb - 8, 0);                                           // E8M0 code of the shared scale 2^(E - 127)
+    const float inv = __uint_as_float((unsigned)(254 - E) << 23);           // 2^(127 - E), exact
+    unsigned w[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(v[4 * h2 + e] * inv, -448.f), 448.f);      // saturate to the e4m3 range, then round to nearest even
+        unsigned pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], pk, true);
+        w[h2] = pk;
+    }
+    if (live) *reinterpret_cast<u32x2*>(q + (size_t)row * ldq + c8 * 8) = u32x2{w[0], w[1]};
+    // the four block codes of a 128-element group -> one dword, written by the group's first lane
+    const int lane = threadIdx.x & 63;
+    const unsigned e0 = (unsigned)E;
+    const unsigned e1 = (unsigned)__shfl(E, (lane & ~15) + 4), e2 = (unsigned)__shfl(E, (lane & ~15) + 8), e3 = (unsigned)__shfl(E, (lane & ~15) + 12);
+    if (live && (lane & 15) == 0) scales[(size_t)(c8 >> 4) * sc_rows + row] = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+}
+
 // MI x NI: 32x32 accumulator blocks per wave along M / N (wave grid (256 / 32 MI) x (TNV / 32 NI)); TNV: tile width.  The 256^2 kernels are
 // <4, 2, 256>; the 256 x 192 kernel <2, 3, 192> (read-back threads whose column chunk lies past the tile's 192 columns sit idle).
-template <int EPI, int MI = 4, int NI = 2, int TNV = TN>
+template <int EPI, int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false>
 __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, int m0, int n0, int tid,
                                                    int wm, int wn, int l31, int hi, int abl) {
     const bool interior = (m0 + TM <= g.M) && (n0 + TNV <= g.N);
@@ -390,6 +423,13 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
+                if constexpr (Q8OUT) {                 // quantise the rounded result instead of storing it (every lane of the wave is here: interior tile)
+                    float vq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vq[e] = (float)o[e];
+                    mx8_quant8(vq, true, m0 + er + 16 * it, en >> 3, g.q8, g.ldq8, g.q8s, g.q8_sc_rows);
+                    continue;
+                }
                 if (abl == 2) { if (y[0] == 123.456f && y[7] == 1.f) cp[0] = o[3]; }
                 // abl 4: non-temporal stores.  Alone the GEMM gains (attn_o 153 -> 140 us, ffn1 861 -> 841 us: the tile no longer
                 // pushes operand panels out of L2), but in the block the next kernel (LN / the next GEMM) then finds its input in
@@ -419,6 +459,13 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
             }
         }
         gemm256_apply<EPI>(y, rvv, gatev, has_gate);
+        if constexpr (Q8OUT) {                         // (N % 256 == 0: column chunks are whole; rows past M skipped above in whole 32-lane halves)
+            float vq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vq[e] = (float)(bf16)y[e];
+            mx8_quant8(vq, true, m, n >> 3, g.q8, g.ldq8, g.q8s, g.q8_sc_rows);
+            continue;
+        }
         bf16* cp = g.C + (size_t)m * g.ldc + n;
         if (efull) {
             bf16x8 o;
@@ -431,7 +478,7 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
     }
 }
 
-template <int MI = 4, int NI = 2, int TNV = TN>
+template <int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false>
 __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, int m0, int n0, int tid,
                                                  int wm, int wn, int l31, int hi, int abl = 0) {
     if (abl == 1) {
@@ -439,12 +486,12 @@ __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&
         return;
     }
     switch (g.epi) {        // uniform: one scalar branch per tile
-        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        default:                     gemm256_epilogue_t<SVI_EPI_BIAS, MI, NI, TNV>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        default:                     gemm256_epilogue_t<SVI_EPI_BIAS, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
     }
 }
 
@@ -1270,37 +1317,15 @@ __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16* __restric
     const bool live = idx < total;
     const int row = live ? (int)(idx / per_row) : 0, c8 = live ? (int)(idx - (long)row * per_row) : 0;
     float v[8];
-    float amax = 0.f;
     if (live) {
         const bf16x8 t = ld_bf16x8(x + (size_t)row * ldx + c8 * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = (float)t[e]; amax = fmaxf(amax, fabsf(v[e])); }
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    amax = fmaxf(amax, __shfl_xor(amax, 2));
-    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);            // biased exponent of the block maximum (0 for zero / subnormal)
-    const int E = max(eb - 8, 0);                                           // E8M0 code of the shared scale 2^(E - 127)
-    const float inv = __uint_as_float((unsigned)(254 - E) << 23);           // 2^(127 - E), exact
-    unsigned w[2];
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        float a[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(v[4 * h2 + e] * inv, -448.f), 448.f);      // saturate to the e4m3 range, then round to nearest even
-        unsigned pk = 0;
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], pk, false);
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], pk, true);
-        w[h2] = pk;
-    }
-    if (live) *reinterpret_cast<u32x2*>(q + (size_t)row * ldq + c8 * 8) = u32x2{w[0], w[1]};
-    // the four block codes of a 128-element group -> one dword, written by the group's first lane
-    const int lane = threadIdx.x & 63;
-    const unsigned e0 = (unsigned)E;
-    const unsigned e1 = (unsigned)__shfl(E, (lane & ~15) + 4), e2 = (unsigned)__shfl(E, (lane & ~15) + 8), e3 = (unsigned)__shfl(E, (lane & ~15) + 12);
-    if (live && (lane & 15) == 0) scales[(size_t)(c8 >> 4) * sc_rows + row] = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+    mx8_quant8(v, live, row, c8, q, ldq, scales, sc_rows);
 }
 
 __device__ __forceinline__ i32x8 mx8_frag(int base, int s, int hi, int row) {      // K bytes [16 hi, +16) and [32 + 16 hi, +16) of step s of `row`
@@ -1389,7 +1414,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mx8_nt_256_kernel(SviMx8Args a, i
         }
         __syncthreads();                    // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
     }
-    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
+    if (g.q8) gemm256_epilogue<4, 2, TN, true>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);      // the result leaves as MX e4m3 + block scales (the next GEMM's operand)
+    else gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
 }
 
 svi_status svi_launch_mx8_quantize(const bf16* x, int ldx, int rows, int K, unsigned char* q, int ldq, unsigned* scales, int sc_rows, hipStream_t st) {
@@ -1410,6 +1436,9 @@ svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, i
     SVI_REQUIRE(g.epi >= 0 && g.epi <= SVI_EPI_BIAS_RELU, "mx8 gemm: unknown epilogue %d", g.epi);
     SVI_REQUIRE((long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31), "mx8 gemm: operand beyond 2 GiB");
     if (g.epi == SVI_EPI_BIAS_GATE_RES) SVI_REQUIRE(g.res != nullptr && g.ldres % 8 == 0 && ((uintptr_t)g.res % 16) == 0, "mx8 gemm: gate/residual epilogue needs an aligned residual");
+    if (g.q8) SVI_REQUIRE(g.q8s && g.N % 256 == 0 && g.ldq8 >= g.N && g.ldq8 % 8 == 0 && ((uintptr_t)g.q8 % 8) == 0 && ((uintptr_t)g.q8s % 4) == 0 &&
+                          g.q8_sc_rows >= g.M && (const void*)g.q8 != (const void*)g.A && (const void*)g.q8s != (const void*)a_scales,
+                          "mx8 gemm: quantised output needs N %% 256 == 0 (N=%d), its own buffers and a scale table covering M", g.N);
     const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
     const int gm_rows = svi_switches().gemm_gm ? svi_switches().gemm_gm : (tn >= 16 ? 5 : 2);
     SviMx8Args a{g, a_scales, sc_rows};

@@ -120,6 +120,26 @@ def test_block_with_the_fp8_mlp_vs_oracle_and_vs_bf16(hip):
     assert 1e-4 < r_16 < 3e-2, r_16                                                  # it IS different arithmetic, by a bounded amount
 
 
+@pytest.mark.parametrize("grid", [(2, 12, 12), (2, 16, 16), (1, 4, 5)])
+def test_quantisation_in_the_ffn1_epilogue_is_bit_identical(hip, grid):
+    """ffn1 quantises its own GELU output to MX e4m3 in the epilogue (default) instead of storing the bf16 activation and quantising it with a
+    second launch (SVI_MX8_FUSED=0): the same values go through the same operations, so the block's output carries the same bits — row counts
+    that end inside a 256-row tile (288, 20) and that fill whole tiles (512: the epilogue's interior path)."""
+    L = hip._lib
+    f, h, w = grid
+    Lt, seed, nt = f * h * w, 1320, 24
+    m = hip.WanDiT.from_state_dict(fp8_state_dict(SEAM, seed), eps=1e-6, num_heads=2, **SEAM)
+    m.ffn_fp8_mfma(True)
+    bx = dev(synth.randn(seed + 5, 1, Lt, SEAM["dim"])); bctx = dev(synth.randn(seed + 6, 1, nt, SEAM["dim"])); btm = dev(0.5 * synth.randn(seed + 7, 1, 6, SEAM["dim"]))
+    fused = m.block_forward(0, bx, bctx, btm, grid)
+    L.set_switch("SVI_MX8_FUSED", 0)
+    try:
+        apart = m.block_forward(0, bx, bctx, btm, grid)
+    finally:
+        L.set_switch("SVI_MX8_FUSED", None)
+    assert torch.isfinite(fused.float()).all() and torch.equal(fused, apart)
+
+
 def test_forward_with_the_fp8_mlp_stays_within_the_stated_distance(hip):
     c, grid, seed = SEAM, (2, 8, 8), 1310
     f, h, w = grid
