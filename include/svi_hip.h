@@ -205,6 +205,13 @@ svi_status svi_attention_fwd(const void* q, const void* k, const void* v, void* 
  * range the fixed reference covers.  Reports, for the LAST such call enqueued on `stream`, how many workgroups were recomputed and
  * how many the launch had (drains the stream; tests use it to prove that adversarial operands take the second pass). */
 svi_status svi_attention_last_flagged(svi_stream stream, int32_t* flagged_out, int32_t* workgroups_out);
+/* Launch planners: pure arithmetic on sizes and the environment switches, no device work (they run on a machine without a GPU).
+ * svi_gemm_plan: the kernel svi_gemm_bf16 takes for [M, K] x [N, K]^T — 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile
+ * (where 192-wide tiles fill the chip's rounds better: sequence-parallel shards), 256 / 257 / 258 = the 256^2 loops.
+ * svi_attention_plan: out4 = {kernel (1 = short key axes, 2 = long-sequence kernel), work items run whole, pieces per remaining item, workgroups}:
+ * the items of a partly filled last round are cut along the key axis (csrc/svi_attention.hip flash_splits). */
+svi_status svi_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t skinny, int32_t* kernel_out);
+svi_status svi_attention_plan(int32_t s_q, int32_t s_kv, int32_t heads, int32_t compute_units, int32_t* out4);
 
 /* nn.LayerNorm(eps) [+ affine w,b] [+ modulate(x, shift, scale)] over rows of x[rows, dim]
  * (models/wan_video_dit.py:150-151,331-333,358,372).  w,b,shift,scale are bf16 [dim] or NULL. */

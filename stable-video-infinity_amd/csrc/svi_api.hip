@@ -380,6 +380,23 @@ extern "C" svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, i
     return svi_launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
 }
 
+// Launch planners (no device work): what the GEMM / attention launchers would do with a problem of these sizes under the current switches.
+extern "C" svi_status svi_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t skinny, int32_t* kernel_out) {
+    SVI_REQUIRE(kernel_out && M > 0 && N > 0 && K > 0, "svi_gemm_plan: bad argument");
+    SviGemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = (N + 7) / 8 * 8; g.epi = epilogue; g.skinny = skinny;
+    *kernel_out = svi_gemm_choose(g);
+    return SVI_OK;
+}
+extern "C" svi_status svi_attention_plan(int32_t s_q, int32_t s_kv, int32_t heads, int32_t compute_units, int32_t* out4) {
+    SVI_REQUIRE(out4 && s_q > 0 && s_kv > 0 && heads > 0 && compute_units > 0, "svi_attention_plan: bad argument");
+    int kernel = 0;
+    const SviFlashSplit sp = svi_flash_plan(s_q, s_kv, heads, compute_units, &kernel);
+    const int items = sp.qblocks * sp.heads;
+    out4[0] = kernel; out4[1] = sp.whole; out4[2] = sp.pieces; out4[3] = sp.whole + (items - sp.whole) * sp.pieces;
+    return SVI_OK;
+}
+
 // MX-fp8 operator seams (opt-in path; see csrc/svi_gemm.hip): quantise bf16 activations, and the block-scaled GEMM itself.
 extern "C" svi_status svi_mx8_quantize(const void* x, int32_t ldx, int32_t rows, int32_t K, void* q, int32_t ldq, void* scales, int32_t sc_rows,
                                        svi_stream stream) {

@@ -487,8 +487,6 @@ template <int N>
 __device__ __forceinline__ void tile_barrier(int& tok) {
     asm volatile("s_waitcnt vmcnt(%c1)\n\ts_barrier" : "+v"(tok) : "n"(N) : "memory");
 }
-// key-axis split of a launch (see flash_splits): items [0, whole) run whole, items [whole, qblocks * heads) in `pieces` workgroups each
-struct SviFlashSplit { int whole, pieces, qblocks, heads; };
 // One PV MFMA:  a[R:R+15] += V^T-fragment x P-fragment
 template <int R>
 __device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) {
@@ -1054,6 +1052,15 @@ static SviFlashSplit flash_splits(int qblocks, int heads, int Lk, int cus) {
     const double whole_t = (double)(n / cus) + 1.0, cut_t = (double)(n / cus) + (1.0 + 0.03 * S) / S;     // ~3 % per piece: prologue, partial store, merge
     if (cut_t < whole_t * 0.95) { sp.whole = n - rem; sp.pieces = S; }
     return sp;
+}
+
+// The launch plan of an attention call, as svi_launch_flash makes it: which kernel (1 = short key axes, 2 = the long-sequence kernel) and the split.
+SviFlashSplit svi_flash_plan(int Lq, int Lk, int heads, int cus, int* kernel_out) {
+    const SviSwitches& sw = svi_switches();
+    const bool v2 = sw.flash_kernel ? sw.flash_kernel == 2 : (Lk >= 2048);     // short key axes (text context) are prologue-bound: v1
+    if (kernel_out) *kernel_out = v2 ? 2 : 1;
+    if (!v2) return SviFlashSplit{((Lq + QB - 1) / QB) * heads, 1, (Lq + QB - 1) / QB, heads};
+    return flash_splits((Lq + QB2 - 1) / QB2, heads, Lk, cus);
 }
 
 // One flag word per workgroup of the optimistic attention pass, in a buffer of its own per (device, stream): launches on one stream

@@ -169,6 +169,10 @@ struct SviGemmArgs {
     unsigned char* q8; int ldq8; unsigned* q8s; int q8_sc_rows;
 };
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
+int svi_gemm_choose(const SviGemmArgs& g);          // which kernel svi_launch_gemm takes (pure; see svi_gemm.hip)
+// how svi_launch_flash splits a launch into work items (pure; see svi_attention.hip): items [0, whole) run whole, the rest in `pieces` workgroups each
+struct SviFlashSplit { int whole, pieces, qblocks, heads; };
+SviFlashSplit svi_flash_plan(int Lq, int Lk, int heads, int cus, int* kernel_out);
 // MX-fp8 (opt-in): bf16 -> e4m3 + E8M0 block scales ([K/128][sc_rows] dwords), and C = epi(A8 W8^T) with g.A / g.W e4m3, lda / ldw in bytes
 svi_status svi_launch_mx8_quantize(const bf16* x, int ldx, int rows, int K, unsigned char* q, int ldq, unsigned* scales, int sc_rows, hipStream_t st);
 svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, int sc_rows, hipStream_t st);

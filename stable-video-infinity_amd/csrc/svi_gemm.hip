@@ -1448,6 +1448,29 @@ svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, i
     return SVI_OK;
 }
 
+// Which kernel a bf16 GEMM of this shape runs on — pure arithmetic on sizes and switches (svi_gemm_plan exposes it; tests/test_plans.py):
+// 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile, 256 / 257 / 258 = the 256^2 loops (v2 / v3 / persistent v3).
+int svi_gemm_choose(const SviGemmArgs& g) {
+    if (g.skinny && g.M <= 128 && g.K % 128 == 0 && !g.bias_along_m && (g.epi == SVI_EPI_BIAS || g.epi == SVI_EPI_BIAS_GATE_RES) && g.ldc % 4 == 0) return 0;
+    const int selM = g.sel_m > 0 ? g.sel_m : g.M, selN = g.sel_n > 0 ? g.sel_n : g.N;
+    const long t256 = (long)((selM + TM - 1) / TM) * ((selN + TN - 1) / TN);
+    const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
+    const SviSwitches& sw = svi_switches();
+    const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 192 : (t256 >= 128);      // 256-row tiles when the problem fills at least half the chip with them
+    if (!(want256 && g.K % BK == 0 && fits32)) return 128;
+    const int ncu = 256;
+    // 256 x 192 tiles where they fill the chip's rounds better (sequence-parallel shards; see the kernel's header).  A 192-wide tile is
+    // 0.75 of a 256-wide one plus ~8 % (6 MFMAs per 5 fragment reads instead of 8 per 6, the same DMA / barrier count per K tile; measured,
+    // tools/gemm_ab.py shards: N = 1536 shard GEMMs gain 4-20 %, the N = 8960 ones — already many rounds of 256-wide tiles — lose 2-10 % and stay)
+    const int tm_s = (selM + TM - 1) / TM;
+    const long r256 = ((long)tm_s * ((selN + TN - 1) / TN) + ncu - 1) / ncu, r192 = ((long)tm_s * ((selN + 192 - 1) / 192) + ncu - 1) / ncu;
+    const bool better = (double)r192 * 0.75 * 1.08 < (double)r256 * 0.97;
+    if (g.N >= 192 && (sw.gemm_kernel == 192 || (sw.gemm_kernel == 0 && better))) return 192;
+    const int nkq = g.K / BK;
+    if ((nkq % 2 == 0) && nkq >= 4 && sw.gemm_kernel == 258) return 258;
+    return sw.gemm_kernel == 256 ? 256 : 257;
+}
+
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     SVI_REQUIRE(g.M >= 0 && g.N >= 0 && g.K > 0, "gemm: bad sizes M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0 || g.N == 0) return SVI_OK;
@@ -1461,7 +1484,9 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
         SVI_REQUIRE(g.res != nullptr && g.ldres % 8 == 0 && ((uintptr_t)g.res % 16) == 0,
                     "gemm: gate/residual epilogue needs an aligned residual");
     }
-    if (g.skinny && g.M <= 128 && g.K % 128 == 0 && !g.bias_along_m && (g.epi == SVI_EPI_BIAS || g.epi == SVI_EPI_BIAS_GATE_RES) && g.ldc % 4 == 0) {
+    const int kind = svi_gemm_choose(g);
+    const SviSwitches& sw = svi_switches();
+    if (kind == 0) {
         dim3 grid((g.N + 15) / 16);
         const bool wide = g.K % 256 == 0;                 // eight K shares when they come out whole
 #define SVI_SKINNY(MB, UN)                                                                                                        \
@@ -1477,59 +1502,35 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
         SVI_LAUNCH_CHECK();
         return SVI_OK;
     }
-    // 256^2 LDS-DMA kernel when the problem fills at least half the chip with 256^2 tiles (and K tiles are whole)
-    {
-        const int selM = g.sel_m > 0 ? g.sel_m : g.M, selN = g.sel_n > 0 ? g.sel_n : g.N;
-        const long t256 = (long)((selM + TM - 1) / TM) * ((selN + TN - 1) / TN);
-        const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
-        const SviSwitches& sw = svi_switches();
-        const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 192 : (t256 >= 128);
-        if (want256 && g.K % BK == 0 && fits32) {
-            const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
-            // measured (tools/gemm_gm.py, v3 loop): N = 1536 (6 column panels): 2 is best (ffn2 1257 vs 1168-1230 TFLOP/s), flat on q/k/v;
-            // N = 8960 (35 column panels, ffn1): 5-6 give 1050 vs 1022 at 2 and 980 at 8 — a 5 x 6 block of concurrent tiles per XCD
-            // needs the fewest operand panels (HBM fetch per launch at 2: 2.2 GB against 0.13 GB of operands, profiles/r1h_gemm_ffn1_pmc.txt)
-            const int gm_rows = sw.gemm_gm ? sw.gemm_gm : (tn >= 16 ? 5 : 2);
-            const int nkq = g.K / BK;
-            const bool can_q = (nkq % 2 == 0) && nkq >= 4 && true;
-            const int ncu = 256;
-            {   // 256 x 192 tiles where they fill the chip's rounds better (sequence-parallel shards; see the kernel's header).  A 192-wide tile is
-                // 0.75 of a 256-wide one plus ~8 % (6 MFMAs per 5 fragment reads instead of 8 per 6, the same DMA / barrier count per K tile; measured,
-                // tools/gemm_ab.py shards: N = 1536 shard GEMMs gain 4-20 %, the N = 8960 ones — already many rounds of 256-wide tiles — lose 2-10 % and stay)
-                const int tm_s = (selM + TM - 1) / TM;
-                const long r256 = ((long)tm_s * ((selN + TN - 1) / TN) + ncu - 1) / ncu, r192 = ((long)tm_s * ((selN + TN3 - 1) / TN3) + ncu - 1) / ncu;
-                const bool better = (double)r192 * 0.75 * 1.08 < (double)r256 * 0.97;
-                if (g.N >= TN3 && (sw.gemm_kernel == 192 || (sw.gemm_kernel == 0 && better))) {
-                    const int tn3 = (g.N + TN3 - 1) / TN3;
-                    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256x192_kernel), LDS256_BYTES));
-                    hipLaunchKernelGGL(gemm_bf16_nt_256x192_kernel, dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 2));
-                    SVI_LAUNCH_CHECK();
-                    return SVI_OK;
-                }
-            }
-            if (can_q && sw.gemm_kernel == 258) {     // persistent variant (A/B only, see its header: bit-identical, no faster)
-                SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256q_kernel), LDS256Q_BYTES));
-                hipLaunchKernelGGL(gemm_bf16_nt_256q_kernel, dim3(std::min(tm * tn, ncu)), dim3(512), LDS256Q_BYTES, st, g, tm, tn, gm_rows);
-                SVI_LAUNCH_CHECK();
-                return SVI_OK;
-            }
-            if (sw.gemm_kernel == 256) {      // the v2 main loop (barrier at the tile boundary), kept for A/B
-                SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<false>), LDS256_BYTES));
-                hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
-            } else {
-                // Tried and dropped: starting the first round's workgroups out of phase (s_sleep by CU index) so that the CUs' store
-                // bursts do not coincide: no gain on ffn1 (17.5 rounds), a loss wherever the tile count is a whole number of rounds.
-                SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<1>), LDS256_BYTES));
+    if (kind != 128) {
+        const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
+        // measured (tools/gemm_gm.py, v3 loop): N = 1536 (6 column panels): 2 is best (ffn2 1257 vs 1168-1230 TFLOP/s), flat on q/k/v;
+        // N = 8960 (35 column panels, ffn1): 5-6 give 1050 vs 1022 at 2 and 980 at 8 — a 5 x 6 block of concurrent tiles per XCD
+        // needs the fewest operand panels (HBM fetch per launch at 2: 2.2 GB against 0.13 GB of operands, profiles/r1h_gemm_ffn1_pmc.txt)
+        const int gm_rows = sw.gemm_gm ? sw.gemm_gm : (tn >= 16 ? 5 : 2);
+        if (kind == 192) {
+            const int tn3 = (g.N + TN3 - 1) / TN3;
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256x192_kernel), LDS256_BYTES));
+            hipLaunchKernelGGL(gemm_bf16_nt_256x192_kernel, dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 2));
+        } else if (kind == 258) {     // persistent variant (A/B only, see its header: bit-identical, no faster)
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256q_kernel), LDS256Q_BYTES));
+            hipLaunchKernelGGL(gemm_bf16_nt_256q_kernel, dim3(std::min(tm * tn, 256)), dim3(512), LDS256Q_BYTES, st, g, tm, tn, gm_rows);
+        } else if (kind == 256) {     // the v2 main loop (barrier at the tile boundary), kept for A/B
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<false>), LDS256_BYTES));
+            hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
+        } else {
+            // Tried and dropped: starting the first round's workgroups out of phase (s_sleep by CU index) so that the CUs' store
+            // bursts do not coincide: no gain on ffn1 (17.5 rounds), a loss wherever the tile count is a whole number of rounds.
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<1>), LDS256_BYTES));
 #ifdef SVI_ABLATIONS          // epilogue timing ablations (tools/gemm_epi_abl.py; results wrong when set): variant builds only
-                const int abl = sw.gemm_epi_abl;
+            const int abl = sw.gemm_epi_abl;
 #else
-                const int abl = 0;
+            const int abl = 0;
 #endif
-                hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);
-            }
-            SVI_LAUNCH_CHECK();
-            return SVI_OK;
+            hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);
         }
+        SVI_LAUNCH_CHECK();
+        return SVI_OK;
     }
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel), 4 * STAGE_BYTES));

@@ -74,6 +74,8 @@ SYMBOLS = [
     ("svi_dit_bind_ffn_fp8", _i32, [_vp, _i32, _i32, _vp]),
     ("svi_dit_ffn_mx8", _i32, [_vp, _i32]),
     ("svi_fp8_e4m3_to_bf16", _i32, [_vp, _vp, _i64, _vp]),
+    ("svi_gemm_plan", _i32, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
+    ("svi_attention_plan", _i32, [_i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     ("svi_prof_enable", _i32, [_i32]),
     ("svi_prof_summary", _i32, [C.c_char_p, _i64]),
     ("svi_prof_select", _i32, [C.c_char_p]),
@@ -157,6 +159,19 @@ def set_switch(name: str, value=None) -> None:
 
 def prof_enable(on: bool) -> None:
     check(lib().svi_prof_enable(1 if on else 0), "svi_prof_enable")
+
+
+def gemm_plan(M: int, N: int, K: int, epilogue: int = 0, skinny: bool = False) -> int:
+    """The kernel svi_gemm_bf16 would take: 0 skinny, 128, 192, 256 / 257 / 258 (see include/svi_hip.h)."""
+    out = _i32(0)
+    check(lib().svi_gemm_plan(M, N, K, epilogue, 1 if skinny else 0, C.byref(out)), "svi_gemm_plan")
+    return out.value
+
+
+def attention_plan(s_q: int, s_kv: int, heads: int, compute_units: int = 256) -> dict:
+    out = (_i32 * 4)()
+    check(lib().svi_attention_plan(s_q, s_kv, heads, compute_units, out), "svi_attention_plan")
+    return {"kernel": out[0], "whole": out[1], "pieces": out[2], "workgroups": out[3]}
 
 
 def prof_select(tags=None) -> None:

@@ -1,0 +1,66 @@
+"""Launch planners (host logic, no GPU): which GEMM kernel and which attention split the launchers choose for the shapes of the C2 clip, of a
+sequence-parallel rank's shard, and under the environment switches.  Pure arithmetic behind the C ABI (svi_gemm_plan, svi_attention_plan)."""
+import pytest
+
+from svi_hip import _lib as L
+
+L_TOK, D, F = 32760, 1536, 8960
+
+
+@pytest.fixture(autouse=True)
+def clean_switches():
+    yield
+    for k in ("SVI_GEMM_KERNEL", "SVI_FLASH_SPLIT", "SVI_FLASH_KERNEL"):
+        L.set_switch(k, None)
+
+
+@pytest.mark.parametrize("M,N,K,want", [
+    (L_TOK, D, D, 257), (L_TOK, F, D, 257), (L_TOK, D, F, 257), (D, L_TOK, D, 257),          # the single-rank C2 shapes: whole rounds of 256^2 tiles
+    (L_TOK // 4, D, D, 192), (L_TOK // 4, D, F, 192), (L_TOK // 4, F, D, 257),                # P = 4 shard: 192 -> 256 tiles for N = 1536; ffn1 keeps 256-wide tiles
+    (L_TOK // 2, D, D, 192), (L_TOK // 2, F, D, 257), (L_TOK // 3, D, D, 192), (L_TOK // 6, D, F, 192),
+    (D, L_TOK // 4, D, 257),                                                                  # the shard's V^T projection: 6 x 43 192-wide tiles would need two rounds
+    (200, 264, 136, 128), (1000, 520, 192, 128), (4096, 4096, 72, 128),                       # small problems / K not a multiple of 64: the 128^2 kernel
+])
+def test_gemm_kernel_choice(M, N, K, want):
+    assert L.gemm_plan(M, N, K) == want
+
+
+def test_gemm_kernel_choice_follows_the_switch_and_the_skinny_hint():
+    assert L.gemm_plan(64, 4096, 4096, skinny=True) == 0 and L.gemm_plan(64, 4096, 4096) == 128
+    L.set_switch("SVI_GEMM_KERNEL", 257)
+    assert L.gemm_plan(L_TOK // 4, D, D) == 257                   # "never the 192-wide tile"
+    L.set_switch("SVI_GEMM_KERNEL", 192)
+    assert L.gemm_plan(L_TOK, D, D) == 192 and L.gemm_plan(300, 128, 64) == 257     # N < 192: not this kernel (a forced 256-row tile stays 256 wide)
+    L.set_switch("SVI_GEMM_KERNEL", 128)
+    assert L.gemm_plan(L_TOK, F, D) == 128
+    L.set_switch("SVI_GEMM_KERNEL", 258)
+    assert L.gemm_plan(L_TOK, D, F) == 258
+
+
+@pytest.mark.parametrize("sq,skv,heads,want", [
+    (L_TOK, L_TOK, 12, dict(kernel=2, whole=1536, pieces=1, workgroups=1536)),        # C2 single rank: 6.0 rounds, nothing to cut
+    (L_TOK, L_TOK, 3, dict(kernel=2, whole=256, pieces=2, workgroups=512)),           # P = 4 rank: 384 items -> 256 whole + 128 in two key halves
+    (L_TOK, L_TOK, 6, dict(kernel=2, whole=768, pieces=1, workgroups=768)),           # P = 2 rank: three whole rounds
+    (L_TOK, L_TOK, 2, dict(kernel=2, whole=256, pieces=1, workgroups=256)),           # P = 6 rank: one whole round
+    (L_TOK, L_TOK, 1, dict(kernel=2, whole=0, pieces=2, workgroups=256)),             # P = 12 rank: half a round -> every item in two pieces
+    (75600, 75600, 2, dict(kernel=2, whole=512, pieces=3, workgroups=752)),           # 720p, a two-head group: 592 items -> 80 left over, three pieces each
+    (L_TOK, 512, 12, dict(kernel=1, whole=3072, pieces=1, workgroups=3072)),          # text cross-attention: the short-key kernel, 128-row q-blocks
+    (8190, 4200, 3, dict(kernel=2, whole=96, pieces=1, workgroups=96)),               # key axis too short to cut (pieces keep >= 4096 keys)
+])
+def test_attention_launch_plan(sq, skv, heads, want):
+    assert L.attention_plan(sq, skv, heads) == want
+
+
+def test_attention_plan_follows_the_switches():
+    L.set_switch("SVI_FLASH_SPLIT", 1)
+    assert L.attention_plan(L_TOK, L_TOK, 3)["pieces"] == 1
+    L.set_switch("SVI_FLASH_SPLIT", 2)
+    assert L.attention_plan(L_TOK, L_TOK, 12) == dict(kernel=2, whole=0, pieces=2, workgroups=3072)
+    L.set_switch("SVI_FLASH_SPLIT", 4)
+    assert L.attention_plan(L_TOK, 9000, 12)["pieces"] == 2       # 9000 keys: at most two pieces of >= 4096
+    L.set_switch("SVI_FLASH_SPLIT", None)
+    L.set_switch("SVI_FLASH_KERNEL", 1)
+    assert L.attention_plan(L_TOK, L_TOK, 12)["kernel"] == 1
+    L.set_switch("SVI_FLASH_KERNEL", None)
+    # another chip (304 compute units): 1536 = 5 x 304 + 16 -> the 16 items left over are cut in four
+    assert L.attention_plan(L_TOK, L_TOK, 12, compute_units=304) == dict(kernel=2, whole=1520, pieces=4, workgroups=1584)
