@@ -42,6 +42,7 @@ static SviSwitches parse_switches() {
     s.vae_up_phases = env_int("SVI_VAE_UP_PHASES", 0, 1);
     s.vae_tile_order = env_int("SVI_VAE_TILE_ORDER", 0, 1);
     s.mx8_fused = env_int("SVI_MX8_FUSED", 0, 1);
+    s.rms_rows = env_int("SVI_RMS_ROWS", 0, 1);
     s.flash_split = env_int("SVI_FLASH_SPLIT", 0, 0);
     if (s.flash_split > 4) s.flash_split = 4;
     { const char* v = getenv("SVI_T5_BUCKETS"); s.t5_host_buckets = v && strcmp(v, "host") == 0; }

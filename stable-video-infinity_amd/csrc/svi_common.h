@@ -74,6 +74,8 @@ struct SviSwitches {
                                  // optimistic pass + flagged second pass (same result within the attention tolerance; bit-identical on benign operands)
     int flash_split = 0;         // SVI_FLASH_SPLIT = 1 : never cut the key axis of the long-sequence attention (bit-identical to the unsplit kernel); 2..4: that many
                                  // pieces wherever the key axis allows; 0 (default): where the workgroup count fills the chip's last round poorly (svi_attention.hip)
+    int rms_rows = 1;            // SVI_RMS_ROWS = 0 : RMSNorm (+RoPE) and LayerNorm (+modulate) with one row per wave (the generic kernels) also for the DiT's shapes, instead of four rows per wave
+                                 // with the next row requested ahead and the gain vector kept in registers (bit-identical)
     int mx8_fused = 1;           // SVI_MX8_FUSED = 0 : (opt-in MX-fp8 MLP) ffn1 stores its bf16 result and a separate launch quantises it, instead of quantising in
                                  // ffn1's epilogue (bit-identical; saves one write and one read of the [L, ffn_dim] activation)
     int cross_dedup = 1;         // SVI_CROSS_DEDUP = 0 : cross-attention walks every context row even where the prompt embedding's trailing rows are

@@ -78,6 +78,84 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16* __restrict__ x,
     }
 }
 
+// The same arithmetic for rows of whole chunks (dim = 512 MAXC): a wave walks RPW consecutive rows with row i + 1 requested before row i is
+// worked on; for MAXC <= 3 (the 1.3B width) the modulation / affine vectors stay in registers instead of being reloaded for every row.
+// Bit-identical to ln_mod_kernel.
+template <int MAXC, int RPW, bool AFFINE, bool MOD>
+__global__ __launch_bounds__(256) void ln_mod_rows_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ out, int ldo, int rows, int dim, float eps,
+                                                          const bf16* __restrict__ w, const bf16* __restrict__ b, const float* __restrict__ shift,
+                                                          const float* __restrict__ scale1p) {
+    constexpr bool HOIST = MAXC <= 3;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    const int row_end = min(rows, row0 + RPW);
+    bf16x8 cur[MAXC], nxt[MAXC];
+    bf16x8 wv[HOIST ? MAXC : 1], bv[HOIST ? MAXC : 1];
+    f32x4 sc[HOIST ? MAXC : 1][2], sh[HOIST ? MAXC : 1][2];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int col = (lane + 64 * c) * 8;
+        cur[c] = ld_bf16x8(x + (size_t)row0 * ldx + col);
+        nxt[c] = cur[c];
+        if constexpr (HOIST) {
+            if constexpr (AFFINE) { wv[c] = ld_bf16x8(w + col); bv[c] = ld_bf16x8(b + col); }
+            if constexpr (MOD) {
+                sc[c][0] = *reinterpret_cast<const f32x4*>(scale1p + col); sc[c][1] = *reinterpret_cast<const f32x4*>(scale1p + col + 4);
+                sh[c][0] = *reinterpret_cast<const f32x4*>(shift + col); sh[c][1] = *reinterpret_cast<const f32x4*>(shift + col + 4);
+            }
+        }
+    }
+    for (int row = row0; row < row_end; ++row) {
+        if (row + 1 < row_end) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) nxt[c] = ld_bf16x8(x + (size_t)(row + 1) * ldx + (lane + 64 * c) * 8);
+        }
+        float v[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[c][j] = (float)cur[c][j]; s += v[c][j]; }
+        const float mean = wave_sum(s) / (float)dim;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float d = v[c][j] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+        bf16* orow = out + (size_t)row * ldo;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = (lane + 64 * c) * 8;
+            bf16x8 wc, bc;
+            f32x4 sc0, sc1, sh0, sh1;
+            if constexpr (HOIST) {
+                if constexpr (AFFINE) { wc = wv[c]; bc = bv[c]; }
+                if constexpr (MOD) { sc0 = sc[c][0]; sc1 = sc[c][1]; sh0 = sh[c][0]; sh1 = sh[c][1]; }
+            } else {
+                if constexpr (AFFINE) { wc = ld_bf16x8(w + col); bc = ld_bf16x8(b + col); }
+                if constexpr (MOD) {
+                    sc0 = *reinterpret_cast<const f32x4*>(scale1p + col); sc1 = *reinterpret_cast<const f32x4*>(scale1p + col + 4);
+                    sh0 = *reinterpret_cast<const f32x4*>(shift + col); sh1 = *reinterpret_cast<const f32x4*>(shift + col + 4);
+                }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = (v[c][j] - mean) * rstd;
+                if constexpr (AFFINE) y = y * (float)wc[j] + (float)bc[j];
+                y = rbf(y);
+                if constexpr (MOD) y = rbf(rbf(y * (j < 4 ? sc0[j & 3] : sc1[j & 3])) + (j < 4 ? sh0[j & 3] : sh1[j & 3]));
+                o[j] = (bf16)y;
+            }
+            st_bf16x8(orow + col, o);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) cur[c] = nxt[c];
+    }
+}
+
 svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int rows, int dim, float eps,
                              const bf16* w, const bf16* b, const float* shift, const float* scale1p,
                              hipStream_t st) {
@@ -88,6 +166,23 @@ svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int row
     if (rows <= 0) return SVI_OK;
     dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
     const int nchunk = dim / 8;
+    // the DiT's widths (whole chunks per lane) and norm kinds (modulated without affine: norm1 / norm2; affine without modulation: norm3): the
+    // multi-row kernel.  The modulation vectors must be 16-byte aligned for its vector loads (the DiT's are).
+    if ((nchunk == 64 * 3 || nchunk == 64 * 10) && svi_switches().rms_rows && ((w != nullptr) != (scale1p != nullptr)) &&
+        ((((uintptr_t)shift | (uintptr_t)scale1p) & 15) == 0)) {
+        constexpr int RPW = 4;
+        dim3 grid_r((rows + ROWS_PER_BLOCK * RPW - 1) / (ROWS_PER_BLOCK * RPW));
+#define SVI_LN_ROWS(MAXC)                                                                                                                 \
+        do {                                                                                                                              \
+            if (w) hipLaunchKernelGGL((ln_mod_rows_kernel<MAXC, RPW, true, false>), grid_r, block, 0, st, x, ldx, out, ldo, rows, dim, eps, w, b, shift, scale1p);   \
+            else hipLaunchKernelGGL((ln_mod_rows_kernel<MAXC, RPW, false, true>), grid_r, block, 0, st, x, ldx, out, ldo, rows, dim, eps, w, b, shift, scale1p);   \
+        } while (0)
+        if (nchunk == 64 * 3) SVI_LN_ROWS(3);
+        else SVI_LN_ROWS(10);
+#undef SVI_LN_ROWS
+        SVI_LAUNCH_CHECK();
+        return SVI_OK;
+    }
     if (nchunk <= 64 * 3)
         hipLaunchKernelGGL(ln_mod_kernel<3>, grid, block, 0, st, x, ldx, out, ldo, rows, dim, eps, w, b, shift, scale1p);
     else if (nchunk <= 64 * 10)
@@ -185,6 +280,72 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
     }
 }
 
+// The same arithmetic for the shapes the DiT runs (every lane holds MAXC whole chunks: dim = 512 MAXC; RoPE from the per-token table or none;
+// in place): a wave walks RPW consecutive rows, requests row i + 1 before it works on row i, and keeps the gain vector in registers — the
+// generic kernel above reloads and unpacks it for every row and has one row in flight per wave.  Bit-identical results.
+template <int MAXC, int RPW, bool ROPE>
+__global__ __launch_bounds__(256) void rmsnorm_rope_rows_kernel(bf16* __restrict__ x, int ld, int rows, int dim, const bf16* __restrict__ weight,
+                                                                const bf16* __restrict__ weight1, float eps, SviRope r, float out_scale, float out_scale1) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    const int row_end = min(rows, row0 + RPW);
+    bf16* xb = x + (size_t)blockIdx.y * dim;
+    if (blockIdx.y) { weight = weight1; out_scale = out_scale1; }
+    bf16x8 wv[MAXC], cur[MAXC], nxt[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        wv[c] = ld_bf16x8(weight + (lane + 64 * c) * 8);
+        cur[c] = ld_bf16x8(xb + (size_t)row0 * ld + (lane + 64 * c) * 8);
+        nxt[c] = cur[c];
+    }
+    for (int row = row0; row < row_end; ++row) {
+        if (row + 1 < row_end) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) nxt[c] = ld_bf16x8(xb + (size_t)(row + 1) * ld + (lane + 64 * c) * 8);
+        }
+        float v[MAXC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[c][j] = (float)cur[c][j]; ss += v[c][j] * v[c][j]; }
+        const float rs = rsqrtf(wave_sum(ss) / (float)dim + eps);
+        const float2* tt = nullptr;
+        if (ROPE) {
+            int tok = row + r.row0;
+            if (r.period > 0) tok %= r.period;
+            tt = r.tab_tok + (size_t)tok * 64;
+        }
+        bf16* xr = xb + (size_t)row * ld;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = (lane + 64 * c) * 8;
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[c][j] * rs) * (float)wv[c][j]);
+            bf16x8 o;
+            if (ROPE) {
+                const int pair0 = (col & 127) >> 1;
+                const f32x4 t01 = *reinterpret_cast<const f32x4*>(tt + pair0), t23 = *reinterpret_cast<const f32x4*>(tt + pair0 + 2);
+                const float cx[4] = {t01[0], t01[2], t23[0], t23[2]}, sy[4] = {t01[1], t01[3], t23[1], t23[3]};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float a = y[2 * p], bq = y[2 * p + 1];
+                    o[2 * p] = (bf16)((a * cx[p] - bq * sy[p]) * out_scale);
+                    o[2 * p + 1] = (bf16)((a * sy[p] + bq * cx[p]) * out_scale);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)(y[j] * out_scale);
+            }
+            st_bf16x8(xr + col, o);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) cur[c] = nxt[c];
+    }
+}
+
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
                                    const SviRope* rope, float out_scale, hipStream_t st) {
     return svi_launch_rmsnorm_rope2(x, ld, rows, dim, weight, nullptr, eps, rope, out_scale, 1.0f, st);
@@ -218,6 +379,21 @@ svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf
         if (scatter) hipLaunchKernelGGL((rmsnorm_rope_kernel<MAXC, true>), grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1, sc);  \
         else hipLaunchKernelGGL((rmsnorm_rope_kernel<MAXC, false>), grid, block, 0, st, x, ld, rows, dim, weight, weight1, eps, use, r, out_scale, out_scale1, sc);        \
     } while (0)
+    // the DiT's shapes (in place, whole chunks per lane, per-token RoPE table or no RoPE): the multi-row kernel
+    if (!scatter && (nchunk == 64 * 3 || nchunk == 64 * 10) && (!rope || r.tab_tok) && svi_switches().rms_rows) {
+        constexpr int RPW = 4;
+        dim3 grid_r((rows + ROWS_PER_BLOCK * RPW - 1) / (ROWS_PER_BLOCK * RPW), weight1 ? 2 : 1);
+#define SVI_RMS_ROWS(MAXC)                                                                                                               \
+        do {                                                                                                                             \
+            if (rope) hipLaunchKernelGGL((rmsnorm_rope_rows_kernel<MAXC, RPW, true>), grid_r, block, 0, st, x, ld, rows, dim, weight, weight1, eps, r, out_scale, out_scale1);   \
+            else hipLaunchKernelGGL((rmsnorm_rope_rows_kernel<MAXC, RPW, false>), grid_r, block, 0, st, x, ld, rows, dim, weight, weight1, eps, r, out_scale, out_scale1);       \
+        } while (0)
+        if (nchunk == 64 * 3) SVI_RMS_ROWS(3);
+        else SVI_RMS_ROWS(10);
+#undef SVI_RMS_ROWS
+        SVI_LAUNCH_CHECK();
+        return SVI_OK;
+    }
     if (nchunk <= 64 * 3) SVI_RMS_LAUNCH(3);
     else if (nchunk <= 64 * 10) SVI_RMS_LAUNCH(10);
     else SVI_RMS_LAUNCH(16);

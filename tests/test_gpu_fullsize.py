@@ -164,6 +164,29 @@ def test_dit_c2_geometry_vs_cpu_oracle(hip):
     assert got.shape == want.shape and r < 2e-2, r
 
 
+@pytest.mark.parametrize("grid", [(2, 9, 7), (3, 16, 16)])
+def test_multi_row_rmsnorm_rope_is_bit_identical(hip, grid):
+    """At the DiT's widths (dim = 1536: three whole 16-byte chunks per lane) RMSNorm (+RoPE from the per-token table) and LayerNorm (+modulate /
+    affine) run four rows per wave with the next row requested ahead and the gain / modulation vectors held in registers; SVI_RMS_ROWS=0
+    selects the generic one-row-per-wave kernels.
+    Same arithmetic, same bits: two blocks at 1.3B widths, the plain forward and the stacked CFG pair (token index modulo the sample
+    length), token counts that are / are not multiples of the 16 rows a workgroup walks (126, 768)."""
+    from svi_hip import _lib as L
+    m = _wan13b_two_blocks(hip)[0]
+    f, h, w = grid
+    x, ctx, t = _rnd(40, 1, 16, f, 2 * h, 2 * w), _rnd(41, 1, 512, 4096), torch.tensor([500.0])
+    a = m.forward(x, t, ctx)
+    pa = m.forward_cfg_pair(x, t, ctx, -ctx)
+    L.set_switch("SVI_RMS_ROWS", 0)
+    try:
+        b = m.forward(x, t, ctx)
+        pb = m.forward_cfg_pair(x, t, ctx, -ctx)
+    finally:
+        L.set_switch("SVI_RMS_ROWS", None)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1])
+
+
 def test_dit_720p_geometry(hip):
     """81 frames at 1280x720 (the I2V-720P configuration's grid, 21x45x80 = 75600 tokens) at 1.3B widths, one block: finite,
     deterministic, and the two-rank sequence-parallel schedule reproduces it — bit for bit with the attention's key axis in one piece
