@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#include <atomic>
 #include "svi_common.h"
 
 #define QB 128            // query rows per workgroup
@@ -1109,16 +1110,20 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     const int lds = 2 * (KT_BYTES + VT_BYTES);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     const SviSwitches& sw = svi_switches();
-    const bool v2 = sw.flash_kernel ? sw.flash_kernel == 2 : (Lk >= 2048);     // short key axes (text context) are prologue-bound: v1
-    if (v2) {
+    static std::atomic<int> cus[64];                             // compute units per device (0: not asked yet)
+    const int dev = svi_current_device();
+    if (dev < 0) return SVI_ERR_HIP;
+    int ncu = 256;
+    if (dev < 64) {
+        ncu = cus[dev].load(std::memory_order_relaxed);
+        if (!ncu) { int n = 0; SVI_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev)); ncu = n > 0 ? n : 256; cus[dev].store(ncu, std::memory_order_relaxed); }
+    }
+    int kernel = 0;
+    const SviFlashSplit sp = svi_flash_plan(Lq, Lk, num_heads, ncu, &kernel);          // the one place that decides kernel and split (svi_attention_plan shows it)
+    if (kernel == 2) {
         typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*, float*, float2*, SviFlashSplit);
         const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
         dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
-        static int cus[64] = {0};                                // compute units per device
-        const int dev = svi_current_device();
-        if (dev < 0) return SVI_ERR_HIP;
-        if (dev < 64 && !cus[dev]) { int n = 0; SVI_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev)); cus[dev] = n > 0 ? n : 256; }
-        const SviFlashSplit sp = flash_splits((int)grid2.x, num_heads, Lk, dev < 64 ? cus[dev] : 256);
         const int n_items = (int)grid2.x * num_heads, n_cut = n_items - sp.whole;
         float* opart = nullptr;
         float2* ml = nullptr;
