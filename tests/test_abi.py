@@ -73,3 +73,19 @@ def test_ops_fail_loudly_without_gpu():
     x = torch.zeros(4, 128, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         svi_hip.layernorm_modulate(x)
+
+
+def test_every_environment_switch_is_documented():
+    """Each SVI_* switch the library parses (csrc/svi_api.hip) is listed in the public header and explained where its field lives
+    (csrc/svi_common.h SviSwitches); the timing ablations of variant builds (-DSVI_ABLATIONS) are the exception: they are not in the product."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "stable-video-infinity_amd", "csrc", "svi_api.hip")).read()
+    product, _, ablations = src.partition("#ifdef SVI_ABLATIONS\n    s.flash_abl")
+    names = set(re.findall(r'(?:env_int|getenv)\("(SVI_[A-Z0-9_]+)"', product))
+    assert len(names) >= 14 and "SVI_FLASH_ABL" not in names
+    header = open(os.path.join(root, "include", "svi_hip.h")).read()
+    common = open(os.path.join(root, "stable-video-infinity_amd", "csrc", "svi_common.h")).read()
+    missing = sorted(n for n in names if n not in header or n not in common)
+    assert not missing, missing
