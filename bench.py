@@ -21,12 +21,20 @@ only data-path exchange is the all-gather of each clip's tail (motion) latents o
 The VAE decode of the finished clip is timed in the same run (outside the K-step region, on the same stream) and
 its time is part of `value`; `config.dit_only_value` reports the a1-only variant.
 
+The single-rank step replays ONE hipGraph per step (the installed sampler's default, DenoiseLoop(graph=True): the ~1500 launches of a
+step as one; bit-identical); `--no-graph` launches eagerly.  `--transport gloo` runs the multi-rank path with the exchanges through
+the host and the ranks sharing the visible device(s): a probe of that code path on a one-GPU box, never a scaling figure.
+
 Extra objects on the JSON line:
   roofline      dominant kernel = self-attention flash kernel: algorithmic 4*L^2*D FLOP per launch divided by
-                its mean launch time measured with HIP events on the launch stream inside the timed region.
-  cpu_baseline  the CPU oracle (a restatement of the reference, oracle/wan_dit_oracle.py) timed on this box's
-                host cores on a bounded sample (one of the 30 blocks of one of the 100 forwards, full size),
-                extrapolated to a clip.  Rank 0, N=1 only.
+                its mean launch time measured with HIP events on the launch stream — inside the timed region with --no-graph; with
+                the hipGraph (default) over eager steps of the same loop run directly behind it (a replay cannot carry event pairs).
+                `traffic` / `mfma_busy_in_clock` come from the rocprofv3 --pmc summaries under profiles/ and are given only when
+                EVERY kernel source hash recorded with them equals the tree being timed.
+  cpu_baseline  the reference's own DiTBlock.forward and WanVideoVAE.decode (oracle/_ref, built by oracle/build_ref.py: kind
+                "reference") — or, where that copy is absent, the oracle's restatement (kind "port") — timed on this box's
+                host cores on a bounded sample (one of the 30 blocks of one of the 100 forwards, full size; 2 of the 21 latent
+                frames), extrapolated to a clip.  Rank 0, N=1 only.
 """
 from __future__ import annotations
 
@@ -83,40 +91,67 @@ def device_weights(cfg: dict, seed: int, device) -> dict:
 
 
 def cpu_baseline_worker() -> None:
-    """Child process: time the oracle's DiTBlock at the full C2 size (L=32760, fp32) and the oracle's VAE decode of two latent
-    frames (5 video frames) at the C2 spatial size; print seconds."""
+    """Child process: time ONE DiTBlock forward at the full C2 size (L=32760, fp32) and the VAE decode of two latent frames (5 video
+    frames) at the C2 spatial size on the host cores; print seconds.  With oracle/_ref present (oracle/build_ref.py: the reference's
+    own modules, copied at build time) it is the REFERENCE's DiTBlock.forward (wan_video_dit.py:354-374) and WanVideoVAE.decode
+    (wan_video_vae.py:777-789) that are timed — kind "reference"; otherwise the oracle's restatement — kind "port"."""
     import synth
-    from oracle import wan_dit_oracle as wdo
-    from oracle import wan_vae_oracle as wvo
+    from oracle import build_ref
     c = dict(synth.WAN_1_3B)
     c["num_layers"] = 1
+    grid = (21, 30, 52)
+    f, h, w = grid
+    L = f * h * w
     sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(0, **c).items()}
-    cfg = wdo.DiTConfig(num_layers=1)
-    L = 21 * 30 * 52
     x = torch.from_numpy(synth.randn(1, 1, L, 1536))
     ctx = torch.from_numpy(synth.randn(2, 1, 512, 1536))
     tm = torch.from_numpy(0.1 * synth.randn(3, 1, 6, 1536))
-    rope = wdo.rope_table_3d(128, (21, 30, 52))
-    t0 = time.time()
-    with torch.no_grad():
-        wdo.dit_block(sd, "blocks.0.", x, ctx, tm, rope, cfg)
-    block_s = time.time() - t0
-    del sd, x
     vsd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(500).items()}
     z = torch.from_numpy(synth.randn(511, 1, 16, 2, 60, 104))
-    t0 = time.time()
-    with torch.no_grad():
-        wvo.vae_decode(vsd, z)
-    vae_s = time.time() - t0
-    print(json.dumps({"block_seconds": block_s, "vae_2_latent_frames_seconds": vae_s, "threads": torch.get_num_threads()}), flush=True)
+    kind = "port"
+    if build_ref.available():
+        try:
+            from oracle import ref_shim
+            dit_mod, vae_mod, _ = ref_shim.load(build_ref.OUT)
+            blk = dit_mod.DiTBlock(False, c["dim"], 12, c["ffn_dim"], 1e-6).eval()
+            blk.load_state_dict({k[len("blocks.0."):]: v for k, v in sd.items() if k.startswith("blocks.0.")}, strict=True)
+            fr = dit_mod.precompute_freqs_cis_3d(128)
+            freqs = torch.cat([fr[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1), fr[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                               fr[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(L, 1, -1)
+            v = vae_mod.WanVideoVAE()
+            v.load_state_dict(vsd, strict=True)
+            kind = "reference"
+        except Exception as ex:      # a broken copy must not pass for the reference: fall back to the port and say so
+            print(f"oracle/_ref present but not importable ({type(ex).__name__}: {ex}); timing the port", file=sys.stderr, flush=True)
+            kind = "port"
+    if kind == "reference":
+        with torch.no_grad():
+            t0 = time.time()
+            blk(x, ctx, tm, freqs)
+            block_s = time.time() - t0
+            t0 = time.time()
+            v.decode([z[0]], device="cpu")
+            vae_s = time.time() - t0
+    else:
+        from oracle import wan_dit_oracle as wdo
+        from oracle import wan_vae_oracle as wvo
+        cfg = wdo.DiTConfig(num_layers=1)
+        rope = wdo.rope_table_3d(128, grid)
+        with torch.no_grad():
+            t0 = time.time()
+            wdo.dit_block(sd, "blocks.0.", x, ctx, tm, rope, cfg)
+            block_s = time.time() - t0
+            t0 = time.time()
+            wvo.vae_decode(vsd, z)
+            vae_s = time.time() - t0
+    print(json.dumps({"block_seconds": block_s, "vae_2_latent_frames_seconds": vae_s, "threads": torch.get_num_threads(), "kind": kind}), flush=True)
 
 
 def cpu_baseline(max_threads: int = 32, timeout_s: int = 300) -> dict:
-    """The CPU oracle (restatement of the reference) on this box's host cores, in a child process pinned to `threads` OpenMP
-    threads, on a bounded sample of the workload: one of the 30 blocks of one of the 100 forwards of a clip at full size, and the
-    VAE decode of 2 of the clip's 21 latent frames (5 of its 81 frames); extrapolated to a clip.  kind "port": the reference is
-    absent on the GPU box; profiles/r2_cpu_reference_vs_port.json (tools/ref_vs_oracle_block.py, build container) times the
-    reference's own DiTBlock / VAE decode beside the oracle's on the same inputs."""
+    """The reference's CPU path on this box's host cores, in a child process pinned to `threads` OpenMP threads, on a bounded sample of
+    the workload: one of the 30 blocks of one of the 100 forwards of a clip at full size, and the VAE decode of 2 of the clip's 21 latent
+    frames (5 of its 81 frames); extrapolated to a clip.  kind "reference": the reference's own DiTBlock / WanVideoVAE from oracle/_ref
+    (oracle/build_ref.py); kind "port": oracle/_ref is absent and the oracle's restatement was timed instead."""
     import subprocess
     threads = max(1, min(max_threads, os.cpu_count() or 1))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
@@ -126,26 +161,43 @@ def cpu_baseline(max_threads: int = 32, timeout_s: int = 300) -> dict:
                            text=True, timeout=timeout_s)
         res = json.loads(r.stdout.strip().splitlines()[-1])
         dt, vt = res["block_seconds"], res["vae_2_latent_frames_seconds"]
+        base["kind"] = res.get("kind", "port")
     except Exception as ex:  # timeout or failure: say so instead of inventing a number
-        return dict(base, value=None, sample=f"oracle DiTBlock at L=32760 + VAE sample did not finish within {timeout_s}s on {threads} threads ({type(ex).__name__})")
+        return dict(base, value=None, sample=f"DiTBlock at L=32760 + VAE sample did not finish within {timeout_s}s on {threads} threads ({type(ex).__name__})")
     clip_s = dt * 30 * 100 + vt * 81.0 / 5.0
-    rel = ""
-    try:
-        # the reference's own modules timed beside the oracle's restatement on one host (tools/ref_vs_oracle_block.py, build container):
-        # applied here to say what the REFERENCE would take on this box's cores, next to the port's measured figure
-        rv = json.load(open(os.path.join(ROOT, "profiles", "r2_cpu_reference_vs_port.json")))
-        rb, rvae = rv["port_over_reference_block"], rv["port_over_reference_vae"]
-        base["reference_over_port"] = {"dit_block_speed": round(rb, 4), "vae_decode_speed": round(rvae, 4),
-                                       "source": "profiles/r2_cpu_reference_vs_port.json"}
-        base["value_reference_estimate"] = 21.0 / (dt / rb * 30 * 100 + vt / rvae * 81.0 / 5.0)
-        rel = (f"; on the build container ({rv['threads']} threads) the reference's own DiTBlock took {rv['reference_block_s']:.1f}s against the oracle's "
-               f"{rv['oracle_block_s']:.1f}s and its VAE decode {rv['reference_vae_decode_2_latent_frames_s']:.1f}s against {rv['oracle_vae_decode_2_latent_frames_s']:.1f}s "
-               f"(value_reference_estimate applies those ratios to this box's port timings)")
-    except Exception:
-        pass
+    what = ("the reference's own DiTBlock.forward (diffsynth/models/wan_video_dit.py:354-374, fp32, F.scaled_dot_product_attention) and WanVideoVAE.decode "
+            "(wan_video_vae.py:777-789) from oracle/_ref") if base["kind"] == "reference" else \
+           "the oracle's restatement (oracle/wan_dit_oracle.py, oracle/wan_vae_oracle.py; oracle/_ref absent)"
     return dict(base, value=21.0 / clip_s,
-                sample=f"1 DiTBlock forward (fp32 oracle, oracle/wan_dit_oracle.py) at L=32760 took {dt:.1f}s and the VAE decode of 2 latent frames "
-                       f"(5 frames 480x832, oracle/wan_vae_oracle.py) {vt:.1f}s on {threads} threads; extrapolated x30 blocks x100 forwards + decode x81/5 per clip{rel}")
+                sample=f"1 DiTBlock forward at L=32760 took {dt:.1f}s and the VAE decode of 2 latent frames (5 frames 480x832) {vt:.1f}s on {threads} threads — {what}; "
+                       f"extrapolated x30 blocks x100 forwards + decode x81/5 per clip")
+
+
+def pmc_summaries() -> dict:
+    """The newest rocprofv3 --pmc summaries under profiles/ (tools/profile_round.sh) that were collected on EXACTLY the kernel sources being
+    timed: every hash of `<tag>_source_hashes.json` must equal the sha256[:16] of the csrc file of that name in this tree.  A summary collected
+    on any other source state is not quoted (VERDICT r3 weak #6): {"why": ...} instead."""
+    import glob
+    import hashlib
+    try:
+        csrc = os.path.join(ROOT, "stable-video-infinity_amd", "csrc")
+        tags = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_source_hashes.json")), key=os.path.getmtime, reverse=True)
+        for f in tags:
+            rec = json.load(open(f))
+            if not rec or any(not os.path.exists(os.path.join(csrc, n)) or hashlib.sha256(open(os.path.join(csrc, n), "rb").read()).hexdigest()[:16] != h
+                              for n, h in rec.items()):
+                continue
+            tag = os.path.basename(f)[:-len("_source_hashes.json")]
+            out = {"tag": tag}
+            for key in ("flash", "gemm_ffn1"):
+                p = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc.json")
+                if os.path.exists(p):
+                    out[key] = json.load(open(p))
+                    out[key + "_file"] = os.path.relpath(p, ROOT)
+            return out
+        return {"why": "no profiles/*_source_hashes.json matches the csrc/*.hip being timed (tools/profile_round.sh was not run on this tree)"}
+    except Exception as ex:
+        return {"why": f"profiles/ not readable ({type(ex).__name__})"}
 
 
 def free_port() -> int:
@@ -155,13 +207,15 @@ def free_port() -> int:
         return sk.getsockname()[1]
 
 
-def launch_ranks(n: int, selftest: bool) -> int:
+def launch_ranks(n: int, selftest: bool, transport: str = "nccl") -> int:
     """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (torch.distributed.run on 127.0.0.1, one
     process per GPU) and hand its exit code on.  Refuses instead of shrinking: N visible GPUs or nothing."""
     import subprocess
     if not selftest:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < n:
+        if transport == "gloo" and have >= 1:
+            pass                                    # --transport gloo: ranks may share a device (probe of the multi-rank path)
+        elif have < n:
             print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {have}: refusing to run fewer ranks than asked for", file=sys.stderr, flush=True)
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -209,8 +263,14 @@ def main() -> None:
                     "a separately toleranced line (tests/test_gpu_mx8.py), never the headline")
     ap.add_argument("--profile-all", action="store_true", help="bracket every tagged kernel family with HIP events inside the timed region (about 1 %% slower steps) "
                     "instead of the dominant kernel there and the full breakdown in 4 extra steps behind it")
-    ap.add_argument("--graph", action="store_true", help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)): for the "
-                    "launch-bound regime (--workload c1); per-kernel event timing is off under capture, so `roofline` is null")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None, help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)). "
+                    "DEFAULT for the single-rank step (what the installed sampler does); per-kernel HIP events cannot be taken inside a replay, so "
+                    "`roofline` / `roofline_all` then come from eager, instrumented steps run directly behind the timed region")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager launches in the timed region (rounds 1-3's behaviour); the dominant kernel is "
+                    "then bracketed by HIP events inside the timed region itself")
+    ap.add_argument("--transport", default="nccl", choices=["nccl", "gloo"], help="process-group backend of a multi-rank run.  nccl (= RCCL over xGMI): one GPU per "
+                    "rank, the measured configuration.  gloo: the exchanges go through the host and the ranks may SHARE a device (rank r -> device r mod visible) — a "
+                    "probe that drives the whole multi-rank code path (shard, exchange, max-over-ranks, aggregation) on a one-GPU box; its line says so and is not a scaling figure")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launcher-selftest", action="store_true", help="only start the ranks, join them over gloo on the CPU and print who joined "
                     "(tests/test_bench_launcher.py: the launch path without GPUs)")
@@ -221,7 +281,7 @@ def main() -> None:
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args.gpus, args.launcher_selftest))
+        sys.exit(launch_ranks(args.gpus, args.launcher_selftest, args.transport))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -238,6 +298,8 @@ def main() -> None:
         dist.destroy_process_group()
         return
     local = int(os.environ.get("SVI_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))      # SVI_BENCH_DEVICE: pin every rank to one device (a probe only)
+    if args.transport == "gloo" and torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        local %= torch.cuda.device_count()          # ranks share devices when there are fewer devices than ranks
     if not torch.cuda.is_available() or local >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} has no GPU {local} ({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible)", file=sys.stderr, flush=True)
         sys.exit(2)
@@ -249,12 +311,16 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        who = join_ranks(dist, dev, args.gpus, "nccl (RCCL)")
-        try:
-            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:
-            rccl = None
+        if args.transport == "gloo":
+            dist.init_process_group("gloo")
+            who = join_ranks(dist, dev, args.gpus, "gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+            who = join_ranks(dist, dev, args.gpus, "nccl (RCCL)")
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
 
     import synth
     import svi_hip
@@ -283,7 +349,11 @@ def main() -> None:
         assert dist is not None and world % 2 == 0, "--cfg-pair needs an even number of ranks"
         from svi_hip.parallel import CfgPair
         pair, pair_idx, units = CfgPair.split_world()
+    if args.graph is None:
+        args.graph = pair is None and not sp       # the single-rank step replays a hipGraph by default (DenoiseLoop's own default)
     loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp, graph=args.graph)
+    eager_loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp, graph=False) if args.graph else loop
+    eager_loop.scheduler = loop.scheduler
     spc = wl["steps_per_clip"]
     loop.scheduler.set_timesteps(spc, shift=5.0)
 
@@ -317,9 +387,9 @@ def main() -> None:
         pose_ms = e0.elapsed_time(e1)
         del pose_video
 
-    def one_step(i: int) -> None:
+    def one_step(i: int, lp=None) -> None:
         j = i % spc
-        loop.step(lat, ts_dev[j:j + 1], loop.scheduler.step_delta(loop.scheduler.timesteps[j]), ctx_pos, ctx_neg, 5.0, **cond)
+        (lp or loop).step(lat, ts_dev[j:j + 1], loop.scheduler.step_delta(loop.scheduler.timesteps[j]), ctx_pos, ctx_neg, 5.0, **cond)
 
     def sync() -> None:
         if dist is not None:
@@ -351,12 +421,28 @@ def main() -> None:
     prof_timed = _lib.prof_summary()
     _lib.prof_enable(False)
     _lib.prof_select(None)
-    prof, prof_steps = prof_timed, args.steps
-    if not args.graph and not args.profile_all:
+    prof, prof_steps, roof_steps = prof_timed, args.steps, args.steps
+    roof_source = "HIP events on the launch stream over the timed region"
+    if args.graph:
+        # a replayed hipGraph cannot carry per-kernel event pairs: the dominant kernel is timed over `roof_steps` EAGER steps of the same loop
+        # state directly behind the timed region (only that kernel bracketed: the step is otherwise undisturbed), then every family
+        loop.drop_graph()
+        roof_steps = max(1, min(4, args.steps))
+        _lib.prof_select(["flash_self"])
+        _lib.prof_enable(True)
+        for i in range(roof_steps):
+            one_step(args.warmup + args.steps + i, eager_loop)
+        torch.cuda.synchronize()
+        prof_timed = _lib.prof_summary()
+        _lib.prof_enable(False)
+        _lib.prof_select(None)
+        roof_source = (f"HIP events on the launch stream over {roof_steps} eager steps run directly behind the timed region (the timed region replays one hipGraph per "
+                       "step, inside which no event pair can be taken; same kernels, same operands)")
+    if not args.profile_all or args.graph:
         prof_steps = max(1, min(4, args.steps))
         _lib.prof_enable(True)
         for i in range(prof_steps):
-            one_step(args.warmup + args.steps + i)
+            one_step(args.warmup + args.steps + roof_steps + i, eager_loop)
         torch.cuda.synchronize()
         prof = _lib.prof_summary()
         _lib.prof_enable(False)
@@ -428,25 +514,14 @@ def main() -> None:
         ach = alg / (per_launch_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel from PMC counters: collected in separate rocprofv3 --pmc passes
         # (tools/profile_round.sh -> profiles/*_flash_pmc.json, corrected as MI355X_MICROARCH.md prescribes); not measurable live
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            import hashlib
-            src_sha = hashlib.sha256(open(os.path.join(ROOT, "stable-video-infinity_amd", "csrc", "svi_attention.hip"), "rb").read()).hexdigest()[:16]
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_flash_pmc.json")), key=os.path.getmtime)
-            for f in reversed(pm):                 # the newest summary collected on THIS kernel source; none -> null, not a stale number
-                rec = json.load(open(f))
-                if rec.get("attention_src_sha") == src_sha and args.workload == "c2":
-                    traffic, traffic_src = rec.get("hbm_bytes"), os.path.relpath(f, ROOT)
-                    break
-            if traffic is None:
-                traffic_src = f"no profiles/*_flash_pmc.json was collected on csrc/svi_attention.hip sha {src_sha} (tools/profile_round.sh)"
-        except Exception:
-            traffic = None
+        pmc = pmc_summaries() if args.workload == "c2" else {"why": "the PMC summaries are collected on the c2 workload"}
+        fp = pmc.get("flash") or {}
+        traffic, traffic_src = fp.get("hbm_bytes"), pmc.get("flash_file") or pmc.get("why")
         roof = {"kernel": "flash_fwd2_kernel (self-attention; one launch = the optimistic pass <...,1> + the flagged second pass <...,2>, which exits "
                           "at once unless a row's exponentials left the optimistic range)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4)}
+                "mfma_busy_in_clock": fp.get("mfma_busy_in_clock"), "l2_hit_rate": fp.get("l2_hit_rate"),
+                "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4), "source": roof_source}
     # ---- every kernel family of the step against the roofline that bounds it (per rank; ms from HIP events on the launch stream) ----
     PEAK_HBM_TBS = 8.0
     shard = dist.get_world_size(sp_group) if sp else 1
@@ -465,9 +540,20 @@ def main() -> None:
         return {"bound": bound, "what": what, "launches_per_step": round(n, 2), "algorithmic_per_step": total, "ms_per_step": round(ms, 3),
                 "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}
     Ls = L // shard if sp else L
+
+    def distinct_keys(c):      # what ctx_tail_scan_kernel leaves on the device: rows up to and including the first of the identical suffix
+        same = (c[0] == c[0, -1]).all(dim=-1)
+        n = c.shape[1] - 1
+        while n > 0 and bool(same[n - 1]):
+            n -= 1
+        return n + 1
+    keys_walked = [distinct_keys(ctx_pos), distinct_keys(ctx_neg)] if os.environ.get("SVI_CROSS_DEDUP", "1") != "0" else [lc, lc]
     roof_all = {
         "flash_self": fam("flash_self", 4.0 * L * L * D / shard, "mfma", "4 L^2 D FLOP per launch (QK^T + PV, all heads)"),
-        "flash_cross": fam("flash_cross", 4.0 * Ls * lc * D, "mfma", "4 L Lc D FLOP per launch (text context; the 257-token image branch is untagged)"),
+        # the cross-attention walks the DISTINCT keys of the zero-padded prompt (svi_dit.hip ctx_tail: n + 1 of the 512): with a few dozen keys
+        # the launch is a read of q and a write of o — HBM-bound — and the matrix work it executes is 4 L (n+1) D, not 4 L Lc D
+        "flash_cross": fam("flash_cross", 4.0 * Ls * D, "hbm", f"q [L, D] bf16 read + o [L, D] bf16 written per launch; keys walked: {keys_walked} of {lc} context rows "
+                           "(identical trailing rows of the zero-padded prompt count as one key)"),
         "gemm_qkv": fam("gemm_qkv", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch (q, k, v^T projections)"),
         "gemm_attn_out": fam("gemm_attn_out", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch, gate + residual epilogue"),
         "gemm_cross": fam("gemm_cross", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch (cross-attention q and o; cached prompt K / V excluded)"),
@@ -488,6 +574,17 @@ def main() -> None:
                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s (f16 MFMA equivalent)", "frac": round(3 * vflop / (vae_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                   "fp32_equivalent_tflops": round(vflop / (vae_ms * 1e-3) / 1e12, 1)}
     roof_all = {k: v for k, v in roof_all.items() if v is not None}
+    if args.workload == "c2" and not sp:
+        pm = pmc_summaries()
+        for fam_name, key in (("flash_self", "flash"), ("gemm_ffn1", "gemm_ffn1")):
+            if fam_name in roof_all and pm.get(key):
+                roof_all[fam_name].update(traffic=pm[key].get("hbm_bytes"), mfma_busy_in_clock=pm[key].get("mfma_busy_in_clock"),
+                                          l2_hit_rate=pm[key].get("l2_hit_rate"), pmc_source=pm.get(key + "_file"))
+    if "flash_cross" in roof_all:
+        fc = roof_all["flash_cross"]
+        mean_keys = sum(keys_walked) / len(keys_walked)
+        fc["executed_tflops"] = round(4.0 * Ls * mean_keys * D * fc["launches_per_step"] / (fc["ms_per_step"] * 1e-3) / 1e12, 1)
+        fc["reference_algorithmic_tflops"] = round(4.0 * Ls * lc * D * fc["launches_per_step"] / (fc["ms_per_step"] * 1e-3) / 1e12, 1)
     line = {
         "metric": {"c2": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step", "c1": "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",
                    "c4": "denoised latent frames/sec, Wan2.1-I2V-14B 81f@832x480 50-step",
@@ -509,6 +606,9 @@ def main() -> None:
                    "dit_tflops": round(flops_step / (dist.get_world_size(sp_group) if sp else 1) / (ms_per_step * 1e-3) / 1e12, 1),
                    "flop_per_step_executed": flops_step, "flop_per_forward_reference": flops_forward,
                    "ranks": who, "rccl": rccl,
+                   "transport": None if world == 1 else ("nccl (RCCL), one GPU per rank" if args.transport == "nccl" else
+                                                         f"gloo through the host, {len({w.get('pci_bus_id') for w in who})} distinct device(s) under {world} ranks: a probe of "
+                                                         "the multi-rank code path, NOT a scaling measurement"),
                    "hip_graph": bool(args.graph), "weights": ("float8_e4m3fn storage; MLP GEMMs on the MX block-scaled fp8 matrix path (activations e4m3 with one E8M0 scale per 32 elements), everything else "
                                "bf16 — NOT the reference's arithmetic, opt-in, separately toleranced") if args.fp8_mfma else
                    "float8_e4m3fn storage, cast to bf16 at bind (reference FP8 mode)" if args.fp8_storage else "bf16",
@@ -516,8 +616,9 @@ def main() -> None:
         "roofline": roof,
         "roofline_all": roof_all,
         "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items()},
-        "kernel_ms_source": ("HIP events of every tagged kernel family inside the timed region" if (args.profile_all or args.graph) else
-                             f"{prof_steps} fully instrumented steps behind the timed region (inside it only the dominant kernel is bracketed by events; `roofline` is from those)"),
+        "kernel_ms_source": ("HIP events of every tagged kernel family inside the timed region" if (args.profile_all and not args.graph) else
+                             f"{prof_steps} fully instrumented eager steps behind the timed region" + (" (which replays one hipGraph per step)" if args.graph else
+                             " (inside it only the dominant kernel is bracketed by events; `roofline` is from those)")),
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

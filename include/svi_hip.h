@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 7
+#define SVI_HIP_ABI_VERSION 8
 
 typedef enum {
     SVI_OK = 0,
@@ -78,7 +78,7 @@ int32_t svi_abi_version(void);
 int32_t svi_device_count(void);
 
 /* A/B tooling: the library reads its environment switches (SVI_FLASH_KERNEL, SVI_FLASH_TWO_PASS, SVI_FLASH_SPLIT, SVI_GEMM_KERNEL, SVI_GEMM_GM,
- * SVI_CROSS_DEDUP, SVI_RMS_ROWS, SVI_MX8_FUSED, SVI_VAE_EXACT_FP32, SVI_VAE_X2H, SVI_VAE_DMA, SVI_VAE_UP_PHASES, SVI_VAE_TILE_ORDER, SVI_T5_BUCKETS — all of them select between kernels that
+ * SVI_CROSS_DEDUP, SVI_RMS_ROWS, SVI_QK_FUSED, SVI_MX8_FUSED, SVI_VAE_EXACT_FP32, SVI_VAE_X2H, SVI_VAE_DMA, SVI_VAE_UP_PHASES, SVI_VAE_TILE_ORDER, SVI_T5_BUCKETS — all of them select between kernels that
  * compute the same result, bit for bit or within the stated parity bounds; csrc/svi_common.h SviSwitches) once, at first use; tools that flip them inside one process
  * call this afterwards.  Switches that change results exist only in variant builds (-DSVI_ABLATIONS), never in the product. */
 svi_status svi_switches_reload(void);
@@ -182,9 +182,13 @@ svi_status svi_dit_sp_head(svi_dit* h, void* head_rows_out, svi_stream stream);
 svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void* out, int32_t T, int32_t H, int32_t W, svi_stream stream);
 int32_t svi_dit_head_ld(svi_dit* h);
 /* Moves whenever device state that a captured hipGraph of this handle's forwards may have baked in stops being valid (workspace
- * growth, a context-cache entry filled or evicted, svi_dit_context_cache, a weight re-bound).  Read it right after a capture;
- * replay only while it is unchanged (svi_hip.DenoiseLoop(graph=True) does). */
+ * growth, a context-cache entry filled or evicted, svi_dit_context_cache, a weight re-bound, a per-stream library buffer freed).  Read it
+ * right after a capture; replay only while it is unchanged (svi_hip.DenoiseLoop does). */
 int64_t svi_dit_generation(svi_dit* h);
+/* The library keeps small device buffers per (device, stream) — the attention kernels' flag words, split-key partial sums — for as long as
+ * the process lives.  A caller that retires a stream (a hipGraph capture stream) releases them here; all_streams != 0: those of every stream
+ * of the current device.  Drains the device.  Graphs captured on the stream must not be replayed afterwards (svi_dit_generation moves). */
+svi_status svi_stream_buffers_release(svi_stream stream, int32_t all_streams);
 svi_status svi_attention_vt_fwd(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vt, int32_t ldvt, void* out,
                                 int32_t ldo, int32_t s_q, int32_t s_kv, int32_t n, int32_t q_prescaled, svi_stream stream);
 
@@ -207,10 +211,11 @@ svi_status svi_attention_fwd(const void* q, const void* k, const void* v, void* 
 svi_status svi_attention_last_flagged(svi_stream stream, int32_t* flagged_out, int32_t* workgroups_out);
 /* Launch planners: pure arithmetic on sizes and the environment switches, no device work (they run on a machine without a GPU).
  * svi_gemm_plan: the kernel svi_gemm_bf16 takes for [M, K] x [N, K]^T — 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile
- * (where 192-wide tiles fill the chip's rounds better: sequence-parallel shards), 256 / 257 / 258 = the 256^2 loops.
+ * (where 192-wide tiles fill the chip's rounds better: sequence-parallel shards), 257 / 259 = the 256^2 loops (v3 / eight-phase); `compute_units` = CUs of the part
+ * the round arithmetic is done for (256 on MI355X; the launcher asks the device).
  * svi_attention_plan: out4 = {kernel (1 = short key axes, 2 = long-sequence kernel), work items run whole, pieces per remaining item, workgroups}:
  * the items of a partly filled last round are cut along the key axis (csrc/svi_attention.hip flash_splits). */
-svi_status svi_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t skinny, int32_t* kernel_out);
+svi_status svi_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t skinny, int32_t compute_units, int32_t* kernel_out);
 svi_status svi_attention_plan(int32_t s_q, int32_t s_kv, int32_t heads, int32_t compute_units, int32_t* out4);
 
 /* nn.LayerNorm(eps) [+ affine w,b] [+ modulate(x, shift, scale)] over rows of x[rows, dim]

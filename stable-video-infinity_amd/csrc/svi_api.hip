@@ -2,6 +2,7 @@
 // (the seams the reference exposes: flash_attention, LayerNorm+modulate, RMSNorm+RoPE, Linear, CFG step).
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <deque>
 #include <mutex>
 #include <vector>
@@ -32,7 +33,7 @@ static SviSwitches parse_switches() {
     s.flash_kernel = env_int("SVI_FLASH_KERNEL", 1, 0);
     if (s.flash_kernel > 2) s.flash_kernel = 0;
     s.gemm_kernel = env_int("SVI_GEMM_KERNEL", 128, 0);
-    if (s.gemm_kernel != 128 && s.gemm_kernel != 192 && s.gemm_kernel != 256 && s.gemm_kernel != 257 && s.gemm_kernel != 258) s.gemm_kernel = 0;
+    if (s.gemm_kernel != 128 && s.gemm_kernel != 192 && s.gemm_kernel != 257 && s.gemm_kernel != 259) s.gemm_kernel = 0;
     s.gemm_gm = env_int("SVI_GEMM_GM", 1, 0);
     s.vae_exact_fp32 = getenv("SVI_VAE_EXACT_FP32") != nullptr;
     s.flash_two_pass = env_int("SVI_FLASH_TWO_PASS", 0, 1);
@@ -42,6 +43,7 @@ static SviSwitches parse_switches() {
     s.vae_up_phases = env_int("SVI_VAE_UP_PHASES", 0, 1);
     s.vae_tile_order = env_int("SVI_VAE_TILE_ORDER", 0, 1);
     s.mx8_fused = env_int("SVI_MX8_FUSED", 0, 1);
+    s.qk_fused = env_int("SVI_QK_FUSED", 0, 1);
     s.rms_rows = env_int("SVI_RMS_ROWS", 0, 1);
     s.flash_split = env_int("SVI_FLASH_SPLIT", 0, 0);
     if (s.flash_split > 4) s.flash_split = 4;
@@ -105,9 +107,39 @@ svi_status svi_ensure_lds(const void* kernel, int bytes) {
 // keyed by (device, stream, kind): work enqueued on one stream is ordered, so a buffer is only ever used by one launch sequence
 // at a time; two streams (or two host threads driving two streams) get buffers of their own and cannot clear or overwrite each
 // other's.  Growing a buffer frees the old one (hipFree drains the device first) — never in steady state.
+// A captured hipGraph bakes these buffers' addresses in: every time one of them is freed (grown, or released) the process-wide generation
+// below moves, svi_dit_generation() includes it, and DenoiseLoop re-captures instead of replaying against freed memory.
+namespace {
+struct StreamSlot { int dev, kind; hipStream_t st; void* p; size_t bytes; long user; };
+std::deque<StreamSlot>& stream_slots() {
+    static std::deque<StreamSlot> slots;    // deque: a slot's address (its host-side `user` word) stays valid as the table grows
+    return slots;
+}
+std::atomic<unsigned long long> g_stream_buffer_generation{0};
+}  // namespace
+unsigned long long svi_stream_buffer_generation() { return g_stream_buffer_generation.load(std::memory_order_relaxed); }
+
+// Frees the library buffers keyed to `stream` on the current device (a capture stream that is being retired); stream = nullptr: those of
+// every stream of the device.  Drains the device first (hipFree).  Graphs captured on such a stream must be dropped by the caller; the
+// generation moves so that DenoiseLoop does.
+extern "C" svi_status svi_stream_buffers_release(svi_stream stream, int32_t all_streams) {
+    const int dev = svi_current_device();
+    if (dev < 0) return SVI_ERR_HIP;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lock(table_mutex());
+    bool any = false;
+    for (StreamSlot& c : stream_slots())
+        if (c.dev == dev && c.p && (all_streams || c.st == st)) {
+            SVI_CHECK_HIP(hipFree(c.p));
+            c.p = nullptr; c.bytes = 0; c.user = 0; any = true;
+        }
+    if (any) g_stream_buffer_generation.fetch_add(1, std::memory_order_relaxed);
+    return SVI_OK;
+}
+
 svi_status svi_stream_buffer(int kind, hipStream_t st, size_t bytes, void** out, long** user_out) {
-    struct Slot { int dev, kind; hipStream_t st; void* p; size_t bytes; long user; };
-    static std::deque<Slot> slots;          // deque: a slot's address (its host-side `user` word) stays valid as the table grows
+    typedef StreamSlot Slot;
+    std::deque<Slot>& slots = stream_slots();
     const int dev = svi_current_device();
     if (dev < 0) return SVI_ERR_HIP;
     std::lock_guard<std::mutex> lock(table_mutex());
@@ -126,7 +158,7 @@ svi_status svi_stream_buffer(int kind, hipStream_t st, size_t bytes, void** out,
             return SVI_ERR_INVALID;
         }
         (void)hipGetLastError();
-        if (s->p) { SVI_CHECK_HIP(hipFree(s->p)); s->p = nullptr; s->bytes = 0; }
+        if (s->p) { SVI_CHECK_HIP(hipFree(s->p)); s->p = nullptr; s->bytes = 0; g_stream_buffer_generation.fetch_add(1, std::memory_order_relaxed); }
         hipError_t e = hipMalloc(&s->p, bytes);
         if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B, buffer kind %d) failed: %s", bytes, kind, hipGetErrorString(e)); return SVI_ERR_OOM; }
         s->bytes = bytes;
@@ -382,11 +414,11 @@ extern "C" svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, i
 }
 
 // Launch planners (no device work): what the GEMM / attention launchers would do with a problem of these sizes under the current switches.
-extern "C" svi_status svi_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t skinny, int32_t* kernel_out) {
-    SVI_REQUIRE(kernel_out && M > 0 && N > 0 && K > 0, "svi_gemm_plan: bad argument");
+extern "C" svi_status svi_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t skinny, int32_t compute_units, int32_t* kernel_out) {
+    SVI_REQUIRE(kernel_out && M > 0 && N > 0 && K > 0 && compute_units > 0, "svi_gemm_plan: bad argument");
     SviGemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = (N + 7) / 8 * 8; g.epi = epilogue; g.skinny = skinny;
-    *kernel_out = svi_gemm_choose(g);
+    *kernel_out = svi_gemm_choose(g, compute_units);
     return SVI_OK;
 }
 extern "C" svi_status svi_attention_plan(int32_t s_q, int32_t s_kv, int32_t heads, int32_t compute_units, int32_t* out4) {

@@ -60,7 +60,7 @@ void svi_set_error(const char* fmt, ...);
 // -DSVI_ABLATIONS (tools/build_variant.py) and are absent from the product library.
 struct SviSwitches {
     int flash_kernel = 0;        // SVI_FLASH_KERNEL = 1 | 2 : force flash_fwd_kernel / flash_fwd2_kernel (0: by key count)
-    int gemm_kernel = 0;         // SVI_GEMM_KERNEL = 128 | 192 | 256 | 257 | 258 : force the 128^2 kernel / the 256 x 192 tile / the v2 256^2 main loop / the v3 loop / the persistent v3 (0: by tile count)
+    int gemm_kernel = 0;         // SVI_GEMM_KERNEL = 128 | 192 | 257 | 259 : force the 128^2 kernel / the 256 x 192 tile / the 256^2 v3 loop / the 256^2 eight-phase loop (0: by tile count)
     int gemm_gm = 0;             // SVI_GEMM_GM = n >= 1 : row panels per tile group (0: per shape)
     int vae_exact_fp32 = 0;      // SVI_VAE_EXACT_FP32 : fp32-MFMA convolution everywhere
     int vae_no_x2h = 0;          // SVI_VAE_X2H = 0 : the three-term bf16 convolution also where the two-term fp16 form applies (same parity bounds)
@@ -76,6 +76,8 @@ struct SviSwitches {
                                  // pieces wherever the key axis allows; 0 (default): where the workgroup count fills the chip's last round poorly (svi_attention.hip)
     int rms_rows = 1;            // SVI_RMS_ROWS = 0 : RMSNorm (+RoPE) and LayerNorm (+modulate) with one row per wave (the generic kernels) also for the DiT's shapes, instead of four rows per wave
                                  // with the next row requested ahead and the gain vector kept in registers (bit-identical)
+    int qk_fused = 1;            // SVI_QK_FUSED = 0 : the self-attention q and k projections as two launches instead of one N = 2 dim launch over the two weight
+                                 // matrices (bit-identical: per element the same kernel and the same k order)
     int mx8_fused = 1;           // SVI_MX8_FUSED = 0 : (opt-in MX-fp8 MLP) ffn1 stores its bf16 result and a separate launch quantises it, instead of quantising in
                                  // ffn1's epilogue (bit-identical; saves one write and one read of the [L, ffn_dim] activation)
     int cross_dedup = 1;         // SVI_CROSS_DEDUP = 0 : cross-attention walks every context row even where the prompt embedding's trailing rows are
@@ -169,9 +171,14 @@ struct SviGemmArgs {
     // svi_launch_gemm_mx8 only: when q8 is set the epilogue's bf16 result is not stored but quantised in place to MX e4m3 ([M][ldq8] bytes) with its
     // E8M0 block scales ([N/128][q8_sc_rows] dwords) — bit for bit what svi_launch_mx8_quantize makes of the stored bf16 tensor.  N % 256 == 0.
     unsigned char* q8; int ldq8; unsigned* q8s; int q8_sc_rows;
+    // two weight matrices side by side along N (the self-attention q | k projections as ONE launch, wan_video_dit.py:227-228): columns n >= n_split
+    // take row n - n_split of W2 (same ldw) and bias2.  n_split must be a multiple of the tile width of the kernel that runs (the launcher falls back
+    // to two launches otherwise); the weights stay the caller's tensors — nothing is packed, so an in-place LoRA merge needs no re-bind.
+    const bf16* W2; const bf16* bias2; int n_split;
 };
+unsigned long long svi_stream_buffer_generation();       // moves whenever a per-stream library buffer is freed (svi_api.hip)
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
-int svi_gemm_choose(const SviGemmArgs& g);          // which kernel svi_launch_gemm takes (pure; see svi_gemm.hip)
+int svi_gemm_choose(const SviGemmArgs& g, int compute_units);          // which kernel svi_launch_gemm takes (pure; see svi_gemm.hip)
 // how svi_launch_flash splits a launch into work items (pure; see svi_attention.hip): items [0, whole) run whole, the rest in `pieces` workgroups each
 struct SviFlashSplit { int whole, pieces, qblocks, heads; };
 SviFlashSplit svi_flash_plan(int Lq, int Lk, int heads, int cus, int* kernel_out);

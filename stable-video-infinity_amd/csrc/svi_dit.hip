@@ -518,8 +518,20 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
     rope.period = nb > 1 ? L / nb : 0;
     // --- self attention: x += gate_msa * o(attn(rope(rms(q)), rope(rms(k)), v))     dit:358,369,226-242
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_a, sc_a, st)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, QK, 2 * D, L, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
+    // q | k as ONE N = 2D launch (dit:227-228 side by side): tile columns below D multiply by Wq, the others by Wk — the LN output is read
+    // once for both, the weights stay the bound tensors (nothing is packed).  Per element the kernel and the k order are those of the two
+    // separate launches (the kernel choice is pinned to the per-projection shape through sel_n): the same bits.
+    if (!svi_switches().qk_fused) {
+        { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, QK, 2 * D, L, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
+        { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
+    } else {
+      SviProfScope _p(PROF_GEMM_QKV, st);
+      SviGemmArgs g{};
+      g.A = w.Hb; g.lda = D; g.W = b.sa.q.w; g.ldw = D; g.C = QK; g.ldc = 2 * D; g.M = L; g.N = 2 * D; g.K = D;
+      g.bias = b.sa.q.b; g.epi = SVI_EPI_BIAS;
+      g.W2 = b.sa.k.w; g.bias2 = b.sa.k.b; g.n_split = D;
+      g.sel_m = nb > 1 ? L / nb : 0; g.sel_n = D;
+      SVI_TRY(svi_launch_gemm(g, st)); }
     { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st, nb)); }
     // q and k in one launch (grid.y = operand): q additionally carries softmax_scale * log2(e) into its single final rounding
     { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope2(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st, scatter)); }
@@ -1148,7 +1160,7 @@ extern "C" int32_t svi_dit_head_ld(svi_dit* h) { return h ? head_ld(h->cfg) : 0;
 // A counter that moves whenever device state a captured hipGraph of this handle's forwards may have baked in stops being valid:
 // the workspace was (re)allocated, a context-cache entry was filled / evicted, the cache was reset, a weight was re-bound.
 // A replay is only legal while the value equals the one read right after the capture.
-extern "C" int64_t svi_dit_generation(svi_dit* h) { return h ? (int64_t)h->generation : -1; }
+extern "C" int64_t svi_dit_generation(svi_dit* h) { return h ? (int64_t)(h->generation + svi_stream_buffer_generation()) : -1; }
 
 extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_inout, const void* context,
                                             const void* t_mod, int32_t f, int32_t hh, int32_t ww, int32_t Lc,

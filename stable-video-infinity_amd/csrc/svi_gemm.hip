@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <atomic>
+#include <algorithm>
 
 #include "svi_common.h"
 #include <cstdio>
@@ -52,6 +54,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
     const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
     const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (g.W2 && n0 >= g.n_split) {                          // q | k side by side: this tile's columns belong to the second matrix
+        g.W = g.W2 - (size_t)g.n_split * g.ldw;
+        g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
+    }
 
     // global -> register staging assignment: 1024 16-byte chunks per operand tile, 4 per thread
     const int ld_row = tid >> 3;            // + 32*j
@@ -238,6 +244,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 // =================================================================================================
 #define TM 256
 #define TN 256
+#ifndef SVI_GEMM_DEFAULT_256
+#define SVI_GEMM_DEFAULT_256 257      // which 256^2 main loop runs by default: 257 = v3 ("256p"), 259 = eight-phase ("256e"); SVI_GEMM_KERNEL overrides per process
+#endif
 #define T_STAGE (TM * BK * 2)          // 32 KiB per operand tile
 #define C2_LD 264
 #define LDS256_BYTES (TM * C2_LD * 2)  // 135168 >= 4 * T_STAGE
@@ -509,127 +518,6 @@ template <class F> __device__ __forceinline__ void static_for16(F&& f) {
     f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});
     f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{}); f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{});
 }
-// acc += W-fragment x X-fragment as an asm statement: `tok` chains all of them in program order, `apin` (the LDS address of the
-// fragment read placed behind this MFMA) keeps that read from being hoisted above it.
-__device__ __forceinline__ void gemm_mfma(int& tok, f32x16& acc, u32x4 w, u32x4 x, int& apin) {
-    asm("v_mfma_f32_32x32x16_bf16 %[c], %[w], %[x], %[c]" : [c] "+v"(acc), [tok] "+v"(tok), [ap] "+v"(apin) : [w] "v"(w), [x] "v"(x));
-}
-
-template <bool use_compiler_loop>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lds0 = (int)(size_t)(lptr_t)smem;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    const int nwg = tiles_m * tiles_n;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-    const int group = swz / (GM * tiles_n);
-    const int first_m = group * GM;
-    const int gm = min(GM, tiles_m - first_m);
-    const int in_group = swz - group * GM * tiles_n;
-    const int tile_n = in_group / gm;
-    const int tile_m = first_m + (in_group - tile_n * gm);
-    const int m0 = tile_m * TM, n0 = tile_n * TN;
-
-    // ---- LDS-DMA assignment: operand tile = 32 pieces of 1 KiB (8 rows); wave w issues pieces w, w+8, w+16, w+24
-    unsigned a_off[4], w_off[4];         // element offsets of this lane's source chunk at k = 0
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (j * 8 + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 8;
-        w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 8;
-    }
-    const int nk = g.K / BK;
-    auto stage = [&](int kt, int buf) {
-        char* As = smem + buf * 2 * T_STAGE;
-        char* Ws = As + T_STAGE;
-        const bf16* ak = g.A + kt * BK;
-        const bf16* wk = g.W + kt * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(ak + a_off[j]), (lptr_t)(As + (j * 8 + wave) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(wk + w_off[j]), (lptr_t)(Ws + (j * 8 + wave) * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][4];                       // [ni][mi]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // Fragment addresses (LDS byte offsets inside a stage): the swizzle XOR makes the 4 k-steps non-additive, the 32-row
-    // sub-tiles (+4096 B) fold into the immediate.
-    int a_addr[4], w_addr[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
-        w_addr[kk] = lds0 + T_STAGE + lds_tile_off(wn * 64 + l31, 2 * kk + hi);
-    }
-    int tok = 0;
-    u32x4 xa[2][4], wb[2][2];               // fragment sets: k-step kk lives in set kk & 1, read one k-step ahead
-    auto read_frags = [&](int kk, int set, int stage_off) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xa[set][i] = *(lds_u32x4_t)(a_addr[kk] + stage_off + i * 32 * 128);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wb[set][i] = *(lds_u32x4_t)(w_addr[kk] + stage_off + i * 32 * 128);
-    };
-    stage(0, 0);
-    __syncthreads();
-    read_frags(0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const int so = cur * 2 * T_STAGE;
-        if constexpr (use_compiler_loop) {
-            // reference form: hipcc schedules (it serialises read -> wait -> 8 MFMAs per k-step; kept for A/B timing)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk) read_frags(kk, 0, so);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[0][ni]), __builtin_bit_cast(bf16x8, xa[0][mi]), acc[ni][mi], 0, 0, 0);
-            }
-        } else {
-            // pinned form: the 6 fragment reads of k-step kk+1 are issued behind the first MFMAs of k-step kk (each read is
-            // tied, through its address register, behind one MFMA statement), so LDS latency runs under the MFMAs instead of
-            // in front of them — the two waves of a SIMD run in lockstep (same barrier) and do not cover for each other.
-            static_for4([&](auto kc) {
-                constexpr int kk = decltype(kc)::value;
-                constexpr int cs = kk & 1, ns = cs ^ 1;
-                static_for8([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    constexpr int ni = i >> 2, mi = i & 3;
-                    int& pin = (i < 4) ? a_addr[(kk + 1) & 3] : w_addr[(kk + 1) & 3];
-                    gemm_mfma(tok, acc[ni][mi], wb[cs][ni], xa[cs][mi], pin);
-                    if constexpr (kk < 3) {
-                        if constexpr (i < 4) xa[ns][i] = *(lds_u32x4_t)(a_addr[kk + 1] + so + i * 32 * 128);
-                        else if constexpr (i < 6) wb[ns][i - 4] = *(lds_u32x4_t)(w_addr[kk + 1] + so + (i - 4) * 32 * 128);
-                    }
-                });
-            });
-        }
-        __syncthreads();                    // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
-        if (kt + 1 < nk) read_frags(0, 0, (cur ^ 1) * 2 * T_STAGE);
-    }
-    asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
-    asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
-
-    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
-}
-
-
 // -------------------------------------------------------------------------------------------------
 // 256^2 kernel, main loop v3 ("256p").  Same tile, LDS image, operand swizzle and epilogue as above; what changes is WHERE the
 // per-tile barrier sits and WHEN the LDS-DMA of the next tile is issued.  In the kernel above every K tile begins with the 8
@@ -679,6 +567,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g
     const int tile_n = in_group / gm;
     const int tile_m = first_m + (in_group - tile_n * gm);
     const int m0 = tile_m * TM, n0 = tile_n * TN;
+    if (g.W2 && n0 >= g.n_split) {                          // q | k side by side: this tile's columns belong to the second matrix
+        g.W = g.W2 - (size_t)g.n_split * g.ldw;
+        g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
+    }
 
     unsigned a_off[4], w_off[4];
 #pragma unroll
@@ -825,6 +717,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256x192_kernel(SviGemmArg
     const int tile_n = in_group / gm;
     const int tile_m = first_m + (in_group - tile_n * gm);
     const int m0 = tile_m * TM, n0 = tile_n * TN3;
+    if (g.W2 && n0 >= g.n_split) {                          // q | k side by side: this tile's columns belong to the second matrix
+        g.W = g.W2 - (size_t)g.n_split * g.ldw;
+        g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
+    }
 
     unsigned a_off[4], w_off[3];
 #pragma unroll
@@ -929,279 +825,198 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256x192_kernel(SviGemmArg
 }
 
 // =================================================================================================
-// Persistent variant of the v3 kernel (same tile, same main loop, same arithmetic per element): one workgroup per CU walks
-// several output tiles, and the LDS-DMA pipeline never drains between them.
+// 256^2 kernel, EIGHT-PHASE main loop ("256e"): same tile, same LDS image, same operand swizzle, same MFMA (32x32x16, weight fragment as
+// A operand), same k order per element and the same epilogue as the v3 kernel above — so the same bits — on another schedule.
 //
-// What a non-persistent tile pays besides its MFMAs (K = 1536: 38 us of main loop in ~47 us): the workgroup launch, a prologue
-// that waits for two K tiles to land with nothing to compute, and an epilogue that takes all of the LDS ([256][264] C tile) behind
-// two workgroup barriers, so nothing of the next tile can be in flight.  Here:
-//   * while the last K tile of output tile i is being multiplied, K tile 0 of output tile i+1 streams into the stage that just
-//     fell free; after the final MFMAs one barrier (all waves have read the other stage; K tile 0 is visible) and K tile 1
-//     follows — both land under the epilogue;
-//   * the epilogue is PRIVATE to a wave: its 128 x 64 sub-tile goes through its own 4 KiB of LDS (the 32 KiB above the four
-//     operand stages) in four 32-row pieces — written in accumulator order, read back as whole 128-byte row segments (8 rows per
-//     store instruction) — with wave-local ordering only, no workgroup barrier;
-//   * tile i+1 starts on registers and LDS that are already there.
-// Same bits as gemm_bf16_nt_256p_kernel: per element the K-summation order and the epilogue arithmetic are unchanged.
-// K / 64 must be even (the stage parity of a tile's first K tile is then always 0).
+// Why: the v3 loop keeps the SIMD's two waves in lockstep (one barrier per K tile, both waves read fragments, issue LDS-DMA and
+// multiply at the same points of their streams) and holds 0.57-0.64 of the matrix pipe in-clock (PMC, profiles/r3n_gemm_ffn1_pmc.txt);
+// the schedule below is the one cdna_hip_programming.md measures at ~0.75 in-clock on this part ("256^2 8-phase template"): the wave
+// rows run ONE BARRIER APART, so that on every SIMD one wave is inside an 8-MFMA cluster (raised priority) while its partner reads the
+// fragments of its next cluster from LDS and issues its share of the LDS-DMA — matrix beside memory on every interval —
+// and the DMA stream is never drained: counted vmcnt, raw s_barrier, two half-tiles always in flight.
 //
-// MEASURED (tools/gemm_ab.py, one box, interleaved; profiles/r2e_gemm_persistent_ab.txt): bit-identical on every C2 shape and
-// within +-3 % of the v3 kernel (q/k/v 948 vs 935 TF, attn-out 929 vs 901, V^T 1061 vs 1048, ffn1 1020 vs 1033, ffn2 1196 vs 1203).
-// The launch / prologue latency this removes was not what a tile pays for: the epilogue is WORK (tools/gemm_epi_abl.py on a variant
-// build, profiles/r2e_gemm_epilogue_ablation.txt: per launch q/k/v 15 us = 4 staging + 2 read-back + 9 stores; attn-out 35 us;
-// ffn1 159 us, 112 of them GELU arithmetic on 293 M elements; ffn2 44 us), it runs with the matrix pipe idle, and the next barrier
-// waits for its stores either way.  Hiding it needs the MFMAs of the next tile in the same wave's instruction stream, i.e. a second
-// accumulator set — 1 wave per SIMD with 512 registers.  Kept selectable (SVI_GEMM_KERNEL=258) as the recorded negative result;
-// NOT the default.  One lesson is baked into its shape: the accumulating asm statements must stay in straight-line code — the same
-// k-step on both sides of a branch made the register allocator shuttle the accumulators through scratch, and a spill store right
-// behind an asm MFMA reads the accumulator without the wait states the compiler would insert for its own MFMAs (wrong results).
+// A K tile (64 deep) is four phases per wave; a phase = { L: fragment reads + one half-tile of DMA ; barrier ; M: 8 MFMAs ; barrier }:
+//   phase 0   L: W(n0), W(n1) of tile t          DMA: W rows   0..127 of tile t+1     M: acc[n0][m0,m1] += W(n0) x A(m0,m1)
+//   phase 1   L: A(m2,m3) of tile t              DMA: W rows 128..255 of tile t+1     M: acc[n1][m0,m1] += W(n1) x A(m0,m1)
+//   phase 2   L: A(m0,m1) of tile t+1            DMA: A rows   0..127 of tile t+2     M: acc[n1][m2,m3] += W(n1) x A(m2,m3)
+//   phase 3   L: -                               DMA: A rows 128..255 of tile t+2     M: acc[n0][m2,m3] += W(n0) x A(m2,m3)
+// (m = 32-row blocks of the wave's 128 rows, n = 32-column blocks of its 64 columns; each cluster walks the tile's four k-steps in
+// order, so an accumulator sees k in the v3 kernel's order.)  24 fragment reads per K tile — the minimum — and every LDS read of tile
+// t is over after phase 1, which is what lets tile t+2 stream into tile t's buffer from phase 2 on with only two LDS buffers.
+// Safety of the hand-off (cdna_hip_programming.md "read a staged buffer one phase after the wait that retires it"):
+//   * a wave waits for its OWN fragment reads (lgkmcnt(0)) BEFORE the barrier that ends its L section: what a later DMA overwrites has
+//     been read by everyone once that barrier is passed (A of tile t: last read in phase 1, first overwritten in phase 2);
+//   * a wave waits for its own DMA shares with a counted vmcnt before that same barrier — vmcnt(4) at the end of phase 1 (the two A
+//     half-tiles of tile t+1 have landed, the two W half-tiles behind them may still fly) and of phase 3 (W of t+1 landed, A of t+2 in
+//     flight) — and the data is first read one phase later, i.e. behind a barrier BOTH wave rows have passed after their waits.
+// Row OOB: the operands are read through buffer descriptors sized to the matrix, rows past M / N read zeros (their results are never stored).
 // =================================================================================================
-#define LDS256Q_BYTES (4 * T_STAGE + 8 * 4096)
-__device__ __forceinline__ int priv_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }   // [32 rows][8 x 16 B]
+#define E_HALF 16384           // a half-tile: 128 rows x 128 B
+#define E_BUF 65536            // one K tile: A [256][128 B] | W [256][128 B]
+#define E_BAR() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int EPI>
-__device__ __forceinline__ void gemm256_epilogue_private(const SviGemmArgs& g, f32x16 (&acc)[2][4], char* priv, int m0, int n0, int lane,
-                                                         int wm, int wn, int l31, int hi) {
-    // this lane's 16-byte chunk in the read-back / store phase: row rb + 8 i of a 32-row piece, columns cb .. cb + 7 of the tile
-    const int rb = lane >> 3, ch = lane & 7;
-    const int cb = wn * 64 + ch * 8, en = n0 + cb;
-    const bool col_ok = en + 8 <= g.N;                       // N is a multiple of 8 chunks or the chunk is handled element-wise below
-    float gatev[8];
-    if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) gatev[e] = (g.gate && en + e < g.N) ? g.gate[en + e] : 0.f;
-    }
-    // bias in accumulator order: columns wn*64 + ni*32 + 8 rg + 4 hi + e
-    u32x2 bnp[2][4];
-    const bool bias_n = g.bias && !g.bias_along_m, bias_m = g.bias && g.bias_along_m;
-    const bool bias_vec = bias_n && (n0 + TN <= g.N) && (((uintptr_t)g.bias & 7) == 0);
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int n = n0 + wn * 64 + ni * 32 + 8 * rg + 4 * hi;
-            if (bias_vec) {
-                bnp[ni][rg] = *reinterpret_cast<const u32x2*>(g.bias + n);
-            } else {
-                unsigned short h4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = (bias_n && n + e < g.N) ? reinterpret_cast<const unsigned short*>(g.bias)[n + e] : (unsigned short)0;
-                bnp[ni][rg][0] = (unsigned)h4[0] | ((unsigned)h4[1] << 16);
-                bnp[ni][rg][1] = (unsigned)h4[2] | ((unsigned)h4[3] << 16);
-            }
-        }
-    const bool has_gate = g.gate != nullptr;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int mrow0 = m0 + wm * 128 + mi * 32;           // first global row of this 32-row piece
-        // residual rows of the piece requested up front: their latency runs under the LDS round trip
-        u32x4 resv[4];
-        if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = mrow0 + rb + 8 * i;
-                if (m < g.M && col_ok) resv[i] = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + en);
-            }
-        }
-        const int mg = mrow0 + l31;
-        const float bmv = (bias_m && mg < g.M) ? (float)g.bias[mg] : 0.f;
-        // y = bf16(acc + bias) in accumulator order -> private LDS piece [32][64]
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const unsigned b01 = bnp[ni][rg][0], b23 = bnp[ni][rg][1];
-                const float bv[4] = {__builtin_bit_cast(float, b01 << 16) + bmv, __builtin_bit_cast(float, b01 & 0xffff0000u) + bmv,
-                                     __builtin_bit_cast(float, b23 << 16) + bmv, __builtin_bit_cast(float, b23 & 0xffff0000u) + bmv};
-                bf16x4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[ni][mi][rg * 4 + e] + bv[e]);
-                *reinterpret_cast<bf16x4*>(priv + priv_off(l31, ni * 4 + rg) + hi * 8) = pk;
-            }
-        // wave-local ordering: LDS operations of one wave complete in order, the compiler's memory model inserts the lgkmcnt wait
-        u32x4 yv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) yv[i] = *reinterpret_cast<const u32x4*>(priv + priv_off(rb + 8 * i, ch));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = mrow0 + rb + 8 * i;
-            const bf16x8 t = __builtin_bit_cast(bf16x8, yv[i]);
-            float y[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = (float)t[e];
-            u32x4 rvv = resv[i];
-            if constexpr (EPI == SVI_EPI_BIAS_GATE_RES) {
-                if (!col_ok && m < g.M) {
-                    bf16x8 tt;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) tt[e] = (en + e < g.N) ? g.res[(size_t)m * g.ldres + en + e] : (bf16)0.f;
-                    rvv = __builtin_bit_cast(u32x4, tt);
-                }
-            }
-            gemm256_apply<EPI>(y, rvv, gatev, has_gate);
-            if (m < g.M) {
-                bf16* cp = g.C + (size_t)m * g.ldc + en;
-                if (col_ok) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
-                    st_bf16x8(cp, o);
-                } else {
-                    for (int e = 0; e < 8 && en + e < g.N; ++e) cp[e] = (bf16)y[e];
-                }
-            }
-        }
-        // the piece is rewritten by the next mi: its reads above have returned (their values were consumed)
-    }
-}
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(lptr_t)smem;          // 0: the dynamic region is all the LDS this kernel has (the buffer flip below is an XOR)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
 
-__device__ __forceinline__ void gemm256q_tile_coords(int seq, int nwg, int tiles_m, int tiles_n, int GM, int& m0, int& n0) {
-    const int xcd = seq & 7, q = nwg >> 3, rr = nwg & 7;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (seq >> 3);
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
     const int group = swz / (GM * tiles_n);
     const int first_m = group * GM;
     const int gm = min(GM, tiles_m - first_m);
     const int in_group = swz - group * GM * tiles_n;
     const int tile_n = in_group / gm;
     const int tile_m = first_m + (in_group - tile_n * gm);
-    m0 = tile_m * TM; n0 = tile_n * TN;
-}
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256q_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lds0 = (int)(size_t)(lptr_t)smem;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int l31 = lane & 31, hi = lane >> 5;
-    char* priv = smem + 4 * T_STAGE + wave * 4096;
-    const int nwg = tiles_m * tiles_n;
-    const int nk = g.K / BK;                               // even, >= 4 (launcher)
+    if (g.W2 && n0 >= g.n_split) {                          // q | k side by side: this tile's columns belong to the second matrix
+        g.W = g.W2 - (size_t)g.n_split * g.ldw;
+        g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
+    }
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, (int)(((unsigned)(g.M - 1) * (unsigned)g.lda + (unsigned)g.K) * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, (int)(((unsigned)(g.N - 1) * (unsigned)g.ldw + (unsigned)g.K) * 2u), 0x00020000);
+    // a wave's DMA instruction covers 8 rows x 128 B; a half-tile is 16 of them, two per wave (rows j * 64 + wave * 8 + lane / 8, j = 0, 1).
+    // The bank swizzle sits on the SOURCE chunk (LDS-DMA writes lane-linear), as in the v3 kernel.
+    const int r8 = wave * 8 + (lane >> 3);
+    const int c8 = (lane & 7) ^ ((r8 >> 1) & 7);
+    const int a_vo = (r8 * g.lda + c8 * 8) * 2, w_vo = (r8 * g.ldw + c8 * 8) * 2;
+    const unsigned a_so0 = (unsigned)m0 * (unsigned)g.lda * 2u, w_so0 = (unsigned)n0 * (unsigned)g.ldw * 2u;
+    const unsigned a_j = 64u * (unsigned)g.lda * 2u, w_j = 64u * (unsigned)g.ldw * 2u;
+    const int nk = g.K / BK;
+    // op 0: A half-tile h of K tile kt -> buffer b;  op 1: W
+    auto stage = [&](auto opc, int h, int kt, int b) {
+        constexpr int op = decltype(opc)::value;
+        const unsigned so = (op ? w_so0 + (unsigned)(2 * h) * w_j : a_so0 + (unsigned)(2 * h) * a_j) + (unsigned)kt * (BK * 2);
+        char* dst = smem + b * E_BUF + op * (2 * E_HALF) + h * E_HALF + wave * 1024;
+        if constexpr (op == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)dst, 16, a_vo, (int)so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(dst + 8192), 16, a_vo, (int)(so + a_j), 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)dst, 16, w_vo, (int)so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + 8192), 16, w_vo, (int)(so + w_j), 0, 0);
+        }
+    };
+    std::integral_constant<int, 0> OPA;
+    std::integral_constant<int, 1> OPW;
 
-    int a_addr[4], w_addr[4];
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_addr[4], w_addr[4];          // this lane's fragment of k-step kk: A block 0 of the wave's rows / W block 0 of its columns, buffer 0
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
-        w_addr[kk] = lds0 + T_STAGE + lds_tile_off(wn * 64 + l31, 2 * kk + hi);
+        w_addr[kk] = lds0 + 2 * E_HALF + lds_tile_off(wn * 64 + l31, 2 * kk + hi);
     }
-    // LDS-DMA source chunks: piece j of a tile covers rows rj[j] .. (8 rows per wave instruction), this lane reads 16-byte chunk c8/8 of
-    // its row (swizzled on the source side).  Tile-invariant; the element offset for the tile with corner row `base` is formed at the
-    // point of use (4 VALU per piece, hidden under the MFMAs) instead of being carried in 16 registers across the tile loop.
-    int rj[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rj[j] = (j * 8 + wave) * 8 + (lane >> 3);
-    const int c8 = ((lane & 7) ^ ((rj[0] >> 1) & 7)) * 8;          // (r >> 1) & 7 is the same for all four pieces (rows differ by 64)
-    auto a_src = [&](int base, int j) { return (unsigned)min(base + rj[j], g.M - 1) * (unsigned)g.lda + (unsigned)c8; };
-    auto w_src = [&](int base, int j) { return (unsigned)min(base + rj[j], g.N - 1) * (unsigned)g.ldw + (unsigned)c8; };
-    int seq = blockIdx.x;
-    int m0, n0;
-    gemm256q_tile_coords(seq, nwg, tiles_m, tiles_n, GM, m0, n0);
+    u32x4 xa0[2][4], xa1[2][4], xw0[4], xw1[4];
 
-    int tok = 0;
-
-    // one k-step (see gemm_bf16_nt_256p_kernel); AM / WN: corner row / column of the tile the DMA pieces belong to
-#define SVI_KSTEPQ(KK, G0, READ, DMA, rso, dk, dso, AM, WN)                                                                     \
-    static_for8([&](auto ic) {                                                                                                  \
-        constexpr int i = decltype(ic)::value;                                                                                  \
-        constexpr int ni = i >> 2, mi = i & 3, cs = (KK) & 1, ns = cs ^ 1, kn = ((KK) + 1) & 3, gi = (G0) + i;                   \
-        int& pin = (i < 4) ? a_addr[kn] : w_addr[kn];                                                                           \
-        gemm_mfma_v(tok, acc[ni][mi], wb[cs][ni], xa[cs][mi], pin);                                                             \
-        if constexpr (READ) {                                                                                                   \
-            if constexpr (i < 4) xa[ns][i] = *(lds_u32x4_t)(a_addr[kn] + (rso) + i * 32 * 128);                                 \
-            else if constexpr (i < 6) wb[ns][i - 4] = *(lds_u32x4_t)(w_addr[kn] + (rso) + (i - 4) * 32 * 128);                  \
-        }                                                                                                                       \
-        if constexpr ((DMA) && gi < 8) {                                                                                        \
-            constexpr int j = gi >> 1;                                                                                          \
-            if constexpr ((gi & 1) == 0)                                                                                        \
-                __builtin_amdgcn_global_load_lds((gptr_t)(g.A + (dk) + a_src(AM, j)), (lptr_t)(smem + (dso) + (j * 8 + wave) * 1024), 16, 0, 0);            \
-            else                                                                                                                \
-                __builtin_amdgcn_global_load_lds((gptr_t)(g.W + (dk) + w_src(WN, j)), (lptr_t)(smem + (dso) + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);  \
-        }                                                                                                                       \
-    })
-
-    // prologue of the FIRST tile: K tiles 0 and 1 in flight, tile 0 landed
+    auto cluster = [&](f32x16& c0, f32x16& c1, const u32x4 (&xa)[2][4], const u32x4 (&xw)[4]) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.A + a_src(m0, j)), (lptr_t)(smem + (j * 8 + wave) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.W + w_src(n0, j)), (lptr_t)(smem + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.A + BK + a_src(m0, j)), (lptr_t)(smem + 2 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.W + BK + w_src(n0, j)), (lptr_t)(smem + 3 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    for (;;) {
-        const int seq_next = seq + (int)gridDim.x;
-        const bool has_next = seq_next < nwg;
-        // the tile whose first two K tiles are fetched while this one finishes; on the last tile of the walk the fetch is repeated for the
-        // current tile (32 KiB once per workgroup, never read) so that the accumulating statements stay in straight-line code: two
-        // copies of a k-step on the two sides of a branch make the register allocator shuttle and spill the accumulators
-        int m0n = m0, n0n = n0;
-        if (has_next) gemm256q_tile_coords(seq_next, nwg, tiles_m, tiles_n, GM, m0n, n0n);
-        u32x4 xa[2][4], wb[2][2];
-        f32x16 acc[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // K tile 0 of this output tile is in stage 0 and visible (prologue barrier / the barrier at the end of the previous tile)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xa[0][i] = *(lds_u32x4_t)(a_addr[0] + i * 32 * 128);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wb[0][i] = *(lds_u32x4_t)(w_addr[0] + i * 32 * 128);
-        SVI_KSTEPQ(0, 8, true, false, 0, 0, 0, m0, n0);
-        SVI_KSTEPQ(1, 16, true, false, 0, 0, 0, m0, n0);
-        SVI_KSTEPQ(2, 24, true, false, 0, 0, 0, m0, n0);
-        int kt = 0;
-        for (; kt + 2 < nk; ++kt) {
-            const int nso = ((kt + 1) & 1) * 2 * T_STAGE;          // stage of K tile kt+1 (read)
-            const int dso = (kt & 1) * 2 * T_STAGE;                // stage K tile kt vacates (DMA target of K tile kt+2)
-            const int dk = (kt + 2) * BK;
-            __syncthreads();                                       // vmcnt(0): K tile kt+1 landed; barrier: K tile kt fully read by all waves
-            SVI_KSTEPQ(3, 0, true, true, nso, dk, dso, m0, n0);
-            SVI_KSTEPQ(0, 8, true, false, nso, dk, dso, m0, n0);
-            SVI_KSTEPQ(1, 16, true, false, nso, dk, dso, m0, n0);
-            SVI_KSTEPQ(2, 24, true, false, nso, dk, dso, m0, n0);
+        for (int kk = 0; kk < 4; ++kk) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xw[kk]), __builtin_bit_cast(bf16x8, xa[0][kk]), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xw[kk]), __builtin_bit_cast(bf16x8, xa[1][kk]), c1, 0, 0, 0);
         }
-        {   // kt = nk - 2 (even): the last K tile sits in stage 1; stage 0 falls free -> K tile 0 of the NEXT output tile
-            const int nso = 2 * T_STAGE;
-            __syncthreads();
-            SVI_KSTEPQ(3, 0, true, true, nso, 0, 0, m0n, n0n);
-            SVI_KSTEPQ(0, 8, true, false, nso, 0, 0, m0, n0);
-            SVI_KSTEPQ(1, 16, true, false, nso, 0, 0, m0, n0);
-            SVI_KSTEPQ(2, 24, true, false, nso, 0, 0, m0, n0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one K tile.  SW: tile t+1 exists (its W half-tiles are staged in phases 0 / 1, its first A fragments read in phase 2);  SA: tile t+2 exists
+    auto ktile = [&](int t, auto swc, auto sac) {
+        constexpr bool SW = decltype(swc)::value, SA = decltype(sac)::value;
+        const int b = t & 1;
+        // ---- phase 0
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            xw0[kk] = *(lds_u32x4_t)(w_addr[kk]);
+            xw1[kk] = *(lds_u32x4_t)(w_addr[kk] + 32 * 128);
         }
-        SVI_KSTEPQ(3, 0, false, false, 0, 0, 0, m0, n0);
-        asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
-        asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
-        // my pieces of the next tile's K tile 0 have landed (issued a whole K tile ago); the barrier makes everyone's visible and says
-        // every wave is done reading stage 1 -> K tile 1 of the next tile may stream in under the epilogue
+        if constexpr (SW) stage(OPW, 0, t + 1, b ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        E_BAR();
+        cluster(acc[0][0], acc[0][1], xa0, xw0);
+        E_BAR();
+        // ---- phase 1
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            xa1[0][kk] = *(lds_u32x4_t)(a_addr[kk] + 64 * 128);
+            xa1[1][kk] = *(lds_u32x4_t)(a_addr[kk] + 96 * 128);
+        }
+        if constexpr (SW) {
+            stage(OPW, 1, t + 1, b ^ 1);
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");       // A of tile t+1 has landed (this wave's shares); its W half-tiles may still fly
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        E_BAR();
+        cluster(acc[1][0], acc[1][1], xa0, xw1);
+        E_BAR();
+        // ---- phase 2
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a_addr[kk] ^= E_BUF;
+        if constexpr (SW) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                xa0[0][kk] = *(lds_u32x4_t)(a_addr[kk]);
+                xa0[1][kk] = *(lds_u32x4_t)(a_addr[kk] + 32 * 128);
+            }
+        }
+        if constexpr (SA) stage(OPA, 0, t + 2, b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        E_BAR();
+        cluster(acc[1][2], acc[1][3], xa1, xw1);
+        E_BAR();
+        // ---- phase 3
+        if constexpr (SA) {
+            stage(OPA, 1, t + 2, b);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   // W of tile t+1 has landed; A of tile t+2 in flight
+        } else if constexpr (SW) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        E_BAR();
+        cluster(acc[0][2], acc[0][3], xa1, xw0);
+        E_BAR();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) w_addr[kk] ^= E_BUF;
+    };
+    std::true_type YES;
+    std::false_type NO;
+
+    // prologue: tile 0 whole, the A half-tiles of tile 1 behind it
+    stage(OPA, 0, 0, 0); stage(OPA, 1, 0, 0); stage(OPW, 0, 0, 0); stage(OPW, 1, 0, 0);
+    if (nk > 1) {
+        stage(OPA, 0, 1, 1); stage(OPA, 1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.A + BK + a_src(m0n, j)), (lptr_t)(smem + 2 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.W + BK + w_src(n0n, j)), (lptr_t)(smem + 3 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-        }
-        switch (g.epi) {        // uniform: one scalar branch per tile
-            case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_private<SVI_EPI_BIAS_GELU_TANH>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
-            case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_private<SVI_EPI_BIAS_GATE_RES>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
-            case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_private<SVI_EPI_BIAS_GELU_ERF>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
-            case SVI_EPI_BIAS_SILU:      gemm256_epilogue_private<SVI_EPI_BIAS_SILU>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
-            case SVI_EPI_BIAS_RELU:      gemm256_epilogue_private<SVI_EPI_BIAS_RELU>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
-            default:                     gemm256_epilogue_private<SVI_EPI_BIAS>(g, acc, priv, m0, n0, lane, wm, wn, l31, hi); break;
-        }
-        if (!has_next) break;
-        seq = seq_next; m0 = m0n; n0 = n0n;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the redundant fetch of the last tile must not outlive the workgroup's LDS
-#undef SVI_KSTEPQ
+    E_BAR();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        xa0[0][kk] = *(lds_u32x4_t)(a_addr[kk]);
+        xa0[1][kk] = *(lds_u32x4_t)(a_addr[kk] + 32 * 128);
+    }
+    if (wm == 1) E_BAR();                                  // the second wave row runs one barrier behind the first from here on
+    int t = 0;
+    for (; t + 2 < nk; ++t) ktile(t, YES, YES);
+    if (nk >= 2) { ktile(t, YES, NO); ++t; }
+    ktile(t, NO, NO);
+    if (wm == 0) E_BAR();
+    asm volatile("s_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
+    asm volatile("s_nop 0" : "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    __syncthreads();                                       // every wave is done with the operand buffers: the C tile may overwrite them
+    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1448,17 +1263,17 @@ svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, i
     return SVI_OK;
 }
 
-// Which kernel a bf16 GEMM of this shape runs on — pure arithmetic on sizes and switches (svi_gemm_plan exposes it; tests/test_plans.py):
-// 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile, 256 / 257 / 258 = the 256^2 loops (v2 / v3 / persistent v3).
-int svi_gemm_choose(const SviGemmArgs& g) {
+// Which kernel a bf16 GEMM of this shape runs on — pure arithmetic on sizes, switches and the device's CU count (svi_gemm_plan exposes it;
+// tests/test_plans.py): 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile, 257 = the 256^2 v3 loop, 259 = the 256^2 eight-phase loop.
+int svi_gemm_choose(const SviGemmArgs& g, int ncu) {
     if (g.skinny && g.M <= 128 && g.K % 128 == 0 && !g.bias_along_m && (g.epi == SVI_EPI_BIAS || g.epi == SVI_EPI_BIAS_GATE_RES) && g.ldc % 4 == 0) return 0;
+    if (ncu <= 0) ncu = 256;
     const int selM = g.sel_m > 0 ? g.sel_m : g.M, selN = g.sel_n > 0 ? g.sel_n : g.N;
     const long t256 = (long)((selM + TM - 1) / TM) * ((selN + TN - 1) / TN);
     const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
     const SviSwitches& sw = svi_switches();
-    const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 192 : (t256 >= 128);      // 256-row tiles when the problem fills at least half the chip with them
+    const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 192 : (t256 >= ncu / 2);      // 256-row tiles when the problem fills at least half the chip with them
     if (!(want256 && g.K % BK == 0 && fits32)) return 128;
-    const int ncu = 256;
     // 256 x 192 tiles where they fill the chip's rounds better (sequence-parallel shards; see the kernel's header).  A 192-wide tile is
     // 0.75 of a 256-wide one plus ~8 % (6 MFMAs per 5 fragment reads instead of 8 per 6, the same DMA / barrier count per K tile; measured,
     // tools/gemm_ab.py shards: N = 1536 shard GEMMs gain 4-20 %, the N = 8960 ones — already many rounds of 256-wide tiles — lose 2-10 % and stay)
@@ -1466,9 +1281,22 @@ int svi_gemm_choose(const SviGemmArgs& g) {
     const long r256 = ((long)tm_s * ((selN + TN - 1) / TN) + ncu - 1) / ncu, r192 = ((long)tm_s * ((selN + 192 - 1) / 192) + ncu - 1) / ncu;
     const bool better = (double)r192 * 0.75 * 1.08 < (double)r256 * 0.97;
     if (g.N >= 192 && (sw.gemm_kernel == 192 || (sw.gemm_kernel == 0 && better))) return 192;
-    const int nkq = g.K / BK;
-    if ((nkq % 2 == 0) && nkq >= 4 && sw.gemm_kernel == 258) return 258;
-    return sw.gemm_kernel == 256 ? 256 : 257;
+    if (sw.gemm_kernel == 257 || sw.gemm_kernel == 259) return sw.gemm_kernel;
+    return SVI_GEMM_DEFAULT_256;
+}
+
+// compute units of the current device, asked once per device (the round arithmetic above; svi_launch_flash keeps the same kind of cache)
+static int gemm_device_cus() {
+    static std::atomic<int> cus[64];
+    const int dev = svi_current_device();
+    if (dev < 0 || dev >= 64) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
@@ -1484,8 +1312,20 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
         SVI_REQUIRE(g.res != nullptr && g.ldres % 8 == 0 && ((uintptr_t)g.res % 16) == 0,
                     "gemm: gate/residual epilogue needs an aligned residual");
     }
-    const int kind = svi_gemm_choose(g);
+    const int kind = svi_gemm_choose(g, gemm_device_cus());
     const SviSwitches& sw = svi_switches();
+    if (g.W2) {        // two weight matrices side by side: one launch when the split falls on a tile boundary of the kernel that runs, else two
+        SVI_REQUIRE(g.n_split > 0 && g.n_split < g.N && !g.bias_along_m && ((uintptr_t)g.W2 % 16) == 0, "gemm: bad weight pair (n_split %d of N %d)", g.n_split, g.N);
+        const int tw = kind == 0 ? 0 : kind == 128 ? BN : kind == 192 ? 192 : TN;
+        if (tw == 0 || g.n_split % tw != 0) {
+            SviGemmArgs a = g, b = g;
+            a.W2 = nullptr; a.bias2 = nullptr; a.n_split = 0; a.N = g.n_split; a.sel_n = g.sel_n > 0 ? g.sel_n : g.N;
+            b.W2 = nullptr; b.bias2 = nullptr; b.n_split = 0; b.W = g.W2; b.bias = g.bias2; b.N = g.N - g.n_split; b.C = g.C + g.n_split;
+            b.res = g.res ? g.res + g.n_split : nullptr; b.gate = g.gate ? g.gate + g.n_split : nullptr; b.sel_n = a.sel_n;
+            SVI_TRY(svi_launch_gemm(a, st));
+            return svi_launch_gemm(b, st);
+        }
+    }
     if (kind == 0) {
         dim3 grid((g.N + 15) / 16);
         const bool wide = g.K % 256 == 0;                 // eight K shares when they come out whole
@@ -1512,12 +1352,9 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             const int tn3 = (g.N + TN3 - 1) / TN3;
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256x192_kernel), LDS256_BYTES));
             hipLaunchKernelGGL(gemm_bf16_nt_256x192_kernel, dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 2));
-        } else if (kind == 258) {     // persistent variant (A/B only, see its header: bit-identical, no faster)
-            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256q_kernel), LDS256Q_BYTES));
-            hipLaunchKernelGGL(gemm_bf16_nt_256q_kernel, dim3(std::min(tm * tn, 256)), dim3(512), LDS256Q_BYTES, st, g, tm, tn, gm_rows);
-        } else if (kind == 256) {     // the v2 main loop (barrier at the tile boundary), kept for A/B
-            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256_kernel<false>), LDS256_BYTES));
-            hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
+        } else if (kind == 259) {     // eight-phase main loop (see its header)
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel), LDS256_BYTES));
+            hipLaunchKernelGGL(gemm_bf16_nt_256e_kernel, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
         } else {
             // Tried and dropped: starting the first round's workgroups out of phase (s_sleep by CU index) so that the CUs' store
             // bursts do not coincide: no gain on ffn1 (17.5 rounds), a loss wherever the tile count is a whole number of rounds.

@@ -55,6 +55,7 @@ SYMBOLS = [
     ("svi_dit_unpatchify", _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_dit_head_ld", _i32, [_vp]),
     ("svi_dit_generation", _i64, [_vp]),
+    ("svi_stream_buffers_release", _i32, [_vp, _i32]),
     ("svi_attention_last_flagged", _i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     ("svi_attention_vt_fwd", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_set_audio", _i32, [_vp, _vp, _vp, _i32]),
@@ -74,7 +75,7 @@ SYMBOLS = [
     ("svi_dit_bind_ffn_fp8", _i32, [_vp, _i32, _i32, _vp]),
     ("svi_dit_ffn_mx8", _i32, [_vp, _i32]),
     ("svi_fp8_e4m3_to_bf16", _i32, [_vp, _vp, _i64, _vp]),
-    ("svi_gemm_plan", _i32, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
+    ("svi_gemm_plan", _i32, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     ("svi_attention_plan", _i32, [_i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     ("svi_prof_enable", _i32, [_i32]),
     ("svi_prof_summary", _i32, [C.c_char_p, _i64]),
@@ -157,14 +158,20 @@ def set_switch(name: str, value=None) -> None:
     check(lib().svi_switches_reload(), "svi_switches_reload")
 
 
+def release_stream_buffers(stream=None) -> None:
+    """Free the library's per-stream device buffers of `stream` (a torch.cuda.Stream that is being retired); None: of every stream of the
+    current device.  Captured graphs of that stream must not be replayed afterwards (DenoiseLoop checks svi_dit_generation and re-captures)."""
+    check(lib().svi_stream_buffers_release(_vp(stream.cuda_stream) if stream is not None else None, 1 if stream is None else 0), "svi_stream_buffers_release")
+
+
 def prof_enable(on: bool) -> None:
     check(lib().svi_prof_enable(1 if on else 0), "svi_prof_enable")
 
 
-def gemm_plan(M: int, N: int, K: int, epilogue: int = 0, skinny: bool = False) -> int:
-    """The kernel svi_gemm_bf16 would take: 0 skinny, 128, 192, 256 / 257 / 258 (see include/svi_hip.h)."""
+def gemm_plan(M: int, N: int, K: int, epilogue: int = 0, skinny: bool = False, compute_units: int = 256) -> int:
+    """The kernel svi_gemm_bf16 would take on a part with `compute_units` CUs: 0 skinny, 128, 192, 257 / 259 (see include/svi_hip.h)."""
     out = _i32(0)
-    check(lib().svi_gemm_plan(M, N, K, epilogue, 1 if skinny else 0, C.byref(out)), "svi_gemm_plan")
+    check(lib().svi_gemm_plan(M, N, K, epilogue, 1 if skinny else 0, compute_units, C.byref(out)), "svi_gemm_plan")
     return out.value
 
 

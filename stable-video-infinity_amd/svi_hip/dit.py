@@ -167,7 +167,12 @@ class WanDiT:
         return any(_version(t) != v for t, v in self._param_versions)
 
     def _refresh_if_weights_changed(self) -> None:
-        if self._ctx_cache_on and self.weights_changed():
+        """Bound bf16 tensors are read in place by the kernels: an in-place write to one needs a re-bind only for what was DERIVED from it —
+        the cached prompt-side projections (context cache on).  In FP8 storage mode the bound bf16 tensors themselves are derived (cast
+        from the e4m3 sources at bind): an in-place write to a source re-binds whether or not the cache is on (otherwise attention
+        would keep the stale casts while the MX-fp8 MLP reads the new bytes)."""
+        fp8_stale = any(_version(t) != v for t, v in self._param_versions if t.dtype == torch.float8_e4m3fn)
+        if fp8_stale or (self._ctx_cache_on and self.weights_changed()):
             self.rebind()
             self._ctx_pins.clear()
 

@@ -29,23 +29,28 @@ class DenoiseLoop:
     """50 x { cond forward, uncond forward, CFG combine, Euler step } with latents resident in HBM."""
 
     def __init__(self, dit: WanDiT, scheduler: Optional[FlowMatchScheduler] = None, cfg_pair=None, sp_group=None, sequence_parallel: bool = False,
-                 graph: bool = False):
+                 graph: Optional[bool] = None):
         """`cfg_pair`: an svi_hip.parallel.CfgPair — this rank then runs only its half of every CFG pair of forwards.
         `sequence_parallel` (+ `sp_group`, default: the world): every forward is spread Ulysses-style over the ranks of the group
         (svi_hip/sequence_parallel.py); all of them hold the full latents and apply the same CFG/Euler update.
         `graph`: the two forwards of a step are captured ONCE into a hipGraph (through torch.cuda.CUDAGraph) and replayed for every
         later step of the clip — the ~1500 launches of a step become one; the timestep is read from a device scalar that is
-        refreshed before each replay.  Pays where a step is launch-bound (BASELINE configs[0]: 1280 tokens); results are bit-identical
-        (the same kernels on the same operands).  Single-rank path without TeaCache only."""
+        refreshed before each replay.  Decisive where a step is launch-bound (BASELINE configs[0]: 1280 tokens), still 1.1 % at the
+        C2 size (profiles/r3m_prof_events_ab.txt); results are bit-identical (the same kernels on the same operands).  Single-rank
+        path without TeaCache only.  Default (None): ON for the single-rank loop, off with a CFG pair / sequence parallelism (their
+        exchanges are host-driven).  The first step of a clip runs eagerly on the capture stream — it IS that step — and is recorded
+        right behind itself; steps 2.. replay."""
         self.dit = dit
         self.cfg_pair = cfg_pair
         self.sequence_parallel, self.sp_group = sequence_parallel, sp_group
         self.scheduler = scheduler or FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
         self._cond = self._uncond = None
-        self.graph = graph
-        self._graph = None            # dict(key, graph, ts, pins, generation) of the captured step, see _forwards_graphed
         if graph and (cfg_pair is not None or sequence_parallel):
             raise ValueError("graph capture covers the single-rank step only")
+        self.graph = (cfg_pair is None and not sequence_parallel) if graph is None else bool(graph)
+        self._graph = None            # dict(key, graph, ts, pins, generation) of the captured step, see _forwards_graphed
+        self._capture_stream = None   # ONE side stream per loop, reused by every re-capture: the library keeps per-stream scratch (flag words,
+                                      # split-K partials) for good, so a fresh pool stream per capture would multiply it (ADVICE r3)
 
     def _forwards(self, latents, timestep, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond) -> None:
         """The DiT forward(s) of one step into self._cond / self._uncond."""
@@ -61,6 +66,14 @@ class DenoiseLoop:
     def drop_graph(self) -> None:
         """Forget the captured step (a later graphed step captures again)."""
         self._graph = None
+
+    def release(self) -> None:
+        """Retire this loop's capture stream: the captured step and the library's per-stream buffers keyed to that stream are freed."""
+        self._graph = None
+        if self._capture_stream is not None:
+            from . import _lib
+            _lib.release_stream_buffers(self._capture_stream)
+            self._capture_stream = None
 
     def _forwards_graphed(self, latents, timestep, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond) -> None:
         """Replay (capture on first use) the hipGraph of this step's forwards.
@@ -83,17 +96,22 @@ class DenoiseLoop:
         stale = self._graph is None or self._graph["key"] != key or self._graph["generation"] != self.dit.generation()
         if stale:
             self._graph = None
-            side = torch.cuda.Stream()                   # warm-up AND capture on one stream: the library's per-stream buffers exist before the capture
+            if self._capture_stream is None or self._capture_stream.device != latents.device:
+                self._capture_stream = torch.cuda.Stream(device=latents.device)
+            side = self._capture_stream                  # eager run AND capture on one stream: the library's per-stream buffers exist before the capture
             side.wait_stream(torch.cuda.current_stream())
             ts_static = timestep.clone()
             with torch.cuda.stream(side):
-                self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)      # workspaces, context cache, flag words
+                # this step itself, eagerly: it also sizes the workspaces, fills the context cache and creates the flag words,
+                # so that the recording below allocates nothing
+                self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)
             side.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side):       # recorded, not executed: self._cond / self._uncond keep the eager step's results
                 self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = dict(key=key, graph=g, ts=ts_static, pins=tensors, generation=self.dit.generation())
+            return
         self._graph["ts"].copy_(timestep)
         self._graph["graph"].replay()
 
@@ -306,9 +324,12 @@ def _hip_sample_with_regular_video(self, latents, prompt_emb_posi, prompt_emb_ne
     scale = float(cfg_scale["text"])
     lat = latents.contiguous().clone()               # the reference's loop leaves its input tensor untouched
     ts_dev = self.scheduler.timesteps.to(device=lat.device, dtype=torch.float32)
-    for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
-        loop.step(lat, ts_dev[progress_id:progress_id + 1], _step_delta_of(self.scheduler, self.scheduler.timesteps[progress_id]),
-                  ctx_p, ctx_n, scale, **tea, **cond)
+    try:
+        for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
+            loop.step(lat, ts_dev[progress_id:progress_id + 1], _step_delta_of(self.scheduler, self.scheduler.timesteps[progress_id]),
+                      ctx_p, ctx_n, scale, **tea, **cond)
+    finally:
+        loop.drop_graph()                 # the captured step reads this clip's tensors: it dies with the clip (as DenoiseLoop.sample)
     return lat
 
 

@@ -65,6 +65,8 @@ class FlowMatchScheduler:
         s = self.sigmas[self._index(timestep)]
         return (1 - s) * original_samples + s * noise
 
+    # interface only: the object stands in for the reference's FlowMatchScheduler wherever a pipeline holds one (flow_match.py:84-97 has these
+    # two); training is outside the path this package serves (out of scope) and nothing here calls them
     def training_target(self, sample, noise, timestep):
         return noise - sample
 

@@ -29,33 +29,10 @@ OUT = os.path.join(HERE, "golden")
 
 
 def import_reference():
-    def ns(name, path):
-        m = types.ModuleType(name)
-        m.__path__ = [path]
-        m.__spec__ = importlib.machinery.ModuleSpec(name, None, is_package=True)
-        sys.modules[name] = m
-
-    for pkg in ("diffsynth", "diffsynth.models", "diffsynth.utils", "diffsynth.schedulers"):
-        ns(pkg, REF + "/" + pkg.replace(".", "/"))
-
-    class Stub(types.ModuleType):
-        def __getattr__(self, k):
-            if k.startswith("__"):
-                raise AttributeError(k)
-            return type(k, (object,), {})
-
-    for n in ("diffusers", "diffusers.configuration_utils", "xfuser", "xfuser.core", "xfuser.core.distributed",
-              "xformers", "xformers.ops", "imageio", "torchvision", "torchvision.transforms"):
-        sys.modules.setdefault(n, Stub(n))
-    sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
-    # AudioProjModel(ModelMixin, ConfigMixin) (wan_video_dit.py:44) must be a real nn.Module for its parameters to register
-    if isinstance(sys.modules["diffusers"], Stub):
-        sys.modules["diffusers"].ModelMixin = torch.nn.Module
-        sys.modules["diffusers.configuration_utils"].ConfigMixin = type("ConfigMixin", (object,), {})
-    dit = importlib.import_module("diffsynth.models.wan_video_dit")
-    vae = importlib.import_module("diffsynth.models.wan_video_vae")
-    fm = importlib.import_module("diffsynth.schedulers.flow_match")
-    return dit, vae, fm
+    """The reference's modules, imported where they lie under /root/reference (oracle/ref_shim.py: SURVEY.md Appendix A)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import ref_shim
+    return ref_shim.load(REF)
 
 
 def t(a):
@@ -434,6 +411,73 @@ def gen_block_14b(dit_mod):
         blk = blk.to(torch.bfloat16)
         o16 = blk(bx.to(torch.bfloat16), bctx.to(torch.bfloat16), btm.to(torch.bfloat16), freqs)[0, rows].float().numpy()
     np.savez(os.path.join(OUT, "dit_block_14b.npz"), block_fp32=o32, block_bf16=o16, rows=np.asarray(rows))
+
+
+def _ref_block_case(dit_mod, cfg, seed, grid, has_img, fname, row_stride=244):
+    """ONE DiTBlock.forward of the reference (wan_video_dit.py:354-374) at the full C2 token count, fp32 and bf16, C2_ROWS kept."""
+    import time
+    f, h, w = grid
+    L = f * h * w
+    nt = 512
+    sd = synth.dit_state_dict(seed, **cfg)
+    blk = dit_mod.DiTBlock(has_img, cfg["dim"], cfg["dim"] // 128, cfg["ffn_dim"], 1e-6).eval()
+    blk.load_state_dict({k[len("blocks.0."):]: t(a) for k, a in sd.items() if k.startswith("blocks.0.")}, strict=True)
+    del sd
+    bx = t(synth.randn(seed + 5, 1, L, cfg["dim"]))
+    bctx = t(synth.randn(seed + 6, 1, nt + (257 if has_img else 0), cfg["dim"]))
+    bctx[:, (257 if has_img else 0) + 64:] = 0          # zero-padded prompt (wan_prompter.py:107-108): 64 live text tokens of 512
+    btm = t(0.5 * synth.randn(seed + 7, 1, 6, cfg["dim"]))
+    fr = dit_mod.precompute_freqs_cis_3d(128)
+    freqs = torch.cat([fr[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1), fr[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                       fr[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(L, 1, -1)
+    rows = synth.C2_ROWS(L, row_stride)
+    with torch.no_grad():
+        t0 = time.time()
+        o32 = blk(bx, bctx, btm, freqs)[0, rows].numpy()
+        print(f"{fname}: reference DiTBlock fp32 at L={L}: {time.time() - t0:.0f} s", flush=True)
+        t0 = time.time()
+        blk = blk.to(torch.bfloat16)
+        o16 = blk(bx.to(torch.bfloat16), bctx.to(torch.bfloat16), btm.to(torch.bfloat16), freqs)[0, rows].float().numpy()
+        print(f"{fname}: bf16: {time.time() - t0:.0f} s", flush=True)
+    np.savez(os.path.join(OUT, fname), block_fp32=o32, block_bf16_bits=synth.bf16_bits(o16), rows=np.asarray(rows))
+
+
+def gen_block_c2(dit_mod):
+    """The reference's own DiTBlock at the headline size (VERDICT r3 weak #2): Wan2.1-T2V-1.3B widths, (21,30,52) grid = 32760 tokens."""
+    _ref_block_case(dit_mod, dict(synth.WAN_1_3B, num_layers=1), synth.B13C2_SEED, synth.C2_GRID, False, "dit_block_c2.npz")
+
+
+def gen_block_14b_c2(dit_mod):
+    """C4 at size: one Wan2.1-I2V-14B DiTBlock (dim 5120, 40 heads, ffn 13824, 257 CLIP + 512 text context) at 32760 tokens."""
+    _ref_block_case(dit_mod, dict(synth.WAN_14B_I2V, num_layers=1), synth.B14C2_SEED, synth.C2_GRID, True, "dit_block_14b_c2.npz", row_stride=488)
+
+
+def gen_c2_full(dit_mod):
+    """Size x depth together (VERDICT r3 weak #1): the reference's 30-layer Wan2.1-T2V-1.3B WanModel.forward (wan_video_dit.py:486-567) on the
+    full C2 latent [1,16,21,60,104] = 32760 tokens — the configuration bench.py times — in fp32 and, the way the pipelines run it, bf16.
+    C1_SEED weights, torch CPU-generator noise (base.py:140-143), zero-padded 512-token prompt.  Output kept on a stride-3 (h, w) lattice."""
+    import time
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    f, h, w = synth.C2_GRID
+    k = synth.C2_FULL_STRIDE
+    t0 = time.time()
+    m = build_ref_dit(dit_mod, cfg, seed)
+    print(f"c2_full: reference WanModel 1.3B built in {time.time() - t0:.0f} s", flush=True)
+    noise = torch.randn((1, 16, f, 2 * h, 2 * w), generator=torch.Generator("cpu").manual_seed(2), dtype=torch.float32)
+    pos = t(synth.text_context(seed + 1, 512, cfg["text_dim"], 64))
+    ts = torch.tensor([991.7355], dtype=torch.float32)
+    with torch.no_grad():
+        t0 = time.time()
+        o32 = m(noise, ts, pos)[0]
+        print(f"c2_full: fp32 forward {time.time() - t0:.0f} s", flush=True)
+        np.savez(os.path.join(OUT, "dit_c2_full.npz"), out_fp32=o32[:, :, ::k, ::k].contiguous().numpy())          # kept in case the bf16 pass dies
+        t0 = time.time()
+        mb = m.to(torch.bfloat16)
+        o16 = mb(noise.to(torch.bfloat16), ts, pos.to(torch.bfloat16))[0].float()
+        print(f"c2_full: bf16 forward {time.time() - t0:.0f} s", flush=True)
+    np.savez(os.path.join(OUT, "dit_c2_full.npz"), out_fp32=o32[:, :, ::k, ::k].contiguous().numpy(),
+             out_bf16_bits=synth.bf16_bits(o16[:, :, ::k, ::k].contiguous().numpy()),
+             out_fp32_norm=np.float64(o32.double().norm().item()), full_rel_bf16_vs_fp32=np.float64(((o16 - o32).double().norm() / o32.double().norm()).item()))
 
 
 def gen_vae_tiled(vae_mod):
@@ -821,6 +865,9 @@ def main(argv=None):
         "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),
         "dit_c4_4blocks": lambda: gen_c4_blocks(dit_mod),
         "dit_depth": lambda: gen_dit_depth(dit_mod, fm),
+        "dit_block_c2": lambda: gen_block_c2(dit_mod),
+        "dit_block_14b_c2": lambda: gen_block_14b_c2(dit_mod),
+        "dit_c2_full": lambda: gen_c2_full(dit_mod),
     }
     names = list(argv if argv is not None else sys.argv[1:]) or list(jobs)
     for n in names:

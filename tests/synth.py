@@ -230,6 +230,9 @@ B14_SEED, B14_GRID = 950, (3, 20, 36)        # golden/dit_block_14b.npz: one 14B
 
 DEPTH_GRID, DEPTH_STEPS = (5, 30, 52), 2     # golden/dit_depth.npz: the 30-layer 1.3B model (C1_SEED weights) on 7800 tokens (>= 2048: the long-sequence
                                              # attention kernel and the 256^2 GEMM), one forward + a 2-step CFG loop
+C2_GRID = (21, 30, 52)                       # BASELINE configs[1]: 81 frames at 832x480 -> latent [16,21,60,104] -> 32760 tokens
+B13C2_SEED, B14C2_SEED = 970, 980            # golden/dit_block_c2.npz / dit_block_14b_c2.npz: ONE reference DiTBlock (1.3B / 14B-I2V widths) at L = 32760
+C2_FULL_STRIDE = 3                           # golden/dit_c2_full.npz: the reference's 30-layer 1.3B forward at C2 (C1_SEED weights), output kept on a stride-3 (h, w) lattice
 C4_SEED, C4_LAYERS = 960, 4                  # golden/dit_c4_4blocks.npz: 4 of the 40 blocks of Wan2.1-I2V-14B end to end (in_dim-36 patchify, img_emb, head) on B14_GRID
 
 
@@ -245,6 +248,13 @@ def bf16_from_bits(b) -> np.ndarray:
 
 def B14_ROWS(L: int):
     return list(range(0, L, 67))
+
+
+def C2_ROWS(L: int, stride: int = 244):
+    """Token rows the C2-size block fixtures keep: a stride that is a multiple of 61 (coprime with the 52-wide row and the 1560-token frame
+    of the C2 grid, so the rows walk through the (h, w) residues and every frame is hit) plus the last row of the ragged last 256-row
+    tile.  1.3B widths: stride 244 (136 rows); 14B widths: stride 488 (69 rows) — the fixtures stay at 1-2 MB."""
+    return list(range(0, L, stride)) + [L - 1]
 
 
 # (name, latent shape, tile_size, tile_stride, seed) / (name, video shape, tile_size, tile_stride, seed): golden/vae_tiled.npz

@@ -1,0 +1,55 @@
+"""-m gpu: bench.py's MULTI-RANK path on a device (VERDICT r3 missing #1 / next #5).  No 8-GPU node has ever been available to the
+round driver, so `bench.py --gpus N` had only ever run its launcher on the CPU.  `--transport gloo` lets N ranks share the one GPU of the
+test box: every kernel runs on the device, the exchanges (tail all-gather, the CFG pair's noise_pred all-gather, the sequence-parallel
+all-to-all / all-gather, the MAX-reduce of elapsed time and the finiteness vote) go through gloo — the same `torch.distributed` calls
+the RCCL run makes.  Checked here on the small workload: the line's aggregation fields; the lines at the C2 size are recorded under
+profiles/ by tools (they are a code-path probe, never a scaling figure: the ranks time-share one GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, *args, "--transport", "gloo", "--workload", "c1", "--steps", "2", "--warmup", "1", "--no-vae", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def common(line, world):
+    assert line["n_gpus"] == world and sorted(w["rank"] for w in line["config"]["ranks"]) == list(range(world))
+    assert "gloo" in line["config"]["transport"] and "NOT a scaling measurement" in line["config"]["transport"]
+    assert line["config"]["outputs_finite"] and line["ms_per_step"] > 0 and line["value"] > 0
+    assert line["cpu_baseline"] is None and line["config"]["rccl"] is None
+
+
+def test_clip_per_rank_two_ranks():
+    line = run(["--gpus", "2"])
+    common(line, 2)
+    assert line["scaling"] == "weak" and line["config"]["parallelism"] == "clip-per-rank x2" and line["config"]["clips_per_gpu"] == 1.0
+    assert line["config"]["hip_graph"] is True            # each rank's own clip: the single-rank step, replayed from its hipGraph
+    # value = 2 clips x 5 latent frames / (10 steps x ms_per_step)
+    assert abs(line["value"] - 2 * 5 / (10 * line["ms_per_step"] / 1000.0)) < 1e-3 * line["value"]
+
+
+def test_cfg_pair_two_ranks():
+    line = run(["--gpus", "2", "--cfg-pair"])
+    common(line, 2)
+    assert line["config"]["parallelism"] == "cfg-pair x1 clips" and line["config"]["clips_per_gpu"] == 0.5 and line["config"]["hip_graph"] is False
+    assert abs(line["value"] - 1 * 5 / (10 * line["ms_per_step"] / 1000.0)) < 1e-3 * line["value"]
+
+
+def test_cfg_pair_times_sequence_parallel_four_ranks():
+    line = run(["--gpus", "4", "--cfg-pair", "--seq-parallel"])
+    common(line, 4)
+    assert line["scaling"] == "strong" and "sequence-parallel over 4 ranks" in line["config"]["parallelism"]
+    assert abs(line["value"] - 1 * 5 / (10 * line["ms_per_step"] / 1000.0)) < 1e-3 * line["value"]

@@ -1,0 +1,111 @@
+"""-m gpu: the configurations BASELINE.json quotes the metric on, checked for VALUES at size x depth together, against outputs of the
+REFERENCE ITSELF (tests/gen_golden.py runs its WanModel / DiTBlock on the build container's CPU).
+
+  dit_c2_full.npz        the reference's 30-layer Wan2.1-T2V-1.3B WanModel.forward (wan_video_dit.py:486-567) on the full C2 latent
+                         [1,16,21,60,104] = 32760 tokens — exactly what bench.py times — fp32 and bf16, kept on a stride-3 (h, w) lattice.
+  dit_block_c2.npz       ONE reference DiTBlock.forward (wan_video_dit.py:354-374) at 1.3B widths on 32760 tokens, C2_ROWS kept.
+  dit_block_14b_c2.npz   the same at the Wan2.1-I2V-14B widths (dim 5120, 40 heads, ffn 13824) with 257 CLIP + 512 text context rows: C4 at size.
+
+Bounds are the ones every smaller whole forward / block already meets (test_gpu_depth.py, test_gpu_configs.py): forward rel-L2 <= 2e-2 vs the
+reference's bf16 run and <= max(2e-2, 2 x the reference's own bf16-vs-fp32 gap) vs its fp32 run; block <= 1.5e-2 vs fp32.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import rel_l2
+from gpu_util import dev, errs, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import svi_hip
+    return svi_hip
+
+
+def _block_case(hip, g, cfg, seed, has_img, name, row_stride=244):
+    f, h, w = synth.C2_GRID
+    L = f * h * w
+    nt = 512
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **cfg).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=cfg["dim"] // 128, **cfg)
+    del sd
+    bx = torch.from_numpy(synth.randn(seed + 5, 1, L, cfg["dim"]))
+    bctx = torch.from_numpy(synth.randn(seed + 6, 1, nt + (257 if has_img else 0), cfg["dim"]))
+    bctx[:, (257 if has_img else 0) + 64:] = 0
+    btm = torch.from_numpy(0.5 * synth.randn(seed + 7, 1, 6, cfg["dim"]))
+    got = m.block_forward(0, dev(bx), dev(bctx), dev(btm), synth.C2_GRID)
+    again = m.block_forward(0, dev(bx), dev(bctx), dev(btm), synth.C2_GRID)
+    rows = [int(r) for r in g["rows"]]
+    assert rows == synth.C2_ROWS(L, row_stride)
+    ref16 = synth.bf16_from_bits(g["block_bf16_bits"])
+    r32, mx, _ = errs(got[0, rows], g["block_fp32"])
+    r16 = errs(got[0, rows], ref16)[0]
+    gap = rel_l2(ref16, g["block_fp32"])
+    report(name, vs_ref_fp32=r32, vs_ref_bf16=r16, ref_bf16_vs_fp32=gap, max_abs=mx, tokens=L, rows=len(rows))
+    assert torch.isfinite(got.float()).all() and torch.equal(got, again)
+    assert r32 < 1.5e-2 and r16 < 2e-2, (r32, r16, gap)
+
+
+def test_1_3b_block_at_32760_tokens_vs_reference(hip, golden):
+    _block_case(hip, golden("dit_block_c2.npz"), dict(synth.WAN_1_3B, num_layers=1), synth.B13C2_SEED, False, "dit_block_c2")
+
+
+def test_14b_i2v_block_at_32760_tokens_vs_reference(hip, golden):
+    _block_case(hip, golden("dit_block_14b_c2.npz"), dict(synth.WAN_14B_I2V, num_layers=1), synth.B14C2_SEED, True, "dit_block_14b_c2", row_stride=488)
+
+
+def test_1_3b_30_layers_at_32760_tokens_vs_reference(hip, golden):
+    """The headline configuration, size x depth: one svi_dit_forward over 30 blocks at L = 32760 against the reference's own output."""
+    g = golden("dit_c2_full.npz")
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    f, h, w = synth.C2_GRID
+    k = synth.C2_FULL_STRIDE
+    sd = {n: torch.from_numpy(v) for n, v in synth.dit_state_dict(seed, **cfg).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=12, **cfg)
+    del sd
+    noise = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=2, device="cpu", dtype=torch.float32)
+    pos = dev(torch.from_numpy(synth.text_context(seed + 1, 512, cfg["text_dim"], 64)))
+    ts = torch.tensor([991.7355])
+    out = m.forward(dev(noise), ts, pos)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    again = m.forward(dev(noise), ts, pos)
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) * 1e3
+    assert tuple(out.shape) == (1, 16, f, 2 * h, 2 * w) and torch.isfinite(out.float()).all() and torch.equal(out, again)
+    lat = out[0, :, :, ::k, ::k]
+    ref16 = synth.bf16_from_bits(g["out_bf16_bits"])
+    gap = rel_l2(ref16, g["out_fp32"])
+    r32, mx, _ = errs(lat, g["out_fp32"])
+    r16 = errs(lat, ref16)[0]
+    report("dit_c2_full_30_layers", vs_ref_fp32=r32, vs_ref_bf16=r16, ref_bf16_vs_fp32_on_lattice=gap, ref_bf16_vs_fp32_whole=float(g["full_rel_bf16_vs_fp32"]),
+           max_abs=mx, tokens=f * h * w, forward_ms=ms)
+    assert r16 < 2e-2 and r32 < max(2e-2, 2 * gap), (r32, r16, gap)
+
+
+@pytest.mark.skipif(os.environ.get("SVI_SLOW_ORACLE") != "1", reason="about 8 minutes of host time on the GPU box: SVI_SLOW_ORACLE=1 (the reference-run fixture above is the same check, stronger)")
+def test_1_3b_30_layers_at_32760_tokens_vs_oracle_on_this_box(hip):
+    """The same forward against oracle.wan_dit_oracle.dit_forward (fp32) computed here on the box's host threads."""
+    from oracle import wan_dit_oracle as wdo
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    f, h, w = synth.C2_GRID
+    sd = {n: torch.from_numpy(v) for n, v in synth.dit_state_dict(seed, **cfg).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=12, **cfg)
+    noise = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=2, device="cpu", dtype=torch.float32)
+    pos = torch.from_numpy(synth.text_context(seed + 1, 512, cfg["text_dim"], 64))
+    ts = torch.tensor([991.7355])
+    got = m.forward(dev(noise), ts, dev(pos)).float().cpu()
+    c = wdo.DiTConfig(dim=cfg["dim"], in_dim=cfg["in_dim"], ffn_dim=cfg["ffn_dim"], out_dim=cfg["out_dim"], text_dim=cfg["text_dim"], freq_dim=cfg["freq_dim"],
+                      patch_size=cfg["patch_size"], num_heads=12, num_layers=30, has_image_input=False)
+    with torch.no_grad():
+        want = wdo.dit_forward(sd, c, noise, ts, pos)
+    r = rel_l2(got.numpy(), want.numpy())
+    report("dit_c2_full_30_layers_vs_oracle_on_box", rel_l2=r)
+    assert r < 2e-2, r

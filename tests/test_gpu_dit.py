@@ -219,7 +219,7 @@ def test_graph_replay_is_bit_identical(hip, name):
     for clip in range(2):
         lat = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=5 + clip, device="cpu", dtype=torch.float32)
         cp, cn = dev(np.asarray(ctx) * (1 + clip)), dev(-np.asarray(ctx))
-        want = hip.DenoiseLoop(m).sample(dev(lat), cp, cn, num_inference_steps=5, cfg_scale=5.0, **kw)
+        want = hip.DenoiseLoop(m, graph=False).sample(dev(lat), cp, cn, num_inference_steps=5, cfg_scale=5.0, **kw)
         loop = hip.DenoiseLoop(m, graph=True)
         got = loop.sample(dev(lat), cp, cn, num_inference_steps=5, cfg_scale=5.0, **kw)
         assert torch.equal(got, want)
@@ -237,7 +237,7 @@ def test_graph_never_replays_against_stale_state(hip):
     m, _ = build(hip, c, seed)
     _, ctx, _ = inputs(c, grid, nt, nv, seed)
     loop = hip.DenoiseLoop(m, graph=True)
-    eager = hip.DenoiseLoop(m)
+    eager = hip.DenoiseLoop(m, graph=False)
     seen = set()
     for clip in range(3):
         lat = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=20 + clip, device="cpu", dtype=torch.float32)

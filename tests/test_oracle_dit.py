@@ -135,6 +135,26 @@ def test_block_at_14b_i2v_widths_matches_reference(golden):
     assert rel_l2(out, g["block_fp32"]) < 2e-5
 
 
+def test_block_at_32760_tokens_matches_reference(golden):
+    """The oracle pinned at the HEADLINE size: one DiTBlock at Wan2.1-T2V-1.3B widths on the full C2 grid (21,30,52) = 32760 tokens against
+    sampled rows of the reference's own DiTBlock.forward at that size (golden/dit_block_c2.npz; about half a minute of host time)."""
+    g = golden("dit_block_c2.npz")
+    c = dict(synth.WAN_1_3B, num_layers=1)
+    seed, grid = synth.B13C2_SEED, synth.C2_GRID
+    f, h, w = grid
+    L = f * h * w
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items() if k.startswith("blocks.0.")}
+    bx = torch.from_numpy(synth.randn(seed + 5, 1, L, c["dim"]))
+    bctx = torch.from_numpy(synth.randn(seed + 6, 1, 512, c["dim"]))
+    bctx[:, 64:] = 0
+    btm = torch.from_numpy(0.5 * synth.randn(seed + 7, 1, 6, c["dim"]))
+    rows = [int(r) for r in g["rows"]]
+    assert rows == synth.C2_ROWS(L)
+    with torch.no_grad():
+        out = wdo.dit_block(sd, "blocks.0.", bx, bctx, btm, wdo.rope_table_3d(128, grid), make_cfg(c), None)[0, rows].numpy()
+    assert rel_l2(out, g["block_fp32"]) < 2e-5
+
+
 def test_talk_variant_matches_reference(golden):
     """model_fn_wan_talk_video / WanModel.forward(audio_embed_tuple=...): AudioProjModel + per-block audio cross-attention, against the
     reference's own fp32 forward (golden/dit_tiny_talk.npz); the audio branch moves the output by 15 %, so its absence cannot hide."""

@@ -5,6 +5,8 @@ import pytest
 from svi_hip import _lib as L
 
 L_TOK, D, F = 32760, 1536, 8960
+DEFAULT_256 = L.gemm_plan(L_TOK, D, D)          # 257 (v3 loop) or 259 (eight-phase loop): whichever the library was built to prefer
+assert DEFAULT_256 in (257, 259)
 
 
 @pytest.fixture(autouse=True)
@@ -15,14 +17,14 @@ def clean_switches():
 
 
 @pytest.mark.parametrize("M,N,K,want", [
-    (L_TOK, D, D, 257), (L_TOK, F, D, 257), (L_TOK, D, F, 257), (D, L_TOK, D, 257),          # the single-rank C2 shapes: whole rounds of 256^2 tiles
-    (L_TOK // 4, D, D, 192), (L_TOK // 4, D, F, 192), (L_TOK // 4, F, D, 257),                # P = 4 shard: 192 -> 256 tiles for N = 1536; ffn1 keeps 256-wide tiles
-    (L_TOK // 2, D, D, 192), (L_TOK // 2, F, D, 257), (L_TOK // 3, D, D, 192), (L_TOK // 6, D, F, 192),
-    (D, L_TOK // 4, D, 257),                                                                  # the shard's V^T projection: 6 x 43 192-wide tiles would need two rounds
+    (L_TOK, D, D, 256), (L_TOK, F, D, 256), (L_TOK, D, F, 256), (D, L_TOK, D, 256),          # the single-rank C2 shapes: whole rounds of 256^2 tiles
+    (L_TOK // 4, D, D, 192), (L_TOK // 4, D, F, 192), (L_TOK // 4, F, D, 256),                # P = 4 shard: 192 -> 256 tiles for N = 1536; ffn1 keeps 256-wide tiles
+    (L_TOK // 2, D, D, 192), (L_TOK // 2, F, D, 256), (L_TOK // 3, D, D, 192), (L_TOK // 6, D, F, 192),
+    (D, L_TOK // 4, D, 256),                                                                  # the shard's V^T projection: 6 x 43 192-wide tiles would need two rounds
     (200, 264, 136, 128), (1000, 520, 192, 128), (4096, 4096, 72, 128),                       # small problems / K not a multiple of 64: the 128^2 kernel
 ])
 def test_gemm_kernel_choice(M, N, K, want):
-    assert L.gemm_plan(M, N, K) == want
+    assert L.gemm_plan(M, N, K) == (DEFAULT_256 if want == 256 else want)          # 256: "a 256^2 loop" (the build's default one)
 
 
 def test_gemm_kernel_choice_follows_the_switch_and_the_skinny_hint():
@@ -30,11 +32,21 @@ def test_gemm_kernel_choice_follows_the_switch_and_the_skinny_hint():
     L.set_switch("SVI_GEMM_KERNEL", 257)
     assert L.gemm_plan(L_TOK // 4, D, D) == 257                   # "never the 192-wide tile"
     L.set_switch("SVI_GEMM_KERNEL", 192)
-    assert L.gemm_plan(L_TOK, D, D) == 192 and L.gemm_plan(300, 128, 64) == 257     # N < 192: not this kernel (a forced 256-row tile stays 256 wide)
+    assert L.gemm_plan(L_TOK, D, D) == 192 and L.gemm_plan(300, 128, 64) == DEFAULT_256     # N < 192: not this kernel (a forced 256-row tile stays 256 wide)
     L.set_switch("SVI_GEMM_KERNEL", 128)
     assert L.gemm_plan(L_TOK, F, D) == 128
-    L.set_switch("SVI_GEMM_KERNEL", 258)
-    assert L.gemm_plan(L_TOK, D, F) == 258
+    L.set_switch("SVI_GEMM_KERNEL", 259)
+    assert L.gemm_plan(L_TOK, D, F) == 259 and L.gemm_plan(L_TOK // 4, D, D) == 259          # the eight-phase loop, wherever a 256-row tile runs
+    L.set_switch("SVI_GEMM_KERNEL", 258)                                                         # not a kernel (any more): ignored
+    assert L.gemm_plan(L_TOK, D, F) == DEFAULT_256
+
+
+def test_gemm_kernel_choice_uses_the_device_cu_count():
+    """The round arithmetic (256 x 192 vs 256^2 tiles, the half-a-chip threshold) is done for the part's own CU count."""
+    assert L.gemm_plan(L_TOK // 4, D, D, compute_units=256) == 192          # 32 x 6 = 192 tiles on 256 CUs: 192-wide tiles fill the round
+    assert L.gemm_plan(L_TOK // 4, D, D, compute_units=192) == DEFAULT_256  # ... on 192 CUs the 256-wide tiles ARE one whole round
+    assert L.gemm_plan(20 * 256, 4 * 256, 512, compute_units=304) == 128    # 80 tiles < half of 304 CUs: the 128^2 kernel
+    assert L.gemm_plan(20 * 256, 4 * 256, 512, compute_units=128) != 128     # ... more than half of 128 CUs: a 256-row tile
 
 
 @pytest.mark.parametrize("sq,skv,heads,want", [
