@@ -554,7 +554,9 @@ def main() -> None:
         # the launch is a read of q and a write of o — HBM-bound — and the matrix work it executes is 4 L (n+1) D, not 4 L Lc D
         "flash_cross": fam("flash_cross", 4.0 * Ls * D, "hbm", f"q [L, D] bf16 read + o [L, D] bf16 written per launch; keys walked: {keys_walked} of {lc} context rows "
                            "(identical trailing rows of the zero-padded prompt count as one key)"),
-        "gemm_qkv": fam("gemm_qkv", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch (q, k, v^T projections)"),
+        # q | k are ONE N = 2D launch (4 L D^2 FLOP), V^T its own (2 L D^2): 3 L D^2 per launch on average; three 2 L D^2 launches with SVI_QK_FUSED=0
+        "gemm_qkv": fam("gemm_qkv", (3.0 if os.environ.get("SVI_QK_FUSED", "1") != "0" else 2.0) * Ls * D * D, "mfma",
+                        "q | k as one launch over the two weight matrices (4 L D^2 FLOP) + the V^T projection (2 L D^2)"),
         "gemm_attn_out": fam("gemm_attn_out", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch, gate + residual epilogue"),
         "gemm_cross": fam("gemm_cross", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch (cross-attention q and o; cached prompt K / V excluded)"),
         "gemm_ffn1": fam("gemm_ffn1", 2.0 * Ls * D * F, "mfma", "2 L D F FLOP per launch, GELU-tanh epilogue"),

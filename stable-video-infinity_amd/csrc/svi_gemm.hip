@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 #define TM 256
 #define TN 256
 #ifndef SVI_GEMM_DEFAULT_256
-#define SVI_GEMM_DEFAULT_256 257      // which 256^2 main loop runs by default: 257 = v3 ("256p"), 259 = eight-phase ("256e"); SVI_GEMM_KERNEL overrides per process
+#define SVI_GEMM_DEFAULT_256 259      // which 256^2 main loop runs by default: 257 = v3 ("256p"), 259 = eight-phase ("256e"); SVI_GEMM_KERNEL overrides per process
 #endif
 #define T_STAGE (TM * BK * 2)          // 32 KiB per operand tile
 #define C2_LD 264

@@ -99,8 +99,8 @@ class DenoiseLoop:
             if self._capture_stream is None or self._capture_stream.device != latents.device:
                 self._capture_stream = torch.cuda.Stream(device=latents.device)
             side = self._capture_stream                  # eager run AND capture on one stream: the library's per-stream buffers exist before the capture
+            ts_static = timestep.clone()                 # made on the current stream BEFORE the side stream is told to wait for it: the eager step reads it
             side.wait_stream(torch.cuda.current_stream())
-            ts_static = timestep.clone()
             with torch.cuda.stream(side):
                 # this step itself, eagerly: it also sizes the workspaces, fills the context cache and creates the flag words,
                 # so that the recording below allocates nothing
