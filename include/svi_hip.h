@@ -211,7 +211,7 @@ svi_status svi_attention_fwd(const void* q, const void* k, const void* v, void* 
 svi_status svi_attention_last_flagged(svi_stream stream, int32_t* flagged_out, int32_t* workgroups_out);
 /* Launch planners: pure arithmetic on sizes and the environment switches, no device work (they run on a machine without a GPU).
  * svi_gemm_plan: the kernel svi_gemm_bf16 takes for [M, K] x [N, K]^T — 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile
- * (where 192-wide tiles fill the chip's rounds better: sequence-parallel shards), 257 / 259 = the 256^2 loops (v3 / eight-phase); `compute_units` = CUs of the part
+ * (where 192-wide tiles fill the chip's rounds better: sequence-parallel shards), 259 / 260 = the 256^2 tile (four / two phases per K tile); `compute_units` = CUs of the part
  * the round arithmetic is done for (256 on MI355X; the launcher asks the device).
  * svi_attention_plan: out4 = {kernel (1 = short key axes, 2 = long-sequence kernel), work items run whole, pieces per remaining item, workgroups}:
  * the items of a partly filled last round are cut along the key axis (csrc/svi_attention.hip flash_splits). */

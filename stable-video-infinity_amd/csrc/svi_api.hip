@@ -33,7 +33,7 @@ static SviSwitches parse_switches() {
     s.flash_kernel = env_int("SVI_FLASH_KERNEL", 1, 0);
     if (s.flash_kernel > 2) s.flash_kernel = 0;
     s.gemm_kernel = env_int("SVI_GEMM_KERNEL", 128, 0);
-    if (s.gemm_kernel != 128 && s.gemm_kernel != 192 && s.gemm_kernel != 257 && s.gemm_kernel != 259) s.gemm_kernel = 0;
+    if (s.gemm_kernel != 128 && s.gemm_kernel != 192 && s.gemm_kernel != 259 && s.gemm_kernel != 260) s.gemm_kernel = 0;
     s.gemm_gm = env_int("SVI_GEMM_GM", 1, 0);
     s.vae_exact_fp32 = getenv("SVI_VAE_EXACT_FP32") != nullptr;
     s.flash_two_pass = env_int("SVI_FLASH_TWO_PASS", 0, 1);

@@ -219,9 +219,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 //
 // Why a second kernel: with the 128^2 tile a K step gives a wave only 16 MFMAs (512 cycles) of cover for the
 // next tile's global loads, so the loop runs at L2/HBM latency, not at MFMA rate (measured 530-610 TFLOP/s).
-// Here a K step is 32 MFMAs per wave and two waves share a SIMD -> 2048 cycles of matrix work per barrier,
-// and the next tile is fetched by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass)
-// issued BEFORE the MFMAs of the current tile (cdna_hip_programming.md §5 "glds vs register staging").
+// Here a K step is 32 MFMAs per wave and two waves share a SIMD -> 2048 cycles of matrix work per K tile,
+// and the operand tiles are fetched by LDS-DMA (no staging VGPRs, no ds_write pass; cdna_hip_programming.md §5 "glds vs register staging").
+// The main loop itself is gemm_bf16_nt_256e_kernel below; its predecessors (rounds 1-3: the lockstep "v2" / "v3" loops with one barrier per
+// K tile, a persistent variant, a 256 x 192 tile on the v3 loop) were bit-identical and slower and are gone from the source — their numbers:
+// profiles/r2e_gemm_persistent_ab.txt, profiles/r4b_gemm_ab.txt.
 //
 // LDS image: per stage A tile [256 rows][128 B] + W tile [256][128 B] = 64 KiB, two stages = 128 KiB.
 // LDS-DMA writes lane-linear (wave-uniform base + lane*16), so the bank swizzle sits on the SOURCE address:
@@ -244,8 +246,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 // =================================================================================================
 #define TM 256
 #define TN 256
+#define TN3 192
 #ifndef SVI_GEMM_DEFAULT_256
-#define SVI_GEMM_DEFAULT_256 259      // which 256^2 main loop runs by default: 257 = v3 ("256p"), 259 = eight-phase ("256e"); SVI_GEMM_KERNEL overrides per process
+#define SVI_GEMM_DEFAULT_256 259      // which schedule of the 256^2 tile runs by default: 259 = four phases per K tile, 260 = two (see gemm_bf16_nt_256e_kernel); SVI_GEMM_KERNEL overrides per process
 #endif
 #define T_STAGE (TM * BK * 2)          // 32 KiB per operand tile
 #define C2_LD 264
@@ -506,362 +509,65 @@ __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&
 
 typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_t;
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"     // LDS addresses are 32-bit; the host pass sees 64-bit pointers
-template <class F> __device__ __forceinline__ void static_for4(F&& f) {
-    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
-}
-template <class F> __device__ __forceinline__ void static_for8(F&& f) {
-    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
-    f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
-}
-template <class F> __device__ __forceinline__ void static_for16(F&& f) {
-    static_for8(f);
-    f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});
-    f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{}); f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{});
-}
-// -------------------------------------------------------------------------------------------------
-// 256^2 kernel, main loop v3 ("256p").  Same tile, LDS image, operand swizzle and epilogue as above; what changes is WHERE the
-// per-tile barrier sits and WHEN the LDS-DMA of the next tile is issued.  In the kernel above every K tile begins with the 8
-// DMA instructions of the next tile issued back to back (≈60 cycles of issue each, nothing else can be issued by the wave
-// meanwhile — and its SIMD partner is doing the same thing) and with the first fragment reads of the tile exposed behind the
-// barrier.  Here the barrier sits between k-steps 2 and 3 of a tile: all four fragment sets of tile t are in registers by
-// then (k-step 3's set was read under k-step 2's MFMAs), so behind the barrier the wave still owns 8 MFMAs of tile t that
-// need no LDS, and under them it (a) reads k-step 0 of tile t+1 — already landed, the barrier's vmcnt(0) waited for it — and
-// (b) starts issuing the DMA of tile t+2 into the buffer tile t just vacated, one instruction every SPREAD MFMAs.  A tile's
-// DMA therefore has a whole K tile of MFMAs (≈1 us) to land with only two LDS stages, and no fragment read is exposed.
-// MFMA statements are `asm volatile` so the DMA builtins keep their place between them.
-// Measured (tools/gemm_ab.py, bit-identical to v2): 8192^3 1054 -> 1196 TFLOP/s, ffn2 1091 -> 1193, qkv 780 -> 810-840,
-// ffn1 829 -> 850; SPREAD 1 and 2 are within noise of each other, 0 (all DMA up front) is 1-2 % behind, 4 (DMA over the whole
-// tile: the last piece lands late) loses 7 %.  Tried on top and dropped: SIMD partners one phase apart ("ping-pong": waves 0-3
-// compute a 32-wide half-tile while 4-7 read fragments and issue DMA, four-stage half-tile ring) ran at the same 1200 TFLOP/s,
-// and tools/power_probe.py shows why: with random operands this kernel already holds the package at its 1400 W limit (sclk
-// 1.80 GHz; all-zero operands: 1000 W, 2.39 GHz, 1428 TFLOP/s), so a schedule that raises pipe utilisation is paid back in clock.
-// -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gemm_mfma_v(int& tok, f32x16& acc, u32x4 w, u32x4 x, int& apin) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %[c], %[w], %[x], %[c]" : [c] "+v"(acc), [tok] "+v"(tok), [ap] "+v"(apin) : [w] "v"(w), [x] "v"(x));
-}
-
-template <int SPREAD>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM, int abl_arg) {
-#ifdef SVI_ABLATIONS
-    const int abl = abl_arg;          // epilogue timing ablations: variant builds only (tools/build_variant.py -DSVI_ABLATIONS)
-#else
-    constexpr int abl = 0;            // the product kernel carries no results-changing switch
-    (void)abl_arg;
-#endif
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lds0 = (int)(size_t)(lptr_t)smem;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    const int nwg = tiles_m * tiles_n;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-    const int group = swz / (GM * tiles_n);
-    const int first_m = group * GM;
-    const int gm = min(GM, tiles_m - first_m);
-    const int in_group = swz - group * GM * tiles_n;
-    const int tile_n = in_group / gm;
-    const int tile_m = first_m + (in_group - tile_n * gm);
-    const int m0 = tile_m * TM, n0 = tile_n * TN;
-    if (g.W2 && n0 >= g.n_split) {                          // q | k side by side: this tile's columns belong to the second matrix
-        g.W = g.W2 - (size_t)g.n_split * g.ldw;
-        g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
-    }
-
-    unsigned a_off[4], w_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (j * 8 + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 8;
-        w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 8;
-    }
-    const int nk = g.K / BK;
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    int a_addr[4], w_addr[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
-        w_addr[kk] = lds0 + T_STAGE + lds_tile_off(wn * 64 + l31, 2 * kk + hi);
-    }
-    int tok = 0;
-    u32x4 xa[2][4], wb[2][2];
-
-    // one k-step: 8 MFMAs on fragment set KK & 1; behind them (READ) the 6 fragment reads of k-step (KK+1)&3 from the stage at
-    // byte offset `rso`, and (DMA) pieces of the tile `dk` K-elements in, into the stage at byte offset `dso`: the MFMA with
-    // running index G0+i (0..31 over the 4 k-steps that follow a barrier) is followed by piece (G0+i)/SPREAD when due.
-#define SVI_KSTEP(KK, G0, READ, DMA, rso, dk, dso)                                                                              \
-    static_for8([&](auto ic) {                                                                                                  \
-        constexpr int i = decltype(ic)::value;                                                                                  \
-        constexpr int ni = i >> 2, mi = i & 3, cs = (KK) & 1, ns = cs ^ 1, kn = ((KK) + 1) & 3, gi = (G0) + i;                   \
-        int& pin = (i < 4) ? a_addr[kn] : w_addr[kn];                                                                           \
-        if constexpr ((DMA) && SPREAD == 0 && gi == 0) {                                                                        \
-            {                                                                                                                   \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                 \
-                    __builtin_amdgcn_global_load_lds((gptr_t)(g.A + dk + a_off[j]), (lptr_t)(smem + dso + (j * 8 + wave) * 1024), 16, 0, 0);            \
-                    __builtin_amdgcn_global_load_lds((gptr_t)(g.W + dk + w_off[j]), (lptr_t)(smem + dso + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);  \
-                }                                                                                                               \
-            }                                                                                                                   \
-        }                                                                                                                       \
-        gemm_mfma_v(tok, acc[ni][mi], wb[cs][ni], xa[cs][mi], pin);                                                             \
-        if constexpr (READ) {                                                                                                   \
-            if constexpr (i < 4) xa[ns][i] = *(lds_u32x4_t)(a_addr[kn] + (rso) + i * 32 * 128);                                 \
-            else if constexpr (i < 6) wb[ns][i - 4] = *(lds_u32x4_t)(w_addr[kn] + (rso) + (i - 4) * 32 * 128);                  \
-        }                                                                                                                       \
-        if constexpr ((DMA) && SPREAD > 0 && (gi % (SPREAD > 0 ? SPREAD : 1)) == (SPREAD > 0 ? SPREAD : 1) - 1 && gi / (SPREAD > 0 ? SPREAD : 1) < 8) {    \
-            constexpr int pc = gi / (SPREAD > 0 ? SPREAD : 1), j = pc >> 1;                                                     \
-            {                                                                                                                   \
-                if constexpr ((pc & 1) == 0)                                                                                    \
-                    __builtin_amdgcn_global_load_lds((gptr_t)(g.A + dk + a_off[j]), (lptr_t)(smem + dso + (j * 8 + wave) * 1024), 16, 0, 0);            \
-                else                                                                                                            \
-                    __builtin_amdgcn_global_load_lds((gptr_t)(g.W + dk + w_off[j]), (lptr_t)(smem + dso + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);  \
-            }                                                                                                                   \
-        }                                                                                                                       \
-    })
-
-    // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-steps 0..2 computed
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.A + a_off[j]), (lptr_t)(smem + (j * 8 + wave) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.W + w_off[j]), (lptr_t)(smem + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-    }
-    if (nk > 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.A + BK + a_off[j]), (lptr_t)(smem + 2 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.W + BK + w_off[j]), (lptr_t)(smem + 3 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xa[0][i] = *(lds_u32x4_t)(a_addr[0] + i * 32 * 128);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) wb[0][i] = *(lds_u32x4_t)(w_addr[0] + i * 32 * 128);
-    SVI_KSTEP(0, 8, true, false, 0, -1, 0);
-    SVI_KSTEP(1, 16, true, false, 0, -1, 0);
-    SVI_KSTEP(2, 24, true, false, 0, -1, 0);
-
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) {
-        const int nso = ((kt + 1) & 1) * 2 * T_STAGE;          // stage of tile kt+1 (read)
-        const int dso = (kt & 1) * 2 * T_STAGE;                // stage tile kt vacates (DMA target of tile kt+2)
-        const int dk = (kt + 2) * BK;
-        __syncthreads();                                       // vmcnt(0): tile kt+1 landed; lgkmcnt(0) + barrier: tile kt fully read by all waves
-        SVI_KSTEP(3, 0, true, true, nso, dk, dso);
-        SVI_KSTEP(0, 8, true, true, nso, dk, dso);
-        SVI_KSTEP(1, 16, true, true, nso, dk, dso);
-        SVI_KSTEP(2, 24, true, true, nso, dk, dso);
-    }
-    if (kt + 1 < nk) {                                         // last tile: nothing left to fetch
-        const int nso = ((kt + 1) & 1) * 2 * T_STAGE;
-        __syncthreads();
-        SVI_KSTEP(3, 0, true, false, nso, -1, 0);
-        SVI_KSTEP(0, 8, true, false, nso, -1, 0);
-        SVI_KSTEP(1, 16, true, false, nso, -1, 0);
-        SVI_KSTEP(2, 24, true, false, nso, -1, 0);
-    }
-    SVI_KSTEP(3, 0, false, false, 0, -1, 0);
-#undef SVI_KSTEP
-    asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
-    asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
-    __syncthreads();                                           // every wave is done with the operand stages: the C tile may overwrite them
-    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl);
-}
-
-
 
 // =================================================================================================
-// 256(M) x 192(N) tile on the v3 main loop: 8 waves as 4(M) x 2(N), 64 x 96 per wave = 2 x 3 MFMA tiles.
+// 256-row tiles, STAGGERED main loop ("256e"): same LDS image, same operand swizzle, same MFMA (32x32x16, weight fragment as A operand), same
+// k order per element and the same epilogue as the v3 kernel above — so the same bits — on another schedule.
 //
-// Why: tile QUANTISATION, not throughput.  A sequence-parallel rank's shard of the C2 clip has M = L / P rows: at P = 4 its N = 1536 GEMMs
-// are 32 x 6 = 192 tiles of 256^2 on 256 compute units — a quarter of the chip idles for the whole launch; at P = 2, 64 x 6 = 384 tiles take two
-// rounds for 1.5 rounds of work.  With 192 columns the same GEMMs are 32 x 8 = 256 and 64 x 8 = 512 tiles: whole rounds of three-quarter
-// tiles.  svi_launch_gemm picks this kernel when that arithmetic says so (never on the single-rank C2 shapes: 128 x 6 = 768 tiles there).
-// Per element the K summation order and the epilogue arithmetic are the 256^2 kernel's: bit-identical results (tests/test_gpu_ops.py).
-// Per K tile a wave issues 7 LDS-DMA pieces (4 of A, 3 of W) behind its first 7 MFMAs of 24; a k-step is 6 MFMAs with 5 fragment reads.
-// LDS: the 256^2 kernels' image (a W stage uses 24 of its 32 KiB), C staged as [256][264] bf16 like theirs.
-// =================================================================================================
-#define TN3 192
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256x192_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lds0 = (int)(size_t)(lptr_t)smem;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    const int nwg = tiles_m * tiles_n;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-    const int group = swz / (GM * tiles_n);
-    const int first_m = group * GM;
-    const int gm = min(GM, tiles_m - first_m);
-    const int in_group = swz - group * GM * tiles_n;
-    const int tile_n = in_group / gm;
-    const int tile_m = first_m + (in_group - tile_n * gm);
-    const int m0 = tile_m * TM, n0 = tile_n * TN3;
-    if (g.W2 && n0 >= g.n_split) {                          // q | k side by side: this tile's columns belong to the second matrix
-        g.W = g.W2 - (size_t)g.n_split * g.ldw;
-        g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
-    }
-
-    unsigned a_off[4], w_off[3];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (j * 8 + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        a_off[j] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + c * 8;
-        if (j < 3) w_off[j] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.ldw + c * 8;
-    }
-    const int nk = g.K / BK;
-
-    f32x16 acc[3][2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    int a_addr[4], w_addr[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        a_addr[kk] = lds0 + lds_tile_off(wm * 64 + l31, 2 * kk + hi);
-        w_addr[kk] = lds0 + T_STAGE + lds_tile_off(wn * 96 + l31, 2 * kk + hi);
-    }
-    int tok = 0;
-    u32x4 xa[2][2], wb[2][3];
-
-    // one k-step: 6 MFMAs (ni = i >> 1, mi = i & 1) on fragment set KK & 1; behind MFMAs 0..4 the five fragment reads of k-step (KK+1)&3
-    // (2 of A, 3 of W); the MFMA with running index gi = G0 + i < 7 over the K tile is followed by DMA piece gi (A0 W0 A1 W1 A2 W2 A3)
-#define SVI_KSTEP3(KK, G0, READ, DMA, rso, dk, dso)                                                                             \
-    static_for8([&](auto ic) {                                                                                                  \
-        constexpr int i = decltype(ic)::value;                                                                                  \
-        if constexpr (i < 6) {                                                                                                  \
-            constexpr int ni = i >> 1, mi = i & 1, cs = (KK) & 1, ns = cs ^ 1, kn = ((KK) + 1) & 3, gi = (G0) + i;               \
-            int& pin = (i < 2) ? a_addr[kn] : w_addr[kn];                                                                       \
-            gemm_mfma_v(tok, acc[ni][mi], wb[cs][ni], xa[cs][mi], pin);                                                         \
-            if constexpr (READ) {                                                                                               \
-                if constexpr (i < 2) xa[ns][i] = *(lds_u32x4_t)(a_addr[kn] + (rso) + i * 32 * 128);                             \
-                else if constexpr (i < 5) wb[ns][i - 2] = *(lds_u32x4_t)(w_addr[kn] + (rso) + (i - 2) * 32 * 128);              \
-            }                                                                                                                   \
-            if constexpr ((DMA) && gi < 7) {                                                                                    \
-                constexpr int j = gi >> 1;                                                                                      \
-                if constexpr ((gi & 1) == 0)                                                                                    \
-                    __builtin_amdgcn_global_load_lds((gptr_t)(g.A + dk + a_off[j]), (lptr_t)(smem + dso + (j * 8 + wave) * 1024), 16, 0, 0);            \
-                else                                                                                                            \
-                    __builtin_amdgcn_global_load_lds((gptr_t)(g.W + dk + w_off[j]), (lptr_t)(smem + dso + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);  \
-            }                                                                                                                   \
-        }                                                                                                                       \
-    })
-
-    // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-steps 0..2 computed
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.A + a_off[j]), (lptr_t)(smem + (j * 8 + wave) * 1024), 16, 0, 0);
-        if (j < 3) __builtin_amdgcn_global_load_lds((gptr_t)(g.W + w_off[j]), (lptr_t)(smem + T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-    }
-    if (nk > 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.A + BK + a_off[j]), (lptr_t)(smem + 2 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-            if (j < 3) __builtin_amdgcn_global_load_lds((gptr_t)(g.W + BK + w_off[j]), (lptr_t)(smem + 3 * T_STAGE + (j * 8 + wave) * 1024), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) xa[0][i] = *(lds_u32x4_t)(a_addr[0] + i * 32 * 128);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) wb[0][i] = *(lds_u32x4_t)(w_addr[0] + i * 32 * 128);
-    SVI_KSTEP3(0, 6, true, false, 0, -1, 0);
-    SVI_KSTEP3(1, 12, true, false, 0, -1, 0);
-    SVI_KSTEP3(2, 18, true, false, 0, -1, 0);
-
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) {
-        const int nso = ((kt + 1) & 1) * 2 * T_STAGE;          // stage of tile kt+1 (read)
-        const int dso = (kt & 1) * 2 * T_STAGE;                // stage tile kt vacates (DMA target of tile kt+2)
-        const int dk = (kt + 2) * BK;
-        __syncthreads();                                       // vmcnt(0): tile kt+1 landed; lgkmcnt(0) + barrier: tile kt fully read by all waves
-        SVI_KSTEP3(3, 0, true, true, nso, dk, dso);
-        SVI_KSTEP3(0, 6, true, true, nso, dk, dso);
-        SVI_KSTEP3(1, 12, true, true, nso, dk, dso);
-        SVI_KSTEP3(2, 18, true, true, nso, dk, dso);
-    }
-    if (kt + 1 < nk) {                                         // last tile: nothing left to fetch
-        const int nso = ((kt + 1) & 1) * 2 * T_STAGE;
-        __syncthreads();
-        SVI_KSTEP3(3, 0, true, false, nso, -1, 0);
-        SVI_KSTEP3(0, 6, true, false, nso, -1, 0);
-        SVI_KSTEP3(1, 12, true, false, nso, -1, 0);
-        SVI_KSTEP3(2, 18, true, false, nso, -1, 0);
-    }
-    SVI_KSTEP3(3, 0, false, false, 0, -1, 0);
-#undef SVI_KSTEP3
-    asm volatile("s_nop 15" : "+v"(tok), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));   // MFMA result -> VALU read
-    asm volatile("s_nop 0" : "+v"(tok), "+v"(acc[2][0]), "+v"(acc[2][1]));
-    __syncthreads();                                           // every wave is done with the operand stages: the C tile may overwrite them
-    gemm256_epilogue<2, 3, TN3>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi);
-}
-
-// =================================================================================================
-// 256^2 kernel, EIGHT-PHASE main loop ("256e"): same tile, same LDS image, same operand swizzle, same MFMA (32x32x16, weight fragment as
-// A operand), same k order per element and the same epilogue as the v3 kernel above — so the same bits — on another schedule.
+// Why: the v3 loop keeps the SIMD's two waves in lockstep (one barrier per K tile; both waves read fragments, issue LDS-DMA and multiply at
+// the same points of their streams) and holds 0.57-0.64 of the matrix pipe in-clock (PMC, profiles/r3n_gemm_ffn1_pmc.txt).  Here, as in the
+// schedule cdna_hip_programming.md measures at ~0.75 in-clock on this part ("256^2 8-phase template"), the two wave rows of the workgroup
+// — the waves that share a SIMD — run ONE BARRIER APART: on every SIMD one wave is inside an MFMA cluster (raised priority) while its
+// partner reads the fragments of its next cluster from LDS and issues its share of the LDS-DMA — matrix beside memory on every interval —
+// and the DMA stream is never drained: counted vmcnt, raw s_barrier, half-tiles always in flight.
+// Measured (tools/gemm_ab.py, bit-identical to the v3 kernel, profiles/r4*_gemm_ab.txt): ffn2 1199 -> 1364 TFLOP/s, ffn1 1058 -> 1145,
+// attn-out 866 -> 936, 8192^3 1168 -> 1329.
 //
-// Why: the v3 loop keeps the SIMD's two waves in lockstep (one barrier per K tile, both waves read fragments, issue LDS-DMA and
-// multiply at the same points of their streams) and holds 0.57-0.64 of the matrix pipe in-clock (PMC, profiles/r3n_gemm_ffn1_pmc.txt);
-// the schedule below is the one cdna_hip_programming.md measures at ~0.75 in-clock on this part ("256^2 8-phase template"): the wave
-// rows run ONE BARRIER APART, so that on every SIMD one wave is inside an 8-MFMA cluster (raised priority) while its partner reads the
-// fragments of its next cluster from LDS and issues its share of the LDS-DMA — matrix beside memory on every interval —
-// and the DMA stream is never drained: counted vmcnt, raw s_barrier, two half-tiles always in flight.
-//
-// A K tile (64 deep) is four phases per wave; a phase = { L: fragment reads + one half-tile of DMA ; barrier ; M: 8 MFMAs ; barrier }:
-//   phase 0   L: W(n0), W(n1) of tile t          DMA: W rows   0..127 of tile t+1     M: acc[n0][m0,m1] += W(n0) x A(m0,m1)
-//   phase 1   L: A(m2,m3) of tile t              DMA: W rows 128..255 of tile t+1     M: acc[n1][m0,m1] += W(n1) x A(m0,m1)
-//   phase 2   L: A(m0,m1) of tile t+1            DMA: A rows   0..127 of tile t+2     M: acc[n1][m2,m3] += W(n1) x A(m2,m3)
-//   phase 3   L: -                               DMA: A rows 128..255 of tile t+2     M: acc[n0][m2,m3] += W(n0) x A(m2,m3)
-// (m = 32-row blocks of the wave's 128 rows, n = 32-column blocks of its 64 columns; each cluster walks the tile's four k-steps in
-// order, so an accumulator sees k in the v3 kernel's order.)  24 fragment reads per K tile — the minimum — and every LDS read of tile
-// t is over after phase 1, which is what lets tile t+2 stream into tile t's buffer from phase 2 on with only two LDS buffers.
+// A phase = { L: fragment reads + LDS-DMA issue ; wait for the own reads (+ counted vmcnt) ; barrier ; M: one MFMA cluster ; barrier }.
+// Tile widths: TNW = 256 (waves 2 x 4, 128 x 64 per wave: MI = 4, NI = 2) or 192 (waves 4 x 2, 64 x 96 per wave: MI = 2, NI = 3 — the tile
+// that fills the rounds of a sequence-parallel shard's N = 1536 GEMMs).  Two schedules of a K tile (64 deep):
+//   PH == 2 (both widths) — clusters of 4 NI MH MFMAs (MH = MI / 2 row blocks):
+//     phase 0   L: W(all NI), A(upper MH row blocks) of tile t    DMA: W of tile t+1    M: acc[.][lower MH] += W x A(lower)   (A(lower) was read in phase 1 of tile t-1)
+//     phase 1   L: A(lower MH row blocks) of tile t+1             DMA: A of tile t+2    M: acc[.][upper MH] += W x A(upper)
+//   PH == 4 (TNW = 256) — clusters of 8 MFMAs:
+//     phase 0   L: W(n0), W(n1) of tile t          DMA: W rows   0..127 of tile t+1     M: acc[n0][m0,m1] += W(n0) x A(m0,m1)
+//     phase 1   L: A(m2,m3) of tile t              DMA: W rows 128..255 of tile t+1     M: acc[n1][m0,m1] += W(n1) x A(m0,m1)
+//     phase 2   L: A(m0,m1) of tile t+1            DMA: A rows   0..127 of tile t+2     M: acc[n1][m2,m3] += W(n1) x A(m2,m3)
+//     phase 3   L: -                               DMA: A rows 128..255 of tile t+2     M: acc[n0][m2,m3] += W(n0) x A(m2,m3)
+// Each cluster walks the tile's four k-steps in order, so an accumulator sees k in the v3 kernel's order.  The minimum of fragment reads per
+// K tile (4 (MI + NI)), and every LDS read of tile t is over one phase into it, which is what lets tile t+2 stream into tile t's buffer
+// with only two LDS buffers.  PH == 2 halves the barriers per MFMA and measures within 1 % of PH == 4 (-3 % on K = 1536, +1 % on K = 8960).
 // Safety of the hand-off (cdna_hip_programming.md "read a staged buffer one phase after the wait that retires it"):
 //   * a wave waits for its OWN fragment reads (lgkmcnt(0)) BEFORE the barrier that ends its L section: what a later DMA overwrites has
-//     been read by everyone once that barrier is passed (A of tile t: last read in phase 1, first overwritten in phase 2);
-//   * a wave waits for its own DMA shares with a counted vmcnt before that same barrier — vmcnt(4) at the end of phase 1 (the two A
-//     half-tiles of tile t+1 have landed, the two W half-tiles behind them may still fly) and of phase 3 (W of t+1 landed, A of t+2 in
-//     flight) — and the data is first read one phase later, i.e. behind a barrier BOTH wave rows have passed after their waits.
+//     been read by everyone once that barrier is passed;
+//   * a wave waits for its own DMA shares with a counted vmcnt before that same barrier (vector memory operations complete in issue order on
+//     this family: vmcnt(n) = everything but the n newest has landed) and the data is first read one phase later, i.e. behind a barrier
+//     BOTH wave rows have passed after their waits.
 // Row OOB: the operands are read through buffer descriptors sized to the matrix, rows past M / N read zeros (their results are never stored).
 // =================================================================================================
-#define E_HALF 16384           // a half-tile: 128 rows x 128 B
-#define E_BUF 65536            // one K tile: A [256][128 B] | W [256][128 B]
+#define E_HALF 16384           // an A half-tile: 128 rows x 128 B
+#define E_BUF 65536            // one K tile: A [256][128 B] | W [<= 256][128 B]
 #define E_BAR() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define E_WAIT(s) asm volatile(s ::: "memory")
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
+template <int PH, int TNW>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM, int abl_arg) {
+    static_assert((TNW == 256 && (PH == 2 || PH == 4)) || (TNW == 192 && PH == 2), "unsupported schedule");
+    constexpr int MI = TNW == 256 ? 4 : 2, NI = TNW == 256 ? 2 : 3, MH = MI / 2;
+    constexpr int WP = TNW / 64;                          // LDS-DMA pieces of a W tile per wave (A: 4, two per half-tile)
+#ifdef SVI_ABLATIONS
+    const int abl = abl_arg;          // timing ablations, variant builds only (tools/gemm_epi_abl.py): 1-4 as in the v3 kernel; 5 = one K tile only; 6 = one K tile, no epilogue
+#else
+    constexpr int abl = 0;
+    (void)abl_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lds0 = (int)(size_t)(lptr_t)smem;          // 0: the dynamic region is all the LDS this kernel has (the buffer flip below is an XOR)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int grp = wave >> 2;                            // the wave row that shares SIMDs with the other one: waves w and w + 4
+    const int wm = TNW == 256 ? wave >> 2 : wave >> 1, wn = TNW == 256 ? wave & 3 : wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
 
     const int nwg = tiles_m * tiles_n;
@@ -874,149 +580,183 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g
     const int in_group = swz - group * GM * tiles_n;
     const int tile_n = in_group / gm;
     const int tile_m = first_m + (in_group - tile_n * gm);
-    const int m0 = tile_m * TM, n0 = tile_n * TN;
-
+    const int m0 = tile_m * TM, n0 = tile_n * TNW;
     if (g.W2 && n0 >= g.n_split) {                          // q | k side by side: this tile's columns belong to the second matrix
         g.W = g.W2 - (size_t)g.n_split * g.ldw;
         g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
     }
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, (int)(((unsigned)(g.M - 1) * (unsigned)g.lda + (unsigned)g.K) * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, (int)(((unsigned)(g.N - 1) * (unsigned)g.ldw + (unsigned)g.K) * 2u), 0x00020000);
-    // a wave's DMA instruction covers 8 rows x 128 B; a half-tile is 16 of them, two per wave (rows j * 64 + wave * 8 + lane / 8, j = 0, 1).
+    // a wave's DMA instruction covers 8 rows x 128 B; piece p = j * 8 + wave of an operand tile holds its rows j * 64 + wave * 8 + lane / 8.
     // The bank swizzle sits on the SOURCE chunk (LDS-DMA writes lane-linear), as in the v3 kernel.
     const int r8 = wave * 8 + (lane >> 3);
     const int c8 = (lane & 7) ^ ((r8 >> 1) & 7);
     const int a_vo = (r8 * g.lda + c8 * 8) * 2, w_vo = (r8 * g.ldw + c8 * 8) * 2;
     const unsigned a_so0 = (unsigned)m0 * (unsigned)g.lda * 2u, w_so0 = (unsigned)n0 * (unsigned)g.ldw * 2u;
     const unsigned a_j = 64u * (unsigned)g.lda * 2u, w_j = 64u * (unsigned)g.ldw * 2u;
-    const int nk = g.K / BK;
-    // op 0: A half-tile h of K tile kt -> buffer b;  op 1: W
-    auto stage = [&](auto opc, int h, int kt, int b) {
-        constexpr int op = decltype(opc)::value;
-        const unsigned so = (op ? w_so0 + (unsigned)(2 * h) * w_j : a_so0 + (unsigned)(2 * h) * a_j) + (unsigned)kt * (BK * 2);
-        char* dst = smem + b * E_BUF + op * (2 * E_HALF) + h * E_HALF + wave * 1024;
-        if constexpr (op == 0) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)dst, 16, a_vo, (int)so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(dst + 8192), 16, a_vo, (int)(so + a_j), 0, 0);
-        } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)dst, 16, w_vo, (int)so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + 8192), 16, w_vo, (int)(so + w_j), 0, 0);
+    const int nk = abl >= 5 ? 1 : g.K / BK;
+    // pieces j0 .. j0 + NJ - 1 of the A (op 0) / W (op 1) tile of K tile kt -> buffer b
+    auto stage = [&](auto opc, auto j0c, auto njc, int kt, int b) {
+        constexpr int op = decltype(opc)::value, j0 = decltype(j0c)::value, NJ = decltype(njc)::value;
+        const unsigned so = (op ? w_so0 : a_so0) + (unsigned)kt * (BK * 2);
+        char* dst = smem + b * E_BUF + op * (2 * E_HALF) + wave * 1024;
+#pragma unroll
+        for (int j = j0; j < j0 + NJ; ++j) {
+            if constexpr (op == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(dst + j * 8192), 16, a_vo, (int)(so + (unsigned)j * a_j), 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + j * 8192), 16, w_vo, (int)(so + (unsigned)j * w_j), 0, 0);
         }
     };
-    std::integral_constant<int, 0> OPA;
+    std::integral_constant<int, 0> OPA, J0;
     std::integral_constant<int, 1> OPW;
+    std::integral_constant<int, 2> J2;
+    std::integral_constant<int, 4> J4;
+    std::integral_constant<int, WP> JW;
 
-    f32x16 acc[2][4];
+    f32x16 acc[NI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int a_addr[4], w_addr[4];          // this lane's fragment of k-step kk: A block 0 of the wave's rows / W block 0 of its columns, buffer 0
+    int a_addr[4], w_addr[4];          // this lane's fragment of k-step kk: row block 0 of the wave's rows (A) / columns (W), buffer 0
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
-        w_addr[kk] = lds0 + 2 * E_HALF + lds_tile_off(wn * 64 + l31, 2 * kk + hi);
+        a_addr[kk] = lds0 + lds_tile_off(wm * (32 * MI) + l31, 2 * kk + hi);
+        w_addr[kk] = lds0 + 2 * E_HALF + lds_tile_off(wn * (32 * NI) + l31, 2 * kk + hi);
     }
-    u32x4 xa0[2][4], xa1[2][4], xw0[4], xw1[4];
-
-    auto cluster = [&](f32x16& c0, f32x16& c1, const u32x4 (&xa)[2][4], const u32x4 (&xw)[4]) {
+    u32x4 xlo[MH][4], xup[MH][4], xw[NI][4];          // A fragments of the lower / upper MH row blocks, W fragments of the NI column blocks
+    auto read_a = [&](u32x4 (&x)[MH][4], int blk0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MH; ++i) x[i][kk] = *(lds_u32x4_t)(a_addr[kk] + (blk0 + i) * 32 * 128);
+    };
+    auto read_w = [&](auto n0c, auto nnc) {
+        constexpr int nb0 = decltype(n0c)::value, NN = decltype(nnc)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = nb0; i < nb0 + NN; ++i) xw[i][kk] = *(lds_u32x4_t)(w_addr[kk] + i * 32 * 128);
+    };
+    // acc[n][mb0 + i] += W(n) x A(i) for n in [nb0, nb0 + NN), i in [0, MH), over the tile's four k-steps
+    auto cluster = [&](auto n0c, auto nnc, int mb0, const u32x4 (&xa)[MH][4]) {
+        constexpr int nb0 = decltype(n0c)::value, NN = decltype(nnc)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xw[kk]), __builtin_bit_cast(bf16x8, xa[0][kk]), c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xw[kk]), __builtin_bit_cast(bf16x8, xa[1][kk]), c1, 0, 0, 0);
-        }
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int n = nb0; n < nb0 + NN; ++n)
+#pragma unroll
+                for (int i = 0; i < MH; ++i)
+                    acc[n][mb0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xw[n][kk]), __builtin_bit_cast(bf16x8, xa[i][kk]), acc[n][mb0 + i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    // one K tile.  SW: tile t+1 exists (its W half-tiles are staged in phases 0 / 1, its first A fragments read in phase 2);  SA: tile t+2 exists
+    std::integral_constant<int, 0> N0;
+    std::integral_constant<int, 1> N1;
+    std::integral_constant<int, NI> NALL;
+    auto flip = [&](int (&ad)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ad[kk] ^= E_BUF;
+    };
+    // one K tile.  SW: tile t+1 exists (its W is staged here, its lower A fragments are read here);  SA: tile t+2 exists (its A is staged here)
     auto ktile = [&](int t, auto swc, auto sac) {
         constexpr bool SW = decltype(swc)::value, SA = decltype(sac)::value;
         const int b = t & 1;
-        // ---- phase 0
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            xw0[kk] = *(lds_u32x4_t)(w_addr[kk]);
-            xw1[kk] = *(lds_u32x4_t)(w_addr[kk] + 32 * 128);
-        }
-        if constexpr (SW) stage(OPW, 0, t + 1, b ^ 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        E_BAR();
-        cluster(acc[0][0], acc[0][1], xa0, xw0);
-        E_BAR();
-        // ---- phase 1
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            xa1[0][kk] = *(lds_u32x4_t)(a_addr[kk] + 64 * 128);
-            xa1[1][kk] = *(lds_u32x4_t)(a_addr[kk] + 96 * 128);
-        }
-        if constexpr (SW) {
-            stage(OPW, 1, t + 1, b ^ 1);
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");       // A of tile t+1 has landed (this wave's shares); its W half-tiles may still fly
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        E_BAR();
-        cluster(acc[1][0], acc[1][1], xa0, xw1);
-        E_BAR();
-        // ---- phase 2
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a_addr[kk] ^= E_BUF;
-        if constexpr (SW) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                xa0[0][kk] = *(lds_u32x4_t)(a_addr[kk]);
-                xa0[1][kk] = *(lds_u32x4_t)(a_addr[kk] + 32 * 128);
+        if constexpr (PH == 2) {
+            // ---- phase 0
+            read_w(N0, NALL);
+            read_a(xup, MH);
+            if constexpr (SW) {
+                stage(OPW, J0, JW, t + 1, b ^ 1);
+                if constexpr (WP == 4) E_WAIT("s_waitcnt vmcnt(4) lgkmcnt(0)");      // A of tile t+1 has landed (this wave's shares); its W may still fly
+                else E_WAIT("s_waitcnt vmcnt(3) lgkmcnt(0)");
+            } else {
+                E_WAIT("s_waitcnt lgkmcnt(0)");
             }
+            E_BAR();
+            cluster(N0, NALL, 0, xlo);
+            E_BAR();
+            // ---- phase 1
+            flip(a_addr); flip(w_addr);
+            if constexpr (SW) read_a(xlo, 0);
+            if constexpr (SA) {
+                stage(OPA, J0, J4, t + 2, b);
+                E_WAIT("s_waitcnt vmcnt(4) lgkmcnt(0)");                              // W of tile t+1 has landed; A of tile t+2 in flight
+            } else if constexpr (SW) {
+                E_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)");
+            }
+            E_BAR();
+            cluster(N0, NALL, MH, xup);
+            E_BAR();
+        } else {
+            // ---- phase 0
+            read_w(N0, NALL);
+            if constexpr (SW) stage(OPW, J0, J2, t + 1, b ^ 1);
+            E_WAIT("s_waitcnt lgkmcnt(0)");
+            E_BAR();
+            cluster(N0, N1, 0, xlo);
+            E_BAR();
+            // ---- phase 1
+            read_a(xup, MH);
+            if constexpr (SW) {
+                stage(OPW, J2, J2, t + 1, b ^ 1);
+                E_WAIT("s_waitcnt vmcnt(4) lgkmcnt(0)");                              // A of tile t+1 has landed; its W half-tiles may still fly
+            } else {
+                E_WAIT("s_waitcnt lgkmcnt(0)");
+            }
+            E_BAR();
+            cluster(N1, N1, 0, xlo);
+            E_BAR();
+            // ---- phase 2
+            flip(a_addr);
+            if constexpr (SW) read_a(xlo, 0);
+            if constexpr (SA) stage(OPA, J0, J2, t + 2, b);
+            E_WAIT("s_waitcnt lgkmcnt(0)");
+            E_BAR();
+            cluster(N1, N1, MH, xup);
+            E_BAR();
+            // ---- phase 3
+            if constexpr (SA) {
+                stage(OPA, J2, J2, t + 2, b);
+                E_WAIT("s_waitcnt vmcnt(4)");                                         // W of tile t+1 has landed; A of tile t+2 in flight
+            } else if constexpr (SW) {
+                E_WAIT("s_waitcnt vmcnt(0)");
+            }
+            E_BAR();
+            cluster(N0, N1, MH, xup);
+            E_BAR();
+            flip(w_addr);
         }
-        if constexpr (SA) stage(OPA, 0, t + 2, b);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        E_BAR();
-        cluster(acc[1][2], acc[1][3], xa1, xw1);
-        E_BAR();
-        // ---- phase 3
-        if constexpr (SA) {
-            stage(OPA, 1, t + 2, b);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   // W of tile t+1 has landed; A of tile t+2 in flight
-        } else if constexpr (SW) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        E_BAR();
-        cluster(acc[0][2], acc[0][3], xa1, xw0);
-        E_BAR();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) w_addr[kk] ^= E_BUF;
     };
     std::true_type YES;
     std::false_type NO;
 
-    // prologue: tile 0 whole, the A half-tiles of tile 1 behind it
-    stage(OPA, 0, 0, 0); stage(OPA, 1, 0, 0); stage(OPW, 0, 0, 0); stage(OPW, 1, 0, 0);
+    // prologue: tile 0 whole, the A tile of tile 1 behind it
+    stage(OPA, J0, J4, 0, 0);
+    stage(OPW, J0, JW, 0, 0);
     if (nk > 1) {
-        stage(OPA, 0, 1, 1); stage(OPA, 1, 1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        stage(OPA, J0, J4, 1, 1);
+        E_WAIT("s_waitcnt vmcnt(4)");
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        E_WAIT("s_waitcnt vmcnt(0)");
     }
     E_BAR();
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        xa0[0][kk] = *(lds_u32x4_t)(a_addr[kk]);
-        xa0[1][kk] = *(lds_u32x4_t)(a_addr[kk] + 32 * 128);
-    }
-    if (wm == 1) E_BAR();                                  // the second wave row runs one barrier behind the first from here on
+    read_a(xlo, 0);
+    if (grp == 1) E_BAR();                                 // the second wave row runs one barrier behind the first from here on
     int t = 0;
     for (; t + 2 < nk; ++t) ktile(t, YES, YES);
     if (nk >= 2) { ktile(t, YES, NO); ++t; }
     ktile(t, NO, NO);
-    if (wm == 0) E_BAR();
-    asm volatile("s_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));   // MFMA result -> VALU read
-    asm volatile("s_nop 0" : "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    if (grp == 0) E_BAR();
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("s_nop 7" : "+v"(acc[n][i]));      // MFMA result -> VALU read
     __syncthreads();                                       // every wave is done with the operand buffers: the C tile may overwrite them
-    gemm256_epilogue(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, 0);
+    gemm256_epilogue<MI, NI, TNW>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl == 5 ? 0 : abl == 6 ? 1 : abl);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1264,7 +1004,7 @@ svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, i
 }
 
 // Which kernel a bf16 GEMM of this shape runs on — pure arithmetic on sizes, switches and the device's CU count (svi_gemm_plan exposes it;
-// tests/test_plans.py): 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile, 257 = the 256^2 v3 loop, 259 = the 256^2 eight-phase loop.
+// tests/test_plans.py): 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile, 259 / 260 = the 256^2 tile with four / two phases per K tile.
 int svi_gemm_choose(const SviGemmArgs& g, int ncu) {
     if (g.skinny && g.M <= 128 && g.K % 128 == 0 && !g.bias_along_m && (g.epi == SVI_EPI_BIAS || g.epi == SVI_EPI_BIAS_GATE_RES) && g.ldc % 4 == 0) return 0;
     if (ncu <= 0) ncu = 256;
@@ -1281,7 +1021,7 @@ int svi_gemm_choose(const SviGemmArgs& g, int ncu) {
     const long r256 = ((long)tm_s * ((selN + TN - 1) / TN) + ncu - 1) / ncu, r192 = ((long)tm_s * ((selN + 192 - 1) / 192) + ncu - 1) / ncu;
     const bool better = (double)r192 * 0.75 * 1.08 < (double)r256 * 0.97;
     if (g.N >= 192 && (sw.gemm_kernel == 192 || (sw.gemm_kernel == 0 && better))) return 192;
-    if (sw.gemm_kernel == 257 || sw.gemm_kernel == 259) return sw.gemm_kernel;
+    if (sw.gemm_kernel == 259 || sw.gemm_kernel == 260) return sw.gemm_kernel;
     return SVI_GEMM_DEFAULT_256;
 }
 
@@ -1348,23 +1088,23 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
         // N = 8960 (35 column panels, ffn1): 5-6 give 1050 vs 1022 at 2 and 980 at 8 — a 5 x 6 block of concurrent tiles per XCD
         // needs the fewest operand panels (HBM fetch per launch at 2: 2.2 GB against 0.13 GB of operands, profiles/r1h_gemm_ffn1_pmc.txt)
         const int gm_rows = sw.gemm_gm ? sw.gemm_gm : (tn >= 16 ? 5 : 2);
-        if (kind == 192) {
+#ifdef SVI_ABLATIONS          // timing ablations (tools/gemm_epi_abl.py; results wrong when set): variant builds only
+        const int abl = sw.gemm_epi_abl;
+#else
+        const int abl = 0;
+#endif
+        if (kind == 192) {            // the 256 x 192 tile (sequence-parallel shards)
             const int tn3 = (g.N + TN3 - 1) / TN3;
-            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256x192_kernel), LDS256_BYTES));
-            hipLaunchKernelGGL(gemm_bf16_nt_256x192_kernel, dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 2));
-        } else if (kind == 259) {     // eight-phase main loop (see its header)
-            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel), LDS256_BYTES));
-            hipLaunchKernelGGL(gemm_bf16_nt_256e_kernel, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows);
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel<2, 192>), LDS256_BYTES));
+            hipLaunchKernelGGL((gemm_bf16_nt_256e_kernel<2, 192>), dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 2), abl);
+        } else if (kind == 260) {
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel<2, 256>), LDS256_BYTES));
+            hipLaunchKernelGGL((gemm_bf16_nt_256e_kernel<2, 256>), dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);
         } else {
             // Tried and dropped: starting the first round's workgroups out of phase (s_sleep by CU index) so that the CUs' store
             // bursts do not coincide: no gain on ffn1 (17.5 rounds), a loss wherever the tile count is a whole number of rounds.
-            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256p_kernel<1>), LDS256_BYTES));
-#ifdef SVI_ABLATIONS          // epilogue timing ablations (tools/gemm_epi_abl.py; results wrong when set): variant builds only
-            const int abl = sw.gemm_epi_abl;
-#else
-            const int abl = 0;
-#endif
-            hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<1>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel<4, 256>), LDS256_BYTES));
+            hipLaunchKernelGGL((gemm_bf16_nt_256e_kernel<4, 256>), dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);
         }
         SVI_LAUNCH_CHECK();
         return SVI_OK;

@@ -5,8 +5,8 @@ import pytest
 from svi_hip import _lib as L
 
 L_TOK, D, F = 32760, 1536, 8960
-DEFAULT_256 = L.gemm_plan(L_TOK, D, D)          # 257 (v3 loop) or 259 (eight-phase loop): whichever the library was built to prefer
-assert DEFAULT_256 in (257, 259)
+DEFAULT_256 = L.gemm_plan(L_TOK, D, D)          # 259 / 260 (four / two phases per K tile): whichever the library was built to prefer
+assert DEFAULT_256 in (259, 260)
 
 
 @pytest.fixture(autouse=True)
@@ -29,15 +29,15 @@ def test_gemm_kernel_choice(M, N, K, want):
 
 def test_gemm_kernel_choice_follows_the_switch_and_the_skinny_hint():
     assert L.gemm_plan(64, 4096, 4096, skinny=True) == 0 and L.gemm_plan(64, 4096, 4096) == 128
-    L.set_switch("SVI_GEMM_KERNEL", 257)
-    assert L.gemm_plan(L_TOK // 4, D, D) == 257                   # "never the 192-wide tile"
+    L.set_switch("SVI_GEMM_KERNEL", 260)
+    assert L.gemm_plan(L_TOK // 4, D, D) == 260                   # "never the 192-wide tile"
     L.set_switch("SVI_GEMM_KERNEL", 192)
     assert L.gemm_plan(L_TOK, D, D) == 192 and L.gemm_plan(300, 128, 64) == DEFAULT_256     # N < 192: not this kernel (a forced 256-row tile stays 256 wide)
     L.set_switch("SVI_GEMM_KERNEL", 128)
     assert L.gemm_plan(L_TOK, F, D) == 128
     L.set_switch("SVI_GEMM_KERNEL", 259)
-    assert L.gemm_plan(L_TOK, D, F) == 259 and L.gemm_plan(L_TOK // 4, D, D) == 259          # the eight-phase loop, wherever a 256-row tile runs
-    L.set_switch("SVI_GEMM_KERNEL", 258)                                                         # not a kernel (any more): ignored
+    assert L.gemm_plan(L_TOK, D, F) == 259 and L.gemm_plan(L_TOK // 4, D, D) == 259          # four phases per K tile, wherever a 256-row tile runs
+    L.set_switch("SVI_GEMM_KERNEL", 257)                                                         # not a kernel (any more): ignored
     assert L.gemm_plan(L_TOK, D, F) == DEFAULT_256
 
 

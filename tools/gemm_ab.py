@@ -26,7 +26,7 @@ def rnd(*shape, scale=1.0):
     return (torch.randn(shape, generator=g, device=dev) * scale).to(torch.bfloat16)
 
 
-KINDS = tuple(os.environ.get("GEMM_AB_KINDS", "257,258").split(","))
+KINDS = tuple(os.environ.get("GEMM_AB_KINDS", "128,259,260").split(","))
 SHAPES = {
     # name: (M, N, K, epilogue, bias_along_m)
     "qkv   [L,D]x[D,D]": (Ltok, D, D, L.EPI_BIAS, 0),

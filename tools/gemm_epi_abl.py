@@ -11,7 +11,7 @@ lib = L.lib(); st = L.current_stream()
 rnd = lambda *s, scale=1.0: (torch.randn(s, generator=g, device=dev) * scale).to(torch.bfloat16)
 SHAPES = {"ffn1 gelu": (Ltok, F, D, L.EPI_BIAS_GELU_TANH), "ffn2 gate+res": (Ltok, D, F, L.EPI_BIAS_GATE_RES),
           "qkv": (Ltok, D, D, L.EPI_BIAS), "attn_o gate+res": (Ltok, D, D, L.EPI_BIAS_GATE_RES)}
-SETS = ["0", "1", "2", "3"]
+SETS = os.environ.get("ABL_SETS", "0,1,2,3").split(",")
 for name, (M, N, K, epi) in SHAPES.items():
     x = rnd(M, K); w = rnd(N, K, scale=K ** -0.5); b = rnd(N); gate = torch.randn(N, generator=g, device=dev); res = rnd(M, N)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
