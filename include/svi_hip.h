@@ -170,6 +170,10 @@ svi_status svi_dit_context_cache(svi_dit* h, int32_t enable);
 svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* timestep, const void* context, const void* clip_feature,
                             const void* y, const void* add_condition, int32_t T, int32_t H, int32_t W, int32_t Lc,
                             int32_t row0, int32_t nrows, svi_stream stream);
+/* svi_dit_sp_block_qkv_part: the same in two pieces — part 1 = LN + modulate and the V^T projection, part 2 = the q | k projection with RMSNorm + RoPE
+ * (0 = both: svi_dit_sp_block_qkv) — so that V^T can be on the wire while q | k are still being made (the gather mode of sequence_parallel.py). */
+svi_status svi_dit_sp_block_qkv_part(svi_dit* h, int32_t layer, void* q_send, void* k_send, void* vt_out, int32_t ldvt, int32_t P, int32_t G,
+                                     int32_t part, svi_stream stream);
 svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* q_send, void* k_send, void* vt_out, int32_t ldvt, int32_t P, int32_t G,
                                 svi_stream stream);
 svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, svi_stream stream);

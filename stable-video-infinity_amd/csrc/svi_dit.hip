@@ -505,8 +505,10 @@ static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16
 // The self-attention third of a block depends on (x, t) only — not on the prompt.  It is written in three pieces so that a
 // sequence-parallel shard can exchange heads for tokens around the attention (svi_dit_sp_*): (1) q | k (RMSNorm + RoPE applied,
 // q pre-scaled) and V^T of the shard's rows [row0, row0 + L), (2) attention, (3) output projection + gate + residual.
+// part: 0 = everything; 1 = LN + modulate and the V^T projection only; 2 = the q | k projection and RMSNorm + RoPE only (after a part-1 call on the
+// same rows: the LN output is still in the workspace) — the sequence-parallel gather mode sends V^T on its way while q | k are still being made.
 static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* modf, int L, int row0, bf16* QK, bf16* VT, int ldvt,
-                            hipStream_t st, const SviScatter* scatter = nullptr, int nb = 1) {
+                            hipStream_t st, const SviScatter* scatter = nullptr, int nb = 1, int part = 0) {
     // L = rows of this launch (nb samples of L / nb tokens each, stacked: the two CFG branches of a step on short sequences)
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
@@ -517,7 +519,8 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
     rope.row0 = row0;
     rope.period = nb > 1 ? L / nb : 0;
     // --- self attention: x += gate_msa * o(attn(rope(rms(q)), rope(rms(k)), v))     dit:358,369,226-242
-    { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_a, sc_a, st)); }
+    if (part != 2) { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, L, D, c.eps, nullptr, nullptr, sh_a, sc_a, st)); }
+    if (part == 1) { SviProfScope _p(PROF_GEMM_QKV, st); return linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st, nb); }
     // q | k as ONE N = 2D launch (dit:227-228 side by side): tile columns below D multiply by Wq, the others by Wk — the LN output is read
     // once for both, the weights stay the bound tensors (nothing is packed).  Per element the kernel and the k order are those of the two
     // separate launches (the kernel choice is pinned to the per-projection shape through sel_n): the same bits.
@@ -532,7 +535,7 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
       g.W2 = b.sa.k.w; g.bias2 = b.sa.k.b; g.n_split = D;
       g.sel_m = nb > 1 ? L / nb : 0; g.sel_n = D;
       SVI_TRY(svi_launch_gemm(g, st)); }
-    { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st, nb)); }
+    if (part == 0) { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st, nb)); }
     // q and k in one launch (grid.y = operand): q additionally carries softmax_scale * log2(e) into its single final rounding
     { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope2(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st, scatter)); }
     return SVI_OK;
@@ -1099,14 +1102,18 @@ extern "C" svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* t
 
 extern "C" svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* q_send, void* k_send, void* vt_out, int32_t ldvt, int32_t P, int32_t G,
                                            svi_stream stream) {
-    SVI_REQUIRE(h && h->sp_active && q_send && k_send && vt_out, "svi_dit_sp_block_qkv: no shard in flight (svi_dit_sp_begin) or null buffer");
+    return svi_dit_sp_block_qkv_part(h, layer, q_send, k_send, vt_out, ldvt, P, G, 0, stream);
+}
+extern "C" svi_status svi_dit_sp_block_qkv_part(svi_dit* h, int32_t layer, void* q_send, void* k_send, void* vt_out, int32_t ldvt, int32_t P, int32_t G,
+                                                int32_t part, svi_stream stream) {
+    SVI_REQUIRE(h && h->sp_active && q_send && k_send && vt_out && part >= 0 && part <= 2, "svi_dit_sp_block_qkv: no shard in flight (svi_dit_sp_begin), null buffer or bad part");
     SVI_REQUIRE_DEVICE(h);
     const int D = h->cfg.dim;
     SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && ldvt >= h->sp_rows && ldvt % 8 == 0, "svi_dit_sp_block_qkv: bad layer / ldvt");
     SVI_REQUIRE(P > 0 && G > 0 && h->cfg.num_heads % (P * G) == 0, "svi_dit_sp_block_qkv: %d heads do not split into %d ranks x %d head groups", h->cfg.num_heads, P, G);
     SviScatter sc{reinterpret_cast<bf16*>(q_send), reinterpret_cast<bf16*>(k_send), P, D / P, D / P / G};
     return block_qkv(h, layer, h->ws.X, h->ws.modf + (size_t)layer * 6 * D, h->sp_rows, h->sp_row0, h->ws.QK, reinterpret_cast<bf16*>(vt_out), ldvt,
-                     reinterpret_cast<hipStream_t>(stream), &sc);
+                     reinterpret_cast<hipStream_t>(stream), &sc, 1, part);
 }
 
 extern "C" svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, svi_stream stream) {

@@ -544,6 +544,11 @@ typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_t;
 //     this family: vmcnt(n) = everything but the n newest has landed) and the data is first read one phase later, i.e. behind a barrier
 //     BOTH wave rows have passed after their waits.
 // Row OOB: the operands are read through buffer descriptors sized to the matrix, rows past M / N read zeros (their results are never stored).
+// Tried on this loop and dropped (round 4, bit-identical, profiles/r4d_gemm_persistent_ab.txt): a PERSISTENT form — one workgroup per CU walking
+// its tiles, the last K tile staging K tiles 0 and 1 of the next output tile, a wave-private epilogue in the 32 KiB above the operand buffers, the
+// one-barrier stagger kept across the boundary.  q/k/v 154 vs 148 us, attn-out 172 vs 154, ffn1 861 vs 786, ffn2 696 vs 654: the private epilogue
+// (four 32-row pieces through 4 KiB, each a wave-local LDS round trip) and the boundary K tiles' scalar bookkeeping cost more than the ~3.7 us of
+// launch + prologue per tile they remove — the same verdict round 2 reached on the lockstep loop.
 // =================================================================================================
 #define E_HALF 16384           // an A half-tile: 128 rows x 128 B
 #define E_BUF 65536            // one K tile: A [256][128 B] | W [<= 256][128 B]

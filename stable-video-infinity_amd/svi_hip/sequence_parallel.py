@@ -209,6 +209,17 @@ class SequenceShard:
         b = self.buf
         L.check(L.lib().svi_dit_sp_block_qkv(self.dit._h, layer, L.ptr(b.q), L.ptr(b.k), L.ptr(b.vt), b.ldvt, 1, 1, L.current_stream()), "svi_dit_sp_block_qkv")
 
+    def block_v_rows(self, layer: int) -> None:
+        """First half of block_qkv_rows: LN + modulate and V^T of this rank's rows -> buf.vt (then on its way to the other ranks)."""
+        b = self.buf
+        L.check(L.lib().svi_dit_sp_block_qkv_part(self.dit._h, layer, L.ptr(b.q), L.ptr(b.k), L.ptr(b.vt), b.ldvt, 1, 1, 1, L.current_stream()), "svi_dit_sp_block_qkv_part")
+
+    def block_qk_rows(self, layer: int) -> None:
+        """Second half: q | k of this rank's rows (RMSNorm + RoPE applied) -> buf.q, buf.k; the same kernels in the same order per element as
+        block_qkv_rows, so the same bits."""
+        b = self.buf
+        L.check(L.lib().svi_dit_sp_block_qkv_part(self.dit._h, layer, L.ptr(b.q), L.ptr(b.k), L.ptr(b.vt), b.ldvt, 1, 1, 2, L.current_stream()), "svi_dit_sp_block_qkv_part")
+
     def attention_rows(self) -> None:
         """This rank's query rows against the gathered K (buf.k_all = [L, dim]) and V^T (buf.vt_all -> buf.vt_full) -> buf.attn [Ls, dim]."""
         b = self.buf
@@ -275,15 +286,16 @@ def _exchange(recv: torch.Tensor, send: torch.Tensor, group, overlap: bool):
     return dist.all_to_all_single(recv, send, group=group, async_op=overlap)
 
 
-def _all_gather_into(out: torch.Tensor, mine: torch.Tensor, group) -> None:
-    """out [P, ...] <- every rank's `mine` (RCCL all-gather; gloo in the tests goes through the host)."""
+def _all_gather_into(out: torch.Tensor, mine: torch.Tensor, group, overlap: bool = False):
+    """out [P, ...] <- every rank's `mine` (RCCL all-gather; gloo in the tests goes through the host).  overlap: an async collective on the
+    communicator's stream — the caller enqueues more kernels and waits on the returned handle where the data is needed."""
     if _staged(mine, group):
         host = mine.cpu().contiguous()
         got = [torch.empty_like(host) for _ in range(out.shape[0])]
         dist.all_gather(got, host, group=group)
         out.copy_(torch.stack(got))
-        return
-    dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+        return None
+    return dist.all_gather_into_tensor(out, mine.contiguous(), group=group, async_op=overlap)
 
 
 def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: Optional[int] = None, tea_mode: int = 0,
@@ -304,9 +316,13 @@ def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: O
         sh.tea(0)
     if sh.mode == "gather":
         for layer in range(dit.num_layers):
-            sh.block_qkv_rows(layer)
-            _all_gather_into(b.k_all, b.k, group)
-            _all_gather_into(b.vt_all, b.vt, group)
+            sh.block_v_rows(layer)                                   # V^T first: its all-gather runs under the q | k projection and RoPE
+            hv = _all_gather_into(b.vt_all, b.vt, group, True)
+            sh.block_qk_rows(layer)
+            hk = _all_gather_into(b.k_all, b.k, group, True)
+            for h_ in (hv, hk):
+                if h_ is not None:
+                    h_.wait()
             sh.attention_rows()
             sh.block_rest_rows(layer)
         if tea_mode == 1:
@@ -347,7 +363,8 @@ def forward_local(dits: Sequence[WanDiT], x, timestep, context, groups: Optional
     if shards[0].mode == "gather":
         for layer in range(dits[0].num_layers):
             for sh in shards:
-                sh.block_qkv_rows(layer)
+                sh.block_v_rows(layer)                               # the split form forward_distributed uses (V^T leaves first)
+                sh.block_qk_rows(layer)
             for sj in shards:
                 for i, si in enumerate(shards):
                     sj.buf.k_all[i].copy_(si.buf.k)

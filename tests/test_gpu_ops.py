@@ -90,7 +90,8 @@ def test_gemm_epilogues(hip, epi):
 
 @pytest.mark.parametrize("M,N,K,epi", [
     (8190, 1536, 1536, "bias"), (700, 1536, 1536, "gate_res"), (513, 8960, 256, "gelu_tanh"), (300, 200, 64, "bias"), (256, 192, 128, "gate_res"),
-    (1030, 1000, 192, "gelu_tanh"), (1536, 1100, 128, "transposed"), (257, 392, 8960, "gate_res"), (777, 520, 128, "bias"), (2048, 512, 192, "gelu_tanh")])
+    (1030, 1000, 192, "gelu_tanh"), (1536, 1100, 128, "transposed"), (257, 392, 8960, "gate_res"), (777, 520, 128, "bias"), (2048, 512, 192, "gelu_tanh"),
+    (2100, 8960, 256, "gelu_tanh"), (32760, 1536, 320, "gate_res"), (16380, 3072, 256, "bias")])      # more tiles than compute units
 def test_gemm_tile_256x192_bit_identical(hip, M, N, K, epi):
     """The 256 x 192 tile kernel (what a sequence-parallel rank's shard GEMMs run on when 256-wide tiles fill the chip's rounds poorly)
     and the 256^2 tile in its two schedules (SVI_GEMM_KERNEL=259 / 260: four / two phases per K tile — wave rows one barrier apart, counted

@@ -317,3 +317,30 @@ def test_install_routing_through_the_real_sampler_source(ref):
     import sys
     for n in ("svi_video_route", "svi_video_sig"):
         sys.modules.pop(n, None)
+
+
+def test_two_speaker_audio_routing_is_unreachable_in_the_reference():
+    """Row N3 remainder (VERDICT r3 missing #4): `SingleStreamMutiAttention.forward` has a two-speaker branch (models/attention.py:417-483:
+    per-speaker 1-D RoPE classes from a reference-attention map), but every call site in the reference passes the literal `human_num=1` with
+    `x_ref_attn_map=None` (models/wan_video_dit.py:364-365, models/wan_video_dit_talk.py:374-375), `SelfAttention.forward` is never handed
+    `ref_target_masks` by a DiTBlock, and the talk pipeline prepares ONE speaker's audio (`audio_prepare_single`, pipelines/svi_video_talk.py:413).
+    The HIP path therefore serves human_num == 1 — what the reference executes.  This test reads the reference's sources and fails the day a call
+    site starts passing anything else, i.e. the day the branch becomes reachable and has to be built."""
+    import ast
+    sites = 0
+    for rel in ("diffsynth/models/wan_video_dit.py", "diffsynth/models/wan_video_dit_talk.py"):
+        tree = ast.parse(open(os.path.join(REF, rel)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "audio_cross_attn":
+                kw = {k.arg: k.value for k in node.keywords}
+                assert isinstance(kw.get("human_num"), ast.Constant) and kw["human_num"].value == 1, (rel, node.lineno)
+                assert isinstance(kw.get("x_ref_attn_map"), ast.Constant) and kw["x_ref_attn_map"].value is None, (rel, node.lineno)
+                sites += 1
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "self_attn":
+                assert not any(k.arg == "ref_target_masks" for k in node.keywords) and len(node.args) <= 2, (rel, node.lineno)
+    assert sites >= 2
+    # nothing in the pipelines names the parameter at all
+    import glob
+    for f in glob.glob(os.path.join(REF, "diffsynth", "pipelines", "*.py")) + glob.glob(os.path.join(REF, "*.py")):
+        src = open(f).read()
+        assert "human_num" not in src and "ref_target_masks" not in src, f
