@@ -189,7 +189,7 @@ def pmc_summaries() -> dict:
                 continue
             tag = os.path.basename(f)[:-len("_source_hashes.json")]
             out = {"tag": tag}
-            for key in ("flash", "gemm_ffn1"):
+            for key in ("flash", "gemm_ffn1", "gemm_ffn2"):
                 p = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc.json")
                 if os.path.exists(p):
                     out[key] = json.load(open(p))
@@ -350,7 +350,10 @@ def main() -> None:
         from svi_hip.parallel import CfgPair
         pair, pair_idx, units = CfgPair.split_world()
     if args.graph is None:
-        args.graph = pair is None and not sp       # the single-rank step replays a hipGraph by default (DenoiseLoop's own default)
+        # the single-rank step replays a hipGraph by default (DenoiseLoop's own default).  With an RCCL communicator in the process (--gpus N > 1) the
+        # default is eager launches: capture beside a live communicator has never run on hardware here (no multi-GPU node was available to any round),
+        # and a scaling run must not hinge on it; --graph turns it on (the gloo probe does: tests/test_gpu_bench_ranks.py)
+        args.graph = pair is None and not sp and (dist is None or args.transport == "gloo")
     loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp, graph=args.graph)
     eager_loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp, graph=False) if args.graph else loop
     eager_loop.scheduler = loop.scheduler
@@ -578,7 +581,7 @@ def main() -> None:
     roof_all = {k: v for k, v in roof_all.items() if v is not None}
     if args.workload == "c2" and not sp:
         pm = pmc_summaries()
-        for fam_name, key in (("flash_self", "flash"), ("gemm_ffn1", "gemm_ffn1")):
+        for fam_name, key in (("flash_self", "flash"), ("gemm_ffn1", "gemm_ffn1"), ("gemm_ffn2", "gemm_ffn2")):
             if fam_name in roof_all and pm.get(key):
                 roof_all[fam_name].update(traffic=pm[key].get("hbm_bytes"), mfma_busy_in_clock=pm[key].get("mfma_busy_in_clock"),
                                           l2_hit_rate=pm[key].get("l2_hit_rate"), pmc_source=pm.get(key + "_file"))

@@ -1089,10 +1089,10 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     }
     if (kind != 128) {
         const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
-        // measured (tools/gemm_gm.py, v3 loop): N = 1536 (6 column panels): 2 is best (ffn2 1257 vs 1168-1230 TFLOP/s), flat on q/k/v;
-        // N = 8960 (35 column panels, ffn1): 5-6 give 1050 vs 1022 at 2 and 980 at 8 — a 5 x 6 block of concurrent tiles per XCD
+        // measured (tools/gemm_gm.py on the staggered loop, round 4): N = 1536 (6 column panels): 4 is best (q/k/v 1143 vs 1112 TFLOP/s at 2, ffn2 1370 vs 1358);
+        // N = 8960 (35 column panels, ffn1): 5 gives 1161 vs 1139 at 2 and 1093 at 8 — a 5 x 6 block of concurrent tiles per XCD
         // needs the fewest operand panels (HBM fetch per launch at 2: 2.2 GB against 0.13 GB of operands, profiles/r1h_gemm_ffn1_pmc.txt)
-        const int gm_rows = sw.gemm_gm ? sw.gemm_gm : (tn >= 16 ? 5 : 2);
+        const int gm_rows = sw.gemm_gm ? sw.gemm_gm : (tn >= 16 ? 5 : 4);
 #ifdef SVI_ABLATIONS          // timing ablations (tools/gemm_epi_abl.py; results wrong when set): variant builds only
         const int abl = sw.gemm_epi_abl;
 #else
@@ -1101,7 +1101,7 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
         if (kind == 192) {            // the 256 x 192 tile (sequence-parallel shards)
             const int tn3 = (g.N + TN3 - 1) / TN3;
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel<2, 192>), LDS256_BYTES));
-            hipLaunchKernelGGL((gemm_bf16_nt_256e_kernel<2, 192>), dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 2), abl);
+            hipLaunchKernelGGL((gemm_bf16_nt_256e_kernel<2, 192>), dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 4), abl);
         } else if (kind == 260) {
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel<2, 256>), LDS256_BYTES));
             hipLaunchKernelGGL((gemm_bf16_nt_256e_kernel<2, 256>), dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);

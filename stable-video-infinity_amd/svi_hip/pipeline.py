@@ -107,7 +107,9 @@ class DenoiseLoop:
                 self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)
             side.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):       # recorded, not executed: self._cond / self._uncond keep the eager step's results
+            # recorded, not executed: self._cond / self._uncond keep the eager step's results.  thread_local: other threads of the process (a
+            # communicator's watchdog, a data loader) are not bound by this capture's rules
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 self._forwards(latents, ts_static, ctx_pos, ctx_neg, cfg_scale, split, cond, ucond)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = dict(key=key, graph=g, ts=ts_static, pins=tensors, generation=self.dit.generation())

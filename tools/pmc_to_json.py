@@ -67,15 +67,17 @@ def main(tag):
                "counters_per_launch": vals, "attention_src_sha": hashes["svi_attention.hip"], "source_hashes": hashes, **derive(vals), "note": note}
         json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_flash_pmc.json"), "w"), indent=1)
         print(json.dumps({k: out.get(k) for k in ("hbm_bytes", "mfma_busy_in_clock", "l2_hit_rate")}))
-    p = os.path.join(ROOT, "gpurun_out", f"{tag}_gemm_ffn1_pmc.txt")
-    if os.path.exists(p):
+    for key, what, alg in (("gemm_ffn1", "ffn1: M = 32760, N = 8960, K = 1536, GELU-tanh epilogue", (32760 * 1536 + 8960 * 1536 + 32760 * 8960) * 2),
+                           ("gemm_ffn2", "ffn2: M = 32760, N = 1536, K = 8960, gate + residual epilogue", (32760 * 8960 + 1536 * 8960 + 2 * 32760 * 1536) * 2)):
+        p = os.path.join(ROOT, "gpurun_out", f"{tag}_{key}_pmc.txt")
+        if not os.path.exists(p):
+            continue
         ks = {k: v for k, v in parse(p).items() if "gemm" in k and v.get("SQ_INSTS_MFMA")}
         if ks:
-            name = max(ks, key=lambda k: ks[k]["SQ_INSTS_MFMA"])          # the ffn1 launch itself (M = 32760, N = 8960, K = 1536, GELU epilogue)
+            name = max(ks, key=lambda k: ks[k]["SQ_INSTS_MFMA"])          # the GEMM launch itself
             vals = ks[name]
-            out = {"kernel": name + " (ffn1: M = 32760, N = 8960, K = 1536, GELU-tanh epilogue)", "counters_per_launch": vals, "source_hashes": hashes,
-                   **derive(vals), "algorithmic_bytes": (32760 * 1536 + 8960 * 1536 + 32760 * 8960) * 2, "note": note}
-            json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_gemm_ffn1_pmc.json"), "w"), indent=1)
+            out = {"kernel": f"{name} ({what})", "counters_per_launch": vals, "source_hashes": hashes, **derive(vals), "algorithmic_bytes": alg, "note": note}
+            json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_{key}_pmc.json"), "w"), indent=1)
             print(json.dumps({k: out.get(k) for k in ("kernel", "hbm_bytes", "mfma_busy_in_clock", "l2_hit_rate")}))
     json.dump(hashes, open(os.path.join(ROOT, "gpurun_out", f"{tag}_source_hashes.json"), "w"), indent=1)
 

@@ -26,5 +26,9 @@ rm -rf gpurun_out/pmc_$TAG/pass*/  # raw CSVs are large; the summary is kept
 tools/pmc_collect.sh gemm_ffn1 gpurun_out/pmcg_$TAG > gpurun_out/pmcg_$TAG.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmcg_$TAG gemm > gpurun_out/${TAG}_gemm_ffn1_pmc.txt
 rm -rf gpurun_out/pmcg_$TAG/pass*/
+# 3b. and for ffn2 (M = 32760, N = 1536, K = 8960, gate + residual epilogue) -> gpurun_out/<tag>_gemm_ffn2_pmc.txt
+tools/pmc_collect.sh gemm_ffn2 gpurun_out/pmch_$TAG > gpurun_out/pmch_$TAG.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmch_$TAG gemm > gpurun_out/${TAG}_gemm_ffn2_pmc.txt
+rm -rf gpurun_out/pmch_$TAG/pass*/
 # 4. JSON summaries (per-launch HBM bytes, mfma_busy_in_clock, L2 hit rate) + the hashes of the sources they were collected on
 python tools/pmc_to_json.py $TAG
