@@ -241,8 +241,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 // placement) so that one workgroup's epilogue falls under the other's main loop: bit-identical, but 840-940 TFLOP/s on every
 // shape against 970-1260 here — half-tiles double the barriers and DMA instructions per MFMA and raise the L2 -> LDS traffic by
 // half, which costs more than the hidden epilogue returns.
-// Tile order: 8 XCD bands (bijective), inside a band groups of 8 row panels walk the column panels, so the 32
-// tiles an XCD runs at once are ~8 row panels x 4 column panels: 12 operand panels for 32 tiles in its L2.
+// Tile order: 8 XCD bands (bijective), inside a band groups of GM row panels (4 for narrow N, 5 for N = 8960: measured, tools/gemm_gm.py) walk the
+// column panels, so the 32 tiles an XCD runs at once are a ~5 x 6 block: ~12 operand panels for 32 tiles in its L2.  That geometry bounds the L2 hit
+// rate at 1 - 12/64 = 0.81 (measured 0.75-0.76, profiles/r4z_gemm_ffn*_pmc.json): 0.85 would need reuse ACROSS rounds, and a round's row panels
+// (5 x 786 KB at K = 1536) already fill the 4 MB L2.
 // =================================================================================================
 #define TM 256
 #define TN 256
@@ -512,15 +514,15 @@ typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_t;
 
 // =================================================================================================
 // 256-row tiles, STAGGERED main loop ("256e"): same LDS image, same operand swizzle, same MFMA (32x32x16, weight fragment as A operand), same
-// k order per element and the same epilogue as the v3 kernel above — so the same bits — on another schedule.
+// k order per element and the same epilogue as the round 1-3 kernels it replaces (and as the 128^2 kernel above) — so the same bits — on another schedule.
 //
-// Why: the v3 loop keeps the SIMD's two waves in lockstep (one barrier per K tile; both waves read fragments, issue LDS-DMA and multiply at
-// the same points of their streams) and holds 0.57-0.64 of the matrix pipe in-clock (PMC, profiles/r3n_gemm_ffn1_pmc.txt).  Here, as in the
+// Why: the round-3 ("v3") loop kept the SIMD's two waves in lockstep (one barrier per K tile; both waves read fragments, issued LDS-DMA and multiplied at
+// the same points of their streams) and held 0.57-0.64 of the matrix pipe in-clock (PMC, profiles/r3n_gemm_ffn1_pmc.txt).  Here, as in the
 // schedule cdna_hip_programming.md measures at ~0.75 in-clock on this part ("256^2 8-phase template"), the two wave rows of the workgroup
 // — the waves that share a SIMD — run ONE BARRIER APART: on every SIMD one wave is inside an MFMA cluster (raised priority) while its
 // partner reads the fragments of its next cluster from LDS and issues its share of the LDS-DMA — matrix beside memory on every interval —
 // and the DMA stream is never drained: counted vmcnt, raw s_barrier, half-tiles always in flight.
-// Measured (tools/gemm_ab.py, bit-identical to the v3 kernel, profiles/r4*_gemm_ab.txt): ffn2 1199 -> 1364 TFLOP/s, ffn1 1058 -> 1145,
+// Measured (tools/gemm_ab.py, bit-identical to the v3 kernel, profiles/r4b_gemm_ab.txt): ffn2 1199 -> 1364 TFLOP/s, ffn1 1058 -> 1145,
 // attn-out 866 -> 936, 8192^3 1168 -> 1329.
 //
 // A phase = { L: fragment reads + LDS-DMA issue ; wait for the own reads (+ counted vmcnt) ; barrier ; M: one MFMA cluster ; barrier }.
@@ -534,7 +536,7 @@ typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_t;
 //     phase 1   L: A(m2,m3) of tile t              DMA: W rows 128..255 of tile t+1     M: acc[n1][m0,m1] += W(n1) x A(m0,m1)
 //     phase 2   L: A(m0,m1) of tile t+1            DMA: A rows   0..127 of tile t+2     M: acc[n1][m2,m3] += W(n1) x A(m2,m3)
 //     phase 3   L: -                               DMA: A rows 128..255 of tile t+2     M: acc[n0][m2,m3] += W(n0) x A(m2,m3)
-// Each cluster walks the tile's four k-steps in order, so an accumulator sees k in the v3 kernel's order.  The minimum of fragment reads per
+// Each cluster walks the tile's four k-steps in order, so an accumulator sees k in increasing order, as in every other kernel of this file.  The minimum of fragment reads per
 // K tile (4 (MI + NI)), and every LDS read of tile t is over one phase into it, which is what lets tile t+2 stream into tile t's buffer
 // with only two LDS buffers.  PH == 2 halves the barriers per MFMA and measures within 1 % of PH == 4 (-3 % on K = 1536, +1 % on K = 8960).
 // Safety of the hand-off (cdna_hip_programming.md "read a staged buffer one phase after the wait that retires it"):
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g
     constexpr int MI = TNW == 256 ? 4 : 2, NI = TNW == 256 ? 2 : 3, MH = MI / 2;
     constexpr int WP = TNW / 64;                          // LDS-DMA pieces of a W tile per wave (A: 4, two per half-tile)
 #ifdef SVI_ABLATIONS
-    const int abl = abl_arg;          // timing ablations, variant builds only (tools/gemm_epi_abl.py): 1-4 as in the v3 kernel; 5 = one K tile only; 6 = one K tile, no epilogue
+    const int abl = abl_arg;          // timing ablations, variant builds only (tools/gemm_epi_abl.py): 1-4 see gemm256_epilogue_t; 5 = one K tile only; 6 = one K tile, no epilogue
 #else
     constexpr int abl = 0;
     (void)abl_arg;
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, (int)(((unsigned)(g.M - 1) * (unsigned)g.lda + (unsigned)g.K) * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, (int)(((unsigned)(g.N - 1) * (unsigned)g.ldw + (unsigned)g.K) * 2u), 0x00020000);
     // a wave's DMA instruction covers 8 rows x 128 B; piece p = j * 8 + wave of an operand tile holds its rows j * 64 + wave * 8 + lane / 8.
-    // The bank swizzle sits on the SOURCE chunk (LDS-DMA writes lane-linear), as in the v3 kernel.
+    // The bank swizzle sits on the SOURCE chunk (LDS-DMA writes lane-linear; header of this section).
     const int r8 = wave * 8 + (lane >> 3);
     const int c8 = (lane & 7) ^ ((r8 >> 1) & 7);
     const int a_vo = (r8 * g.lda + c8 * 8) * 2, w_vo = (r8 * g.ldw + c8 * 8) * 2;
