@@ -205,3 +205,29 @@ def test_dit_720p_geometry(hip):
         assert torch.equal(a, sp.forward_local(ms[:2], x, t, ctx))
     finally:
         L.set_switch("SVI_FLASH_SPLIT", None)
+
+
+@pytest.mark.parametrize("grid", [(2, 9, 7), (5, 30, 52), (21, 30, 52)])
+def test_fused_q_k_projection_is_bit_identical(hip, grid):
+    """The self-attention q and k projections as ONE N = 2 dim launch over the two bound weight tensors (tile columns below dim multiply by Wq, the others by
+    Wk; nothing is packed) against two launches (SVI_QK_FUSED=0): per element the same kernel and the same k order, so the same bits — on the 128^2 kernel (126
+    tokens), on the 256-row tiles (7800 tokens) and at the full C2 size; the plain forward, the stacked / paired CFG forward, and a sequence-parallel shard
+    (whose N = 1536 GEMMs run the 256 x 192 tile: 1536 = 8 x 192, the split falls on a tile boundary)."""
+    from svi_hip import _lib as L, sequence_parallel as sp
+    ms = _wan13b_two_blocks(hip, 3)
+    f, h, w = grid
+    x, ctx, t = _rnd(50, 1, 16, f, 2 * h, 2 * w), _rnd(51, 1, 512, 4096), torch.tensor([640.0])
+    a = ms[0].forward(x, t, ctx)
+    pa = ms[0].forward_cfg_pair(x, t, ctx, -ctx)
+    sa = sp.forward_local(ms[1:3], x, t, ctx) if (f * h * w) % 2 == 0 else None
+    L.set_switch("SVI_QK_FUSED", 0)
+    try:
+        b = ms[0].forward(x, t, ctx)
+        pb = ms[0].forward_cfg_pair(x, t, ctx, -ctx)
+        sb = sp.forward_local(ms[1:3], x, t, ctx) if sa is not None else None
+    finally:
+        L.set_switch("SVI_QK_FUSED", None)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1])
+    if sa is not None:
+        assert torch.equal(sa, sb)
