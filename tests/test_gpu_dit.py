@@ -276,6 +276,46 @@ def test_graph_never_replays_against_stale_state(hip):
         m.context_cache(False)
 
 
+def test_first_graphed_step_and_stream_buffer_release(hip):
+    """Round 4: the hipGraph is the single-rank default and the clip's FIRST step is the eager run on the loop's capture stream itself (its result is kept, not a
+    discarded warm-up).  (a) Throw-away loops used for one step each, with other work enqueued right behind them, give the eager step's bits every time (a
+    timestep copy that raced the capture stream made ~40 % of such first steps wrong before the fix); (b) DenoiseLoop.release() / svi_stream_buffers_release
+    free the library's per-stream buffers, move svi_dit_generation, and the loop captures again and still matches."""
+    from svi_hip import _lib as L
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    f, h, w = grid
+    m, _ = build(hip, c, seed)
+    _, ctx, _ = inputs(c, grid, nt, nv, seed)
+    cp, cn = dev(np.asarray(ctx)), dev(-np.asarray(ctx))
+    x = dev(hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=41, device="cpu", dtype=torch.float32))
+    t = torch.tensor([ts], device="cuda")
+    want = x.clone()
+    hip.DenoiseLoop(m, graph=False).step(want, t, -0.04, cp, cn, 5.0)
+    for i in range(12):
+        got = x.clone()
+        hip.DenoiseLoop(m).step(got, t, -0.04, cp, cn, 5.0)          # temporary loop: destroyed while its CFG / Euler kernel may still be queued
+        m.forward(x, torch.tensor([500.0 + i]), cp)                    # more work on the same handle right behind
+        assert torch.equal(got, want), i
+    loop = hip.DenoiseLoop(m)
+    a = x.clone()
+    loop.step(a, t, -0.04, cp, cn, 5.0)
+    loop.step(a, t, -0.04, cp, cn, 5.0)                                # a replay
+    gen0 = m.generation()
+    assert loop._graph is not None and loop._capture_stream is not None
+    # long-sequence attention on the capture stream creates per-stream flag words there; a short model has none: create one explicitly
+    with torch.cuda.stream(loop._capture_stream):
+        q = dev(synth.randn(3, 1, 2304, 128))
+        hip.flash_attention(q, q, q, 1)
+    torch.cuda.synchronize()
+    loop.release()
+    assert loop._graph is None and loop._capture_stream is None and m.generation() != gen0
+    b = x.clone()
+    loop.step(b, t, -0.04, cp, cn, 5.0)
+    loop.step(b, t, -0.04, cp, cn, 5.0)
+    assert torch.equal(a, b)
+    L.release_stream_buffers(None)                                     # every stream of the device: legal at any quiet point
+
+
 @pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
 def test_identical_trailing_context_rows_count_as_one_key(hip, name):
     """The prompter zero-fills a prompt embedding past the prompt's tokens and cross-attention attends to all rows without a mask:
