@@ -189,7 +189,7 @@ def pmc_summaries() -> dict:
                 continue
             tag = os.path.basename(f)[:-len("_source_hashes.json")]
             out = {"tag": tag}
-            for key in ("flash", "gemm_ffn1", "gemm_ffn2"):
+            for key in ("flash", "flash_qk8", "gemm_ffn1", "gemm_ffn2"):
                 p = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc.json")
                 if os.path.exists(p):
                     out[key] = json.load(open(p))
@@ -261,6 +261,9 @@ def main() -> None:
     ap.add_argument("--fp8-mfma", action="store_true", help="opt-in MX-fp8 MLP (north_star 'bf16/fp8 MFMA'): FP8 weight storage + both MLP GEMMs of every block on "
                     "v_mfma_scale_f32_32x32x64_f8f6f4 with per-32-element activation scales.  Arithmetic the reference never performs (it computes in bf16): "
                     "a separately toleranced line (tests/test_gpu_mx8.py), never the headline")
+    ap.add_argument("--fp8-attn", action="store_true", help="opt-in quantised QK^T (SVI_ATTN_QK8=1): every long-sequence self-attention quantises Q and K to MX e4m3 (one E8M0 "
+                    "scale per 32 channels) and takes QK^T on v_mfma_scale_f32_32x32x64_f8f6f4; P·V stays bf16.  Arithmetic the reference never performs (its dispatch only "
+                    "ACCEPTS a quantised-QK^T backend, wan_video_dit.py:116-147): a separately toleranced line (tests/test_gpu_attn_qk8.py), never the headline")
     ap.add_argument("--profile-all", action="store_true", help="bracket every tagged kernel family with HIP events inside the timed region (about 1 %% slower steps) "
                     "instead of the dominant kernel there and the full breakdown in 4 extra steps behind it")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None, help="replay each step's two forwards from one hipGraph (DenoiseLoop(graph=True)). "
@@ -338,6 +341,9 @@ def main() -> None:
     dit.bind(weights)
     if args.fp8_mfma:
         dit.ffn_fp8_mfma(True)
+    if args.fp8_attn:
+        from svi_hip import _lib as _L
+        _L.set_switch("SVI_ATTN_QK8", 1)
     pair, units, sp_group, sp = None, world, None, False
     if args.seq_parallel and dist is not None:
         sp, units = True, 1
@@ -510,6 +516,7 @@ def main() -> None:
     if pair:
         flops_step = per_fwd                 # a rank of a CFG pair runs one branch
     fl = prof_timed.get("flash_self", {"count": 0, "ms": 0.0})          # the dominant kernel: events over the timed region itself
+    fp8_attn_on = args.fp8_attn or os.environ.get("SVI_ATTN_QK8", "0") not in ("", "0")
     roof = None
     if fl["count"]:
         per_launch_ms = fl["ms"] / fl["count"]
@@ -525,6 +532,16 @@ def main() -> None:
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "mfma_busy_in_clock": fp.get("mfma_busy_in_clock"), "l2_hit_rate": fp.get("l2_hit_rate"),
                 "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4), "source": roof_source}
+        if fp8_attn_on:
+            # half of the launch's FLOP (QK^T) runs on the MX fp8 pipe (dense peak 2x bf16), half (P·V) on bf16: the launch's bound is the harmonic mix;
+            # the launch also holds the two quantiser kernels.  PMC: the summary of the fp8 kernel (profiles/<tag>_flash_qk8_pmc.json), never the bf16 kernel's.
+            mixed = PEAK_BF16_TFLOPS / 0.75
+            fq = pmc.get("flash_qk8") or {}
+            roof.update({"kernel": "flash_fwd2_kernel<QK8> + 2 x mx8_quantize_kernel (opt-in SVI_ATTN_QK8: QK^T on v_mfma_scale_f32_32x32x64_f8f6f4, P·V bf16)", "peak": round(mixed, 1),
+                         "frac": round(ach / mixed, 4), "peak_note": "QK^T at the MX fp8 dense peak (2 x bf16), P·V at the bf16 peak: 1 / (0.5 / 5000 + 0.5 / 2500) TFLOP/s",
+                         "frac_of_bf16_peak": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": fq.get("hbm_bytes"),
+                         "traffic_source": pmc.get("flash_qk8_file") or pmc.get("why") or "no PMC summary of the fp8 kernel on this tree",
+                         "mfma_busy_in_clock": fq.get("mfma_busy_in_clock"), "l2_hit_rate": fq.get("l2_hit_rate")})
     # ---- every kernel family of the step against the roofline that bounds it (per rank; ms from HIP events on the launch stream) ----
     PEAK_HBM_TBS = 8.0
     shard = dist.get_world_size(sp_group) if sp else 1
@@ -596,7 +613,8 @@ def main() -> None:
                    "c5": "denoised latent frames/sec, Wan2.1-I2V-14B + pose embedder (dance) 81f@832x480 50-step, FP8 weight storage"}[args.workload],
         "value": round(value, 5), "unit": "latent frames/s", "n_gpus": len(who), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.seq_parallel else "weak", "vs_baseline": None,
-        "dtype": "bf16 (MLP GEMMs: MX fp8 e4m3, opt-in)" if args.fp8_mfma else "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
+        "dtype": ("bf16 (" + ", ".join((["MLP GEMMs"] if args.fp8_mfma else []) + (["self-attention QK^T"] if fp8_attn_on else [])) + ": MX fp8 e4m3, opt-in)")
+                 if (args.fp8_mfma or fp8_attn_on) else "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
         "config": {"workload": wl["desc"], "step": (f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; the pose condition enters the conditional branch only, so the two "
                                                     "forwards share nothing) + CFG + Euler") if wl.get("pose") else
                    f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
@@ -614,7 +632,10 @@ def main() -> None:
                    "transport": None if world == 1 else ("nccl (RCCL), one GPU per rank" if args.transport == "nccl" else
                                                          f"gloo through the host, {len({w.get('pci_bus_id') for w in who})} distinct device(s) under {world} ranks: a probe of "
                                                          "the multi-rank code path, NOT a scaling measurement"),
-                   "hip_graph": bool(args.graph), "weights": ("float8_e4m3fn storage; MLP GEMMs on the MX block-scaled fp8 matrix path (activations e4m3 with one E8M0 scale per 32 elements), everything else "
+                   "hip_graph": bool(args.graph),
+                   "attention": ("self-attention QK^T on the MX block-scaled fp8 matrix path (Q, K quantised per call: e4m3, one E8M0 scale per 32 channels), P·V and the softmax bf16 / fp32 — "
+                                 "NOT the reference's arithmetic, opt-in, separately toleranced (tests/test_gpu_attn_qk8.py)") if fp8_attn_on else "bf16",
+                   "weights": ("float8_e4m3fn storage; MLP GEMMs on the MX block-scaled fp8 matrix path (activations e4m3 with one E8M0 scale per 32 elements), everything else "
                                "bf16 — NOT the reference's arithmetic, opt-in, separately toleranced") if args.fp8_mfma else
                    "float8_e4m3fn storage, cast to bf16 at bind (reference FP8 mode)" if args.fp8_storage else "bf16",
                    "outputs_finite": finite},

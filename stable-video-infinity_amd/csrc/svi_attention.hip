@@ -305,6 +305,12 @@ __device__ __forceinline__ void q_put(bf16x8 v) {              // a[R:R+3] = v
                  "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
                  :: "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
 }
+template <int R>
+__device__ __forceinline__ void q_put_words(u32x4 u) {         // a[R:R+3] = u
+    asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
+                 "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+                 :: "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
+}
 // One QK^T MFMA:  s (+)= K-fragment x Q-fragment(a[R:R+3]); the first of a chain starts from the -M tuple `cneg`
 // (it has to be a VGPR tuple: an MFMA's C and D operands must be in the same half of the register file).
 // `apin` (the LDS address of a later fragment read) is listed in/out only to keep that read behind this MFMA.
@@ -404,6 +410,56 @@ __device__ __forceinline__ void qk_stmt(int& tok, f32x16& s, u32x4 kf, u32x4 kf2
         else asm("v_exp_f32 %[u0], %[x0]\n\t" SVI_EXP1 SVI_QKN SVI_ADDU0 SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[u0], %[t1]\n\t" SVI_DOT SVI_END
                  : SVI_QK_OUT("+v"), [u0] "=&v"(u0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w) : SVI_QK_IN, [x0] "v"(x0), [x1] "v"(x1));
     }
+}
+
+// ---- QK8 (opt-in; SVI_ATTN_QK8): QK^T on v_mfma_scale_f32_32x32x64_f8f6f4 ------------------------------------------------------------
+// Q and K arrive as OCP MX e4m3 (one E8M0 scale per 32 consecutive channels, svi_launch_mx8_quantize), P·V stays bf16.  One statement
+// is 64 matrix-pipe cycles and covers a 64-channel step: s (+)= K8-fragment (8 VGPRs) x Q8-fragment a[R:R+7], block scales in byte 2 SEL
+// of `ksc` / `qsc` (the lane's word already shifted by 8 hi: lane half hi carries blocks hi and 2 + hi — operand layout as measured for
+// the MX GEMM, svi_gemm.hip).  A statement carries up to TWO score pairs of the B work (four exponentials): ten plain VALU issue slots
+// hide behind it.  The two v_exp (or the s_nop) in front of the MFMA are also the wait states a just-written operand register needs.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+#define SVI_Q8M(c) "v_mfma_scale_f32_32x32x64_f8f6f4 %[s], %[kf], a[%c[q0]:%c[q1]], " c ", %[ks], %[qs] op_sel_hi:[%c[sel],%c[sel],0]\n\t"
+#define SVI_Q8_PAIR_A "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\tv_cvt_pk_bf16_f32 %[w0], %[t0], %[t1]\n\t"
+#define SVI_Q8_EXP_B "v_exp_f32 %[t2], %[x2]\n\tv_exp_f32 %[t3], %[x3]\n\t"
+#define SVI_Q8_MEXP_B "v_mul_f32 %[t2], %[x2], %[c]\n\tv_mul_f32 %[t3], %[x3], %[c]\n\tv_exp_f32 %[t2], %[t2]\n\tv_exp_f32 %[t3], %[t3]\n\t"
+#define SVI_Q8_PAIR_B "v_add_f32 %[a0], %[a0], %[t2]\n\tv_add_f32 %[a1], %[a1], %[t3]\n\tv_cvt_pk_bf16_f32 %[w1], %[t2], %[t3]\n\t"
+#define SVI_Q8_OUT(sc) [s] sc(s), [tok] "+v"(tok), [ap] "+v"(apin)
+#define SVI_Q8_IN [kf] "v"(kf), [ks] "v"(ksc), [qs] "v"(qsc), [q0] "n"(R), [q1] "n"(R + 7), [sel] "n"(SEL)
+#define SVI_Q8_B_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a0] "+v"(sum0), [a1] "+v"(sum1), [w0] "=&v"(w0), [w1] "=&v"(w1)
+#define SVI_Q8_B_IN [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3)
+// DMA: 0 none, 1 one 16-byte-per-lane LDS-DMA piece behind the statement.  PAIRS: 0 (bare, s_nop 1 in front) or 2.
+template <int R, int SEL, bool FIRST, int PAIRS, bool DMA, bool MULC>
+__device__ __forceinline__ void qk8_stmt(int& tok, f32x16& s, i32x8 kf, int ksc, int qsc, int& apin, const f32x16& cneg, float x0, float x1, float x2,
+                                         float x3, float c, float& sum0, float& sum1, unsigned& w0, unsigned& w1, const SviDma& d) {
+    const u32x4 rs = d.rs;
+    const int vo = d.vo, so = d.so, m0v = d.m0v;
+    float t0, t1, t2, t3;
+    static_assert(PAIRS == 0 || PAIRS == 2, "a QK8 statement is bare or carries two pairs");
+    static_assert(!(FIRST && DMA), "first statements of a chain issue no LDS-DMA");
+    if constexpr (PAIRS == 0 && !DMA) {
+        if constexpr (FIRST) asm("s_nop 1\n\t" SVI_Q8M("%[cn]") SVI_END : SVI_Q8_OUT("=&v") : SVI_Q8_IN, [cn] "v"(cneg));
+        else asm("s_nop 1\n\t" SVI_Q8M("%[s]") SVI_END : SVI_Q8_OUT("+v") : SVI_Q8_IN);
+    } else if constexpr (PAIRS == 0) {
+        asm volatile(SVI_DMA_M0 "s_nop 1\n\t" SVI_Q8M("%[s]") SVI_DMA SVI_END : SVI_Q8_OUT("+v") : SVI_Q8_IN, SVI_DMA_IN);
+    } else if constexpr (!DMA) {
+        if constexpr (FIRST && MULC) asm(SVI_MEXP0 SVI_MEXP1 SVI_Q8M("%[cn]") SVI_Q8_PAIR_A SVI_Q8_MEXP_B SVI_Q8_PAIR_B SVI_END : SVI_Q8_OUT("=&v"), SVI_Q8_B_OUT : SVI_Q8_IN, [cn] "v"(cneg), SVI_Q8_B_IN, [c] "s"(c));
+        else if constexpr (FIRST) asm(SVI_EXP0 SVI_EXP1 SVI_Q8M("%[cn]") SVI_Q8_PAIR_A SVI_Q8_EXP_B SVI_Q8_PAIR_B SVI_END : SVI_Q8_OUT("=&v"), SVI_Q8_B_OUT : SVI_Q8_IN, [cn] "v"(cneg), SVI_Q8_B_IN);
+        else if constexpr (MULC) asm(SVI_MEXP0 SVI_MEXP1 SVI_Q8M("%[s]") SVI_Q8_PAIR_A SVI_Q8_MEXP_B SVI_Q8_PAIR_B SVI_END : SVI_Q8_OUT("+v"), SVI_Q8_B_OUT : SVI_Q8_IN, SVI_Q8_B_IN, [c] "s"(c));
+        else asm(SVI_EXP0 SVI_EXP1 SVI_Q8M("%[s]") SVI_Q8_PAIR_A SVI_Q8_EXP_B SVI_Q8_PAIR_B SVI_END : SVI_Q8_OUT("+v"), SVI_Q8_B_OUT : SVI_Q8_IN, SVI_Q8_B_IN);
+    } else {
+        if constexpr (MULC) asm volatile(SVI_DMA_M0 SVI_MEXP0 SVI_MEXP1 SVI_Q8M("%[s]") SVI_Q8_PAIR_A SVI_Q8_MEXP_B SVI_Q8_PAIR_B SVI_DMA SVI_END : SVI_Q8_OUT("+v"), SVI_Q8_B_OUT : SVI_Q8_IN, SVI_Q8_B_IN, [c] "s"(c), SVI_DMA_IN);
+        else asm volatile(SVI_DMA_M0 SVI_EXP0 SVI_EXP1 SVI_Q8M("%[s]") SVI_Q8_PAIR_A SVI_Q8_EXP_B SVI_Q8_PAIR_B SVI_DMA SVI_END : SVI_Q8_OUT("+v"), SVI_Q8_B_OUT : SVI_Q8_IN, SVI_Q8_B_IN, SVI_DMA_IN);
+    }
+}
+
+// One score pair of the B work on its own (the complete QK8 kernel only: it runs on flagged workgroups, its schedule is not tuned); chained through tok so
+// that hipcc keeps it where it is written and its temporaries die inside the statement.
+template <bool MULC>
+__device__ __forceinline__ void pair_stmt(int& tok, float x0, float x1, float c, float& sum0, float& sum1, unsigned& w) {
+    float t0, t1;
+    if constexpr (MULC) asm(SVI_MEXP0 SVI_MEXP1 "s_nop 0\n\t" SVI_ADD0 SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]" : [tok] "+v"(tok), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w) : [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c));
+    else asm(SVI_EXP0 SVI_EXP1 "s_nop 0\n\t" SVI_ADD0 SVI_ADD1 "v_cvt_pk_bf16_f32 %[w], %[t0], %[t1]" : [tok] "+v"(tok), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w) : [x0] "v"(x0), [x1] "v"(x1));
 }
 
 #define SVI_PV_OUT [tok] "+v"(tok), [ap] "+v"(apin)
@@ -510,13 +566,20 @@ __device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) 
 //           a flagged one recomputes its 256 rows with the tracked maximum and overwrites the optimistic result.
 //       On benign operands (every DiT forward measured so far) no flag is ever raised and modes 1 + 2 give the bits of mode 0 (the
 //       reference does not move there either); adversarial operands (tests: spikes, ramps, a late giant key) take the second pass.
-template <int TAG, int ABL = 0, bool MULC = false, int MODE = 0>
+// QK8 (opt-in, SVI_ATTN_QK8): Q and K are MX e4m3 bytes (ldq / ldk in bytes) with their block-scale words qscale / kscale ([head][rows] dwords, byte b =
+//       channel block b of that head); QK^T runs on the scaled fp8 MFMA at twice the bf16 rate, everything behind the scores is unchanged.
+template <int TAG, int ABL = 0, bool MULC = false, int MODE = 0, bool QK8 = false>
 __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restrict__ Q, int ldq,
                                                             const bf16* __restrict__ K, int ldk,
                                                             const bf16* __restrict__ VT, int ldvt,
                                                             bf16* __restrict__ O, int ldo, int Lq, int Lk,
                                                             float scale_log2e, int* __restrict__ flags,
-                                                            float* __restrict__ opart, float2* __restrict__ ml, SviFlashSplit sp) {
+                                                            float* __restrict__ opart, float2* __restrict__ ml, SviFlashSplit sp,
+                                                            const unsigned* __restrict__ qscale, const unsigned* __restrict__ kscale, int qs_rows, int ks_rows) {
+    static_assert(!QK8 || ABL == 0, "no ablations of the fp8 QK^T variant");
+    constexpr int EB = QK8 ? 1 : 2;             // bytes per Q / K element
+    // QK8: the Q fragments are half the size (32 registers), so everything the kernel owns sits 32 registers higher and hipcc may park values in a[0:95]
+    constexpr int OREG0 = QK8 ? SVI_OREG0 + 32 : SVI_OREG0, QREG0 = QK8 ? SVI_QREG0 + 32 : SVI_QREG0;
     constexpr bool OPT = MODE == 1;
     // BAL (optimistic kernel only): one score per MFMA statement everywhere.  The optimistic pass never waits for a row maximum, so the
     // exponentials of tile t can start as soon as S(t) is complete: its 32 score pairs per lane are spread as
@@ -550,7 +613,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         if (is_piece) {
             const int tiles = (Lk + KB - 1) / KB, per = (tiles + sp.pieces - 1) / sp.pieces;
             const int k0 = piece * per * KB, k1 = min(Lk, k0 + per * KB);
-            K += (size_t)k0 * ldk;
+            K = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(K) + (size_t)k0 * ldk * EB);
+            if constexpr (QK8) kscale += k0;
             VT += k0;
             vt_skip = k0;
             Lk = k1 - k0;
@@ -572,21 +636,36 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     const int row0 = qblock * QB2 + wave * 64 + l31;
 
     // ---- Q fragments of both row groups -> a[192:255]; O accumulators a[64:191] = 0 ----------------------------
+    int qsc[2] = {0, 0};                         // QK8: this lane's Q block scales, blocks hi (byte 0) and 2 + hi (byte 2) of row group g
     static_for<0, 2>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         const int qr = row0 + 32 * g;
+        if constexpr (QK8) {
+            // 64-channel step st: bytes [64 st + 16 hi, +16) -> a[.. +0..3], bytes [64 st + 32 + 16 hi, +16) -> a[.. +4..7]
+            const unsigned char* qp = reinterpret_cast<const unsigned char*>(Q) + (size_t)min(qr, Lq - 1) * ldq + head * DH + hi * 16;
+            static_for<0, 2>([&](auto sc_) {
+                constexpr int st = decltype(sc_)::value;
+                u32x4 lo = *reinterpret_cast<const u32x4*>(qp + 64 * st), up = *reinterpret_cast<const u32x4*>(qp + 64 * st + 32);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = (qr < Lq) ? lo[e] : 0u; up[e] = (qr < Lq) ? up[e] : 0u; }
+                q_put_words<QREG0 + (g * 2 + st) * 8>(lo);
+                q_put_words<QREG0 + (g * 2 + st) * 8 + 4>(up);
+            });
+            qsc[g] = (int)(qscale[(size_t)head * qs_rows + min(qr, Lq - 1)] >> (8 * hi));
+        } else {
         const bf16* qp = Q + (size_t)min(qr, Lq - 1) * ldq + head * DH + hi * 8;
         static_for<0, 8>([&](auto kc) {
             constexpr int kk = decltype(kc)::value;
             bf16x8 v = ld_bf16x8(qp + kk * 16);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (qr < Lq) ? v[e] : (bf16)0.f;
-            q_put<SVI_QREG0 + (g * 8 + kk) * 4>(v);
+            q_put<QREG0 + (g * 8 + kk) * 4>(v);
         });
+        }
     });
     int tok = 0;
     asm volatile("; reserve the accumulation half" ::: SVI_ALL_AGPRS);
-    static_for<0, 128>([&](auto rc) { o_zero<SVI_OREG0 + decltype(rc)::value>(tok); });
+    static_for<0, 128>([&](auto rc) { o_zero<OREG0 + decltype(rc)::value>(tok); });
     asm volatile("s_nop 4" : "+v"(tok));        // v_accvgpr_write -> MFMA operand wait states
 
     // ---- LDS-DMA: a tile is 16 pieces of 1 KiB; wave w moves pieces w, w+4, w+8, w+12 -----------------------------
@@ -597,29 +676,40 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     const int last = 2 * npairs - 1;             // tiles 0 .. last; a tile index >= ntiles is fully masked
     const int lds0 = (int)(size_t)(lptr_t)smem;  // 0: all LDS of this kernel is the dynamic region (stage XOR below relies on it)
     constexpr int VST0 = 4 * KT_BYTES;
-    u32x4 k_rs, v_rs;
+    u32x4 k_rs, v_rs, ks_rs;                     // ks_rs (QK8): this head's K block-scale words, one dword per key; keys past Lk read 0 (scale 2^-127)
     {
         const unsigned long long kb = (unsigned long long)K, vb = (unsigned long long)VT;
+        if constexpr (QK8) {
+            const unsigned long long sb = (unsigned long long)(kscale + (size_t)head * ks_rows);
+            ks_rs[0] = (unsigned)sb; ks_rs[1] = (unsigned)(sb >> 32) & 0xffffu; ks_rs[2] = (unsigned)Lk * 4u; ks_rs[3] = 0x00020000u;
+        } else ks_rs = u32x4{0u, 0u, 0u, 0u};
         k_rs[0] = (unsigned)kb; k_rs[1] = (unsigned)(kb >> 32) & 0xffffu;
-        k_rs[2] = (unsigned)(((size_t)(Lk - 1) * ldk + (size_t)(head + 1) * DH) * 2); k_rs[3] = 0x00020000u;
+        k_rs[2] = (unsigned)(((size_t)(Lk - 1) * ldk + (size_t)(head + 1) * DH) * EB); k_rs[3] = 0x00020000u;
         v_rs[0] = (unsigned)vb; v_rs[1] = (unsigned)(vb >> 32) & 0xffffu;
         v_rs[2] = (unsigned)(((size_t)((head + 1) * DH - 1) * ldvt + (size_t)ldvt - (size_t)vt_skip) * 2); v_rs[3] = 0x00020000u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             k_rs[i] = __builtin_amdgcn_readfirstlane(k_rs[i]);
             v_rs[i] = __builtin_amdgcn_readfirstlane(v_rs[i]);
+            if constexpr (QK8) ks_rs[i] = __builtin_amdgcn_readfirstlane(ks_rs[i]);
         }
     }
     // byte offset of this lane's source chunk of piece 0 inside tile 0; piece j = wave + 4 j lies 16 j key rows (K) / 32 j
     // channel rows (V^T) further on, and its swizzle is the same (16 j = 0 mod 16, 32 j / 2 = 0 mod 8): a scalar offset.
     int koff0, voff0;
     {
+        if constexpr (QK8) {                                   // fp8 K tile: the V^T tile's image — 8 rows of 128 B per piece, 8 pieces, wave w moves w and w + 4
+            const int kr_ = 8 * wave + (lane >> 3);
+            koff0 = kr_ * ldk + head * DH + (((lane & 7) ^ ((kr_ >> 1) & 7)) << 4);
+        } else {
         const int kr_ = 4 * wave + (lane >> 4);                // K tile: 4 rows of 256 B per piece
         koff0 = (kr_ * ldk + head * DH + (((lane & 15) ^ (kr_ & 15)) << 3)) * 2;
+        }
         const int vr_ = 8 * wave + (lane >> 3);                // V^T tile: 8 rows of 128 B per piece
         voff0 = ((head * DH + vr_) * ldvt + (((lane & 7) ^ ((vr_ >> 1) & 7)) << 3)) * 2;
     }
-    const int kstep = 16 * ldk * 2, vstep = 32 * ldvt * 2;   // piece j -> j + 1
+    const int kstep = QK8 ? 32 * ldk : 16 * ldk * 2, vstep = 32 * ldvt * 2;   // piece j -> j + 1
+    constexpr int KSC_OFF = 8192;                  // QK8: a K stage is 8 KiB of e4m3 rows + the tile's 64 scale words behind them (stage pitch stays 16 KiB)
     const int piece0 = lds0 + wave * 1024;         // LDS address of this wave's piece j of a stage: piece0 + stage + 4096 j
     // scalar byte offset of tile t inside K: t * KB * ldk * 2; inside V^T: t * KB * 2
     // prologue-only staging through the compiler's own builtin (it waits for these with vmcnt(0) at the __syncthreads)
@@ -627,8 +717,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(VT), 0, (int)v_rs[2], 0x00020000);
     auto stage_k = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(smem + (t & 3) * KT_BYTES + (wave + 4 * j) * 1024), 16, koff0, t * KB * ldk * 2 + j * kstep, 0, 0);
+        for (int j = 0; j < (QK8 ? 2 : 4); ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(smem + (t & 3) * KT_BYTES + (wave + 4 * j) * 1024), 16, koff0, t * KB * ldk * EB + j * kstep, 0, 0);
+        if constexpr (QK8) {   // every wave fetches the tile's 64 scale words (the same 256 bytes): uniform LDS-DMA counts per wave
+            const __amdgpu_buffer_rsrc_t ks_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(kscale + (size_t)head * ks_rows), 0, Lk * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ks_rsrc, (lptr_t)(smem + (t & 3) * KT_BYTES + KSC_OFF), 4, lane * 4, t * KB * 4, 0, 0);
+        }
     };
     auto stage_v = [&](int t) {
 #pragma unroll
@@ -655,11 +749,25 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     // pair (inside the odd tile, after its own K reads): odd tiles read base + 16 KiB, even tiles the flipped base + 0.
     int kaddr[8], vaddr[4];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) kaddr[kk] = lds0 + k_off(krow, 2 * kk + hi);
+    for (int kk = 0; kk < 8; ++kk) {
+        // QK8: [2 st + e] = chunk 4 st + 2 e + hi of the lane's key row (the two 16-byte halves of 64-channel step st), [4] = the row's scale word
+        if constexpr (QK8) kaddr[kk] = kk < 4 ? lds0 + v_off(krow, 4 * (kk >> 1) + 2 * (kk & 1) + hi) : lds0 + KSC_OFF + 4 * krow;
+        else kaddr[kk] = lds0 + k_off(krow, 2 * kk + hi);
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) vaddr[c] = lds0 + VST0 + v_off(l31, 2 * c + hi);
     f32x16 sA[2][2], sB[2][2];                   // score tiles: even tiles live in sA, odd tiles in sB
     u32x4 kf[4], vf[4];                          // fragment rings; kf[0..2] / vf[0..2] are filled one phase ahead
+    // QK8: a K fragment is two 16-byte reads; fragment f' = 2 tt + st of a tile lives in kf[2 (f' & 1)] (low half) and kf[2 (f' & 1) + 1]; fragments 0 and 1
+    // are read one phase ahead, fragment f' + 2 behind the second statement of fragment f'.  ksw: the raw scale words of key rows krow and krow + 32
+    // (read one phase ahead); ksc: the same shifted by 8 hi.
+    unsigned ksw[2] = {0u, 0u};
+    int ksc[2] = {0, 0};
+    typedef const __attribute__((address_space(3))) unsigned* lds_u32_t;
+    auto kfrag = [&](int fi) -> i32x8 {
+        const u32x4 lo = kf[2 * fi], up = kf[2 * fi + 1];
+        return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
+    };
     float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float ma[2], mb[2];                          // per-lane running maxima of the tile in phase 2 (two chains per row group)
 
@@ -680,6 +788,51 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         constexpr int vd = VST0 + decltype(vd_c)::value * VT_BYTES;
         const int so_v = t * KB * 2;
         if constexpr (!BAL) ps[0][0] = ps[0][1] = ps[1][0] = ps[1][1] = 0.f;
+        if constexpr (QK8) {
+            // Eight statements k = 2 f' + g (f' = 2 tt + st) of 64 cycles.  BAL: each carries the two pairs 2k, 2k + 1 of the 16 this phase owes (same
+            // order and words as the bf16 schedule); otherwise the statements are bare and the 20 pairs follow them as plain code (the complete kernel
+            // only runs on flagged workgroups).  Statements 2, 3, 6, 7 issue the four pieces of V(t); fragment f' + 2 is read behind statement 2 f' + 1,
+            // the first V^T fragments of phase 2 behind statements 5, 6, 7.
+            ksc[0] = (int)(ksw[0] >> (8 * hi));
+            ksc[1] = (int)(ksw[1] >> (8 * hi));
+            static_for<0, 4>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                constexpr int tt = f >> 1, st = f & 1;
+                static_for<0, 2>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    constexpr int k = 2 * f + g;
+                    constexpr bool dma = st == 1;
+                    constexpr int piece = tt * 2 + g;
+                    int& pin = *((k == 1 || k == 3) ? &kaddr[2 * st] : &vaddr[0]);
+                    const SviDma d = {v_rs, voff0, so_v + piece * vstep, piece0 + vd + 4096 * piece};
+                    unsigned w0 = 0, w1 = 0;
+                    if constexpr (BAL && WITH_B) {
+                        constexpr int grp = k >> 1, wa = 2 * (k & 1);                  // pairs q1 = 2k, 2k + 1: group q1 >> 2, words q1 & 3
+                        constexpr int pg = (grp == 0 || grp == 2) ? 1 : 0, tb = grp == 3 ? 1 : 0, psb = (grp == 1 || grp == 2) ? 1 : 0, r0 = 2 * (4 * psb + wa);
+                        qk8_stmt<QREG0 + (g * 2 + st) * 8, st, st == 0, 2, dma, MULC>(tok, sn[g][tt], kfrag(f & 1), ksc[tt], qsc[g], pin, cneg[g], so[pg][tb][r0], so[pg][tb][r0 + 1],
+                                                                                         so[pg][tb][r0 + 2], so[pg][tb][r0 + 3], scale_log2e, ps[pg][0], ps[pg][1], w0, w1, dma ? d : no_dma);
+                        pw[pg][tb][psb][wa] = w0;
+                        pw[pg][tb][psb][wa + 1] = w1;
+                    } else {
+                        qk8_stmt<QREG0 + (g * 2 + st) * 8, st, st == 0, 0, dma, MULC>(tok, sn[g][tt], kfrag(f & 1), ksc[tt], qsc[g], pin, cneg[g], 0.f, 0.f, 0.f, 0.f, scale_log2e,
+                                                                                         ps[0][0], ps[0][1], w0, w1, dma ? d : no_dma);
+                        if constexpr (WITH_B) {
+                            static_for<(5 * k) / 2, (5 * (k + 1)) / 2>([&](auto pc) {        // pairs 0..19 of tile t-1, two or three behind each statement
+                                constexpr int pi = decltype(pc)::value, pg = pi & 1, tb = pi >> 4, w = (pi >> 1) & 7, r0 = 2 * w;
+                                unsigned wd;
+                                pair_stmt<MULC>(tok, so[pg][tb][r0], so[pg][tb][r0 + 1], scale_log2e, ps[pg][0], ps[pg][1], wd);
+                                pw[pg][tb][w >> 2][w & 3] = wd;
+                            });
+                        }
+                    }
+                    if constexpr (g == 1 && f + 2 < 4) {
+                        kf[2 * (f & 1)] = *(lds_u32x4_t)(kaddr[2 * st] + ks + ((f + 2) >> 1) * 32 * 128);
+                        kf[2 * (f & 1) + 1] = *(lds_u32x4_t)(kaddr[2 * st + 1] + ks + ((f + 2) >> 1) * 32 * 128);
+                    }
+                    if constexpr (k >= 5) vf[k - 5] = *(lds_u32x4_t)(vaddr[0] + vs + (k - 5) * 32 * 128);
+                });
+            });
+        } else
         static_for<0, 16>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int tt = f >> 3, kk = f & 7, f3 = (f + 3) & 15;
@@ -696,7 +849,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     constexpr int q1 = k >> 1, grp = q1 >> 2, w4 = q1 & 3;
                     constexpr int pg = (grp == 0 || grp == 2) ? 1 : 0, tb = grp == 3 ? 1 : 0, psb = (grp == 1 || grp == 2) ? 1 : 0, r0 = 2 * (4 * psb + w4);
                     constexpr int fill = !WITH_B ? SVI_F_NONE : (k & 1) ? SVI_F_EB : SVI_F_EA;
-                    qk_stmt<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin, cneg[g], so[pg][tb][r0],
+                    qk_stmt<QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin, cneg[g], so[pg][tb][r0],
                                                                                     so[pg][tb][r0 + 1], scale_log2e, tcar, ps[pg][0], ps[pg][1], wd,
                                                                                     dma ? d : no_dma);
                     if constexpr (fill == SVI_F_EB) pw[pg][tb][psb][w4] = wd;
@@ -707,7 +860,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     constexpr int pg = pi & 1, tb = pi >> 4, w = (pi >> 1) & 7, r0 = 2 * w;
                     constexpr int fill = !WITH_B ? SVI_F_NONE : whole ? SVI_F_E2 : (si & 1) ? SVI_F_EB : SVI_F_EA;
                     // even fragments wait for themselves and their successor at once (none to wait for behind fragment 15)
-                    qk_stmt<SVI_QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin, cneg[g], so[pg][tb][r0],
+                    qk_stmt<QREG0 + (g * 8 + kk) * 4, kk == 0, fill, dma, MULC>(tok, sn[g][tt], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin, cneg[g], so[pg][tb][r0],
                                                                                     so[pg][tb][r0 + 1], scale_log2e, tcar, ps[pg][0], ps[pg][1], wd,
                                                                                     dma ? d : no_dma);
                     if constexpr (fill == SVI_F_E2 || fill == SVI_F_EB) pw[pg][tb][w >> 2][w & 3] = wd;
@@ -731,11 +884,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         constexpr bool WITH_B = WITH_PV && !(ABL & 1);
         constexpr bool WITH_NEXT = decltype(with_next)::value;
         constexpr int vs = decltype(vs_c)::value * VT_BYTES, kn = decltype(kn_c)::value * KT_BYTES;
-        const int kd = ((t + 3) & 3) * KT_BYTES, so_k = (t + 3) * KB * ldk * 2;
+        const int kd = ((t + 3) & 3) * KT_BYTES, so_k = (t + 3) * KB * ldk * EB;
         // MFMA result (the last QK^T MFMAs) -> VALU read, and VALU-written P -> MFMA operand: wait states by hand.  In the balanced optimistic
         // schedule nothing reads the new scores before statement 24 of this phase and the last P word written in phase 1 is first read by
         // statement 16, so an unmasked tile needs no wait here (SVI_FLASH_SHORT_NOP=0 keeps the 16 states)
         if constexpr (BAL && !MASKED && (SVI_FLASH_SHORT_NOP != 0)) asm("s_nop 0" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
+        else if constexpr (QK8) asm("s_nop 15\n\ts_nop 7" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));      // a 16-pass MFMA's result
         else asm("s_nop 15" : "+v"(tok), "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1]));
         if (MASKED) {
             const int key_base = t * KB;
@@ -758,8 +912,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 constexpr int ga = j >> 4, ia = j & 15, ta = ia >> 3, ra = 2 * (ia & 7);     // A: scores ra, ra+1 of sn[ga][ta]
                 float& mch = (ia & 1) ? mb[ga] : ma[ga];
                 if constexpr (WITH_PV) {
-                    int& pin = *((f + 3 < 16) ? &vaddr[f3 >> 2] : &kaddr[nf]);
-                    constexpr bool dma = (j >= 24) && !(j & 1) && !(ABL & 8);
+                    int& pin = *((f + 3 < 16) ? &vaddr[f3 >> 2] : &kaddr[QK8 ? 2 * nf : nf]);
+                    constexpr bool dma = (j >= 24) && !(j & 1) && !(ABL & 8) && !(QK8 && j >= 28);       // QK8: a K tile is two pieces per wave
                     const SviDma d = {k_rs, koff0, so_k + ((j >> 1) & 3) * kstep, piece0 + kd + 4096 * ((j >> 1) & 3)};
                     unsigned wd = 0;
                     if constexpr (BAL) {
@@ -770,7 +924,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                         // (psb: the PAIR's half of its key block — not the fragment's `sb` of the enclosing scope, which names this statement's P operand)
                         constexpr int pg = own ? 0 : (grp == 1 ? 0 : 1), tb = own ? 0 : 1, psb = own ? 0 : (grp == 0 ? 0 : 1), r0 = 2 * (4 * psb + w4);
                         constexpr int fill = !WITH_B ? SVI_F_NONE : (j & 1) ? SVI_F_EB : SVI_F_EA;
-                        pv_stmt<SVI_OREG0 + (g * 4 + d4) * 16, false, fill, dma, MULC>(
+                        pv_stmt<OREG0 + (g * 4 + d4) * 16, false, fill, dma, MULC>(
                             tok, vf[f & 3], vf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pw[g][tt][sb], pin, mch, 0.f, 0.f,
                             own ? sn[pg][tb][r0] : so[pg][tb][r0], own ? sn[pg][tb][r0 + 1] : so[pg][tb][r0 + 1],
                             scale_log2e, tcar, ps[pg][0], ps[pg][1], wd, dma ? d : no_dma);
@@ -781,7 +935,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     constexpr int fill = (!WITH_B || j >= 24) ? SVI_F_NONE : (j & 1) ? SVI_F_EB : SVI_F_EA;
                     constexpr bool amax = !((ABL & 2) || (ABL & 32) || (ABL & 1024) || OPT);
                     constexpr bool rest = amax || (ABL & 1024) || OPT;   // optimistic mode / ABL 1024: only the row-maximum pieces are left out
-                    pv_stmt<SVI_OREG0 + (g * 4 + d4) * 16, amax, rest ? fill : SVI_F_NONE, rest && dma, MULC>(
+                    pv_stmt<OREG0 + (g * 4 + d4) * 16, amax, rest ? fill : SVI_F_NONE, rest && dma, MULC>(
                         tok, vf[f & 3], vf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pw[g][tt][sb], pin, mch, sn[ga][ta][ra], sn[ga][ta][ra + 1], so[pg][1][r0], so[pg][1][r0 + 1],
                         scale_log2e, tcar, ps[pg][0], ps[pg][1], wd, dma ? d : no_dma);
                     if constexpr (rest && fill == SVI_F_EB) pw[pg][1][w >> 2][w & 3] = wd;
@@ -789,7 +943,19 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     constexpr int rg2 = (SPLIT && f >= 12 && !(ABL & 8)) ? 1 : 0;               // statements 24, 26, 28, 30 carry the K pieces
                     if constexpr (g == rg2 && f + 3 < 16 && !(ABL & 4))
                         vf[(f + 3) & 3] = *(lds_u32x4_t)(vaddr[f3 >> 2] + vs + (f3 & 3) * 32 * 128);
-                    if constexpr (g == rg2 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
+                    if constexpr (g == rg2 && f + 3 >= 16 && WITH_NEXT) {
+                        if constexpr (!QK8) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
+                        else if constexpr (nf < 2) {         // fragments 0 and 1 of tile t+1 (key block 0, both 64-channel steps)
+                            kf[2 * nf] = *(lds_u32x4_t)(kaddr[2 * nf] + kn);
+                            kf[2 * nf + 1] = *(lds_u32x4_t)(kaddr[2 * nf + 1] + kn);
+                        } else {                             // ... and its scale words
+                            ksw[0] = *(lds_u32_t)(kaddr[4] + kn);
+                            ksw[1] = *(lds_u32_t)(kaddr[4] + kn + 128);
+                        }
+                    }
+                    if constexpr (QK8 && j == 28)            // the scale words of K(t+3): one dword per lane, behind the tile's two K pieces
+                        asm volatile("s_mov_b32 m0, %[m0v]\n\ts_nop 0\n\tbuffer_load_dword %[vo], %[rs], %[so] offen lds"
+                                     : "+v"(tok) : [m0v] "s"(lds0 + kd + KSC_OFF), [vo] "v"(lane * 4), [rs] "s"(ks_rs), [so] "s"((t + 3) * KB * 4));
                     if constexpr (WITH_B && j == 23 && !BAL) {       // all 32 pairs of tile t-1 are done: fold the row sums
                         l_run[0] = l_run[0] * alpha[0] + (ps[0][0] + ps[0][1]);
                         l_run[1] = l_run[1] * alpha[1] + (ps[1][0] + ps[1][1]);
@@ -797,7 +963,16 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                     }
                 } else {
                     mch = vmax3(mch, sn[ga][ta][ra], sn[ga][ta][ra + 1]);
-                    if constexpr (g == 0 && f + 3 >= 16 && WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
+                    if constexpr (g == 0 && f + 3 >= 16 && WITH_NEXT) {
+                        if constexpr (!QK8) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
+                        else if constexpr (nf < 2) {
+                            kf[2 * nf] = *(lds_u32x4_t)(kaddr[2 * nf] + kn);
+                            kf[2 * nf + 1] = *(lds_u32x4_t)(kaddr[2 * nf + 1] + kn);
+                        } else {
+                            ksw[0] = *(lds_u32_t)(kaddr[4] + kn);
+                            ksw[1] = *(lds_u32_t)(kaddr[4] + kn + 128);
+                        }
+                    }
                 }
             });
         });
@@ -839,7 +1014,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         commit(sn, delta);
         static_for<0, 2>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            static_for<0, 16>([&](auto rc) { o_scale4<SVI_OREG0 + g * 64 + 4 * decltype(rc)::value>(tok, alpha[g]); });
+            static_for<0, 16>([&](auto rc) { o_scale4<OREG0 + g * 64 + 4 * decltype(rc)::value>(tok, alpha[g]); });
         });
         asm("s_nop 4" : "+v"(tok));             // v_accvgpr_write -> MFMA SrcC wait states
     };
@@ -854,7 +1029,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         for (int kk = 0; kk < 8; ++kk) kaddr[kk] ^= 2 * KT_BYTES;      // this tile's K reads are done: move to the other half
         phase2(sB, sA, I0{}, I0{}, t, masked_tag, std::true_type{}, with_next);
         const bool need = outgrown();
-        if constexpr (!(ABL & 256)) tile_barrier<4>(tok);
+        if constexpr (!(ABL & 256)) tile_barrier<QK8 ? 3 : 4>(tok);
         if constexpr ((ABL & 256) && !(ABL & 512)) asm volatile("s_waitcnt vmcnt(4)" : "+v"(tok) :: "memory");
         return need;
     };
@@ -862,7 +1037,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
         phase1(sA, sB, I0{}, I1{}, I0{}, t, std::true_type{});
         phase2(sA, sB, I1{}, I1{}, t, masked_tag, std::true_type{}, with_next);
         const bool need = outgrown();
-        if constexpr (!(ABL & 256)) tile_barrier<4>(tok);
+        if constexpr (!(ABL & 256)) tile_barrier<QK8 ? 3 : 4>(tok);
         if constexpr ((ABL & 256) && !(ABL & 512)) asm volatile("s_waitcnt vmcnt(4)" : "+v"(tok) :: "memory");
         return need;
     };
@@ -873,13 +1048,35 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     kf[0] = *(lds_u32x4_t)(kaddr[0]);
     kf[1] = *(lds_u32x4_t)(kaddr[1]);
     kf[2] = *(lds_u32x4_t)(kaddr[2]);
+    if constexpr (QK8) {
+        kf[3] = *(lds_u32x4_t)(kaddr[3]);
+        ksw[0] = *(lds_u32_t)(kaddr[4]);
+        ksw[1] = *(lds_u32_t)(kaddr[4] + 128);
+    }
     {   // S(0) -> sA from K stage 0: plain statements, no DMA, no B; then the fragments of tile 1 (K stage 1)
+        if constexpr (QK8) {
+            ksc[0] = (int)(ksw[0] >> (8 * hi));
+            ksc[1] = (int)(ksw[1] >> (8 * hi));
+            unsigned w0 = 0, w1 = 0;
+            static_for<0, 4>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                constexpr int tt = f >> 1, st = f & 1;
+                qk8_stmt<QREG0 + (0 * 2 + st) * 8, st, st == 0, 0, false, MULC>(tok, sA[0][tt], kfrag(f & 1), ksc[tt], qsc[0], kaddr[2 * st], cneg[0], 0.f, 0.f, 0.f, 0.f, scale_log2e,
+                                                                                  ps[0][0], ps[0][1], w0, w1, no_dma);
+                qk8_stmt<QREG0 + (1 * 2 + st) * 8, st, st == 0, 0, false, MULC>(tok, sA[1][tt], kfrag(f & 1), ksc[tt], qsc[1], kaddr[2 * st], cneg[1], 0.f, 0.f, 0.f, 0.f, scale_log2e,
+                                                                                  ps[0][0], ps[0][1], w0, w1, no_dma);
+                if constexpr (f + 2 < 4) {
+                    kf[2 * (f & 1)] = *(lds_u32x4_t)(kaddr[2 * st] + ((f + 2) >> 1) * 32 * 128);
+                    kf[2 * (f & 1) + 1] = *(lds_u32x4_t)(kaddr[2 * st + 1] + ((f + 2) >> 1) * 32 * 128);
+                }
+            });
+        } else
         static_for<0, 16>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int tt = f >> 3, kk = f & 7, f3 = (f + 3) & 15;
-            qk_mfma<SVI_QREG0 + kk * 4, kk == 0>(tok, sA[0][tt], kf[f & 3], kaddr[f3 & 7], cneg[0]);
+            qk_mfma<QREG0 + kk * 4, kk == 0>(tok, sA[0][tt], kf[f & 3], kaddr[f3 & 7], cneg[0]);
             if constexpr (f + 3 < 16) kf[(f + 3) & 3] = *(lds_u32x4_t)(kaddr[f3 & 7] + ((f + 3) >> 3) * 32 * 256);
-            qk_mfma<SVI_QREG0 + (8 + kk) * 4, kk == 0>(tok, sA[1][tt], kf[f & 3], kaddr[f3 & 7], cneg[1]);
+            qk_mfma<QREG0 + (8 + kk) * 4, kk == 0>(tok, sA[1][tt], kf[f & 3], kaddr[f3 & 7], cneg[1]);
         });
         phase2(sA, sB, I0{}, I1{}, 0, std::true_type{}, std::false_type{}, std::true_type{});
         const float d0[2] = {row_max(0), row_max(1)};                  // first reference = the row maxima of tile 0 (any sign)
@@ -946,8 +1143,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             constexpr int f = decltype(fc)::value;
             constexpr int tt = f >> 3, sb = (f >> 2) & 1, d = f & 3;
             const u32x4 vfr = *(lds_u32x4_t)(vaddr[f >> 2] + VT_BYTES + d * 32 * 128);   // V(last) sits in stage last & 1 == 1
-            pv_mfma<SVI_OREG0 + (0 * 4 + d) * 16>(tok, vfr, pw[0][tt][sb], vaddr[0]);
-            pv_mfma<SVI_OREG0 + (1 * 4 + d) * 16>(tok, vfr, pw[1][tt][sb], vaddr[0]);
+            pv_mfma<OREG0 + (0 * 4 + d) * 16>(tok, vfr, pw[0][tt][sb], vaddr[0]);
+            pv_mfma<OREG0 + (1 * 4 + d) * 16>(tok, vfr, pw[1][tt][sb], vaddr[0]);
         });
     }
 
@@ -973,10 +1170,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 static_for<0, 4>([&](auto qc) {
                     constexpr int rg = decltype(qc)::value;
                     f32x4 v;
-                    v[0] = o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 0>(tok);
-                    v[1] = o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 1>(tok);
-                    v[2] = o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 2>(tok);
-                    v[3] = o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 3>(tok);
+                    v[0] = o_get<OREG0 + (g * 4 + d) * 16 + rg * 4 + 0>(tok);
+                    v[1] = o_get<OREG0 + (g * 4 + d) * 16 + rg * 4 + 1>(tok);
+                    v[2] = o_get<OREG0 + (g * 4 + d) * 16 + rg * 4 + 2>(tok);
+                    v[3] = o_get<OREG0 + (g * 4 + d) * 16 + rg * 4 + 3>(tok);
                     if (qr < Lq) *reinterpret_cast<f32x4*>(op + 32 * d + 8 * rg) = v;
                 });
             });
@@ -994,10 +1191,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             static_for<0, 4>([&](auto qc) {
                 constexpr int rg = decltype(qc)::value;
                 bf16x4 pk;
-                pk[0] = (bf16)(o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 0>(tok) * inv);
-                pk[1] = (bf16)(o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 1>(tok) * inv);
-                pk[2] = (bf16)(o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 2>(tok) * inv);
-                pk[3] = (bf16)(o_get<SVI_OREG0 + (g * 4 + d) * 16 + rg * 4 + 3>(tok) * inv);
+                pk[0] = (bf16)(o_get<OREG0 + (g * 4 + d) * 16 + rg * 4 + 0>(tok) * inv);
+                pk[1] = (bf16)(o_get<OREG0 + (g * 4 + d) * 16 + rg * 4 + 1>(tok) * inv);
+                pk[2] = (bf16)(o_get<OREG0 + (g * 4 + d) * 16 + rg * 4 + 2>(tok) * inv);
+                pk[3] = (bf16)(o_get<OREG0 + (g * 4 + d) * 16 + rg * 4 + 3>(tok) * inv);
                 if (qr < Lq) *reinterpret_cast<bf16x4*>(op + 32 * d + 8 * rg) = pk;
             });
         });
@@ -1121,9 +1318,36 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     int kernel = 0;
     const SviFlashSplit sp = svi_flash_plan(Lq, Lk, num_heads, ncu, &kernel);          // the one place that decides kernel and split (svi_attention_plan shows it)
     if (kernel == 2) {
-        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*, float*, float2*, SviFlashSplit);
+        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*, float*, float2*, SviFlashSplit, const unsigned*,
+                               const unsigned*, int, int);
         const int lds2 = 4 * KT_BYTES + 2 * VT_BYTES;          // four K stages, two V^T stages
         dim3 grid2((Lq + QB2 - 1) / QB2, num_heads), block2(256);
+        // SVI_ATTN_QK8 (opt-in, never the default): Q and K are quantised to MX e4m3 here (per 32-channel block, the MLP's quantiser) into a per-stream
+        // buffer and QK^T runs on the scaled fp8 MFMA; P·V, the softmax and every launch decision are those of the bf16 kernel.
+        const bool qk8 = sw.attn_qk8 != 0;
+        const unsigned* qsc = nullptr;
+        const unsigned* ksc = nullptr;
+        int qs_rows = 0, ks_rows = 0;
+        if (qk8) {
+            const int dim = num_heads * DH;
+            qs_rows = (Lq + 3) & ~3;
+            ks_rows = (Lk + 3) & ~3;
+            const size_t q_bytes = ((size_t)Lq * dim + 255) & ~(size_t)255, k_bytes = ((size_t)Lk * dim + 255) & ~(size_t)255;
+            const size_t qs_bytes = (size_t)num_heads * qs_rows * 4, ks_bytes = (size_t)num_heads * ks_rows * 4;
+            void* buf = nullptr;
+            SVI_TRY(svi_stream_buffer(SVI_BUF_FLASH_QK8, st, q_bytes + k_bytes + qs_bytes + ks_bytes, &buf, nullptr));
+            unsigned char* q8 = reinterpret_cast<unsigned char*>(buf);
+            unsigned char* k8 = q8 + q_bytes;
+            unsigned* qs = reinterpret_cast<unsigned*>(k8 + k_bytes);
+            unsigned* ks = qs + (size_t)num_heads * qs_rows;
+            SVI_TRY(svi_launch_mx8_quantize(Q, ldq, Lq, dim, q8, dim, qs, qs_rows, st));
+            SVI_TRY(svi_launch_mx8_quantize(K, ldk, Lk, dim, k8, dim, ks, ks_rows, st));
+            Q = reinterpret_cast<const bf16*>(q8);
+            K = reinterpret_cast<const bf16*>(k8);
+            ldq = ldk = dim;
+            qsc = qs;
+            ksc = ks;
+        }
         const int n_items = (int)grid2.x * num_heads, n_cut = n_items - sp.whole;
         float* opart = nullptr;
         float2* ml = nullptr;
@@ -1144,7 +1368,10 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
 #endif
         if (two_pass) SVI_TRY(flash_flags(st, nwg, &flags));
         kern_t kern;
-        if (two_pass)
+        if (qk8)
+            kern = two_pass ? (q_prescaled ? flash_fwd2_kernel<0, 0, false, 1, true> : flash_fwd2_kernel<0, 0, true, 1, true>)
+                            : (q_prescaled ? flash_fwd2_kernel<0, 0, false, 0, true> : flash_fwd2_kernel<0, 0, true, 0, true>);
+        else if (two_pass)
             kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false, 1> : flash_fwd2_kernel<1, 0, false, 1>)
                                : (Lq == Lk ? flash_fwd2_kernel<0, 0, true, 1> : flash_fwd2_kernel<1, 0, true, 1>);
         else
@@ -1176,13 +1403,14 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         }
 #endif
         SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(kern), lds2));
-        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml, sp);
+        hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml, sp, qsc, ksc, qs_rows, ks_rows);
         SVI_LAUNCH_CHECK();
         if (two_pass) {
             kern_t safe = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false, 2> : flash_fwd2_kernel<1, 0, false, 2>)
                                       : (Lq == Lk ? flash_fwd2_kernel<0, 0, true, 2> : flash_fwd2_kernel<1, 0, true, 2>);
+            if (qk8) safe = q_prescaled ? flash_fwd2_kernel<0, 0, false, 2, true> : flash_fwd2_kernel<0, 0, true, 2, true>;
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(safe), lds2));
-            hipLaunchKernelGGL(safe, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml, sp);
+            hipLaunchKernelGGL(safe, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml, sp, qsc, ksc, qs_rows, ks_rows);
             SVI_LAUNCH_CHECK();
         }
         if (sp.pieces > 1) {

@@ -80,6 +80,9 @@ struct SviSwitches {
                                  // matrices (bit-identical: per element the same kernel and the same k order)
     int mx8_fused = 1;           // SVI_MX8_FUSED = 0 : (opt-in MX-fp8 MLP) ffn1 stores its bf16 result and a separate launch quantises it, instead of quantising in
                                  // ffn1's epilogue (bit-identical; saves one write and one read of the [L, ffn_dim] activation)
+    int attn_qk8 = 0;            // SVI_ATTN_QK8 = 1 : (opt-in, never the default) the long-sequence attention quantises Q and K to MX e4m3 (one E8M0 scale per 32
+                                 // channels) and takes QK^T on the scaled fp8 MFMA at twice the bf16 rate; P·V stays bf16.  Arithmetic the reference never
+                                 // performs (its dispatch accepts a quantised-QK^T backend, wan_video_dit.py:116-147): own oracle, own tolerance, own bench line
     int cross_dedup = 1;         // SVI_CROSS_DEDUP = 0 : cross-attention walks every context row even where the prompt embedding's trailing rows are
                                  // identical (the prompter's zero padding); default: m identical keys = one key counted m times (same softmax)
     int t5_host_buckets = 0;     // SVI_T5_BUCKETS = host : the text encoder's relative-position bucket table in the HOST's fp32 arithmetic (what the
@@ -94,7 +97,7 @@ const SviSwitches& svi_switches();
 svi_status svi_ensure_lds(const void* kernel, int bytes);
 // Library-owned device buffers outside any handle, one per (device, stream, kind); see svi_api.hip.  `user_out`: a host-side word
 // that lives with the buffer (only the thread driving that stream touches it).
-enum SviBufKind { SVI_BUF_FLASH_FLAGS = 0, SVI_BUF_SEAM_SCRATCH = 1, SVI_BUF_SEAM_SMALL = 2, SVI_BUF_FLASH_SPLIT = 3 };
+enum SviBufKind { SVI_BUF_FLASH_FLAGS = 0, SVI_BUF_SEAM_SCRATCH = 1, SVI_BUF_SEAM_SMALL = 2, SVI_BUF_FLASH_SPLIT = 3, SVI_BUF_FLASH_QK8 = 4 };
 svi_status svi_stream_buffer(int kind, hipStream_t st, size_t bytes, void** out, long** user_out);
 // The device current on this thread, or -1 (message set).
 int svi_current_device();

@@ -2,7 +2,8 @@
 
     python tools/audit_flash2.py
 Compiles svi_attention.hip with -save-temps into a scratch dir and checks, for every flash_fwd2_kernel instantiation:
-  * hipcc-generated v_accvgpr_read/write (printed `aN`, our inline asm prints `a[N]`) only touch a0..a63;
+  * hipcc-generated v_accvgpr_read/write (printed `aN`, our inline asm prints `a[N]`) only touch a0..a63 (a0..a95 in the QK8
+    instantiations, whose owned registers start 32 higher);
   * no scratch (private segment) access between the loop header and the loop's last back-edge;
   * reports VGPR/AGPR/scratch/spill figures and the per-tile instruction mix of the steady loop.
 Exit status 1 on a violation.
@@ -63,8 +64,9 @@ while i < len(asm):
     if mix:
         top = sorted(mix.items(), key=lambda kv: -kv[1])[:14]
         print("   loop mix (2 tiles): " + ", ".join(f"{k} {v}" for k, v in top))
-    if idx and max(idx) >= 64:
-        print("   VIOLATION: hipcc uses an AGPR >= a64 (owned by the kernel)")
+    own0 = 96 if re.search(r"Lb1EEv", name) else 64          # last template argument: QK8
+    if idx and max(idx) >= own0:
+        print(f"   VIOLATION: hipcc uses an AGPR >= a{own0} (owned by the kernel)")
         bad = 1
     if loop_scratch:
         print("   VIOLATION: scratch access inside the tile loop")

@@ -1,0 +1,33 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root):  tools/final_lines.sh <tag>
+# The round's closing artefacts on the frozen tree, beside tools/profile_round.sh <tag>: the full -m gpu suite, smoke(), and the bench lines
+# (driver-shaped default, eager, C1, C4, and the opt-in fp8 lines) -> gpurun_out/<tag>_*; copy them to profiles/ afterwards.
+set -u
+TAG=${1:-r1}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+rm -f gpurun_out/parity_report.jsonl
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gputests.log 2>&1
+tail -3 gpurun_out/${TAG}_gputests.log
+cp gpurun_out/parity_report.jsonl gpurun_out/${TAG}_parity_report.jsonl 2>/dev/null
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" > gpurun_out/${TAG}_smoke.log 2>&1
+tail -1 gpurun_out/${TAG}_smoke.log
+line() { # name, args...
+  local name=$1; shift
+  timeout 900 python bench.py "$@" 2> gpurun_out/${TAG}_bench_${name}.err | grep '"metric"' | tail -1 > gpurun_out/${TAG}_bench_${name}.json
+  python - "$name" gpurun_out/${TAG}_bench_${name}.json <<'PY'
+import json, sys
+try:
+    j = json.load(open(sys.argv[2]))
+    print(sys.argv[1], j["ms_per_step"], j["value"], (j.get("roofline") or {}).get("frac"), (j.get("roofline") or {}).get("traffic"))
+except Exception as ex:
+    print(sys.argv[1], "FAILED", ex)
+PY
+}
+line default --gpus 1 --steps 20 --warmup 5
+line no_graph --steps 10 --warmup 3 --no-graph --no-cpu-baseline
+line fp8_attn --steps 10 --warmup 3 --fp8-attn --no-cpu-baseline
+line fp8_mfma --steps 10 --warmup 3 --fp8-mfma --no-cpu-baseline
+line fp8_mfma_attn --steps 10 --warmup 3 --fp8-mfma --fp8-attn --no-cpu-baseline
+line c1 --workload c1 --steps 10 --warmup 3 --no-cpu-baseline
+line c4 --workload c4 --steps 3 --warmup 1 --no-cpu-baseline

@@ -1,4 +1,4 @@
-"""Aggregate rocprofv3 --pmc CSV passes per kernel: python tools/pmc_summary.py <dir> [kernel-substring]"""
+"""Aggregate rocprofv3 --pmc CSV passes per kernel: python tools/pmc_summary.py <dir> [kernel-substring[|kernel-substring...]]"""
 import csv
 import glob
 import sys
@@ -11,7 +11,7 @@ cnt = defaultdict(lambda: defaultdict(int))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if sub and sub not in k:
+        if sub and not any(x in k for x in sub.split("|")):
             continue
         k = k.replace("(anonymous namespace)::", "").split("(")[0][:60]
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"])

@@ -67,6 +67,20 @@ def main(tag):
                "counters_per_launch": vals, "attention_src_sha": hashes["svi_attention.hip"], "source_hashes": hashes, **derive(vals), "note": note}
         json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_flash_pmc.json"), "w"), indent=1)
         print(json.dumps({k: out.get(k) for k in ("hbm_bytes", "mfma_busy_in_clock", "l2_hit_rate")}))
+    # the opt-in fp8 QK^T attention (SVI_ATTN_QK8=1): the same probe; the two quantiser launches are listed beside the attention kernels
+    p = os.path.join(ROOT, "gpurun_out", f"{tag}_flash_qk8_pmc.txt")
+    if os.path.exists(p):
+        allk = parse(p)
+        ks = {k: v for k, v in allk.items() if "flash_fwd2_kernel" in k}
+        vals = {}
+        for v in ks.values():
+            for c, x in v.items():
+                vals[c] = vals.get(c, 0.0) + x
+        qz = {k: v for k, v in allk.items() if "mx8_quantize" in k}
+        out = {"kernel": "flash_fwd2_kernel<QK8> (opt-in SVI_ATTN_QK8: QK^T on v_mfma_scale_f32_32x32x64_f8f6f4, P·V bf16; L=32760, 12 heads; both passes)",
+               "kernels_summed": sorted(ks), "counters_per_launch": vals, "quantiser_counters_per_dispatch": qz, "source_hashes": hashes, **derive(vals), "note": note}
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_flash_qk8_pmc.json"), "w"), indent=1)
+        print(json.dumps({k: out.get(k) for k in ("kernel", "hbm_bytes", "mfma_busy_in_clock", "l2_hit_rate")}))
     for key, what, alg in (("gemm_ffn1", "ffn1: M = 32760, N = 8960, K = 1536, GELU-tanh epilogue", (32760 * 1536 + 8960 * 1536 + 32760 * 8960) * 2),
                            ("gemm_ffn2", "ffn2: M = 32760, N = 1536, K = 8960, gate + residual epilogue", (32760 * 8960 + 1536 * 8960 + 2 * 32760 * 1536) * 2)):
         p = os.path.join(ROOT, "gpurun_out", f"{tag}_{key}_pmc.txt")

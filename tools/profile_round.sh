@@ -30,5 +30,9 @@ rm -rf gpurun_out/pmcg_$TAG/pass*/
 tools/pmc_collect.sh gemm_ffn2 gpurun_out/pmch_$TAG > gpurun_out/pmch_$TAG.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmch_$TAG gemm > gpurun_out/${TAG}_gemm_ffn2_pmc.txt
 rm -rf gpurun_out/pmch_$TAG/pass*/
+# 3c. the opt-in fp8 QK^T attention: the attention probe under SVI_ATTN_QK8=1 -> gpurun_out/<tag>_flash_qk8_pmc.txt
+SVI_ATTN_QK8=1 tools/pmc_collect.sh attn gpurun_out/pmcq_$TAG > gpurun_out/pmcq_$TAG.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmcq_$TAG "flash|mx8_quantize" > gpurun_out/${TAG}_flash_qk8_pmc.txt
+rm -rf gpurun_out/pmcq_$TAG/pass*/
 # 4. JSON summaries (per-launch HBM bytes, mfma_busy_in_clock, L2 hit rate) + the hashes of the sources they were collected on
 python tools/pmc_to_json.py $TAG
