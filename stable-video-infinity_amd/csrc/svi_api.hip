@@ -45,6 +45,7 @@ static SviSwitches parse_switches() {
     s.mx8_fused = env_int("SVI_MX8_FUSED", 0, 1);
     s.qk_fused = env_int("SVI_QK_FUSED", 0, 1);
     s.attn_qk8 = env_int("SVI_ATTN_QK8", 0, 0) != 0;
+    s.qk8_fused = env_int("SVI_QK8_FUSED", 0, 1);
     s.rms_rows = env_int("SVI_RMS_ROWS", 0, 1);
     s.flash_split = env_int("SVI_FLASH_SPLIT", 0, 0);
     if (s.flash_split > 4) s.flash_split = 4;

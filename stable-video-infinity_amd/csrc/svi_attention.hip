@@ -1297,16 +1297,23 @@ extern "C" svi_status svi_attention_last_flagged(svi_stream stream, int32_t* fla
     return SVI_OK;
 }
 
-svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt, bf16* O,
-                            int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st, const int* key_tail) {
-    SVI_REQUIRE(Lq > 0 && Lk > 0 && num_heads > 0, "attention: bad sizes Lq=%d Lk=%d heads=%d", Lq, Lk, num_heads);
-    SVI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: leading dims must be multiples of 8");
-    SVI_REQUIRE(ldvt >= ((Lk + 7) / 8) * 8, "attention: V^T leading dim %d < keys rounded up to 8", ldvt);
-    SVI_REQUIRE(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)VT % 16) == 0 &&
-                    ((uintptr_t)O % 8) == 0, "attention: operands must be 16-byte aligned");
-    const int lds = 2 * (KT_BYTES + VT_BYTES);
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
-    const SviSwitches& sw = svi_switches();
+// The per-stream operand buffers of the fp8 QK^T mode: [Lq x dim] + [Lk x dim] e4m3 bytes, then the two scale tables ([head][rows] dwords).
+static svi_status flash_qk8_buffers(int Lq, int Lk, int num_heads, hipStream_t st, SviQk8* out) {
+    const int dim = num_heads * DH;
+    out->ld8 = dim;
+    out->qs_rows = (Lq + 3) & ~3;
+    out->ks_rows = (Lk + 3) & ~3;
+    const size_t q_bytes = ((size_t)Lq * dim + 255) & ~(size_t)255, k_bytes = ((size_t)Lk * dim + 255) & ~(size_t)255;
+    const size_t qs_bytes = (size_t)num_heads * out->qs_rows * 4, ks_bytes = (size_t)num_heads * out->ks_rows * 4;
+    void* buf = nullptr;
+    SVI_TRY(svi_stream_buffer(SVI_BUF_FLASH_QK8, st, q_bytes + k_bytes + qs_bytes + ks_bytes, &buf, nullptr));
+    out->q8 = reinterpret_cast<unsigned char*>(buf);
+    out->k8 = out->q8 + q_bytes;
+    out->qs = reinterpret_cast<unsigned*>(out->k8 + k_bytes);
+    out->ks = out->qs + (size_t)num_heads * out->qs_rows;
+    return SVI_OK;
+}
+static int flash_device_cus(int* out) {
     static std::atomic<int> cus[64];                             // compute units per device (0: not asked yet)
     const int dev = svi_current_device();
     if (dev < 0) return SVI_ERR_HIP;
@@ -1315,6 +1322,33 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         ncu = cus[dev].load(std::memory_order_relaxed);
         if (!ncu) { int n = 0; SVI_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev)); ncu = n > 0 ? n : 256; cus[dev].store(ncu, std::memory_order_relaxed); }
     }
+    *out = ncu;
+    return SVI_OK;
+}
+svi_status svi_flash_qk8_prepare(int Lq, int Lk, int num_heads, hipStream_t st, SviQk8* out, bool* use) {
+    *use = false;
+    if (!svi_switches().attn_qk8) return SVI_OK;
+    int ncu = 256, kernel = 0;
+    SVI_TRY((svi_status)flash_device_cus(&ncu));
+    (void)svi_flash_plan(Lq, Lk, num_heads, ncu, &kernel);
+    if (kernel != 2) return SVI_OK;
+    SVI_TRY(flash_qk8_buffers(Lq, Lk, num_heads, st, out));
+    *use = true;
+    return SVI_OK;
+}
+
+svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt, bf16* O,
+                            int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st, const int* key_tail, const SviQk8* pre) {
+    SVI_REQUIRE(Lq > 0 && Lk > 0 && num_heads > 0, "attention: bad sizes Lq=%d Lk=%d heads=%d", Lq, Lk, num_heads);
+    SVI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: leading dims must be multiples of 8");
+    SVI_REQUIRE(ldvt >= ((Lk + 7) / 8) * 8, "attention: V^T leading dim %d < keys rounded up to 8", ldvt);
+    SVI_REQUIRE(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)VT % 16) == 0 &&
+                    ((uintptr_t)O % 8) == 0, "attention: operands must be 16-byte aligned");
+    const int lds = 2 * (KT_BYTES + VT_BYTES);
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
+    const SviSwitches& sw = svi_switches();
+    int ncu = 256;
+    SVI_TRY((svi_status)flash_device_cus(&ncu));
     int kernel = 0;
     const SviFlashSplit sp = svi_flash_plan(Lq, Lk, num_heads, ncu, &kernel);          // the one place that decides kernel and split (svi_attention_plan shows it)
     if (kernel == 2) {
@@ -1328,25 +1362,22 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         const unsigned* qsc = nullptr;
         const unsigned* ksc = nullptr;
         int qs_rows = 0, ks_rows = 0;
+        SVI_REQUIRE(!pre || qk8, "attention: pre-quantised operands were handed to a launch that does not take the fp8 QK^T kernel");
         if (qk8) {
-            const int dim = num_heads * DH;
-            qs_rows = (Lq + 3) & ~3;
-            ks_rows = (Lk + 3) & ~3;
-            const size_t q_bytes = ((size_t)Lq * dim + 255) & ~(size_t)255, k_bytes = ((size_t)Lk * dim + 255) & ~(size_t)255;
-            const size_t qs_bytes = (size_t)num_heads * qs_rows * 4, ks_bytes = (size_t)num_heads * ks_rows * 4;
-            void* buf = nullptr;
-            SVI_TRY(svi_stream_buffer(SVI_BUF_FLASH_QK8, st, q_bytes + k_bytes + qs_bytes + ks_bytes, &buf, nullptr));
-            unsigned char* q8 = reinterpret_cast<unsigned char*>(buf);
-            unsigned char* k8 = q8 + q_bytes;
-            unsigned* qs = reinterpret_cast<unsigned*>(k8 + k_bytes);
-            unsigned* ks = qs + (size_t)num_heads * qs_rows;
-            SVI_TRY(svi_launch_mx8_quantize(Q, ldq, Lq, dim, q8, dim, qs, qs_rows, st));
-            SVI_TRY(svi_launch_mx8_quantize(K, ldk, Lk, dim, k8, dim, ks, ks_rows, st));
-            Q = reinterpret_cast<const bf16*>(q8);
-            K = reinterpret_cast<const bf16*>(k8);
-            ldq = ldk = dim;
-            qsc = qs;
-            ksc = ks;
+            SviQk8 b{};
+            if (pre) b = *pre;                     // the producer of q | k wrote the e4m3 rows and scales itself (svi_flash_qk8_prepare's buffers)
+            else {
+                SVI_TRY(flash_qk8_buffers(Lq, Lk, num_heads, st, &b));
+                SVI_TRY(svi_launch_mx8_quantize(Q, ldq, Lq, num_heads * DH, b.q8, b.ld8, b.qs, b.qs_rows, st));
+                SVI_TRY(svi_launch_mx8_quantize(K, ldk, Lk, num_heads * DH, b.k8, b.ld8, b.ks, b.ks_rows, st));
+            }
+            Q = reinterpret_cast<const bf16*>(b.q8);
+            K = reinterpret_cast<const bf16*>(b.k8);
+            ldq = ldk = b.ld8;
+            qsc = b.qs;
+            ksc = b.ks;
+            qs_rows = b.qs_rows;
+            ks_rows = b.ks_rows;
         }
         const int n_items = (int)grid2.x * num_heads, n_cut = n_items - sp.whole;
         float* opart = nullptr;
@@ -1378,7 +1409,7 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
             kern = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false> : flash_fwd2_kernel<1, 0, false>)
                                : (Lq == Lk ? flash_fwd2_kernel<0, 0, true> : flash_fwd2_kernel<1, 0, true>);
 #ifdef SVI_ABLATIONS       // timing-only ablations (tools/attn_abl.py; results wrong), see the kernel's ABL parameter: variant builds only
-        switch (q_prescaled ? sw.flash_abl : 0) {
+        switch ((q_prescaled && !qk8) ? sw.flash_abl : 0) {
             case 1: kern = flash_fwd2_kernel<0, 1>; break;
             case 2: kern = flash_fwd2_kernel<0, 2>; break;
             case 3: kern = flash_fwd2_kernel<0, 3>; break;
@@ -1419,6 +1450,7 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         }
         return SVI_OK;
     }
+    SVI_REQUIRE(!pre, "attention: pre-quantised operands were handed to a launch that takes the short-key kernel");
     SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(flash_fwd_kernel<0>), lds));
     SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(flash_fwd_kernel<1>), lds));
     dim3 grid((Lq + QB - 1) / QB, num_heads), block(256);

@@ -83,6 +83,8 @@ struct SviSwitches {
     int attn_qk8 = 0;            // SVI_ATTN_QK8 = 1 : (opt-in, never the default) the long-sequence attention quantises Q and K to MX e4m3 (one E8M0 scale per 32
                                  // channels) and takes QK^T on the scaled fp8 MFMA at twice the bf16 rate; P·V stays bf16.  Arithmetic the reference never
                                  // performs (its dispatch accepts a quantised-QK^T backend, wan_video_dit.py:116-147): own oracle, own tolerance, own bench line
+    int qk8_fused = 1;           // SVI_QK8_FUSED = 0 : (opt-in fp8 QK^T) the DiT's RMSNorm + RoPE launch writes bf16 q | k and the attention call quantises them with two more
+                                 // launches, instead of the RMSNorm + RoPE kernel writing the e4m3 rows and block scales itself (bit-identical)
     int cross_dedup = 1;         // SVI_CROSS_DEDUP = 0 : cross-attention walks every context row even where the prompt embedding's trailing rows are
                                  // identical (the prompter's zero padding); default: m identical keys = one key counted m times (same softmax)
     int t5_host_buckets = 0;     // SVI_T5_BUCKETS = host : the text encoder's relative-position bucket table in the HOST's fp32 arithmetic (what the
@@ -125,6 +127,39 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+
+// Eight consecutive elements of a row (a quarter of a 32-element MX block) -> e4m3 bytes + the block's E8M0 code.  Lane layout: lane & 3 = the
+// quarter inside its block, lane & 15 = the eighth inside its 128-element group (whose four codes make one dword, written by the group's first
+// lane); the 16 lanes of a group hold the same row and are all live or all dead.  Shared by mx8_quantize_kernel and the GEMM epilogue that
+// quantises its own result (SviGemmArgs::q8): the same operations, the same bits.
+__device__ __forceinline__ void mx8_quant8(const float (&v)[8], bool live, int row, int c8, unsigned char* __restrict__ q, int ldq,
+                                           unsigned* __restrict__ scales, int sc_rows) {
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);            // biased exponent of the block maximum (0 for zero / subnormal)
+    const int E = max(eb - 8, 0);                                           // E8M0 code of the shared scale 2^(E - 127)
+    const float inv = __uint_as_float((unsigned)(254 - E) << 23);           // 2^(127 - E), exact
+    unsigned w[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(v[4 * h2 + e] * inv, -448.f), 448.f);      // saturate to the e4m3 range, then round to nearest even
+        unsigned pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], pk, true);
+        w[h2] = pk;
+    }
+    if (live) *reinterpret_cast<u32x2*>(q + (size_t)row * ldq + c8 * 8) = u32x2{w[0], w[1]};
+    // the four block codes of a 128-element group -> one dword, written by the group's first lane
+    const int lane = threadIdx.x & 63;
+    const unsigned e0 = (unsigned)E;
+    const unsigned e1 = (unsigned)__shfl(E, (lane & ~15) + 4), e2 = (unsigned)__shfl(E, (lane & ~15) + 8), e3 = (unsigned)__shfl(E, (lane & ~15) + 12);
+    if (live && (lane & 15) == 0) scales[(size_t)(c8 >> 4) * sc_rows + row] = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+}
 
 // gelu_tanh(x) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi)(x + 0.044715 x^3).  1 + tanh(u) = 2 sigmoid(2u), so
 // gelu_tanh(x) = x / (1 + exp(-2u)): one v_exp + one v_rcp instead of a tanhf expansion (fp32-accurate;
@@ -195,8 +230,13 @@ svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, i
 #define SVI_QK_SCALE_LOG2E 0.12751743f
 // (svi_launch_flash: q/k token-major with row strides, V TRANSPOSED [heads*128, ldvt])
 // key_tail (device, optional; short key axes only): {n, m} — attend to keys 0 .. n-1 and count key n-1 m times (keys n-1 .. Lk-1 are identical)
+// qk8 (opt-in fp8 QK^T only): Q and K already quantised by the caller into the buffers svi_flash_qk8_prepare handed out (the DiT's RMSNorm + RoPE kernel
+// writes them instead of the bf16 rows); nullptr: svi_launch_flash quantises the bf16 operands itself when the mode is on.
+struct SviQk8 { unsigned char* q8; unsigned char* k8; unsigned* qs; unsigned* ks; int ld8, qs_rows, ks_rows; };
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt,
-                            bf16* O, int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st, const int* key_tail = nullptr);
+                            bf16* O, int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st, const int* key_tail = nullptr, const SviQk8* qk8 = nullptr);
+// *use = whether svi_launch_flash will run this shape on the fp8 QK^T kernel (switch on, long key axis); if so `out` names the per-stream operand buffers
+svi_status svi_flash_qk8_prepare(int Lq, int Lk, int num_heads, hipStream_t st, SviQk8* out, bool* use);
 
 svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int rows, int dim, float eps,
                              const bf16* w, const bf16* b, const float* shift, const float* scale1p,
@@ -218,6 +258,11 @@ svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf1
                                    const SviRope* rope, float out_scale, hipStream_t st);
 svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf16* weight, const bf16* weight1, float eps,
                                     const SviRope* rope, float out_scale, float out_scale1, hipStream_t st, const SviScatter* scatter = nullptr);
+// The same launch writing MX e4m3 rows + block scales for both operands INSTEAD of the bf16 rows (operand 0 -> q8 / qs, operand 1 -> k8 / ks): the bits
+// svi_launch_mx8_quantize makes of the bf16 rows.  Only the DiT's shapes (svi_rmsnorm_rope_q8_ok); rope is required.
+bool svi_rmsnorm_rope_q8_ok(int dim, const SviRope* rope);
+svi_status svi_launch_rmsnorm_rope2_q8(bf16* x, int ld, int rows, int dim, const bf16* weight, const bf16* weight1, float eps, const SviRope* rope, float out_scale,
+                                       float out_scale1, hipStream_t st, const SviQk8& out);
 // receive side of the two exchanges: V^T pieces [P(src)][Dp][lds] -> [Dp][L8] (token axis = source-major), attention output pieces
 // [G][P(src = owner of head block)][Ls][Dg] -> [Ls][P*Dp] token rows
 svi_status svi_launch_sp_unpack_vt(const bf16* recv, bf16* out, int P, int Dp, int Ls, int lds, int L8, hipStream_t st);

@@ -507,8 +507,9 @@ static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16
 // q pre-scaled) and V^T of the shard's rows [row0, row0 + L), (2) attention, (3) output projection + gate + residual.
 // part: 0 = everything; 1 = LN + modulate and the V^T projection only; 2 = the q | k projection and RMSNorm + RoPE only (after a part-1 call on the
 // same rows: the LN output is still in the workspace) — the sequence-parallel gather mode sends V^T on its way while q | k are still being made.
+// q8 (opt-in fp8 QK^T attention, plain forward only): RMSNorm + RoPE writes q | k as MX e4m3 rows + block scales into *q8 instead of the bf16 rows of QK.
 static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* modf, int L, int row0, bf16* QK, bf16* VT, int ldvt,
-                            hipStream_t st, const SviScatter* scatter = nullptr, int nb = 1, int part = 0) {
+                            hipStream_t st, const SviScatter* scatter = nullptr, int nb = 1, int part = 0, const SviQk8* q8 = nullptr) {
     // L = rows of this launch (nb samples of L / nb tokens each, stacked: the two CFG branches of a step on short sequences)
     const svi_dit_config& c = h->cfg;
     const BlockW& b = h->blocks[layer];
@@ -537,6 +538,7 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
       SVI_TRY(svi_launch_gemm(g, st)); }
     if (part == 0) { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st, nb)); }
     // q and k in one launch (grid.y = operand): q additionally carries softmax_scale * log2(e) into its single final rounding
+    if (q8) { SviProfScope _p(PROF_RMS_ROPE, st); return svi_launch_rmsnorm_rope2_q8(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st, *q8); }
     { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope2(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st, scatter)); }
     return SVI_OK;
 }
@@ -554,11 +556,15 @@ static svi_status block_attn_out(svi_dit* h, int layer, bf16* X, const bf16* att
 static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* modf, int L, hipStream_t st, int nb = 1) {
     Workspace& w = h->ws;
     const int D = h->cfg.dim;
-    SVI_TRY(block_qkv(h, layer, X, modf, nb * L, 0, w.QK, w.VT, w.ldvt, st, nullptr, nb));
+    // opt-in fp8 QK^T: where the attention will take that kernel, RMSNorm + RoPE writes its operands (e4m3 rows + block scales) instead of bf16 q | k
+    SviQk8 q8{};
+    bool fused = false;
+    if (nb == 1 && svi_switches().qk8_fused && svi_rmsnorm_rope_q8_ok(D, &h->rope)) SVI_TRY(svi_flash_qk8_prepare(L, L, h->cfg.num_heads, st, &q8, &fused));
+    SVI_TRY(block_qkv(h, layer, X, modf, nb * L, 0, w.QK, w.VT, w.ldvt, st, nullptr, nb, 0, fused ? &q8 : nullptr));
     for (int s = 0; s < nb; ++s) {          // sample s attends over its own token rows / V^T columns [s L, (s+1) L)
         const size_t ro = (size_t)s * L;
         SviProfScope _p(PROF_FLASH_SELF, st);
-        SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, w.QK + ro * 2 * D + D, 2 * D, w.VT + ro, w.ldvt, w.Hb + ro * D, D, L, L, h->cfg.num_heads, 1, st));
+        SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, w.QK + ro * 2 * D + D, 2 * D, w.VT + ro, w.ldvt, w.Hb + ro * D, D, L, L, h->cfg.num_heads, 1, st, nullptr, fused ? &q8 : nullptr));
     }
     return block_attn_out(h, layer, X, w.Hb, modf, nb * L, st, nb);
 }

@@ -283,9 +283,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
 // The same arithmetic for the shapes the DiT runs (every lane holds MAXC whole chunks: dim = 512 MAXC; RoPE from the per-token table or none;
 // in place): a wave walks RPW consecutive rows, requests row i + 1 before it works on row i, and keeps the gain vector in registers — the
 // generic kernel above reloads and unpacks it for every row and has one row in flight per wave.  Bit-identical results.
-template <int MAXC, int RPW, bool ROPE>
+// Q8 (opt-in fp8 QK^T attention): the result rows leave as MX e4m3 bytes + E8M0 block scales (operand blockIdx.y -> q8o.q8 / q8o.k8) instead of bf16 —
+// a lane's 8 channels are a quarter of a 32-channel block and 16 lanes one head: the quantiser's own lane layout (mx8_quant8), so the bits are those
+// svi_launch_mx8_quantize makes of the bf16 rows this kernel would have written.
+template <int MAXC, int RPW, bool ROPE, bool Q8 = false>
 __global__ __launch_bounds__(256) void rmsnorm_rope_rows_kernel(bf16* __restrict__ x, int ld, int rows, int dim, const bf16* __restrict__ weight,
-                                                                const bf16* __restrict__ weight1, float eps, SviRope r, float out_scale, float out_scale1) {
+                                                                const bf16* __restrict__ weight1, float eps, SviRope r, float out_scale, float out_scale1, SviQk8 q8o = SviQk8{}) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * RPW;
     if (row0 >= rows) return;
@@ -339,11 +342,36 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_rows_kernel(bf16* __restrict
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (bf16)(y[j] * out_scale);
             }
-            st_bf16x8(xr + col, o);
+            if constexpr (Q8) {
+                float vq[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vq[j] = (float)o[j];
+                mx8_quant8(vq, true, row, lane + 64 * c, blockIdx.y ? q8o.k8 : q8o.q8, q8o.ld8, blockIdx.y ? q8o.ks : q8o.qs, blockIdx.y ? q8o.ks_rows : q8o.qs_rows);
+            } else {
+                st_bf16x8(xr + col, o);
+            }
         }
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) cur[c] = nxt[c];
     }
+}
+
+bool svi_rmsnorm_rope_q8_ok(int dim, const SviRope* rope) {
+    return (dim == 512 * 3 || dim == 512 * 10) && rope && rope->tab_tok && svi_switches().rms_rows;
+}
+svi_status svi_launch_rmsnorm_rope2_q8(bf16* x, int ld, int rows, int dim, const bf16* weight, const bf16* weight1, float eps, const SviRope* rope, float out_scale,
+                                       float out_scale1, hipStream_t st, const SviQk8& out) {
+    SVI_REQUIRE(svi_rmsnorm_rope_q8_ok(dim, rope) && weight1 && ld >= 2 * dim && ld % 8 == 0, "rmsnorm -> e4m3: only the DiT's q | k launch (dim %d)", dim);
+    SVI_REQUIRE(out.q8 && out.k8 && out.qs && out.ks && out.ld8 >= dim && out.ld8 % 8 == 0 && out.qs_rows >= rows && out.ks_rows >= rows, "rmsnorm -> e4m3: bad output buffers");
+    SVI_REQUIRE(rope->npf + rope->nph + rope->npw == 64 && rope->row0 >= 0 && (rope->period > 0 ? rope->period == rope->f * rope->h * rope->w : rope->row0 + rows <= rope->f * rope->h * rope->w),
+                "rope grid %dx%dx%d does not cover rows [%d, %d)", rope->f, rope->h, rope->w, rope->row0, rope->row0 + rows);
+    if (rows <= 0) return SVI_OK;
+    constexpr int RPW = 4;
+    dim3 grid_r((rows + ROWS_PER_BLOCK * RPW - 1) / (ROWS_PER_BLOCK * RPW), 2), block(256);
+    if (dim == 512 * 3) hipLaunchKernelGGL((rmsnorm_rope_rows_kernel<3, RPW, true, true>), grid_r, block, 0, st, x, ld, rows, dim, weight, weight1, eps, *rope, out_scale, out_scale1, out);
+    else hipLaunchKernelGGL((rmsnorm_rope_rows_kernel<10, RPW, true, true>), grid_r, block, 0, st, x, ld, rows, dim, weight, weight1, eps, *rope, out_scale, out_scale1, out);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
 }
 
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,

@@ -296,38 +296,7 @@ __device__ __forceinline__ void gemm256_apply(float (&y)[8], const u32x4& res, c
     }
 }
 
-// Eight consecutive elements of a row (a quarter of a 32-element MX block) -> e4m3 bytes + the block's E8M0 code.  Lane layout: lane & 3 = the
-// quarter inside its block, lane & 15 = the eighth inside its 128-element group (whose four codes make one dword, written by the group's first
-// lane); the 16 lanes of a group hold the same row and are all live or all dead.  Shared by mx8_quantize_kernel and the GEMM epilogue that
-// quantises its own result (SviGemmArgs::q8): the same operations, the same bits.
-__device__ __forceinline__ void mx8_quant8(const float (&v)[8], bool live, int row, int c8, unsigned char* __restrict__ q, int ldq,
-                                           unsigned* __restrict__ scales, int sc_rows) {
-    float amax = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    amax = fmaxf(amax, __shfl_xor(amax, 2));
-    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);            // biased exponent of the block maximum (0 for zero / subnormal)
-    const int E = max(eb - 8, 0);                                           // E8M0 code of the shared scale 2^(E - 127)
-    const float inv = __uint_as_float((unsigned)(254 - E) << 23);           // 2^(127 - E), exact
-    unsigned w[2];
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        float a[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(v[4 * h2 + e] * inv, -448.f), 448.f);      // saturate to the e4m3 range, then round to nearest even
-        unsigned pk = 0;
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], pk, false);
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], pk, true);
-        w[h2] = pk;
-    }
-    if (live) *reinterpret_cast<u32x2*>(q + (size_t)row * ldq + c8 * 8) = u32x2{w[0], w[1]};
-    // the four block codes of a 128-element group -> one dword, written by the group's first lane
-    const int lane = threadIdx.x & 63;
-    const unsigned e0 = (unsigned)E;
-    const unsigned e1 = (unsigned)__shfl(E, (lane & ~15) + 4), e2 = (unsigned)__shfl(E, (lane & ~15) + 8), e3 = (unsigned)__shfl(E, (lane & ~15) + 12);
-    if (live && (lane & 15) == 0) scales[(size_t)(c8 >> 4) * sc_rows + row] = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
-}
+// (mx8_quant8 — eight consecutive elements of a row -> e4m3 bytes + the block's E8M0 code — lives in svi_common.h: the RMSNorm + RoPE kernel shares it)
 
 // MI x NI: 32x32 accumulator blocks per wave along M / N (wave grid (256 / 32 MI) x (TNV / 32 NI)); TNV: tile width.  The 256^2 kernels are
 // <4, 2, 256>; the 256 x 192 kernel <2, 3, 192> (read-back threads whose column chunk lies past the tile's 192 columns sit idle).

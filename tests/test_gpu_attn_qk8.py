@@ -11,6 +11,7 @@ oracle/mx8_oracle.py plus fp64 attention, and the statements made are:
                  deliberately harsh channel magnitudes used here — e4m3 keeps 3 mantissa bits) and shown to be ALL of the distance from the bf16 kernel;
                  it is BOUNDED where the mode is meant to be used: the 30-layer forward at 7800 tokens (dit_depth.npz, made by the reference) stays
                  <= 5e-2 of the bf16-arithmetic forward and so does the 2-step CFG loop (measured 6e-3 / 2e-2; distance to the reference's fp32 run unchanged)
+  fused          in the DiT the RMSNorm + RoPE launch writes the e4m3 rows and scales itself; SVI_QK8_FUSED=0 (bf16 rows + quantiser launches): bit-identical
   default        the mode is off unless SVI_ATTN_QK8=1; with it off the attention's bits are those of the bf16 kernel
 """
 import ctypes as C
@@ -181,6 +182,9 @@ def test_forward_at_depth_stays_within_the_stated_distance(hip, golden):
         got = m.forward(dev(noise), sch.timesteps[:1], pos)
         flagged, nwg = last_flagged()
         lat = hip.DenoiseLoop(m).sample(dev(noise), pos, neg, num_inference_steps=synth.DEPTH_STEPS, cfg_scale=5.0, sigma_shift=5.0)
+    with qk8(SVI_QK8_FUSED=0):          # bf16 q | k written, two quantiser launches in front of every attention call: the same bits
+        unfused = m.forward(dev(noise), sch.timesteps[:1], pos)
+    assert torch.equal(got, unfused)
     r = errs(got, base)[0]
     rl = errs(lat, lat_base)[0]
     report("dit_depth_qk8", fwd_qk8_vs_bf16_arithmetic=r, fwd_qk8_vs_ref_fp32=errs(got[0], g["fwd_fp32"])[0], fwd_bf16_vs_ref_fp32=errs(base[0], g["fwd_fp32"])[0],
