@@ -150,8 +150,19 @@ def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_switch_epoch = 0
+
+
+def switch_epoch() -> int:
+    """How many times set_switch() has re-read the library's switches in this process.  Captured step graphs carry it in their key: a graph recorded
+    under other switches (SVI_ATTN_QK8 changes the arithmetic, the rest the kernels) is never replayed."""
+    return _switch_epoch
+
+
 def set_switch(name: str, value=None) -> None:
     """A/B tooling: set (or, with None, remove) one of the library's environment switches and make the library re-read them."""
+    global _switch_epoch
+    _switch_epoch += 1
     if value is None:
         os.environ.pop(name, None)
     else:

@@ -14,6 +14,7 @@ from typing import Callable, Dict, Optional
 
 import torch
 
+from . import _lib as L
 from . import ops
 from .dit import WanDiT, _version, model_fn_wan_video
 from .scheduler import FlowMatchScheduler
@@ -85,6 +86,7 @@ class DenoiseLoop:
             key records each one's address, shape and version counter (an in-place write makes a new key);
           * the key carries the DiT's host-side epoch (context_cache() on / off, re-bind) and the C side's generation counter
             (svi_dit_generation: workspace growth, a context entry filled or evicted) as read right after the capture;
+          * the key carries the count of in-process switch reloads (_lib.set_switch): a graph recorded under other library switches is not replayed;
           * sample() drops the graph when the clip is done.
         Anything else re-captures."""
         def ident(t):
@@ -92,7 +94,7 @@ class DenoiseLoop:
         self.dit._refresh_if_weights_changed()          # a LoRA merge since the last step re-binds (and moves the epoch) BEFORE the key is formed
         tensors = [latents, ctx_pos, ctx_neg, self._cond, self._uncond] + [v for _, v in sorted(cond.items()) if isinstance(v, torch.Tensor)]
         key = (tuple(ident(t) for t in tensors), tuple(sorted(k for k, v in cond.items() if v is not None)), float(cfg_scale), bool(split),
-               self.dit.epoch())
+               self.dit.epoch(), L.switch_epoch())
         stale = self._graph is None or self._graph["key"] != key or self._graph["generation"] != self.dit.generation()
         if stale:
             self._graph = None

@@ -192,3 +192,34 @@ def test_forward_at_depth_stays_within_the_stated_distance(hip, golden):
            flagged=flagged, workgroups=nwg)
     assert torch.isfinite(got.float()).all() and flagged == 0
     assert r < 5e-2 and rl < 5e-2, (r, rl)
+
+
+def test_a_kept_loop_recaptures_when_the_switch_moves(hip):
+    """The mode changes the arithmetic, so a step graph recorded under the other setting must not be replayed: a DenoiseLoop kept across
+    _lib.set_switch() calls re-captures (the switch-reload count is part of its key) and gives the eager loop's bits under each setting."""
+    c = dict(dim=512, in_dim=16, ffn_dim=1024, out_dim=16, text_dim=64, freq_dim=256, patch_size=(1, 2, 2), num_layers=2, has_image_input=False)
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(900, **c).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=4, **c)
+    f, h, w = 4, 16, 32                                                   # 2048 tokens: the long-sequence kernel
+    x = dev(synth.randn(901, 1, 16, f, 2 * h, 2 * w))
+    cp, cn = dev(synth.text_context(902, 24, 64, 17)), dev(synth.text_context(903, 24, 64, 9))
+    t = torch.tensor([712.5], device="cuda")
+    loop, eager = hip.DenoiseLoop(m, graph=True), hip.DenoiseLoop(m, graph=False)
+
+    def both():
+        a, b = x.clone(), x.clone()
+        for _ in range(2):
+            loop.step(a, t, -0.03, cp, cn, 5.0)
+            eager.step(b, t, -0.03, cp, cn, 5.0)
+        return a, b
+    try:
+        a0, b0 = both()
+        assert torch.equal(a0, b0)
+        with qk8():
+            a1, b1 = both()
+        assert torch.equal(a1, b1) and not torch.equal(a1, a0)
+        a2, b2 = both()
+        assert torch.equal(a2, b2) and torch.equal(a2, a0)
+        report("attn_qk8_loop_recapture", qk8_vs_bf16_two_steps=errs(a1, a0)[0])
+    finally:
+        loop.drop_graph()
