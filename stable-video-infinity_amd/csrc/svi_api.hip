@@ -63,8 +63,12 @@ static SviSwitches& switches_storage() {
     return sw;
 }
 const SviSwitches& svi_switches() { return switches_storage(); }
+static std::atomic<unsigned long long> g_stream_buffer_generation{0};      // moves whenever a per-stream library buffer is freed or the switches are re-read
 extern "C" svi_status svi_switches_reload(void) {
     switches_storage() = parse_switches();
+    // what a captured step graph has baked in includes the kernels the switches selected (and, with SVI_ATTN_QK8, the arithmetic): move the
+    // generation svi_dit_generation reports so that every DenoiseLoop re-captures
+    g_stream_buffer_generation.fetch_add(1, std::memory_order_relaxed);
     return SVI_OK;
 }
 
@@ -117,7 +121,6 @@ std::deque<StreamSlot>& stream_slots() {
     static std::deque<StreamSlot> slots;    // deque: a slot's address (its host-side `user` word) stays valid as the table grows
     return slots;
 }
-std::atomic<unsigned long long> g_stream_buffer_generation{0};
 }  // namespace
 unsigned long long svi_stream_buffer_generation() { return g_stream_buffer_generation.load(std::memory_order_relaxed); }
 

@@ -576,7 +576,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                                                             float scale_log2e, int* __restrict__ flags,
                                                             float* __restrict__ opart, float2* __restrict__ ml, SviFlashSplit sp,
                                                             const unsigned* __restrict__ qscale, const unsigned* __restrict__ kscale, int qs_rows, int ks_rows) {
-    static_assert(!QK8 || ABL == 0, "no ablations of the fp8 QK^T variant");
+#ifndef SVI_ABLATIONS
+    static_assert(!QK8 || ABL == 0, "ablations of the fp8 QK^T variant exist in variant builds only");
+#endif
     constexpr int EB = QK8 ? 1 : 2;             // bytes per Q / K element
     // QK8: the Q fragments are half the size (32 registers), so everything the kernel owns sits 32 registers higher and hipcc may park values in a[0:95]
     constexpr int OREG0 = QK8 ? SVI_OREG0 + 32 : SVI_OREG0, QREG0 = QK8 ? SVI_QREG0 + 32 : SVI_QREG0;
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     //   12 pairs (kb 2 g 1, kb 3 g 0, kb 3 g 1)         on statements 0..23 of phase 2 of tile t+1    (each before the PV statement that reads its word)
     // instead of 20 pairs on phase 1 (8 of its statements carrying a whole pair: 2 v_exp + 2 v_add + pack in one 32-cycle MFMA shadow,
     // more than fits) and 12 on phase 2.  Row sums run in four accumulators per lane over the whole key axis (no per-tile fold).
-    constexpr bool BAL = OPT && ABL == 0 && (SVI_FLASH_BALANCED != 0);
+    constexpr bool BAL = OPT && (ABL == 0 || QK8) && (SVI_FLASH_BALANCED != 0);      // (the fp8 variant's timing ablations keep the balanced schedule)
     // rg(f, dma): the row-group statement (0 or 1) of fragment f behind which that fragment's look-ahead LDS read is issued: normally g = 0;
     // where the g = 0 statement also issues an LDS-DMA piece (s_mov m0 + buffer_load ... lds on top of its score), the g = 1 statement
     constexpr bool SPLIT = BAL && (SVI_FLASH_DMA_SPLIT != 0);
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                 static_for<0, 2>([&](auto gc) {
                     constexpr int g = decltype(gc)::value;
                     constexpr int k = 2 * f + g;
-                    constexpr bool dma = st == 1;
+                    constexpr bool dma = st == 1 && !(ABL & 8);
                     constexpr int piece = tt * 2 + g;
                     int& pin = *((k == 1 || k == 3) ? &kaddr[2 * st] : &vaddr[0]);
                     const SviDma d = {v_rs, voff0, so_v + piece * vstep, piece0 + vd + 4096 * piece};
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
                             ksw[1] = *(lds_u32_t)(kaddr[4] + kn + 128);
                         }
                     }
-                    if constexpr (QK8 && j == 28)            // the scale words of K(t+3): one dword per lane, behind the tile's two K pieces
+                    if constexpr (QK8 && j == 28 && !(ABL & 8))   // the scale words of K(t+3): one dword per lane, behind the tile's two K pieces
                         asm volatile("s_mov_b32 m0, %[m0v]\n\ts_nop 0\n\tbuffer_load_dword %[vo], %[rs], %[so] offen lds"
                                      : "+v"(tok) : [m0v] "s"(lds0 + kd + KSC_OFF), [vo] "v"(lane * 4), [rs] "s"(ks_rs), [so] "s"((t + 3) * KB * 4));
                     if constexpr (WITH_B && j == 23 && !BAL) {       // all 32 pairs of tile t-1 are done: fold the row sums
@@ -1395,7 +1397,7 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
         int* flags = nullptr;
         bool two_pass = sw.flash_two_pass != 0 && nwg <= SVI_FLASH_MAX_FLAGS;
 #ifdef SVI_ABLATIONS
-        if (sw.flash_abl) two_pass = false;
+        if (sw.flash_abl && !qk8) two_pass = false;
 #endif
         if (two_pass) SVI_TRY(flash_flags(st, nwg, &flags));
         kern_t kern;
@@ -1430,6 +1432,16 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
             case 1280: kern = flash_fwd2_kernel<0, 1280>; break;
             case 1792: kern = flash_fwd2_kernel<0, 1792>; break;
             case 1039: kern = flash_fwd2_kernel<0, 1039>; break;
+            default: break;
+        }
+#endif
+#ifdef SVI_ABLATIONS       // timing-only ablations of the optimistic fp8 kernel (tools/attn_qk8_abl.py; results wrong): 1 no softmax fillers, 8 no LDS-DMA, 256 no barrier
+        if (qk8 && two_pass && q_prescaled) switch (sw.flash_abl) {
+            case 1: kern = flash_fwd2_kernel<0, 1, false, 1, true>; break;
+            case 8: kern = flash_fwd2_kernel<0, 8, false, 1, true>; break;
+            case 9: kern = flash_fwd2_kernel<0, 9, false, 1, true>; break;
+            case 264: kern = flash_fwd2_kernel<0, 264, false, 1, true>; break;
+            case 265: kern = flash_fwd2_kernel<0, 265, false, 1, true>; break;
             default: break;
         }
 #endif
