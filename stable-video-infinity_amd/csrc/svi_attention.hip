@@ -1327,14 +1327,14 @@ static int flash_device_cus(int* out) {
     *out = ncu;
     return SVI_OK;
 }
-svi_status svi_flash_qk8_prepare(int Lq, int Lk, int num_heads, hipStream_t st, SviQk8* out, bool* use) {
+svi_status svi_flash_qk8_prepare(int Lq, int Lk, int num_heads, hipStream_t st, SviQk8* out, bool* use, int batch) {
     *use = false;
     if (!svi_switches().attn_qk8) return SVI_OK;
     int ncu = 256, kernel = 0;
     SVI_TRY((svi_status)flash_device_cus(&ncu));
     (void)svi_flash_plan(Lq, Lk, num_heads, ncu, &kernel);
     if (kernel != 2) return SVI_OK;
-    SVI_TRY(flash_qk8_buffers(Lq, Lk, num_heads, st, out));
+    SVI_TRY(flash_qk8_buffers(batch * Lq, batch * Lk, num_heads, st, out));
     *use = true;
     return SVI_OK;
 }

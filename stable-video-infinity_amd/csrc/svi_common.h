@@ -236,7 +236,13 @@ struct SviQk8 { unsigned char* q8; unsigned char* k8; unsigned* qs; unsigned* ks
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt,
                             bf16* O, int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st, const int* key_tail = nullptr, const SviQk8* qk8 = nullptr);
 // *use = whether svi_launch_flash will run this shape on the fp8 QK^T kernel (switch on, long key axis); if so `out` names the per-stream operand buffers
-svi_status svi_flash_qk8_prepare(int Lq, int Lk, int num_heads, hipStream_t st, SviQk8* out, bool* use);
+// batch > 1: room for that many samples stacked one under the other (sample s: rows [s Lq, (s+1) Lq) of q8 / qs, [s Lk, ..) of k8 / ks; svi_qk8_sample)
+svi_status svi_flash_qk8_prepare(int Lq, int Lk, int num_heads, hipStream_t st, SviQk8* out, bool* use, int batch = 1);
+inline SviQk8 svi_qk8_sample(const SviQk8& b, int s, int Lq, int Lk) {
+    SviQk8 v = b;
+    v.q8 += (size_t)s * Lq * b.ld8; v.k8 += (size_t)s * Lk * b.ld8; v.qs += (size_t)s * Lq; v.ks += (size_t)s * Lk;
+    return v;
+}
 
 svi_status svi_launch_ln_mod(const bf16* x, int ldx, bf16* out, int ldo, int rows, int dim, float eps,
                              const bf16* w, const bf16* b, const float* shift, const float* scale1p,

@@ -12,6 +12,7 @@
 //   Fb  [L, F]      FFN hidden (GELU applied in the producing GEMM's epilogue)
 //   CTX [Lc(+257), D], CK [.., D], CVT [D, ..]   projected context and its per-block K / V^T
 //   modf f32 [layers][6][D]   (modulation + t_mod), bf16-rounded, with (1+scale) pre-added
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -559,12 +560,13 @@ static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* mo
     // opt-in fp8 QK^T: where the attention will take that kernel, RMSNorm + RoPE writes its operands (e4m3 rows + block scales) instead of bf16 q | k
     SviQk8 q8{};
     bool fused = false;
-    if (nb == 1 && svi_switches().qk8_fused && svi_rmsnorm_rope_q8_ok(D, &h->rope)) SVI_TRY(svi_flash_qk8_prepare(L, L, h->cfg.num_heads, st, &q8, &fused));
+    if (svi_switches().qk8_fused && svi_rmsnorm_rope_q8_ok(D, &h->rope)) SVI_TRY(svi_flash_qk8_prepare(L, L, h->cfg.num_heads, st, &q8, &fused, nb));
     SVI_TRY(block_qkv(h, layer, X, modf, nb * L, 0, w.QK, w.VT, w.ldvt, st, nullptr, nb, 0, fused ? &q8 : nullptr));
     for (int s = 0; s < nb; ++s) {          // sample s attends over its own token rows / V^T columns [s L, (s+1) L)
         const size_t ro = (size_t)s * L;
         SviProfScope _p(PROF_FLASH_SELF, st);
-        SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, w.QK + ro * 2 * D + D, 2 * D, w.VT + ro, w.ldvt, w.Hb + ro * D, D, L, L, h->cfg.num_heads, 1, st, nullptr, fused ? &q8 : nullptr));
+        const SviQk8 q8s = svi_qk8_sample(q8, s, L, L);
+        SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, w.QK + ro * 2 * D + D, 2 * D, w.VT + ro, w.ldvt, w.Hb + ro * D, D, L, L, h->cfg.num_heads, 1, st, nullptr, fused ? &q8s : nullptr));
     }
     return block_attn_out(h, layer, X, w.Hb, modf, nb * L, st, nb);
 }
@@ -899,19 +901,24 @@ static svi_status forward_one(svi_dit* h, const bf16* x, const float* timestep, 
 // is computed once and its X snapshot restored for the second forward: 1/60 of a step's self-attention work, results bit-
 // identical to two svi_dit_forward calls (same kernels on the same operands; tests/test_gpu_dit.py).
 //
-// Short sequences (L <= SVI_PAIR_STACK_MAX tokens, e.g. BASELINE configs[0] with 1280): after the shared part the two branches are
-// STACKED — X holds 2 L rows, conditional on top — and every row-local kernel (norms, projections, MLP, head) runs once over both:
-// half the launches, and GEMMs that offered 120 tiles to 256 CUs offer 240.  Attention runs per branch (own rows; own prompt K / V).
+// After the shared part the two branches are STACKED — X holds 2 L rows, conditional on top — and every row-local kernel (norms, projections,
+// MLP, head) runs once over both: half the launches, GEMMs that offered 120 tiles to 256 CUs at BASELINE configs[0] (1280 tokens) offer 240, and at
+// the C2 size ffn1's 17.5 rounds of tiles per branch become 35 whole ones (same box, alternating: 425.1-428.3 -> 422.2-423.1 ms per step).
+// Attention runs per branch (own rows; own prompt K / V).  Taken whenever the widest stacked activation stays below 2 GiB (the GEMM's buffer
+// descriptors and row offsets are 32-bit): every BASELINE size at 1.3B and 14B widths; not the 1.3B model at 720p.
 // Each GEMM keeps the kernel a one-branch launch would pick (SviGemmArgs.sel_m / sel_n), so outputs stay bit-identical to two
 // svi_dit_forward calls.  Needs the context cache (each prompt's projected context and K / V in buffers of its own).
-#define SVI_PAIR_STACK_MAX 8192
+#ifndef SVI_PAIR_STACK_MAX
+#define SVI_PAIR_STACK_MAX (1 << 20)       // tokens (A/B builds: -DSVI_PAIR_STACK_MAX=8192 is the round-1..4 behaviour: short sequences only)
+#endif
 static svi_status forward_pair(svi_dit* h, const bf16* x, const float* timestep, const bf16* ctx_a, const bf16* ctx_b, const bf16* clip,
                                const bf16* y, const bf16* addc, bf16* out_a, bf16* out_b, int T, int H, int W, int Lc, hipStream_t st) {
     const svi_dit_config& c = h->cfg;
     const int D = c.dim;
     const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
     const int L = f * hh * ww;
-    const bool stacked = h->ctx_cache_on && L <= SVI_PAIR_STACK_MAX && L % 8 == 0 && ctx_a != ctx_b;
+    const size_t widest = (size_t)std::max(c.ffn_dim, 2 * D);
+    const bool stacked = h->ctx_cache_on && L <= SVI_PAIR_STACK_MAX && L % 8 == 0 && ctx_a != ctx_b && (size_t)2 * L * widest * 2 < ((size_t)1 << 31);
     SVI_TRY(ensure_workspace(h, stacked ? 2 * L : L, Lc, st));
     SVI_TRY(ensure_rope(h, f, hh, ww));
     Workspace& w = h->ws;
