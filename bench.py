@@ -546,19 +546,30 @@ def main() -> None:
     PEAK_HBM_TBS = 8.0
     shard = dist.get_world_size(sp_group) if sp else 1
 
-    def fam(tag, work_per_launch, bound, what, total_fn=None):
+    # The CFG pair's STACKED form (svi_dit.hip forward_pair: after the shared block-0 self-attention third, every row-local kernel runs ONCE over both
+    # branches' rows): a launch then covers 2 L rows.  Work is counted in L-row launch EQUIVALENTS: S self-attention thirds and R rest-thirds per step.
+    ffn1_n = (prof.get("gemm_ffn1") or {"count": 0})["count"] / max(prof_steps, 1)
+    stacked = world == 1 and not pair and not sp and not wl.get("pose") and 0 < ffn1_n < 1.5 * NL
+    S_eq, R_eq = 2 * NL - (1 if shared else 0), 2 * NL
+
+    def fam(tag, work_per_launch, bound, what, total_fn=None, third=None):
         rec = prof.get(tag)
         if not rec or not rec["count"]:
             return None
         ms = rec["ms"] / prof_steps
         n = rec["count"] / prof_steps
-        total = total_fn(n) if total_fn else work_per_launch * n
+        # third: which part of a block the family's launches belong to ("self" / "rest" / "ln": one self + two rest per block) — only used when stacked
+        n_eq = n if not (stacked and third) else n * {"self": S_eq / NL, "rest": R_eq / NL, "ln": (S_eq + 2 * R_eq) / (3 * NL)}[third]
+        total = total_fn(n_eq) if total_fn else work_per_launch * n_eq
         if bound == "mfma":
             ach, peak, unit = total / (ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
         else:
             ach, peak, unit = total / (ms * 1e-3) / 1e12, PEAK_HBM_TBS, "TB/s"
-        return {"bound": bound, "what": what, "launches_per_step": round(n, 2), "algorithmic_per_step": total, "ms_per_step": round(ms, 3),
-                "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}
+        out = {"bound": bound, "what": what, "launches_per_step": round(n, 2), "algorithmic_per_step": total, "ms_per_step": round(ms, 3),
+               "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}
+        if stacked and third:
+            out["launch_equivalents_per_step"] = round(n_eq, 2)       # the CFG pair is stacked: most launches of this family cover both branches' rows (2 L)
+        return out
     Ls = L // shard if sp else L
 
     def distinct_keys(c):      # what ctx_tail_scan_kernel leaves on the device: rows up to and including the first of the identical suffix
@@ -576,17 +587,18 @@ def main() -> None:
                            "(identical trailing rows of the zero-padded prompt count as one key)"),
         # q | k are ONE N = 2D launch (4 L D^2 FLOP), V^T its own (2 L D^2): 3 L D^2 per launch on average; three 2 L D^2 launches with SVI_QK_FUSED=0
         "gemm_qkv": fam("gemm_qkv", (3.0 if os.environ.get("SVI_QK_FUSED", "1") != "0" else 2.0) * Ls * D * D, "mfma",
-                        "q | k as one launch over the two weight matrices (4 L D^2 FLOP) + the V^T projection (2 L D^2)"),
-        "gemm_attn_out": fam("gemm_attn_out", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch, gate + residual epilogue"),
-        "gemm_cross": fam("gemm_cross", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch (cross-attention q and o; cached prompt K / V excluded)"),
-        "gemm_ffn1": fam("gemm_ffn1", 2.0 * Ls * D * F, "mfma", "2 L D F FLOP per launch, GELU-tanh epilogue"),
-        "gemm_ffn2": fam("gemm_ffn2", 2.0 * Ls * D * F, "mfma", "2 L D F FLOP per launch, gate + residual epilogue"),
-        "ln_modulate": fam("ln_modulate", 4.0 * Ls * D, "hbm", "2 L D bf16 read + written per launch"),
+                        "q | k as one launch over the two weight matrices (4 L D^2 FLOP) + the V^T projection (2 L D^2)", third="self"),
+        "gemm_attn_out": fam("gemm_attn_out", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch, gate + residual epilogue", third="self"),
+        "gemm_cross": fam("gemm_cross", 2.0 * Ls * D * D, "mfma", "2 L D^2 FLOP per launch (cross-attention q and o; cached prompt K / V excluded)", third="rest"),
+        "gemm_ffn1": fam("gemm_ffn1", 2.0 * Ls * D * F, "mfma", "2 L D F FLOP per launch, GELU-tanh epilogue", third="rest"),
+        "gemm_ffn2": fam("gemm_ffn2", 2.0 * Ls * D * F, "mfma", "2 L D F FLOP per launch, gate + residual epilogue", third="rest"),
+        "ln_modulate": fam("ln_modulate", 4.0 * Ls * D, "hbm", "2 L D bf16 read + written per launch", third="ln"),
         # q|k launch: [L, 2D] read + written; cross-attention q launch: [L, D] read + written -> mean of the two launch kinds per block
         # two launch kinds under one tag: the cross-attention q launch ([L, D] read + written, once per block and forward) and the q|k launch
         # ([L, 2D] read + written: every other launch of the tag)
         "rmsnorm_rope": fam("rmsnorm_rope", None, "hbm", "q|k launches: 8 L D bytes read + written, cross-attention q launches: 4 L D",
-                            total_fn=lambda n: 4.0 * Ls * D * min(n, NL * (1 if pair else 2)) + 8.0 * Ls * D * max(0.0, n - NL * (1 if pair else 2))),
+                            total_fn=(lambda n: 4.0 * Ls * D * R_eq + 8.0 * Ls * D * S_eq) if stacked else
+                            (lambda n: 4.0 * Ls * D * min(n, NL * (1 if pair else 2)) + 8.0 * Ls * D * max(0.0, n - NL * (1 if pair else 2)))),
     }
     if vae_ms is not None and (T, H, W) == (21, 60, 104):
         vflop = 2.754e14                      # SURVEY 8d, measured by flop counter: fp32 FLOP of one 81f@480x832 decode
@@ -618,6 +630,7 @@ def main() -> None:
         "config": {"workload": wl["desc"], "step": (f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; the pose condition enters the conditional branch only, so the two "
                                                     "forwards share nothing) + CFG + Euler") if wl.get("pose") else
                    f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
+                   "cfg_pair_stacked": bool(stacked),       # behind the shared block-0 self-attention, every row-local kernel runs once over both branches' rows (2 L); bit-identical
                    "steps_per_clip": spc, "tokens": L, "clips_per_gpu": round(units / world, 4),
                    "parallelism": (f"one clip: {'cfg-pair x ' if pair else ''}sequence-parallel over {world} ranks" if args.seq_parallel else
                                    f"cfg-pair x{units} clips" if pair else f"clip-per-rank x{world}"),

@@ -6,12 +6,14 @@ set -u
 TAG=${1:-r1}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+if [ -z "${LINES_ONLY:-}" ]; then      # LINES_ONLY=1: only the bench lines (after a bench.py-only change on an already tested tree)
 rm -f gpurun_out/parity_report.jsonl
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gputests.log 2>&1
 tail -3 gpurun_out/${TAG}_gputests.log
 cp gpurun_out/parity_report.jsonl gpurun_out/${TAG}_parity_report.jsonl 2>/dev/null
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" > gpurun_out/${TAG}_smoke.log 2>&1
 tail -1 gpurun_out/${TAG}_smoke.log
+fi
 line() { # name, args...
   local name=$1; shift
   timeout 900 python bench.py "$@" 2> gpurun_out/${TAG}_bench_${name}.err | grep '"metric"' | tail -1 > gpurun_out/${TAG}_bench_${name}.json
