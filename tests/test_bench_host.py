@@ -99,3 +99,27 @@ print(float((got - ref).norm() / ref.norm()))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert float(r.stdout.strip().splitlines()[-1]) < 2e-5
+
+
+def test_committed_default_line_counts_stacked_launches_in_row_equivalents():
+    """The CFG pair is stacked at the C2 size: a row-local launch covers both branches' rows.  bench.py must count such families in L-row launch
+    equivalents (59 self-attention thirds + 60 rest-thirds per step), or their roofline fractions halve.  Checked on the committed driver-shaped line."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = os.path.join(root, "profiles", "r4z_bench_default.json")
+    if not os.path.exists(p):
+        import pytest
+        pytest.skip("no committed r4z line")
+    j = json.load(open(p))
+    assert j["config"]["cfg_pair_stacked"] is True and j["config"]["hip_graph"] is True
+    ra = j["roofline_all"]
+    want = {"gemm_qkv": 118, "gemm_attn_out": 59, "gemm_cross": 120, "gemm_ffn1": 60, "gemm_ffn2": 60, "ln_modulate": 179}
+    for k, n in want.items():
+        assert abs(ra[k]["launch_equivalents_per_step"] - n) < 0.01, (k, ra[k])
+        assert ra[k]["launches_per_step"] < n
+    assert 0.40 < ra["gemm_ffn1"]["frac"] < 0.60 and 0.45 < ra["gemm_ffn2"]["frac"] < 0.65 and 0.6 < ra["ln_modulate"]["frac"] < 0.9
+    r = j["roofline"]
+    assert r["traffic"] and r["mfma_busy_in_clock"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # the family sum is the step
+    assert abs(sum(j["kernel_ms_per_step"].values()) - j["ms_per_step"]) < 0.03 * j["ms_per_step"]
