@@ -6,7 +6,7 @@ oracle and never falls back to PyTorch math.
 """
 from . import _lib
 from .dit import WanDiT, model_fn_wan_talk_video, model_fn_wan_video
-from .ops import cfg3_step_, cfg_step_, flash_attention, layernorm_modulate, linear, rmsnorm_rope_
+from .ops import cfg3_step_, cfg_step_, flash_attention, fp8_attention, fp8_attention_enabled, layernorm_modulate, linear, rmsnorm_rope_
 from .pipeline import DenoiseLoop, generate_noise, install
 from .scheduler import FlowMatchScheduler
 from .vae import WanVideoVAE
@@ -17,5 +17,5 @@ from .encoders import WanImageEncoder, WanTextEncoder
 from . import checkpoint, lora, sequence_parallel
 from .stream import StreamLoop, u8_to_video, video_to_u8
 
-__all__ = ["WanDiT", "model_fn_wan_video", "model_fn_wan_talk_video", "cfg3_step_", "flash_attention", "layernorm_modulate", "rmsnorm_rope_", "linear",
+__all__ = ["WanDiT", "model_fn_wan_video", "model_fn_wan_talk_video", "cfg3_step_", "flash_attention", "fp8_attention", "fp8_attention_enabled", "layernorm_modulate", "rmsnorm_rope_", "linear",
            "cfg_step_", "DenoiseLoop", "generate_noise", "install", "FlowMatchScheduler", "WanVideoVAE", "condition_mask", "condition_video", "image_condition", "TeaCache", "PoseEmbedder", "WanTextEncoder", "WanImageEncoder", "StreamLoop", "video_to_u8", "u8_to_video", "_lib"]

@@ -40,6 +40,19 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads
     return out
 
 
+def fp8_attention(enable: bool = True) -> None:
+    """Opt-in, process-wide, NOT the reference's arithmetic: every long-sequence attention call (flash_attention above, the DiT's self-attention) quantises
+    Q and K to MX e4m3 and takes QK^T on the scaled fp8 matrix path; softmax and P·V stay as they are.  The reference's own dispatch offers this place to a
+    quantised-QK^T backend (models/wan_video_dit.py:116-147, SageAttention).  Same as SVI_ATTN_QK8=1 in the environment; loops that hold a captured step graph
+    re-capture.  Separately toleranced: tests/test_gpu_attn_qk8.py."""
+    L.set_switch("SVI_ATTN_QK8", 1 if enable else None)
+
+
+def fp8_attention_enabled() -> bool:
+    import os
+    return os.environ.get("SVI_ATTN_QK8", "0") not in ("", "0")
+
+
 def layernorm_modulate(x: torch.Tensor, eps: float = 1e-6, weight: Optional[torch.Tensor] = None,
                        bias: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
                        scale: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -83,3 +83,18 @@ def test_bench_knows_the_flag():
     import os
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
     assert '"--fp8-attn"' in src and 'SVI_ATTN_QK8' in src and "never the headline" in src
+
+
+def test_python_switch_is_the_environment_switch_and_moves_the_graph_key():
+    """svi_hip.fp8_attention() = SVI_ATTN_QK8 + a switch reload: off by default, and every flip moves the count captured step graphs are keyed on."""
+    import os
+    import svi_hip
+    from svi_hip import _lib as L
+    assert not svi_hip.fp8_attention_enabled()
+    e0, g0 = L.switch_epoch(), None
+    try:
+        svi_hip.fp8_attention(True)
+        assert os.environ.get("SVI_ATTN_QK8") == "1" and svi_hip.fp8_attention_enabled() and L.switch_epoch() == e0 + 1
+    finally:
+        svi_hip.fp8_attention(False)
+    assert "SVI_ATTN_QK8" not in os.environ and not svi_hip.fp8_attention_enabled() and L.switch_epoch() == e0 + 2
