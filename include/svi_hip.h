@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 8
+#define SVI_HIP_ABI_VERSION 9
 
 typedef enum {
     SVI_OK = 0,
@@ -154,6 +154,12 @@ svi_status svi_dit_forward_cfg_pair(svi_dit* h, const void* x, const float* time
  * pointer do not change while the cache is on; svi_dit_context_cache(h, 0), or binding a weight, drops all entries
  * (4 entries, least recently used first). */
 svi_status svi_dit_context_cache(svi_dit* h, int32_t enable);
+/* The rolling window's clip boundary (test_svi.py:424-476: every clip re-enters SVIVideoPipeline.__call__ with the next prompt): the caller has
+ * written the NEXT prompt's embedding (and CLIP feature) into the tensors a cache entry is keyed by; the entry is recomputed IN PLACE — projected
+ * context, identical-suffix summary, every block's cross-attention K / V^T (models/wan_video_dit.py:272-274) — in the buffers it already owns.
+ * No device address moves and svi_dit_generation does not, so a hipGraph of the step captured for the previous clip replays on the new prompt.
+ * Stream-ordered.  Without an entry for (context, clip_feature, Lc) it is a first fill (allocates; the generation moves). */
+svi_status svi_dit_context_refill(svi_dit* h, const void* context, const void* clip_feature, int32_t Lc, svi_stream stream);
 
 /* Sequence-parallel (Ulysses) pieces of one forward — SURVEY §8e axis 3; the reference's USP path: the token chunk / all_gather of
  * pipelines/svi_video.py:119-135 and the all-to-all attention of distributed/xdit_context_parallel.py.  A rank owns token rows

@@ -571,6 +571,26 @@ static svi_status run_block_self(svi_dit* h, int layer, bf16* X, const float* mo
     return block_attn_out(h, layer, X, w.Hb, modf, nb * L, st, nb);
 }
 
+// Block `layer`'s cross-attention K / V^T of one projected context (dit:272-274; with the CLIP branch also k_img / v_img, :289-291): what the
+// context cache keeps per entry.  CTX = [257 CLIP rows (has_image_input) | Lc text rows] x dim.
+static svi_status fill_block_kv(svi_dit* h, int layer, const bf16* CTX, int Lc, const CtxKV& kv, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const BlockW& b = h->blocks[layer];
+    Workspace& w = h->ws;
+    const int D = c.dim;
+    const int img = c.has_image_input ? 257 : 0;
+    const bf16* ctx_txt = CTX + (size_t)img * D;
+    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(ctx_txt, D, b.ca.k, kv.CK, D, Lc, D, D, SVI_EPI_BIAS, st)); }
+    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(kv.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, 1.0f, st)); }
+    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, kv.CVT, w.ldcvt, Lc, D, D, st)); }
+    if (img) {
+        SVI_TRY(linear(CTX, D, b.ca.k_img, kv.CKi, D, img, D, D, SVI_EPI_BIAS, st));
+        SVI_TRY(svi_launch_rmsnorm_rope(kv.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, 1.0f, st));
+        SVI_TRY(linear_transposed(CTX, D, b.ca.v_img, kv.CVTi, w.ldcvti, img, D, D, st));
+    }
+    return SVI_OK;
+}
+
 // Cross-attention and MLP thirds of a block.
 // nb > 1: X holds nb samples stacked (nb * L rows); sample s attends to its own context (CTXs[s], kvs[s]) — the conditional and the
 // unconditional prompt of a CFG step.  Row-local work (norms, projections, MLP) runs once over all rows.
@@ -591,20 +611,10 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
     for (int s = 0; s < nb; ++s) {
         const CtxKV& kv = kvs[s];
         const bf16* CTX = CTXs[s];
-        const bf16* ctx_txt = CTX + (size_t)img * D;
         const size_t ro = (size_t)s * L;
-        if (kv.compute) {
-            { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(ctx_txt, D, b.ca.k, kv.CK, D, Lc, D, D, SVI_EPI_BIAS, st)); }
-            { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(kv.CK, D, Lc, D, b.ca.norm_k, c.eps, nullptr, 1.0f, st)); }
-            { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_transposed(ctx_txt, D, b.ca.v, kv.CVT, w.ldcvt, Lc, D, D, st)); }
-        }
+        if (kv.compute) SVI_TRY(fill_block_kv(h, layer, CTX, Lc, kv, st));
         { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb + ro * D, D, L, Lc, H, 1, st, kv.tail)); }
         if (img) {
-            if (kv.compute) {
-                SVI_TRY(linear(CTX, D, b.ca.k_img, kv.CKi, D, img, D, D, SVI_EPI_BIAS, st));
-                SVI_TRY(svi_launch_rmsnorm_rope(kv.CKi, D, img, D, b.ca.norm_k_img, c.eps, nullptr, 1.0f, st));
-                SVI_TRY(linear_transposed(CTX, D, b.ca.v_img, kv.CVTi, w.ldcvti, img, D, D, st));
-            }
             SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CKi, D, kv.CVTi, w.ldcvti, w.A2 + ro * D, D, L, img, H, 1, st));
         }
     }
@@ -760,10 +770,28 @@ static svi_status stage_time(svi_dit* h, const float* timestep, hipStream_t st) 
     return SVI_OK;
 }
 
+// text_embedding(context) (and img_emb(clip_feature) in front of it) -> CTXp [257 | Lc rows, dim]; the identical-suffix summary -> tail.   svi_video.py:94-99
+static svi_status project_context(svi_dit* h, const bf16* context, const bf16* clip, int Lc, bf16* CTXp, int* tail, hipStream_t st) {
+    const svi_dit_config& c = h->cfg;
+    const int D = c.dim;
+    Workspace& w = h->ws;
+    const int img = c.has_image_input ? 257 : 0;
+    SVI_TRY(stage_ctx_tail(context, Lc, c.text_dim, tail, st));
+    SVI_TRY(linear(context, c.text_dim, h->text0, w.CTXH, D, Lc, D, c.text_dim, SVI_EPI_BIAS_GELU_TANH, st));
+    SVI_TRY(linear(w.CTXH, D, h->text2, CTXp + (size_t)img * D, D, Lc, D, D, SVI_EPI_BIAS, st));
+    if (img) {
+        SVI_REQUIRE(clip, "has_image_input model needs clip_feature");
+        SVI_TRY(svi_launch_ln_mod(clip, 1280, w.IMG0, 1280, 257, 1280, 1e-5f, h->img_ln0_w, h->img_ln0_b, nullptr, nullptr, st));
+        SVI_TRY(linear(w.IMG0, 1280, h->img1, w.IMG1, 1280, 257, 1280, 1280, SVI_EPI_BIAS_GELU_ERF, st));
+        SVI_TRY(linear(w.IMG1, 1280, h->img3, w.IMGD, D, 257, D, 1280, SVI_EPI_BIAS, st));      // own [264, D] rows: Hb holds only L rows (L < 257 on tiny grids / shards)
+        SVI_TRY(svi_launch_ln_mod(w.IMGD, D, CTXp, D, 257, D, 1e-5f, h->img_ln4_w, h->img_ln4_b, nullptr, nullptr, st));
+    }
+    return SVI_OK;
+}
+
 // text (and CLIP image) context: projected here or taken from the context cache      svi_video.py:94-99
 static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* clip, const bf16* y, int Lc, CtxUse* use, hipStream_t st) {
     const svi_dit_config& c = h->cfg;
-    const int D = c.dim;
     Workspace& w = h->ws;
     const int img = c.has_image_input ? 257 : 0;
     CtxEntry* ce = nullptr;
@@ -801,20 +829,8 @@ static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* cli
         ce->stamp = ++h->ctx_clock;
     }
     bf16* CTXp = ce ? ce->CTX : w.CTX;
-    if (ctx_compute) {
-        SVI_TRY(stage_ctx_tail(context, Lc, c.text_dim, ce ? ce->tail : w.tail, st));
-        SVI_TRY(linear(context, c.text_dim, h->text0, w.CTXH, D, Lc, D, c.text_dim, SVI_EPI_BIAS_GELU_TANH, st));
-        SVI_TRY(linear(w.CTXH, D, h->text2, CTXp + (size_t)img * D, D, Lc, D, D, SVI_EPI_BIAS, st));
-        if (img) {
-            SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
-            SVI_TRY(svi_launch_ln_mod(clip, 1280, w.IMG0, 1280, 257, 1280, 1e-5f, h->img_ln0_w, h->img_ln0_b, nullptr, nullptr, st));
-            SVI_TRY(linear(w.IMG0, 1280, h->img1, w.IMG1, 1280, 257, 1280, 1280, SVI_EPI_BIAS_GELU_ERF, st));
-            SVI_TRY(linear(w.IMG1, 1280, h->img3, w.IMGD, D, 257, D, 1280, SVI_EPI_BIAS, st));      // own [264, D] rows: Hb holds only L rows (L < 257 on tiny grids / shards)
-            SVI_TRY(svi_launch_ln_mod(w.IMGD, D, CTXp, D, 257, D, 1e-5f, h->img_ln4_w, h->img_ln4_b, nullptr, nullptr, st));
-        }
-    } else if (img) {
-        SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
-    }
+    if (img) SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
+    if (ctx_compute) SVI_TRY(project_context(h, context, clip, Lc, CTXp, ce ? ce->tail : w.tail, st));
     use->ce = ce; use->CTXp = CTXp; use->compute = ctx_compute;
     return SVI_OK;
 }
@@ -1074,6 +1090,35 @@ extern "C" svi_status svi_dit_forward_cfg_pair(svi_dit* h, const void* x, const 
         bf16* oa = reinterpret_cast<bf16*>(out_cond) + b * (size_t)c.out_dim * thw;
         bf16* ob = reinterpret_cast<bf16*>(out_uncond) + b * (size_t)c.out_dim * thw;
         SVI_TRY(forward_pair(h, xb, timestep + b, ca, cbn, clb, yb, ab, oa, ob, T, H, W, Lc, st));
+    }
+    return SVI_OK;
+}
+
+// A rolling window hands the NEXT clip's prompt embedding (and CLIP feature) to the model in the SAME device tensors (the caller copied the new
+// values into them): the entry keyed by these pointers is recomputed IN PLACE — projected context, identical-suffix summary, every block's
+// cross-attention K / V^T — in the buffers it already owns.  No address moves and svi_dit_generation stays where it is, so a hipGraph of the step
+// captured for the previous clip (which reads exactly these buffers) replays on the new prompt.  Stream-ordered: enqueue it on the stream the
+// replays run on.  Without an entry for the key it is the first fill (allocation; the generation moves, as in a forward's miss).
+extern "C" svi_status svi_dit_context_refill(svi_dit* h, const void* context, const void* clip_feature, int32_t Lc, svi_stream stream) {
+    SVI_REQUIRE(h && context, "svi_dit_context_refill: null argument");
+    SVI_REQUIRE_DEVICE(h);
+    SVI_REQUIRE(h->ctx_cache_on, "svi_dit_context_refill: the context cache is off (svi_dit_context_cache(h, 1) first)");
+    SVI_REQUIRE(Lc > 0, "svi_dit_context_refill: bad context length %d", Lc);
+    const svi_dit_config& c = h->cfg;
+    SVI_REQUIRE(!c.has_image_input || clip_feature, "has_image_input model needs clip_feature");
+    SVI_TRY(svi_dit_check_bound(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bf16* ctx = reinterpret_cast<const bf16*>(context);
+    const bf16* clip = c.has_image_input ? reinterpret_cast<const bf16*>(clip_feature) : nullptr;
+    Workspace& w = h->ws;
+    if (!w.base || w.Lc != Lc) SVI_TRY(ensure_workspace(h, w.L > 0 ? w.L : 8, Lc, st));      // the projection's scratch rows (CTXH, IMG*) are laid out per Lc
+    CtxUse cu{};
+    SVI_TRY(stage_context(h, ctx, clip, /*y: only its presence is checked*/ ctx, Lc, &cu, st));
+    SVI_REQUIRE(cu.ce != nullptr, "svi_dit_context_refill: no cache entry");
+    if (!cu.compute) SVI_TRY(project_context(h, ctx, clip, Lc, cu.CTXp, cu.ce->tail, st));      // a hit: the same buffers, new contents
+    for (int l = 0; l < c.num_layers; ++l) {
+        CtxKV kv = kv_of(h, cu, l);
+        SVI_TRY(fill_block_kv(h, l, cu.CTXp, Lc, kv, st));
     }
     return SVI_OK;
 }

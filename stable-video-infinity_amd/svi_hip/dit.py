@@ -56,6 +56,12 @@ class PromptPins:
     def clear(self) -> None:
         self._pins = {}
 
+    def repin(self, tensors) -> None:
+        """The C-side entries of these tensors were just recomputed from their present contents (WanDiT.refill_context): record the versions."""
+        for t in tensors:
+            if t is not None:
+                self._pins[t.data_ptr()] = (t, _version(t), tuple(t.shape))
+
     def admit(self, tensors) -> bool:
         """Pin the prompt-side tensors of one call.  Returns True when the cache entries made so far are no longer trustworthy
         (a pinned tensor changed, or more prompts are in flight than are kept) — the caller then drops them; the tensors of this
@@ -107,6 +113,31 @@ class WanDiT:
         m = cls(**config_of_module(wan_model))
         m.bind(dict(wan_model.state_dict()))
         return m
+
+    def check_module_in_place(self, wan_model) -> None:
+        """The parameters of the nn.Module this handle borrows from must still be where they were bound: on the GPU, same storage.  A parameter
+        that moved ON the device (re-created by a loader, `.to()` to another GPU dtype and back) is re-bound; one that left the device, or a
+        module tree whose keys changed (VRAM-management wrappers rename them: `norm3.module.weight`), is refused — the kernels would
+        otherwise keep reading the stale copies this handle holds alive."""
+        sd = wan_model.state_dict()
+        moved = False
+        for name, p in sd.items():
+            bound = self._fp8_sources.get(name)
+            if bound is None:
+                bound = self._params.get(name)
+            if bound is None:
+                raise RuntimeError(f"svi_hip: pipe.dit's state dict now has the key {name!r}, which was not there at install() — modules were wrapped or "
+                                   "replaced (enable_vram_management?): call svi_hip.install(pipe) again")
+            if not p.is_cuda:
+                raise RuntimeError(f"svi_hip: parameter {name} of pipe.dit now lives on {p.device} — the DiT was offloaded after install(); the HIP backend "
+                                   "keeps it resident: call svi_hip.install(pipe) again (it moves the models back and neutralises the offload calls)")
+            if p.data_ptr() != bound.data_ptr() or p.dtype != bound.dtype:
+                moved = True
+        if len(sd) != len(self._params):
+            raise RuntimeError("svi_hip: pipe.dit lost parameters since install(): call svi_hip.install(pipe) again")
+        if moved:
+            self._fp8_sources = {}
+            self.bind({k: v for k, v in sd.items()})
 
     def bind(self, state_dict: Dict[str, torch.Tensor]) -> None:
         lib = L.lib()
@@ -185,6 +216,28 @@ class WanDiT:
         self._ctx_cache_on = bool(enable)
         self._ctx_pins.clear()
         self._epoch += 1
+
+    def refill_context(self, context: torch.Tensor, clip_feature: Optional[torch.Tensor] = None) -> None:
+        """The rolling window's clip boundary: `context` (and `clip_feature`) are tensors the context cache already knows, and the caller has
+        just written the NEXT clip's prompt embedding (CLIP feature) into them in place.  The cache entry keyed by their addresses is recomputed
+        in the buffers it owns (svi_dit_context_refill: projected context, every block's cross-attention K / V^T); nothing moves, so a captured
+        step graph that reads those buffers stays valid (epoch() and generation() do not change) and the pins take the tensors' new versions."""
+        if not self._ctx_cache_on:
+            raise RuntimeError("refill_context: the context cache is off")
+        if not self.has_image_input:
+            clip_feature = None
+        for t in (context, clip_feature):
+            if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous()):
+                raise ValueError("refill_context: context / clip_feature must be contiguous CUDA bf16 tensors")
+        if context.dim() != 3 or context.shape[2] != self.text_dim:
+            raise ValueError(f"refill_context: context must be [B, Lc, {self.text_dim}] (got {tuple(context.shape)})")
+        self._refresh_if_weights_changed()
+        B, Lc = context.shape[0], context.shape[1]
+        for b in range(B):          # the entries are keyed per sample (svi_dit_forward walks the batch with these offsets)
+            cp = context.data_ptr() + b * Lc * self.text_dim * 2
+            fp = None if clip_feature is None else clip_feature.data_ptr() + b * 257 * 1280 * 2
+            L.check(L.lib().svi_dit_context_refill(self._h, cp, fp, Lc, L.current_stream()), "svi_dit_context_refill")
+        self._ctx_pins.repin([context, clip_feature])
 
     def _prompt_args(self, *tensors):
         """The prompt-side inputs (context(s), clip_feature) as contiguous bf16; see context_cache()."""

@@ -48,7 +48,7 @@ class StreamLoop:
         test_svi.py passes args.tiled, default False).  The conditioning encode is never tiled, as in the reference (:350)."""
         if num_motion_frames < 1:
             raise ValueError("an image-conditioned stream hands at least one motion frame from clip to clip (test_svi.py:472-476)")
-        self.loop = DenoiseLoop(dit)
+        self.loop = DenoiseLoop(dit, resident=True)      # every clip of the stream replays the step graph the first one captured
         self.vae, self.clip_encoder = vae, clip_encoder
         self.num_motion_frames, self.num_frames = num_motion_frames, num_frames
         self.steps, self.cfg_scale, self.sigma_shift = num_inference_steps, cfg_scale, sigma_shift
@@ -72,7 +72,17 @@ class StreamLoop:
         tlat = (self.num_frames - 1) // 4 + 1
         pieces = []
         self.trace = []
-        for k in range(start_clip, num_clips):
+        cache_was_on = self.loop.dit._ctx_cache_on
+        try:
+            self._clips(range(start_clip, num_clips), num_clips, motion, ref, prompts, prompt_repeat_times, use_first_prompt_only, clip_feature, pieces, H, W, tlat)
+        finally:
+            if not cache_was_on:
+                self.loop.close()      # the resident loop keeps the context cache on from clip to clip; hand the model back as it came
+        return torch.cat(pieces, dim=0)
+
+    def _clips(self, clips, num_clips, motion, ref, prompts, prompt_repeat_times, use_first_prompt_only, clip_feature, pieces, H, W, tlat) -> None:
+        from .parallel import clip_prompt_index, clip_seed
+        for k in clips:
             first = u8_to_video(motion)                                          # preprocess_image of every motion frame
             y = image_condition(self.vae, first, ref, self.num_frames, self.ref_pad_cfg, self.ref_pad_num)
             if self.clip_encoder is None:
@@ -94,4 +104,3 @@ class StreamLoop:
             self.trace.append(dict(clip=k, seed=seed, motion=motion, y=y, latents=lat, frames=frames))
             motion = frames[-self.num_motion_frames:]
             pieces.append(frames[:-self.num_motion_frames] if k < num_clips - 1 else frames)
-        return torch.cat(pieces, dim=0)

@@ -480,6 +480,61 @@ def gen_c2_full(dit_mod):
              out_fp32_norm=np.float64(o32.double().norm().item()), full_rel_bf16_vs_fp32=np.float64(((o16 - o32).double().norm() / o32.double().norm()).item()))
 
 
+def gen_c2_loop(dit_mod, fm):
+    """The LOOP at the headline size: a 2-step CFG-5 flow-match loop (svi_video.py:392-421: cond forward, uncond forward,
+    u + 5 (c - u), scheduler.step) of the reference's 30-layer 1.3B WanModel on the full C2 latent [1,16,21,60,104] = 32760 tokens: 4 forwards
+    in fp32 and 4 in bf16 (the way the pipelines run it).  Weights, noise and the positive prompt are dit_c2_full.npz's; the negative prompt has
+    32 valid rows (so the two branches walk different key counts).  Final latents kept on the stride-3 (h, w) lattice."""
+    import time
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    f, h, w = synth.C2_GRID
+    k = synth.C2_FULL_STRIDE
+    t0 = time.time()
+    m = build_ref_dit(dit_mod, cfg, seed)
+    print(f"c2_loop: reference WanModel 1.3B built in {time.time() - t0:.0f} s", flush=True)
+    noise = torch.randn((1, 16, f, 2 * h, 2 * w), generator=torch.Generator("cpu").manual_seed(2), dtype=torch.float32)
+    pos = t(synth.text_context(seed + 1, 512, cfg["text_dim"], 64))
+    neg = t(synth.text_context(seed + 2, 512, cfg["text_dim"], 32))
+
+    def loop(model, lat, pos, neg, tag):
+        s = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        s.set_timesteps(synth.C2_LOOP_STEPS, shift=5.0)
+        with torch.no_grad():
+            for i, ts in enumerate(s.timesteps):
+                tt = ts.unsqueeze(0)
+                t1 = time.time()
+                c = model(lat, tt, pos)
+                u = model(lat, tt, neg)
+                lat = s.step(u + 5.0 * (c - u), s.timesteps[i], lat)
+                print(f"c2_loop: {tag} step {i} {time.time() - t1:.0f} s", flush=True)
+        return lat
+
+    l32 = loop(m, noise, pos, neg, "fp32")[0]
+    np.savez(os.path.join(OUT, "dit_c2_loop.npz"), lat_fp32=l32[:, :, ::k, ::k].contiguous().numpy())          # kept in case the bf16 pass dies
+    mb = m.to(torch.bfloat16)
+    l16 = loop(mb, noise.to(torch.bfloat16), pos.to(torch.bfloat16), neg.to(torch.bfloat16), "bf16")[0].float()
+    np.savez(os.path.join(OUT, "dit_c2_loop.npz"), lat_fp32=l32[:, :, ::k, ::k].contiguous().numpy(),
+             lat_bf16_bits=synth.bf16_bits(l16[:, :, ::k, ::k].contiguous().numpy()),
+             lat_fp32_norm=np.float64(l32.double().norm().item()), full_rel_bf16_vs_fp32=np.float64(((l16 - l32).double().norm() / l32.double().norm()).item()))
+
+
+def gen_vae_c2_full(vae_mod):
+    """The whole 81-frame decode at the headline size against the reference (frames 6..81 were pinned by causality only):
+    WanVideoVAE.decode (wan_video_vae.py:777-789) of the 21-latent-frame tensor tests/test_gpu_configs.py builds (seeds 511 | 513); kept:
+    frames 40..44 and 76..80 on the stride-7 pixel lattice."""
+    import time
+    v = vae_mod.WanVideoVAE()
+    v.load_state_dict({k: t(a) for k, a in synth.vae_state_dict(500).items()}, strict=True)
+    k = synth.C2_VIDEO_STRIDE
+    z21 = torch.cat([t(synth.randn(511, 16, 2, 60, 104)), t(synth.randn(513, 16, 19, 60, 104))], dim=1)
+    t0 = time.time()
+    with torch.no_grad():
+        video = v.decode([z21], device="cpu")[0]                                       # [3,81,480,832]
+    print(f"vae_c2_full: reference decode of 21 latent frames {time.time() - t0:.0f} s", flush=True)
+    assert tuple(video.shape) == (3, 81, 480, 832)
+    np.savez(os.path.join(OUT, "vae_c2_full.npz"), mid=video[:, 40:45, ::k, ::k].contiguous().numpy(), tail=video[:, 76:81, ::k, ::k].contiguous().numpy())
+
+
 def gen_vae_tiled(vae_mod):
     """WanVideoVAE.tiled_decode / tiled_encode (wan_video_vae.py:643-744) on multi-tile problems, through the public
     decode/encode(tiled=True): 3x3 and ragged tile grids, including tile values beyond +-1 before the blend's final clamp."""
@@ -868,6 +923,8 @@ def main(argv=None):
         "dit_block_c2": lambda: gen_block_c2(dit_mod),
         "dit_block_14b_c2": lambda: gen_block_14b_c2(dit_mod),
         "dit_c2_full": lambda: gen_c2_full(dit_mod),
+        "dit_c2_loop": lambda: gen_c2_loop(dit_mod, fm),
+        "vae_c2_full": lambda: gen_vae_c2_full(vae_mod),
     }
     names = list(argv if argv is not None else sys.argv[1:]) or list(jobs)
     for n in names:

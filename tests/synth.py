@@ -232,6 +232,7 @@ DEPTH_GRID, DEPTH_STEPS = (5, 30, 52), 2     # golden/dit_depth.npz: the 30-laye
                                              # attention kernel and the 256^2 GEMM), one forward + a 2-step CFG loop
 C2_GRID = (21, 30, 52)                       # BASELINE configs[1]: 81 frames at 832x480 -> latent [16,21,60,104] -> 32760 tokens
 B13C2_SEED, B14C2_SEED = 970, 980            # golden/dit_block_c2.npz / dit_block_14b_c2.npz: ONE reference DiTBlock (1.3B / 14B-I2V widths) at L = 32760
+C2_LOOP_STEPS = 2                            # golden/dit_c2_loop.npz: a 2-step CFG loop of the same model on the same latent
 C2_FULL_STRIDE = 3                           # golden/dit_c2_full.npz: the reference's 30-layer 1.3B forward at C2 (C1_SEED weights), output kept on a stride-3 (h, w) lattice
 C4_SEED, C4_LAYERS = 960, 4                  # golden/dit_c4_4blocks.npz: 4 of the 40 blocks of Wan2.1-I2V-14B end to end (in_dim-36 patchify, img_emb, head) on B14_GRID
 

@@ -41,3 +41,15 @@ def test_gpus_n_refuses_when_the_devices_are_not_there():
 def test_world_size_mismatch_is_refused():
     r = run(["--gpus", "2", "--launcher-selftest"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_a_rank_that_never_joins_is_named_and_the_run_fails():
+    """8-GPU preflight: the first multi-GPU run of bench.py will be unattended.  A rank that never enters a collective must turn
+    into a non-zero exit whose stderr names it — not a silent hang until the driver's own limit.  Rank 1 of 2 sleeps in front of the join; rank 0's
+    watchdog fires after --rank-timeout, reads every rank's last stage and names rank 1."""
+    r = run(["--gpus", "2", "--launcher-selftest", "--selftest-hang-rank", "1", "--rank-timeout", "4"], timeout=180)
+    assert r.returncode != 0
+    assert "made no progress" in r.stderr and "rank 1" in r.stderr.split("furthest behind:")[-1]
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+    # every rank left its heartbeat lines
+    assert "bench.py[rank 0/2" in r.stderr and "bench.py[rank 1/2" in r.stderr

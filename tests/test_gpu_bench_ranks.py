@@ -17,9 +17,9 @@ pytestmark = pytest.mark.gpu
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def run(args, timeout=900):
+def run(args, timeout=900, vae=False):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, BENCH, *args, "--transport", "gloo", "--workload", "c1", "--steps", "2", "--warmup", "1", "--no-vae", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, BENCH, *args, "--transport", "gloo", "--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + ([] if vae else ["--no-vae"]),
                        env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -53,3 +53,32 @@ def test_cfg_pair_times_sequence_parallel_four_ranks():
     common(line, 4)
     assert line["scaling"] == "strong" and "sequence-parallel over 4 ranks" in line["config"]["parallelism"]
     assert abs(line["value"] - 1 * 5 / (10 * line["ms_per_step"] / 1000.0)) < 1e-3 * line["value"]
+
+
+def test_rolling_window_and_full_clips_two_ranks():
+    """BASELINE configs[2] as bench.py runs it (--window K): 3 clips over 2 ranks (clip k -> rank k mod 2), each denoised, decoded and turned into
+    8-bit frames, the frames all-gathered and the window stitched (every clip but the last loses its motion frame); `value` is the window's frames
+    per second of wall clock.  The resident loop captures its step graph once per rank; the A/B against re-capturing per clip gives the same video.
+    Beside it the two timed complete clips (config.full_clip_s / full_clip_steady_s)."""
+    line = run(["--gpus", "2", "--window", "3", "--window-ab"], vae=True)
+    common(line, 2)
+    w = line["config"]["window"]
+    assert w["resident"]["clips"] == 3 and w["resident"]["clips_this_rank"] == 2 and w["resident"]["stitched_frames"] == 16 * 2 + 17
+    assert w["resident"]["captures"] == 1 and w["recapture_per_clip"]["captures"] == 2 and w["same_video"] is True
+    assert abs(line["value"] - 3 * 5 / w["resident"]["wall_s"]) < 1e-3 * line["value"]
+    assert "rolling window of 3 clips" in line["config"]["workload"]
+    c = line["config"]
+    assert c["full_clip_s"] > 0 and c["full_clip_steady_s"] > 0 and c["full_clip_breakdown"]["step_graph_captures_over_both_clips"] == 1
+    assert abs(c["value_full_clip"] - 2 * 5 / c["full_clip_s"]) < 1e-3 * c["value_full_clip"]
+
+
+def test_full_clip_single_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, "--workload", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = line["config"]
+    assert line["n_gpus"] == 1 and c["hip_graph"] is True and c["window"] is None
+    assert c["full_clip_s"] > c["full_clip_steady_s"] * 0.5 and c["full_clip_breakdown"]["step_graph_captures_over_both_clips"] == 1
+    # the steady clip is the extrapolation's twin: 10 replayed steps + decode (+ 8-bit frames, input copies); generous bound on the tiny workload
+    assert 0.8 < c["full_clip_steady_vs_extrapolated"] < 2.0, c

@@ -317,6 +317,83 @@ def test_first_graphed_step_and_stream_buffer_release(hip):
 
 
 @pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
+def test_context_refill_recomputes_an_entry_in_place(hip, name):
+    """svi_dit_context_refill (the rolling window's clip boundary): the next prompt (and CLIP feature) is written INTO the tensors a cache entry is
+    keyed by; the entry is recomputed where it stands — same bits as an uncached forward on the new values, and neither epoch() nor generation()
+    moves (a captured step graph stays valid)."""
+    c, grid, nt, nv, ts, seed = CASES[name]
+    m, _ = build(hip, c, seed)
+    x, ctx, kw = inputs(c, grid, nt, nv, seed)
+    xd, t = dev(x), torch.tensor([ts])
+    kwd = {k: dev(v) for k, v in kw.items()}
+    ctx_a, ctx_b = dev(ctx), dev(torch.from_numpy(synth.randn(seed + 301, *ctx.shape)))
+    ctx_b[:, nv - 2:] = 0                                  # another identical-suffix length: the tail summary must be recomputed too
+    kwb = dict(kwd)
+    if "clip_feature" in kwd:
+        kwb["clip_feature"] = dev(torch.from_numpy(synth.randn(seed + 302, *kw["clip_feature"].shape)))
+    want_a = m.forward(xd, t, ctx_a, **kwd).clone()
+    want_b = m.forward(xd, t, ctx_b, **kwb).clone()
+    assert not torch.equal(want_a, want_b)
+    m.context_cache(True)
+    try:
+        slot, slot_kw = ctx_a.clone(), {k: v.clone() for k, v in kwd.items()}
+        assert torch.equal(m.forward(xd, t, slot, **slot_kw), want_a)
+        assert torch.equal(m.forward(xd, t, slot, **slot_kw), want_a)          # a hit
+        e0, g0 = m.epoch(), m.generation()
+        slot.copy_(ctx_b)
+        if "clip_feature" in slot_kw:
+            slot_kw["clip_feature"].copy_(kwb["clip_feature"])
+        m.refill_context(slot, slot_kw.get("clip_feature"))
+        assert (m.epoch(), m.generation()) == (e0, g0)
+        assert torch.equal(m.forward(xd, t, slot, **slot_kw), want_b)          # served from the refilled entry
+        assert (m.epoch(), m.generation()) == (e0, g0)
+        slot.copy_(ctx_a)                                                      # an in-place write WITHOUT a refill is still caught (pins): never stale
+        if "clip_feature" in slot_kw:
+            slot_kw["clip_feature"].copy_(kwd["clip_feature"])
+        assert torch.equal(m.forward(xd, t, slot, **slot_kw), want_a)
+    finally:
+        m.context_cache(False)
+
+
+@pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
+def test_resident_loop_replays_one_graph_across_clips(hip, name):
+    """DenoiseLoop(resident=True): the loop owns the clip's device tensors, every clip's inputs are copied in, prompt entries are refilled in place, and
+    the step graph captured by the first clip is what every later clip of the same shapes replays — no eager step, no re-capture.  Same bits as the
+    eager loop for every clip; a clip of another shape captures anew; results do not alias the loop's tensors."""
+    c, grid, nt, nv, ts, seed = CASES[name]
+    f, h, w = grid
+    m, _ = build(hip, c, seed)
+    _, ctx, kw = inputs(c, grid, nt, nv, seed)
+    loop = hip.DenoiseLoop(m, resident=True)
+    eager = hip.DenoiseLoop(m, graph=False)
+    assert loop.resident and loop.graph
+    neg = dev(-np.asarray(ctx))
+
+    def clip_inputs(clip):
+        lat = dev(hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=60 + clip, device="cpu", dtype=torch.float32))
+        cp = dev(np.asarray(ctx) * (1.0 + 0.25 * (clip % 3)))                   # a new prompt tensor per clip; the negative prompt is one tensor throughout
+        return lat, cp, {k: dev(np.asarray(v) * (1.0 + 0.1 * clip)) for k, v in kw.items()}
+    wants = []
+    for clip in range(4):
+        lat, cp, kwd = clip_inputs(clip)
+        wants.append(eager.sample(lat, cp, neg, num_inference_steps=3, cfg_scale=5.0, **kwd))
+    lat2 = dev(hip.generate_noise((1, 16, f, 4 * h, 2 * w), seed=70, device="cpu", dtype=torch.float32))
+    kw2 = {k: (dev(synth.randn(seed + 9, 1, v.shape[1], f, 4 * h, 2 * w)) if k == "y" else dev(v)) for k, v in kw.items()}
+    want2 = eager.sample(lat2, dev(ctx), neg, num_inference_steps=2, cfg_scale=5.0, **kw2)
+    gots = []
+    for clip in range(4):
+        lat, cp, kwd = clip_inputs(clip)
+        gots.append(loop.sample(lat, cp, neg, num_inference_steps=3, cfg_scale=5.0, **kwd))
+        assert m._ctx_cache_on and torch.equal(gots[-1], wants[clip]), clip
+        del lat, cp, kwd
+    assert loop.captures == 1
+    assert all(torch.equal(g, w) for g, w in zip(gots, wants))  # earlier results were not overwritten by later clips
+    assert torch.equal(loop.sample(lat2, dev(ctx), neg, num_inference_steps=2, cfg_scale=5.0, **kw2), want2) and loop.captures == 2
+    loop.close()
+    assert not m._ctx_cache_on
+
+
+@pytest.mark.parametrize("name", ["tiny_t2v", "tiny_i2v"])
 def test_identical_trailing_context_rows_count_as_one_key(hip, name):
     """The prompter zero-fills a prompt embedding past the prompt's tokens and cross-attention attends to all rows without a mask:
     identical input rows -> identical K / V rows -> one key counted m times (csrc/svi_dit.hip ctx_tail_*).  (i) with a zero-padded

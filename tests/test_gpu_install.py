@@ -326,5 +326,58 @@ def test_install_sampler_is_the_denoise_loop_and_keeps_the_reference_bits(name, 
         a_t = (posi, nega, img, {}, {"tea_cache": tp}, {"tea_cache": tn}, {}, False, {"text": scale}, lambda it: it)
         a_s = (posi, nega, img, {}, {"tea_cache": sp}, {"tea_cache": sn}, {}, False, {"text": scale}, lambda it: it)
         assert torch.equal(fast_pipe._sample_with_regular_video(lat, *a_t), slow_pipe._sample_with_regular_video(lat, *a_s))
+        # the rolling window's next clips (test_svi.py:424-476 re-enters __call__ per clip): new latents / prompt tensors each time, the reference loop's bits
+        # each time — and the installed sampler's resident loop replays the step graph it captured once (DenoiseLoop.adopt)
+        loop = fast_pipe._svi_hip_loop
+        assert loop.resident
+        caps = loop.captures
+        wants = []
+        clips = [(dev(np.asarray(x) * (0.5 + 0.25 * k)), {"context": dev(np.asarray(ctx) * (0.7 + 0.1 * k))}) for k in range(3)]
+        for lat_k, posi_k in clips:
+            wants.append(slow_pipe._sample_with_regular_video(lat_k, posi_k, *args[1:]))
+        fast_pipe._sample_with_regular_video(clips[0][0], clips[0][1], *args[1:])          # (the slow calls above went through the same handle: re-establish the graph)
+        caps = loop.captures
+        for (lat_k, posi_k), want in zip(clips, wants):
+            assert torch.equal(fast_pipe._sample_with_regular_video(lat_k, posi_k, *args[1:]), want)
+        assert loop.captures == caps                         # three clips, no capture
     finally:
         del sys.modules[modname]
+
+
+def test_install_refuses_offload_behind_its_back_and_rebinds_moved_parameters(pipeline_module):
+    """install() borrows the DiT's parameters by pointer.  A parameter that is re-created on the device after install() (a loader, a dtype round trip)
+    is re-bound at the next clip; one that left the device — `pipe.dit.cpu()`, the offload machinery — is refused with a RuntimeError, never computed on
+    a stale copy.  enable_vram_management / enable_cpu_offload on the installed pipeline are no-ops."""
+    import svi_hip
+    from svi_hip import pipeline
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    dit, sd = wan_model_double(c, seed)
+    pipe = pipeline_module.SVIVideoPipeline(dit, None)
+    pipe.cpu_offload = True                                  # as after the reference's enable_vram_management (svi_video.py:241)
+    pipe.enable_cpu_offload = types.MethodType(lambda self: setattr(self, "cpu_offload", True), pipe)
+    pipe.enable_vram_management = types.MethodType(lambda self, num_persistent_param_in_dit=None: self.enable_cpu_offload(), pipe)
+    svi_hip.install(pipe, vae=False)
+    assert pipe.cpu_offload is False
+    pipe.enable_vram_management(num_persistent_param_in_dit=6 * 10 ** 9)       # test_svi.py:351 after install(): nothing happens
+    pipe.enable_cpu_offload()
+    assert pipe.cpu_offload is False
+    hip = pipe._svi_hip_dit
+    pipeline._assert_resident(pipe, hip, full=True)
+    x, ctx, _ = inputs(c, grid, nt, nv, seed)
+    lat, t, cd = dev(x), torch.tensor([ts], device="cuda"), dev(ctx)
+    before = pipeline_module.model_fn_wan_video(dit, lat, timestep=t, context=cd).clone()
+    # a parameter re-created on the device: picked up (the new values are what the next clip computes with)
+    w = dit.blocks[0].ffn._modules["0"].weight
+    dit.blocks[0].ffn._modules["0"].weight = torch.nn.Parameter((w.data * 0.5).clone(), requires_grad=False)
+    pipeline._assert_resident(pipe, hip, full=True)
+    after = pipeline_module.model_fn_wan_video(dit, lat, timestep=t, context=cd)
+    direct = svi_hip.WanDiT.from_state_dict(dict(dit.state_dict()), eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    assert not torch.equal(after, before) and torch.equal(after, direct.forward(lat, t, cd))
+    # a parameter that left the device: refused
+    dit.blocks[0].ffn._modules["0"].weight = torch.nn.Parameter(w.data.cpu(), requires_grad=False)
+    with pytest.raises(RuntimeError, match="offloaded after install"):
+        pipeline._assert_resident(pipe, hip, full=True)
+    dit.blocks[0].ffn._modules["0"].weight = torch.nn.Parameter(w.data.clone(), requires_grad=False)
+    pipe.cpu_offload = True                                  # the flag alone (the class's own enable_cpu_offload reached around the rebind)
+    with pytest.raises(RuntimeError, match="install"):
+        pipeline._assert_resident(pipe, hip)

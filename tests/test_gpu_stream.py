@@ -48,6 +48,8 @@ def test_stream_loop_composition(n_motion):
     video = sl.run(img, ref, prompts, CLIPS)
     assert video.dtype == torch.uint8 and tuple(video.shape) == ((NF - n_motion) * (CLIPS - 1) + NF, H, W, 3)
     tr = sl.trace
+    assert sl.loop.resident and sl.loop.captures == 1                                        # three clips, ONE captured step graph (replayed by clips 2 and 3)
+    assert not dit._ctx_cache_on                                                             # the model comes back as it was handed in
     assert [t["seed"] for t in tr] == [0, 42, 84]                                            # seed = chunk_idx * seed_times
     assert torch.equal(tr[0]["motion"].cpu(), img)
     refv = svi_hip.u8_to_video(ref[None].cuda())[0]

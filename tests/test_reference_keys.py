@@ -344,3 +344,105 @@ def test_two_speaker_audio_routing_is_unreachable_in_the_reference():
     for f in glob.glob(os.path.join(REF, "diffsynth", "pipelines", "*.py")) + glob.glob(os.path.join(REF, "*.py")):
         src = open(f).read()
         assert "human_num" not in src and "ref_target_masks" not in src, f
+
+
+# ---------------------------------------------------------------------------------------------------------------- offload neutralised
+def _compiled_offload_pipeline(ref, name="svi_video_offload"):
+    """A pipeline class made of the reference's OWN sources — SVIVideoPipeline.enable_vram_management (svi_video.py:156-241) and BasePipeline's
+    enable_cpu_offload (base.py:105-106), compiled with ast, nothing retyped — over the real wrapper classes of vram_management/layers.py."""
+    import ast
+    import importlib
+    import sys
+    import types
+    dit_mod, vae_mod, _ = ref
+    vm = importlib.import_module("diffsynth.vram_management")
+    te = importlib.import_module("diffsynth.models.wan_video_text_encoder")
+    tree = ast.parse(open(os.path.join(REF, "diffsynth/pipelines/svi_video.py")).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "SVIVideoPipeline")
+    evm = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "enable_vram_management")
+    base = ast.parse(open(os.path.join(REF, "diffsynth/pipelines/base.py")).read())
+    bcls = next(n for n in base.body if isinstance(n, ast.ClassDef) and n.name == "BasePipeline")
+    eco = next(n for n in bcls.body if isinstance(n, ast.FunctionDef) and n.name == "enable_cpu_offload")
+    mod_ast = ast.Module(body=[ast.ClassDef(name="SVIVideoPipeline", bases=[], keywords=[], body=[evm, eco], decorator_list=[])], type_ignores=[])
+    ast.fix_missing_locations(mod_ast)
+    mod = types.ModuleType(name)
+    sys.modules[name] = mod
+    mod.__dict__.update(torch=torch, enable_vram_management=vm.enable_vram_management, AutoWrappedModule=vm.AutoWrappedModule,
+                        AutoWrappedLinear=vm.AutoWrappedLinear, T5RelativeEmbedding=te.T5RelativeEmbedding, T5LayerNorm=te.T5LayerNorm,
+                        RMSNorm=dit_mod.RMSNorm, RMS_norm=vae_mod.RMS_norm, CausalConv3d=vae_mod.CausalConv3d, Upsample=vae_mod.Upsample)
+    exec(compile(mod_ast, name + ".py", "exec"), mod.__dict__)
+    mod.SVIVideoPipeline.__module__ = name
+    return mod, vm
+
+
+def _offload_pipe(ref, mod):
+    dit_mod, vae_mod, _ = ref
+    te = __import__("importlib").import_module("diffsynth.models.wan_video_text_encoder")
+    c = synth.TINY_DIT
+    pipe = mod.SVIVideoPipeline.__new__(mod.SVIVideoPipeline)
+    pipe.device, pipe.torch_dtype, pipe.cpu_offload = "cpu", torch.bfloat16, False
+    pipe.dit = dit_mod.WanModel(eps=1e-6, num_heads=synth.num_heads_of(c), **c).to(torch.bfloat16)
+    pipe.text_encoder = te.WanTextEncoder(vocab=64, dim=32, dim_attn=32, dim_ffn=64, num_heads=2, num_layers=1, num_buckets=8).to(torch.bfloat16)
+    pipe.vae = vae_mod.WanVideoVAE()
+    pipe.image_encoder = None
+    return pipe
+
+
+def test_enable_vram_management_is_harmless_before_and_after_install(ref, capsys):
+    """test_svi.py:316-351 ends in `pipe.enable_vram_management(num_persistent_param_in_dit=args.num_persistent_param_in_dit)` — called
+    unconditionally.  The residency half of install() (`_make_resident` + `_neutralise_offload`) against the reference's real wrapper
+    machinery, in both orders: AFTER line 351 the wrappers are undone (checkpoint keys, the very same Parameter objects, cpu_offload off);
+    BEFORE it the call statement itself — compiled out of test_svi.py — does nothing and says so once.  And the class's own function invoked
+    on the instance afterwards is refused at the next clip."""
+    import ast
+    import sys
+    import types
+    from svi_hip import pipeline
+    mod, vm = _compiled_offload_pipeline(ref)
+    try:
+        # the call statement of test_svi.py:351, as written there
+        tree = ast.parse(open(os.path.join(REF, "test_svi.py")).read())
+        stmt = next(n for n in ast.walk(tree) if isinstance(n, ast.Expr) and isinstance(n.value, ast.Call) and isinstance(n.value.func, ast.Attribute)
+                    and n.value.func.attr == "enable_vram_management")
+        assert 340 <= stmt.lineno <= 360
+        line_351 = compile(ast.fix_missing_locations(ast.Module(body=[stmt], type_ignores=[])), "test_svi.py", "exec")
+        args = types.SimpleNamespace(num_persistent_param_in_dit=6 * 10 ** 9)
+
+        # ---- install AFTER line 351
+        pipe = _offload_pipe(ref, mod)
+        keys = {n: list(m.state_dict()) for n, m in (("dit", pipe.dit), ("vae", pipe.vae), ("text_encoder", pipe.text_encoder))}
+        params = {n: p for n, p in pipe.dit.named_parameters()}
+        exec(line_351, {"pipe": pipe, "args": args})
+        assert pipe.cpu_offload and pipe.dit.vram_management_enabled
+        assert any(type(m).__name__ == "AutoWrappedLinear" for m in pipe.dit.modules()) and list(pipe.dit.state_dict()) != keys["dit"]
+        with pytest.raises(RuntimeError, match="VRAM management"):
+            pipeline._assert_resident(pipe, None)
+        pipeline._make_resident(pipe, device="cpu")
+        pipeline._neutralise_offload(pipe)
+        assert not pipe.cpu_offload and not pipe.dit.vram_management_enabled
+        for n, m in (("dit", pipe.dit), ("vae", pipe.vae), ("text_encoder", pipe.text_encoder)):
+            assert list(m.state_dict()) == keys[n], n
+            assert not any(type(x).__name__ in pipeline._WRAPPERS for x in m.modules())
+        assert all(p is params[n] for n, p in pipe.dit.named_parameters())          # nothing was copied: the same Parameter objects
+        pipeline._assert_resident(pipe, None)
+
+        # ---- install BEFORE line 351
+        pipe = _offload_pipe(ref, mod)
+        keys = list(pipe.dit.state_dict())
+        pipeline._make_resident(pipe, device="cpu")
+        pipeline._neutralise_offload(pipe)
+        capsys.readouterr()
+        exec(line_351, {"pipe": pipe, "args": args})
+        exec(line_351, {"pipe": pipe, "args": args})
+        err = capsys.readouterr().err
+        assert err.count("enable_vram_management() is a no-op") == 1                   # says so, once
+        pipe.enable_cpu_offload()
+        assert not pipe.cpu_offload and list(pipe.dit.state_dict()) == keys and not getattr(pipe.dit, "vram_management_enabled", False)
+        pipeline._assert_resident(pipe, None)
+
+        # ---- the class's own function on the instance, behind install()'s back: refused at the next clip
+        type(pipe).enable_vram_management(pipe, num_persistent_param_in_dit=None)
+        with pytest.raises(RuntimeError, match="install"):
+            pipeline._assert_resident(pipe, None)
+    finally:
+        sys.modules.pop("svi_video_offload", None)
