@@ -768,12 +768,19 @@ def main() -> None:
             n -= 1
         return n + 1
     keys_walked = [distinct_keys(ctx_pos), distinct_keys(ctx_neg)] if os.environ.get("SVI_CROSS_DEDUP", "1") != "0" else [lc, lc]
+    # default: the cross-attention query is normalised by the attention kernel as it reads q (the q projection's epilogue leaves the row statistics; the tag
+    # then also holds the tiny kernel that folds them: 2 launches per block and branch, one [L, D] read + one write between them).  SVI_CROSS_FUSED=0:
+    # the query is normalised in place by its own launch (under rmsnorm_rope: one more [L, D] read + write per block and branch)
+    cross_fused = os.environ.get("SVI_CROSS_FUSED", "1") != "0"
+    n_cross_units = NL * (1 if pair else 2)          # (block, branch) pairs per step and rank
     roof_all = {
         "flash_self": fam("flash_self", 4.0 * L * L * D / shard, "mfma", "4 L^2 D FLOP per launch (QK^T + PV, all heads)"),
         # the cross-attention walks the DISTINCT keys of the zero-padded prompt (svi_dit.hip ctx_tail: n + 1 of the 512): with a few dozen keys
         # the launch is a read of q and a write of o — HBM-bound — and the matrix work it executes is 4 L (n+1) D, not 4 L Lc D
         "flash_cross": fam("flash_cross", 4.0 * Ls * D, "hbm", f"q [L, D] bf16 read + o [L, D] bf16 written per launch; keys walked: {keys_walked} of {lc} context rows "
-                           "(identical trailing rows of the zero-padded prompt count as one key)"),
+                           "(identical trailing rows of the zero-padded prompt count as one key)" +
+                           ("; q is the raw projection, RMS-normalised as it is read; the tag also holds row_rs_kernel (the statistic): 2 launches per block and branch" if cross_fused else ""),
+                           total_fn=(lambda n: (4.0 * Ls * D + (D // 64 + 1) * 4.0 * Ls) * n / 2.0) if cross_fused else None),
         # q | k are ONE N = 2D launch (4 L D^2 FLOP), V^T its own (2 L D^2): 3 L D^2 per launch on average; three 2 L D^2 launches with SVI_QK_FUSED=0
         "gemm_qkv": fam("gemm_qkv", (3.0 if os.environ.get("SVI_QK_FUSED", "1") != "0" else 2.0) * Ls * D * D, "mfma",
                         "q | k as one launch over the two weight matrices (4 L D^2 FLOP) + the V^T projection (2 L D^2)", third="self"),
@@ -786,8 +793,9 @@ def main() -> None:
         # two launch kinds under one tag: the cross-attention q launch ([L, D] read + written, once per block and forward) and the q|k launch
         # ([L, 2D] read + written: every other launch of the tag)
         "rmsnorm_rope": fam("rmsnorm_rope", None, "hbm", "q|k launches: 8 L D bytes read + written, cross-attention q launches: 4 L D",
-                            total_fn=(lambda n: 4.0 * Ls * D * R_eq + 8.0 * Ls * D * S_eq) if stacked else
-                            (lambda n: 4.0 * Ls * D * min(n, NL * (1 if pair else 2)) + 8.0 * Ls * D * max(0.0, n - NL * (1 if pair else 2)))),
+                            total_fn=(lambda n: (0.0 if cross_fused else 4.0 * Ls * D * R_eq) + 8.0 * Ls * D * S_eq) if stacked else
+                            (lambda n: 8.0 * Ls * D * n) if cross_fused else
+                            (lambda n: 4.0 * Ls * D * min(n, n_cross_units) + 8.0 * Ls * D * max(0.0, n - n_cross_units))),
     }
     if vae_ms is not None and (T, H, W) == (21, 60, 104):
         vflop = 2.754e14                      # SURVEY 8d, measured by flop counter: fp32 FLOP of one 81f@480x832 decode
@@ -806,8 +814,10 @@ def main() -> None:
     if "flash_cross" in roof_all:
         fc = roof_all["flash_cross"]
         mean_keys = sum(keys_walked) / len(keys_walked)
-        fc["executed_tflops"] = round(4.0 * Ls * mean_keys * D * fc["launches_per_step"] / (fc["ms_per_step"] * 1e-3) / 1e12, 1)
-        fc["reference_algorithmic_tflops"] = round(4.0 * Ls * lc * D * fc["launches_per_step"] / (fc["ms_per_step"] * 1e-3) / 1e12, 1)
+        attn_launches = fc["launches_per_step"] / (2.0 if cross_fused else 1.0)
+        fc["executed_tflops"] = round(4.0 * Ls * mean_keys * D * attn_launches / (fc["ms_per_step"] * 1e-3) / 1e12, 1)
+        fc["reference_algorithmic_tflops"] = round(4.0 * Ls * lc * D * attn_launches / (fc["ms_per_step"] * 1e-3) / 1e12, 1)
+        fc["query_rmsnorm_fused"] = cross_fused
     line = {
         "metric": {"c2": "denoised latent frames/sec, Wan2.1-1.3B 81f@832x480 50-step", "c1": "denoised latent frames/sec, Wan2.1-1.3B 17f@256x256 10-step",
                    "c4": "denoised latent frames/sec, Wan2.1-I2V-14B 81f@832x480 50-step",

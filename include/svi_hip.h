@@ -207,6 +207,20 @@ svi_status svi_stream_buffers_release(svi_stream stream, int32_t all_streams);
 svi_status svi_attention_vt_fwd(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vt, int32_t ldvt, void* out,
                                 int32_t ldo, int32_t s_q, int32_t s_kv, int32_t n, int32_t q_prescaled, svi_stream stream);
 
+/* CrossAttention.forward's query path (models/wan_video_dit.py:296,299: q = norm_q(self.q(x)); x = attn(q, k, v)) as the DiT block runs it by default:
+ *   svi_linear_row_stats    C = bf16(A W^T + bias) [M, N] AND the statistic of RMSNorm over the full width (dit:192-197): row_sumsq [N/64][ldss] = sums of
+ *                           squares of the rounded results per aligned 64-column group (left by the GEMM's epilogue: fixed summation tree, the same in every
+ *                           tile kernel), rs_out[m] = rsqrt(sum_g row_sumsq[g][m] / N + eps).
+ *   svi_cross_attention_fwd softmax(q' k^T) v over a SHORT key axis (the prompt) with q' = bf16(bf16(bf16(q q_rs[row]) q_gain) q_out_scale) formed as the rows
+ *                           are read (q_rs NULL: q is used as it is; either way q carries softmax_scale*log2e already); vt = V transposed [n*128, ldvt];
+ *                           key_tail as in svi_dit's cross-attention (device {n, m}: keys n-1.. identical, counted m times) or NULL.  One [s_q, n*128] read and
+ *                           one write per call — the separately normalised q never exists in memory. */
+svi_status svi_linear_row_stats(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
+                                const void* bias, float eps, float* row_sumsq, int32_t ldss, float* rs_out, svi_stream stream);
+svi_status svi_cross_attention_fwd(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vt, int32_t ldvt, void* out, int32_t ldo,
+                                   int32_t s_q, int32_t s_kv, int32_t n, const int32_t* key_tail, const float* q_rs, const void* q_gain,
+                                   float q_out_scale, svi_stream stream);
+
 /* DiTBlock.forward(x, context, t_mod, freqs) for block `layer` (models/wan_video_dit.py:354-374).
  *   x_inout bf16 [L, dim] (L = f*h*w, updated in place); context bf16 [Lc(+257), dim] ALREADY
  *   projected by text_embedding/img_emb; t_mod bf16 [6, dim]; freqs implied by the (f,h,w) grid. */

@@ -1,5 +1,6 @@
 // svi_api.hip — C-ABI glue of libsvi_hip.so: error plumbing and the operator-level entry points
 // (the seams the reference exposes: flash_attention, LayerNorm+modulate, RMSNorm+RoPE, Linear, CFG step).
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -39,6 +40,7 @@ static SviSwitches parse_switches() {
     s.flash_two_pass = env_int("SVI_FLASH_TWO_PASS", 0, 1);
     s.vae_no_x2h = env_int("SVI_VAE_X2H", 0, 1) == 0;
     s.cross_dedup = env_int("SVI_CROSS_DEDUP", 0, 1);
+    s.cross_fused = env_int("SVI_CROSS_FUSED", 0, 1);
     s.vae_dma = env_int("SVI_VAE_DMA", 0, 1);
     s.vae_up_phases = env_int("SVI_VAE_UP_PHASES", 0, 1);
     s.vae_tile_order = env_int("SVI_VAE_TILE_ORDER", 0, 1);
@@ -416,6 +418,43 @@ extern "C" svi_status svi_gemm_bf16(const void* A, int32_t lda, const void* W, i
     g.bias = reinterpret_cast<const bf16*>(bias); g.bias_along_m = bias_along_m; g.epi = epilogue; g.gate = gate;
     g.res = reinterpret_cast<const bf16*>(res); g.ldres = ldres;
     return svi_launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The cross-attention query path as the DiT block runs it, in two seams (CrossAttention.forward, models/wan_video_dit.py:266-303: q = norm_q(self.q(x)), then
+// attention against the prompt's K / V): the projection that also leaves the RMSNorm statistic, and the short-key attention that normalises q as it reads it.
+extern "C" svi_status svi_linear_row_stats(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
+                                           const void* bias, float eps, float* row_sumsq, int32_t ldss, float* rs_out, svi_stream stream) {
+    SVI_REQUIRE(A && W && C && row_sumsq && rs_out, "svi_linear_row_stats: null argument");
+    SVI_REQUIRE(N > 0 && N % 64 == 0 && ldss >= M, "svi_linear_row_stats: N = %d must be a multiple of 64 and ldss >= M", N);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SviGemmArgs g{};
+    g.A = reinterpret_cast<const bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const bf16*>(W); g.ldw = ldw;
+    g.C = reinterpret_cast<bf16*>(C); g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = reinterpret_cast<const bf16*>(bias); g.epi = SVI_EPI_BIAS;
+    g.rowss = row_sumsq; g.ldss = ldss;
+    SVI_TRY(svi_launch_gemm(g, st));
+    return svi_launch_row_rs(row_sumsq, N / 64, ldss, M, N, eps, rs_out, st);
+}
+extern "C" svi_status svi_cross_attention_fwd(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vt, int32_t ldvt, void* out, int32_t ldo,
+                                              int32_t s_q, int32_t s_kv, int32_t n, const int32_t* key_tail, const float* q_rs, const void* q_gain,
+                                              float q_out_scale, svi_stream stream) {
+    SVI_REQUIRE(q && k && vt && out, "svi_cross_attention_fwd: null argument");
+    SVI_REQUIRE(s_q > 0 && s_kv > 0 && n > 0 && ldq >= n * 128 && ldk >= n * 128 && ldo >= n * 128 && ldvt >= s_kv, "svi_cross_attention_fwd: bad sizes");
+    SVI_REQUIRE((q_rs == nullptr) == (q_gain == nullptr), "svi_cross_attention_fwd: q_rs and q_gain come together");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SviProfScope _p(PROF_FLASH_CROSS, st);
+    const SviQNorm qn{q_rs, reinterpret_cast<const bf16*>(q_gain), q_out_scale};
+    int key_blocks = 0;          // the host's copy of how many 32-key blocks are walked (the DiT reads it once per prompt; here per call, outside a capture)
+    if (key_tail) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        int n = 0;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone &&
+            hipMemcpyAsync(&n, key_tail, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && n > 0)
+            key_blocks = (std::min(n, s_kv) + 31) / 32;
+        else (void)hipGetLastError();
+    }
+    return svi_launch_flash_cross(reinterpret_cast<const bf16*>(q), ldq, reinterpret_cast<const bf16*>(k), ldk, reinterpret_cast<const bf16*>(vt), ldvt,
+                                  reinterpret_cast<bf16*>(out), ldo, s_q, s_kv, n, st, key_tail, q_rs ? &qn : nullptr, key_blocks);
 }
 
 // Launch planners (no device work): what the GEMM / attention launchers would do with a problem of these sizes under the current switches.

@@ -45,26 +45,50 @@ __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((
 __device__ __forceinline__ int perm23(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 // TAG only names the instantiation (0 = self-attention, 1 = cross-attention) so that profiles tell them apart.
-template <int TAG>
+// STAGED (the DiT's cross-attention: tens of thousands of query rows against a few dozen keys — the launch is a read of q and a write of o, HBM-bound):
+//   * the workgroup's 128 query rows x 256 B arrive by row-contiguous 16-byte loads (16 lanes per row) and reach the MFMA's fragment layout through
+//     LDS, and the output tile leaves the same way — the plain kernel's per-lane fragment loads and 8-byte scattered stores move 32 / 16 bytes per row
+//     and instruction;
+//   * heads are the FAST grid axis: the 12 workgroups that cover one block of rows run together, so a row's 3 KiB are read (and written) while
+//     the DRAM page is open instead of 256 B at a time, one head per pass over the tensor;
+//   * STAGED == 2: q is the RAW projection output and RMSNorm (full width: the statistic rs[row] comes from the projection's epilogue, SviGemmArgs::rowss
+//     + row_rs_kernel) is applied on the way into LDS — q' = bf16(bf16(bf16(q rs) gain) out_scale), the rounding points of rmsnorm_rope_kernel — so the
+//     separate normalisation pass (one more [L, D] read + write per block and branch) does not exist.
+#define CR_KEYS 128       // flash_cross_resident_kernel holds up to this many keys of one head in LDS
+#define CQ_LD 272         // bytes per row of the staged output tile (256 + 16: 16-byte aligned rows, rows 16 apart share a bank pair at worst)
+template <int TAG, int STAGED = 0>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restrict__ Q, int ldq,
                                                            const bf16* __restrict__ K, int ldk,
                                                            const bf16* __restrict__ VT, int ldvt,
                                                            bf16* __restrict__ O, int ldo, int Lq, int Lk_full,
-                                                           float scale_log2e, const int* __restrict__ key_tail) {
+                                                           float scale_log2e, const int* __restrict__ key_tail,
+                                                           const float* __restrict__ q_rs = nullptr, const bf16* __restrict__ q_gain = nullptr, float q_out_scale = 1.0f,
+                                                           int long_keys_only = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // key_tail = {n, m}: keys n-1 .. Lk_full-1 are identical (the caller's statement), so the softmax over all Lk_full keys equals the
     // softmax over keys 0 .. n-1 with key n-1 counted m times, i.e. with log2(m) added to its score in the exponent's units
     const int Lk = key_tail ? min(max(key_tail[0], 1), Lk_full) : Lk_full;
+    (void)long_keys_only;
     const float tail_bias = (key_tail && key_tail[1] > 1) ? __builtin_amdgcn_logf((float)key_tail[1]) / scale_log2e : 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int head = blockIdx.y;
-    const int q_row = blockIdx.x * QB + wave * 32 + l31;
+    const int head = STAGED ? blockIdx.x : blockIdx.y;
+    const int row_base = (STAGED ? blockIdx.y : blockIdx.x) * QB;
+    const int q_row = row_base + wave * 32 + l31;
     const bool q_ok = q_row < Lq;
 
     // ---- Q fragments (B-operand of S^T): 8 k-steps x 8 bf16 ------------------------------------------
     bf16x8 qf[8];
-    {
+    u32x4 rq[STAGED ? 8 : 1];
+    const int qc = tid & 15, qr = tid >> 4;          // staged: this thread's 16-byte column chunk and first row (+ 16 per j)
+    if constexpr (STAGED) {
+        const bf16* qp = Q + head * DH + qc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = row_base + qr + 16 * j;
+            rq[j] = row < Lq ? *reinterpret_cast<const u32x4*>(qp + (size_t)row * ldq) : u32x4{0u, 0u, 0u, 0u};
+        }
+    } else {
         const bf16* qp = Q + (size_t)(q_ok ? q_row : 0) * ldq + head * DH + hi * 8;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
@@ -189,8 +213,40 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
     };
 
     load_tile(0);
+    if constexpr (STAGED) {
+        // the query tile passes through the second stage's 32 KiB (K-tile image: 256-byte rows, the same chunk swizzle) before tile 1 needs it
+        char* Qs = smem + (KT_BYTES + VT_BYTES);
+        bf16x8 wv;
+        float rsv[8];
+        if constexpr (STAGED == 2) {
+            wv = ld_bf16x8(q_gain + head * DH + qc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = row_base + qr + 16 * j;
+                rsv[j] = row < Lq ? q_rs[row] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            u32x4 outv = rq[j];
+            if constexpr (STAGED == 2) {
+                const bf16x8 t = __builtin_bit_cast(bf16x8, rq[j]);
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (bf16)(rbf(rbf((float)t[e] * rsv[j]) * (float)wv[e]) * q_out_scale);
+                outv = __builtin_bit_cast(u32x4, o8);
+            }
+            *reinterpret_cast<u32x4*>(Qs + k_off(qr + 16 * j, qc)) = outv;
+        }
+    }
     store_tile(0);
     __syncthreads();
+    if constexpr (STAGED) {
+        const char* Qs = smem + (KT_BYTES + VT_BYTES);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Qs + k_off(wave * 32 + l31, 2 * kk + hi));
+        __syncthreads();          // every wave holds its fragments before tile 1 is written over them
+    }
     for (int t = 0; t + 1 < ntiles; ++t) {
         const int cur = t & 1;
         load_tile(t + 1);
@@ -204,6 +260,28 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
     // ---- normalise and store: lane holds O[q_row][32 d + (r&3) + 8 (r>>2) + 4 hi] --------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
+    if constexpr (STAGED) {
+        __syncthreads();          // the last tile's K / V^T fragments have been read: the output tile takes the buffer
+        char* Os = smem;
+        char* orow = Os + (wave * 32 + l31) * CQ_LD + 8 * hi;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[d][rg * 4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + 64 * d + 16 * rg) = pk;
+            }
+        __syncthreads();
+        bf16* op = O + head * DH + qc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = row_base + qr + 16 * j;
+            if (row < Lq) *reinterpret_cast<u32x4*>(op + (size_t)row * ldo) = *reinterpret_cast<const u32x4*>(Os + (qr + 16 * j) * CQ_LD + qc * 16);
+        }
+        return;
+    }
     if (q_ok) {
         bf16* op = O + (size_t)q_row * ldo + head * DH + 4 * hi;
 #pragma unroll
@@ -218,6 +296,187 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
     }
 }
 
+
+// =================================================================================================
+// Cross-attention with the head's K / V^T RESIDENT in LDS (the DiT's text cross-attention: 32760 query rows against the few dozen distinct keys of a
+// zero-padded prompt; per launch one read of q and one write of o — HBM-bound, and flash_fwd_kernel<1, STAGED> runs it at latency, not bandwidth: every
+// 128-row workgroup fetches K / V^T again, loads its q tile, computes and stores in sequence, two workgroups per CU).
+//   * ONE 512-thread workgroup per CU: head = blockIdx.x, a contiguous range of query rows = blockIdx.y (32-row units split evenly over gridDim.y);
+//     heads are the fast grid axis, so the 12 workgroups of a row range walk it together and a row's 3 KiB are touched while its DRAM pages are open.
+//   * up to 128 keys: K [key][128 ch] and V^T [ch][key] (32 KiB each, 16-byte chunks XOR-swizzled by row) are loaded once per workgroup;
+//   * the query rows stream through a 64 KiB tile, 256 rows per iteration: row-contiguous 16-byte loads for iteration i + 1 are in flight (registers)
+//     while iteration i computes; RMSNorm (NORM: rs[row] from the q projection's epilogue, rounding points of rmsnorm_rope_kernel) is applied on the way
+//     into LDS; the output tile leaves through the same LDS cells, row-contiguously.  Two barriers per iteration;
+//   * all keys are at hand, so the softmax is exact in one sweep (scores for every key block, the row maximum, exponentials, P V): no online rescaling.
+// A prompt with more than 128 distinct keys returns at once; the streaming kernel launched beside it (long_keys_only) serves it.
+// =================================================================================================
+#define CR_ROWS 256
+#define CR_LDS (2 * CR_KEYS * 256 + CR_ROWS * 256)
+template <bool NORM, int NKB>
+__global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16* __restrict__ Q, int ldq, const bf16* __restrict__ K, int ldk,
+                                                                      const bf16* __restrict__ VT, int ldvt, bf16* __restrict__ O, int ldo, int Lq, int Lk_full,
+                                                                      const int* __restrict__ key_tail, const float* __restrict__ q_rs,
+                                                                      const bf16* __restrict__ q_gain, float q_out_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // NKB = 32-key blocks walked, known to the launcher (the host's copy of key_tail[0]); the exact count is read here
+    const int Lk = min(key_tail ? min(max(key_tail[0], 1), Lk_full) : Lk_full, 32 * NKB);
+    const float tail_bias = (key_tail && key_tail[1] > 1) ? __builtin_amdgcn_logf((float)key_tail[1]) : 0.f;      // (q carries softmax_scale * log2e: scores are exponents)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int head = blockIdx.x;
+    const int units = (Lq + 31) >> 5;
+    const int r_begin = (int)((long)units * blockIdx.y / gridDim.y) * 32;
+    const int r_end = min((int)((long)units * (blockIdx.y + 1) / gridDim.y) * 32, Lq);
+    if (r_begin >= r_end) return;
+    char* Ks = smem;
+    char* Vs = smem + CR_KEYS * 256;
+    char* QO = smem + 2 * CR_KEYS * 256;
+    const int sc = tid & 15, sr = tid >> 4;          // staging: this thread's 16-byte chunk and first row (+ 32 per j)
+
+    {   // the head's K / V^T, once.  Rows / columns past the last key are clamped to it: finite duplicates that the -inf mask removes
+        const int last_key = Lk - 1, last_chunk = (Lk - 1) & ~7;
+        const bf16* kb = K + head * DH + sc * 8;
+        const bf16* vb = VT + (size_t)(head * DH) * ldvt + min(sc * 8, last_chunk);
+        u32x4 a[NKB], b[4];
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) a[j] = *reinterpret_cast<const u32x4*>(kb + (size_t)min(sr + 32 * j, last_key) * ldk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u32x4*>(vb + (size_t)(sr + 32 * j) * ldvt);
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) *reinterpret_cast<u32x4*>(Ks + k_off(sr + 32 * j, sc)) = a[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(Vs + k_off(sr + 32 * j, sc)) = b[j];
+    }
+    const int krow = perm23(l31);
+    bf16x8 wv;
+    if constexpr (NORM) wv = ld_bf16x8(q_gain + head * DH + sc * 8);
+    u32x4 rq[8];
+    float rsv[8];
+    // Uniform base pointers + 32-bit per-lane element offsets (the launcher refuses tensors of 2^31 elements): one address register per access, nothing
+    // to precompute and keep.  Loads never branch: a row past the workgroup's range is clamped to its last row (finite, never stored).
+    const bf16* qh = Q + head * DH;
+    bf16* oh = O + head * DH;
+    auto issue = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = min(base + sr + 32 * j, r_end - 1);
+            rq[j] = *reinterpret_cast<const u32x4*>(qh + (unsigned)(row * ldq + sc * 8));
+            if constexpr (NORM) rsv[j] = q_rs[row];
+        }
+    };
+    // The output tile of iteration i stays in LDS (in the cells of its query tile) and goes to memory at the top of iteration i + 1, BEHIND that
+    // iteration's wait for its query rows and in front of the write of the new tile into the same cells.  (Loads and stores share one counter on this part
+    // and may retire out of order with respect to each other, so the compiler waits for everything outstanding whenever both kinds are: stores issued
+    // right in front of that wait would put their round trip on the critical path of every iteration; issued behind it they have an iteration's time.)
+    auto flush = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = base + sr + 32 * j;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(QO + k_off(sr + 32 * j, sc));
+            if (row < r_end) *reinterpret_cast<u32x4*>(oh + (unsigned)(row * ldo + sc * 8)) = v;
+        }
+    };
+    // One 32-row group of this wave against NKB key blocks: scores, exact softmax, P V, the output rows into the query rows' cells (this wave's own 32
+    // rows: nobody else read them).  Register r of s[kb] is key 32 kb + 16 (r >> 3) + 8 hi + (r & 7); lane holds O[row][32 d + 8 rg + 4 hi + e].
+    auto compute = [&]() {
+        bf16x8 qf[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(QO + k_off(wave * 32 + l31, 2 * kk + hi));
+        f32x16 s[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            bf16x8 kf[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(Ks + k_off(32 * kb + krow, 2 * kk + hi));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s[kb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);              // one key block's fragments in flight at a time
+        }
+        // (opaque copies: the 16 x 4 select masks below are loop-invariant, and hoisted out of the row loop they cost more registers than the loop has)
+        int lk_here = Lk;
+        float bias_here = tail_bias;
+        asm volatile("" : "+s"(lk_here), "+v"(bias_here));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                      // the last block holds the counted key and whatever lies past the last key
+            const int key = 32 * (NKB - 1) + 16 * (r >> 3) + 8 * hi + (r & 7);
+            const float biased = s[NKB - 1][r] + (key == lk_here - 1 ? bias_here : 0.f);
+            s[NKB - 1][r] = key >= lk_here ? -INFINITY : biased;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));                 // (the other 16 keys of each block live in lane ^ 32)
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 pf[NKB][2];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] - mx);
+                ps[r & 3] += p;
+                pf[kb][r >> 3][r & 7] = (bf16)p;
+            }
+        float l_tot = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        l_tot += __shfl_xor(l_tot, 32);
+        f32x16 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                bf16x8 vf[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) vf[d] = *reinterpret_cast<const bf16x8*>(Vs + k_off(32 * d + l31, 4 * kb + 2 * sb + hi));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d], pf[kb][sb], o[d], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        const float inv = 1.0f / l_tot;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[d][rg * 4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(QO + k_off(wave * 32 + l31, 4 * d + rg) + 8 * hi) = pk;
+            }
+    };
+    issue(r_begin);
+    for (int base = r_begin; base < r_end; base += CR_ROWS) {
+        // ---- this iteration's query rows, normalised (the wait for them is here)
+        u32x4 outv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            outv[j] = rq[j];
+            if constexpr (NORM) {
+                const bf16x8 t = __builtin_bit_cast(bf16x8, rq[j]);
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (bf16)(rbf(rbf((float)t[e] * rsv[j]) * (float)wv[e]) * q_out_scale);
+                outv[j] = __builtin_bit_cast(u32x4, o8);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (base + CR_ROWS < r_end) issue(base + CR_ROWS);          // the next iteration's rows are on their way while this one computes
+        __builtin_amdgcn_sched_barrier(0);
+        if (base > r_begin) flush(base - CR_ROWS);                    // the previous iteration's output rows leave the cells ...
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(QO + k_off(sr + 32 * j, sc)) = outv[j];      // ... that this iteration's query rows take
+        __syncthreads();
+        compute();
+        __syncthreads();
+        if (base + CR_ROWS >= r_end) flush(base);                     // the last iteration's rows leave at once
+    }
+}
 
 // =================================================================================================
 // v2 — 256 query rows per workgroup: 4 waves x 64 rows (two 32-row groups g = 0,1 per wave), ONE wave per SIMD
@@ -1336,6 +1595,50 @@ svi_status svi_flash_qk8_prepare(int Lq, int Lk, int num_heads, hipStream_t st, 
     if (kernel != 2) return SVI_OK;
     SVI_TRY(flash_qk8_buffers(batch * Lq, batch * Lk, num_heads, st, out));
     *use = true;
+    return SVI_OK;
+}
+
+svi_status svi_launch_flash_cross(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt, bf16* O, int ldo, int Lq, int Lk, int num_heads,
+                                  hipStream_t st, const int* key_tail, const SviQNorm* norm, int key_blocks) {
+    SVI_REQUIRE(Lq > 0 && Lk > 0 && num_heads > 0 && num_heads <= 65535, "cross attention: bad sizes Lq=%d Lk=%d heads=%d", Lq, Lk, num_heads);
+    SVI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0, "cross attention: leading dims must be multiples of 8");
+    SVI_REQUIRE(ldvt >= ((Lk + 7) / 8) * 8, "cross attention: V^T leading dim %d < keys rounded up to 8", ldvt);
+    SVI_REQUIRE(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)VT % 16) == 0 && ((uintptr_t)O % 16) == 0, "cross attention: operands must be 16-byte aligned");
+    SVI_REQUIRE((long)(Lq - 1) * ldq + (long)num_heads * DH < (1L << 31) && (long)(Lq - 1) * ldo + (long)num_heads * DH < (1L << 31), "cross attention: query / output tensors of 2^31 elements or more");
+    SVI_REQUIRE(!norm || (norm->rs && norm->gain && ((uintptr_t)norm->gain % 16) == 0), "cross attention: incomplete query normalisation");
+    // Which kernel serves a call depends on the number of keys WALKED only (so a sequence-parallel shard and the whole sequence take the same one): up to
+    // CR_KEYS the resident kernel (instantiated per number of 32-key blocks), beyond it the streaming one.  With a key_tail that count lives on the device;
+    // key_blocks is the caller's host copy of ceil(key_tail[0] / 32) (the DiT reads it back once per prompt), <= 0 where it has none: streaming kernel.
+    if (!key_tail) key_blocks = (Lk + 31) / 32;
+    const int lds = 2 * (KT_BYTES + VT_BYTES);
+    static_assert(QB * CQ_LD <= 2 * (KT_BYTES + VT_BYTES), "the staged output tile must fit the K / V^T stages");
+    const float* rs = norm ? norm->rs : nullptr;
+    const bf16* gain = norm ? norm->gain : nullptr;
+    const float osc = norm ? norm->out_scale : 1.0f;
+    if (key_blocks >= 1 && key_blocks <= CR_KEYS / 32) {
+        int ncu = 256;
+        SVI_TRY((svi_status)flash_device_cus(&ncu));
+        const int chunks = std::max(1, std::min(std::max(ncu / num_heads, 1), (Lq + CR_ROWS - 1) / CR_ROWS));
+        dim3 grid(num_heads, chunks), block(512);
+        typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, const int*, const float*, const bf16*, float);
+        static const kern_t table[2][4] = {
+            {flash_cross_resident_kernel<false, 1>, flash_cross_resident_kernel<false, 2>, flash_cross_resident_kernel<false, 3>, flash_cross_resident_kernel<false, 4>},
+            {flash_cross_resident_kernel<true, 1>, flash_cross_resident_kernel<true, 2>, flash_cross_resident_kernel<true, 3>, flash_cross_resident_kernel<true, 4>}};
+        const kern_t kern = table[norm ? 1 : 0][key_blocks - 1];
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(kern), CR_LDS));
+        hipLaunchKernelGGL(kern, grid, block, CR_LDS, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, key_tail, rs, gain, osc);
+        SVI_LAUNCH_CHECK();
+        return SVI_OK;
+    }
+    dim3 grid(num_heads, (Lq + QB - 1) / QB), block(256);
+    if (norm) {
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(flash_fwd_kernel<1, 2>), lds));
+        hipLaunchKernelGGL((flash_fwd_kernel<1, 2>), grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, 1.0f, key_tail, rs, gain, osc, 0);
+    } else {
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(flash_fwd_kernel<1, 1>), lds));
+        hipLaunchKernelGGL((flash_fwd_kernel<1, 1>), grid, block, lds, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, 1.0f, key_tail, rs, gain, osc, 0);
+    }
+    SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
 

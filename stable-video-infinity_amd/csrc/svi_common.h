@@ -85,6 +85,8 @@ struct SviSwitches {
                                  // performs (its dispatch accepts a quantised-QK^T backend, wan_video_dit.py:116-147): own oracle, own tolerance, own bench line
     int qk8_fused = 1;           // SVI_QK8_FUSED = 0 : (opt-in fp8 QK^T) the DiT's RMSNorm + RoPE launch writes bf16 q | k and the attention call quantises them with two more
                                  // launches, instead of the RMSNorm + RoPE kernel writing the e4m3 rows and block scales itself (bit-identical)
+    int cross_fused = 1;         // SVI_CROSS_FUSED = 0 : the cross-attention query is normalised by its own kernel (RMSNorm in place) and attended by flash_fwd_kernel<1>
+                                 // (rounds 1-4); default: the q projection's epilogue leaves the row sums of squares and flash_cross_kernel normalises as it reads
     int cross_dedup = 1;         // SVI_CROSS_DEDUP = 0 : cross-attention walks every context row even where the prompt embedding's trailing rows are
                                  // identical (the prompter's zero padding); default: m identical keys = one key counted m times (same softmax)
     int t5_host_buckets = 0;     // SVI_T5_BUCKETS = host : the text encoder's relative-position bucket table in the HOST's fp32 arithmetic (what the
@@ -213,6 +215,11 @@ struct SviGemmArgs {
     // take row n - n_split of W2 (same ldw) and bias2.  n_split must be a multiple of the tile width of the kernel that runs (the launcher falls back
     // to two launches otherwise); the weights stay the caller's tensors — nothing is packed, so an in-place LoRA merge needs no re-bind.
     const bf16* W2; const bf16* bias2; int n_split;
+    // row statistics of the OUTPUT (the cross-attention q projection feeding an RMSNorm over the full width, dit:194-197,296): when set, every tiled
+    // kernel's epilogue also leaves the sum of squares of the rounded bf16 results of row m over each aligned 64-column group g in rowss[g * ldss + m]
+    // (N % 64 == 0, SVI_EPI_BIAS).  Per group: a lane sums its 8 columns in order, then a fixed xor-1/2/4 tree over the group's 8 lanes — the same tree in
+    // the 128^2, 256 x 192 and 256^2 kernels, so the statistics do not depend on which kernel (or how many rows) a launch ran with.
+    float* rowss; int ldss;
 };
 unsigned long long svi_stream_buffer_generation();       // moves whenever a per-stream library buffer is freed (svi_api.hip)
 svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st);
@@ -235,6 +242,17 @@ svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, i
 struct SviQk8 { unsigned char* q8; unsigned char* k8; unsigned* qs; unsigned* ks; int ld8, qs_rows, ks_rows; };
 svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt,
                             bf16* O, int ldo, int Lq, int Lk, int num_heads, int q_prescaled, hipStream_t st, const int* key_tail = nullptr, const SviQk8* qk8 = nullptr);
+// Cross-attention over a SHORT key axis (the prompt: <= 512 keys, a few dozen distinct) with the query's RMSNorm applied as the rows are read:
+//   q' = bf16(bf16(bf16(q * rs[row]) * gain) * out_scale)      — RMSNorm.forward's rounding points (dit:192-197) and the scale folded in as svi_launch_rmsnorm_rope does
+// Q holds the RAW projection output; rs[row] = rsqrt(mean(q^2) + eps) from svi_launch_row_rs; norm == nullptr: Q is used as it is (pre-scaled).
+// One [Lq, D] read and one write per launch instead of the separate normalisation's extra round trip.
+struct SviQNorm { const float* rs; const bf16* gain; float out_scale; };
+// key_blocks: the caller's HOST copy of ceil(key_tail[0] / 32) — how many 32-key blocks are walked; 1 .. 4: K / V^T stay resident in LDS (kernel instantiated
+// per block count), more: the streaming kernel; <= 0: not known on the host -> the streaming kernel (any count).  Ignored without a key_tail (Lk decides).
+svi_status svi_launch_flash_cross(const bf16* Q, int ldq, const bf16* K, int ldk, const bf16* VT, int ldvt, bf16* O, int ldo, int Lq, int Lk, int num_heads,
+                                  hipStream_t st, const int* key_tail, const SviQNorm* norm, int key_blocks = 0);
+// rs[m] = rsqrt(sum_g rowss[g * ldss + m] / dim + eps), groups summed in index order (rowss: see SviGemmArgs)
+svi_status svi_launch_row_rs(const float* rowss, int groups, int ldss, int rows, int dim, float eps, float* rs, hipStream_t st);
 // *use = whether svi_launch_flash will run this shape on the fp8 QK^T kernel (switch on, long key axis); if so `out` names the per-stream operand buffers
 // batch > 1: room for that many samples stacked one under the other (sample s: rows [s Lq, (s+1) Lq) of q8 / qs, [s Lk, ..) of k8 / ks; svi_qk8_sample)
 svi_status svi_flash_qk8_prepare(int Lq, int Lk, int num_heads, hipStream_t st, SviQk8* out, bool* use, int batch = 1);

@@ -53,6 +53,8 @@ struct Workspace {
     bf16 *X, *X2, *Hb, *QK, *VT, *Fb, *CTX, *CTXH, *CK, *CVT, *CKi, *CVTi, *A2, *PATCH, *HO, *IMG0, *IMG1, *IMGD;
     bf16 *e, *h1, *t, *st, *tmod;
     float *modf, *headf;
+    float *RSS = nullptr, *RS = nullptr;      // cross-attention q: per-64-column row sums of squares [dim / 64][ldss] from the projection's epilogue, rs [L]
+    int ldss = 0;
     int* tail = nullptr;            // identical-suffix summary of the text context when no cache entry holds it
     unsigned char* Q8 = nullptr;    // MX-fp8 MLP: e4m3 activations [L, max(D, F)] and their block scales [F/128][sc_rows]
     unsigned* S8 = nullptr;
@@ -74,11 +76,12 @@ struct CtxEntry {
     bf16* CTX = nullptr;
     std::vector<bf16*> CK, CVT, CKi, CVTi;
     int* tail = nullptr;            // {effective key count, multiplicity of the last effective key}: see ctx_tail_*_kernel
+    int key_blocks = 0;             // host copy of ceil(tail[0] / 32): how many 32-key blocks the cross-attention walks; 0 = not read (filled under capture)
     bool filled = false;
     unsigned long long stamp = 0;
 };
 
-struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; const int* tail; };
+struct CtxKV { bf16 *CK, *CVT, *CKi, *CVTi; bool compute; const int* tail; int key_blocks; };
 
 struct svi_dit {
     svi_dit_config cfg;
@@ -338,7 +341,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     const int kpatch = c.in_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho = (size_t)c.out_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho_ld = (ho + 7) / 8 * 8;
-    size_t oX, oX2, oH, oQK, oVT, oF, oCTX, oCTXH, oCK, oCVT, oCKi, oCVTi, oA2, oP, oHO, oI0, oI1, oID, oe, oh1, ot, ost, otm, omodf, oheadf, otail, oQ8 = 0, oS8 = 0;
+    size_t oX, oX2, oH, oQK, oVT, oF, oCTX, oCTXH, oCK, oCVT, oCKi, oCVTi, oA2, oP, oHO, oI0, oI1, oID, oe, oh1, ot, ost, otm, omodf, oheadf, otail, oRSS, oRS, oQ8 = 0, oS8 = 0;
     const bool mx8 = h->ffn_mx8;
     auto layout = [&](int l, int lc) -> size_t {
         const size_t Lctx = (size_t)lc + img;
@@ -355,6 +358,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
         oe = take(c.freq_dim * 2); oh1 = take(D * 2); ot = take(D * 2); ost = take(D * 2); otm = take(6 * D * 2);
         omodf = take((size_t)c.num_layers * 6 * D * 4); oheadf = take(2 * D * 4);
         otail = take((size_t)(lc + 8) * 4);
+        oRSS = take((D / 64) * (size_t)ldvt * 4); oRS = take((size_t)ldvt * 4);
         if (mx8) { oQ8 = take((size_t)l * F); oS8 = take((size_t)(F / 128) * (size_t)(((l + 255) / 256) * 256) * 4); }
         return off;
     };
@@ -390,6 +394,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     w.modf = reinterpret_cast<float*>(w.base + omodf);
     w.headf = reinterpret_cast<float*>(w.base + oheadf);
     w.tail = reinterpret_cast<int*>(w.base + otail);
+    w.RSS = reinterpret_cast<float*>(w.base + oRSS); w.RS = reinterpret_cast<float*>(w.base + oRS); w.ldss = ldvt;
     w.Q8 = mx8 ? reinterpret_cast<unsigned char*>(w.base + oQ8) : nullptr;
     w.S8 = mx8 ? reinterpret_cast<unsigned*>(w.base + oS8) : nullptr;
     w.sc_rows = ((L + 255) / 256) * 256;
@@ -606,16 +611,35 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
     const float *sh_m = modf + 3 * D, *sc_m = modf + 4 * D, *g_m = modf + 5 * D;
     // --- cross attention: x += o(attn(rms(q(norm3 x)), rms(k ctx), v ctx) [+ image branch])   dit:370,266-303
     { SviProfScope _p(PROF_LN, st); SVI_TRY(svi_launch_ln_mod(X, D, w.Hb, D, R, D, c.eps, b.norm3_w, b.norm3_b, nullptr, nullptr, st)); }
-    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.q, w.QK, 2 * D, R, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
-    { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, R, D, b.ca.norm_q, c.eps, nullptr, SVI_QK_SCALE_LOG2E, st)); }
+    // The query's RMSNorm (full width, dit:296) is applied by the attention kernel as it reads q: the projection's epilogue leaves the row sums of squares
+    // (per 64-column group; one tiny kernel folds them into rs[row]), so the normalised q never makes its own trip through HBM.  SVI_CROSS_FUSED=0:
+    // normalise in place, then attend (rounds 1-4).  The two differ only where the order of the fp32 sum of squares moves a bf16 rounding of q.
+    const bool fused = svi_switches().cross_fused && D % 64 == 0 && D % 8 == 0 && R <= w.ldss;
+    {
+        SviProfScope _p(PROF_GEMM_CROSS, st);
+        SviGemmArgs g{};
+        g.A = w.Hb; g.lda = D; g.W = b.ca.q.w; g.ldw = D; g.C = w.QK; g.ldc = 2 * D; g.M = R; g.N = D; g.K = D;
+        g.bias = b.ca.q.b; g.epi = SVI_EPI_BIAS;
+        g.sel_m = nb > 1 ? R / nb : 0;
+        if (fused) { g.rowss = w.RSS; g.ldss = w.ldss; }
+        SVI_TRY(svi_launch_gemm(g, st));
+    }
+    if (fused) { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_row_rs(w.RSS, D / 64, w.ldss, R, D, c.eps, w.RS, st)); }      // (timed with the attention it feeds)
+    else { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope(w.QK, 2 * D, R, D, b.ca.norm_q, c.eps, nullptr, SVI_QK_SCALE_LOG2E, st)); }
     for (int s = 0; s < nb; ++s) {
         const CtxKV& kv = kvs[s];
         const bf16* CTX = CTXs[s];
         const size_t ro = (size_t)s * L;
+        const SviQNorm qn{w.RS + ro, b.ca.norm_q, SVI_QK_SCALE_LOG2E};
         if (kv.compute) SVI_TRY(fill_block_kv(h, layer, CTX, Lc, kv, st));
-        { SviProfScope _p(PROF_FLASH_CROSS, st); SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb + ro * D, D, L, Lc, H, 1, st, kv.tail)); }
+        {
+            SviProfScope _p(PROF_FLASH_CROSS, st);
+            if (fused) SVI_TRY(svi_launch_flash_cross(w.QK + ro * 2 * D, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb + ro * D, D, L, Lc, H, st, kv.tail, &qn, kv.key_blocks));
+            else SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CK, D, kv.CVT, w.ldcvt, w.Hb + ro * D, D, L, Lc, H, 1, st, kv.tail));
+        }
         if (img) {
-            SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CKi, D, kv.CVTi, w.ldcvti, w.A2 + ro * D, D, L, img, H, 1, st));
+            if (fused) SVI_TRY(svi_launch_flash_cross(w.QK + ro * 2 * D, 2 * D, kv.CKi, D, kv.CVTi, w.ldcvti, w.A2 + ro * D, D, L, img, H, st, nullptr, &qn));
+            else SVI_TRY(svi_launch_flash(w.QK + ro * 2 * D, 2 * D, kv.CKi, D, kv.CVTi, w.ldcvti, w.A2 + ro * D, D, L, img, H, 1, st));
         }
     }
     if (img) SVI_TRY(svi_launch_add_bf16(w.Hb, w.A2, (int64_t)R * D, st));
@@ -750,7 +774,7 @@ static svi_status mod_one(const bf16* modulation, const bf16* tmod, float* modf,
 
 // ---- stages of one forward (svi_video.py:74-137).  forward_one() runs them in the reference's order; forward_pair() shares
 // the stages that do not depend on the prompt between the conditional and the unconditional forward of a CFG step.
-struct CtxUse { CtxEntry* ce; bf16* CTXp; bool compute; };
+struct CtxUse { CtxEntry* ce; bf16* CTXp; bool compute; int key_blocks; };
 
 // timestep embedding -> t, t_mod, per-block modulation rows                     svi_video.py:92-93
 static svi_status stage_time(svi_dit* h, const float* timestep, hipStream_t st) {
@@ -787,6 +811,17 @@ static svi_status project_context(svi_dit* h, const bf16* context, const bf16* c
         SVI_TRY(svi_launch_ln_mod(w.IMGD, D, CTXp, D, 257, D, 1e-5f, h->img_ln4_w, h->img_ln4_b, nullptr, nullptr, st));
     }
     return SVI_OK;
+}
+
+// How many keys the cross-attention will walk for this prompt decides its kernel (svi_launch_flash_cross: up to 128 keys stay resident in LDS, in a kernel
+// instantiated per 32-key block count); the count is made on the device (ctx_tail_scan_kernel).  It is read back once per projection — here, outside any
+// capture — so that the launches need no device-side dispatch.  Under capture (or on any error) it stays unknown (0: the streaming kernel, any count).
+static int read_key_blocks(const int* tail_dev, hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    int n = 0;
+    if (hipMemcpyAsync(&n, tail_dev, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n > 0 ? (n + 31) / 32 : 0;
 }
 
 // text (and CLIP image) context: projected here or taken from the context cache      svi_video.py:94-99
@@ -830,8 +865,13 @@ static svi_status stage_context(svi_dit* h, const bf16* context, const bf16* cli
     }
     bf16* CTXp = ce ? ce->CTX : w.CTX;
     if (img) SVI_REQUIRE(clip && y, "has_image_input model needs clip_feature and y");
-    if (ctx_compute) SVI_TRY(project_context(h, context, clip, Lc, CTXp, ce ? ce->tail : w.tail, st));
-    use->ce = ce; use->CTXp = CTXp; use->compute = ctx_compute;
+    int key_blocks = ce ? ce->key_blocks : 0;
+    if (ctx_compute) {
+        SVI_TRY(project_context(h, context, clip, Lc, CTXp, ce ? ce->tail : w.tail, st));
+        key_blocks = (svi_switches().cross_fused && svi_switches().cross_dedup) ? read_key_blocks(ce ? ce->tail : w.tail, st) : 0;
+        if (ce) ce->key_blocks = key_blocks;
+    }
+    use->ce = ce; use->CTXp = CTXp; use->compute = ctx_compute; use->key_blocks = key_blocks;
     return SVI_OK;
 }
 
@@ -853,7 +893,8 @@ static svi_status stage_embed(svi_dit* h, const bf16* x, const bf16* y, const bf
 static CtxKV kv_of(svi_dit* h, const CtxUse& u, int l) {
     Workspace& w = h->ws;
     const int* tail = svi_switches().cross_dedup ? (u.ce ? u.ce->tail : w.tail) : nullptr;
-    return CtxKV{u.ce ? u.ce->CK[l] : w.CK, u.ce ? u.ce->CVT[l] : w.CVT, u.ce ? u.ce->CKi[l] : w.CKi, u.ce ? u.ce->CVTi[l] : w.CVTi, u.compute, tail};
+    return CtxKV{u.ce ? u.ce->CK[l] : w.CK, u.ce ? u.ce->CVT[l] : w.CVT, u.ce ? u.ce->CKi[l] : w.CKi, u.ce ? u.ce->CVTi[l] : w.CVTi, u.compute, tail,
+                 u.key_blocks};
 }
 
 // head (dit:401-404): LN + modulation + Linear(dim -> out_dim * patch volume) on the rows in X -> HO [L, ho_ld]
@@ -1115,7 +1156,12 @@ extern "C" svi_status svi_dit_context_refill(svi_dit* h, const void* context, co
     CtxUse cu{};
     SVI_TRY(stage_context(h, ctx, clip, /*y: only its presence is checked*/ ctx, Lc, &cu, st));
     SVI_REQUIRE(cu.ce != nullptr, "svi_dit_context_refill: no cache entry");
-    if (!cu.compute) SVI_TRY(project_context(h, ctx, clip, Lc, cu.CTXp, cu.ce->tail, st));      // a hit: the same buffers, new contents
+    if (!cu.compute) {                                                                           // a hit: the same buffers, new contents
+        const int before = cu.ce->key_blocks;
+        SVI_TRY(project_context(h, ctx, clip, Lc, cu.CTXp, cu.ce->tail, st));
+        cu.ce->key_blocks = cu.key_blocks = (svi_switches().cross_fused && svi_switches().cross_dedup) ? read_key_blocks(cu.ce->tail, st) : 0;
+        if (cu.ce->key_blocks != before) ++h->generation;     // a captured step holds cross-attention launches made for the OLD key-block count (svi_launch_flash_cross): it must not be replayed
+    }
     for (int l = 0; l < c.num_layers; ++l) {
         CtxKV kv = kv_of(h, cu, l);
         SVI_TRY(fill_block_kv(h, l, cu.CTXp, Lc, kv, st));
@@ -1241,6 +1287,6 @@ extern "C" svi_status svi_dit_block_forward(svi_dit* h, int32_t layer, void* x_i
     SVI_TRY(ensure_rope(h, f, hh, ww));
     float* modf = h->ws.modf + (size_t)layer * 6 * D;
     SVI_TRY(mod_one(h->blocks[layer].modulation, reinterpret_cast<const bf16*>(t_mod), modf, D, 6, (1 << 1) | (1 << 4), 6, st));
-    CtxKV kv{h->ws.CK, h->ws.CVT, h->ws.CKi, h->ws.CVTi, true, nullptr};      // the context arrives projected: no statement about its input rows
+    CtxKV kv{h->ws.CK, h->ws.CVT, h->ws.CKi, h->ws.CVTi, true, nullptr, 0};      // the context arrives projected: no statement about its input rows
     return run_block(h, layer, reinterpret_cast<bf16*>(x_inout), reinterpret_cast<const bf16*>(context), modf, L, Lc, kv, st);
 }

@@ -356,6 +356,31 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_rows_kernel(bf16* __restrict
     }
 }
 
+// rs[m] = rsqrt(mean_n q[m][n]^2 + eps) from the per-64-column sums of squares the q projection's epilogue left (SviGemmArgs::rowss): groups summed in
+// index order; the division and the rsqrt are rmsnorm_rope_kernel's.  flash_cross_kernel applies the normalisation as it reads q.
+__global__ __launch_bounds__(256) void row_rs_kernel(const float* __restrict__ rowss, int groups, int ldss, int rows, float dim, float eps, float* __restrict__ rs) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= rows) return;
+    float ss = 0.f;
+    int g = 0;
+    for (; g + 8 <= groups; g += 8) {          // eight loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = rowss[(size_t)(g + i) * ldss + m];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += v[i];
+    }
+    for (; g < groups; ++g) ss += rowss[(size_t)g * ldss + m];
+    rs[m] = rsqrtf(ss / dim + eps);
+}
+svi_status svi_launch_row_rs(const float* rowss, int groups, int ldss, int rows, int dim, float eps, float* rs, hipStream_t st) {
+    SVI_REQUIRE(rowss && rs && groups > 0 && groups * 64 == dim && ldss >= rows, "row_rs: bad layout (groups %d, dim %d, ldss %d, rows %d)", groups, dim, ldss, rows);
+    if (rows <= 0) return SVI_OK;
+    hipLaunchKernelGGL(row_rs_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, rowss, groups, ldss, rows, (float)dim, eps, rs);      // (1024 workgroups at the C2 size: every CU busy)
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
 bool svi_rmsnorm_rope_q8_ok(int dim, const SviRope* rope) {
     return (dim == 512 * 3 || dim == 512 * 10) && rope && rope->tab_tok && svi_switches().rms_rows;
 }

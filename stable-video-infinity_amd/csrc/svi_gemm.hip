@@ -40,6 +40,18 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {   // byte offs
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// SviGemmArgs::rowss — sum of squares of row m's rounded results over the aligned 64-column group that holds columns [n, n + 8): this lane's 8 columns in
+// order, then the xor-1/2/4 tree over the group's 8 lanes (lane & 7 == the chunk's position in the group in every tiled kernel's read-back loop).
+__device__ __forceinline__ void gemm_rowss_store(const SviGemmArgs& g, const bf16x8& o, int m, int n, int lane_chunk) {
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = (float)o[e]; ss += f * f; }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    ss += __shfl_xor(ss, 4);
+    if ((lane_chunk & 7) == 0) g.rowss[(size_t)(n >> 6) * g.ldss + m] = ss;
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -206,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
             st_bf16x8(cp, o);
+            if (g.rowss) gemm_rowss_store(g, o, m, n, cc);          // (N % 64 == 0: a group's 8 lanes are all here)
         } else {
             for (int e = 0; e < 8 && n + e < g.N; ++e) cp[e] = (bf16)y[e];
         }
@@ -419,6 +432,9 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
                 // HBM instead of L2 / MALL and gives the time back: step 470.3 vs 469.7 ms.  Ordinary stores stay.
                 else if (abl == 4) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(cp + (size_t)(16 * it) * g.ldc));
                 else st_bf16x8(cp + (size_t)(16 * it) * g.ldc, o);
+                if constexpr (EPI == SVI_EPI_BIAS && !Q8OUT) {
+                    if (g.rowss) gemm_rowss_store(g, o, m0 + er + 16 * it, en, ecc);
+                }
             }
         }
         return;
@@ -455,6 +471,9 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
             st_bf16x8(cp, o);
+            if constexpr (EPI == SVI_EPI_BIAS && !Q8OUT) {
+                if (g.rowss) gemm_rowss_store(g, o, m, n, ecc);
+            }
         } else {
             for (int e = 0; e < 8 && n + e < g.N; ++e) cp[e] = (bf16)y[e];
         }
@@ -1030,6 +1049,9 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     }
     const int kind = svi_gemm_choose(g, gemm_device_cus());
     const SviSwitches& sw = svi_switches();
+    if (g.rowss)
+        SVI_REQUIRE(kind != 0 && g.N % 64 == 0 && g.epi == SVI_EPI_BIAS && !g.bias_along_m && !g.W2 && g.ldss >= g.M && ((uintptr_t)g.rowss % 4) == 0,
+                    "gemm: row statistics need a tiled kernel, N %% 64 == 0 (N = %d), the plain bias epilogue and ldss >= M", g.N);
     if (g.W2) {        // two weight matrices side by side: one launch when the split falls on a tile boundary of the kernel that runs, else two
         SVI_REQUIRE(g.n_split > 0 && g.n_split < g.N && !g.bias_along_m && ((uintptr_t)g.W2 % 16) == 0, "gemm: bad weight pair (n_split %d of N %d)", g.n_split, g.N);
         const int tw = kind == 0 ? 0 : kind == 128 ? BN : kind == 192 ? 192 : TN;

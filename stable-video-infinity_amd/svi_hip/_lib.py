@@ -66,6 +66,8 @@ SYMBOLS = [
     ("svi_dit_forward_cfg_pair", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_context_cache", _i32, [_vp, _i32]),
     ("svi_dit_context_refill", _i32, [_vp, _vp, _vp, _i32, _vp]),
+    ("svi_linear_row_stats", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _i32, _vp, _vp]),
+    ("svi_cross_attention_fwd", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _vp]),
     ("svi_dit_block_forward", _i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     ("svi_attention_fwd", _i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_layernorm_modulate", _i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),

@@ -141,3 +141,36 @@ def cfg3_step_(latents: torch.Tensor, cond: torch.Tensor, uncond: torch.Tensor, 
     L.check(L.lib().svi_cfg3_step(L.ptr(latents), L.ptr(cond), L.ptr(uncond), L.ptr(drop_text), latents.numel(), float(text_scale),
                                   float(audio_scale), float(dsigma), L.current_stream()), "cfg3_step")
     return latents
+
+
+def linear_row_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, eps: float = 1e-6):
+    """nn.Linear whose epilogue also leaves RMSNorm's statistic of the OUTPUT rows (svi_linear_row_stats): returns (y bf16 [M, N], rs fp32 [M] =
+    rsqrt(mean(y^2) + eps), row_sumsq fp32 [N/64, M]).  The cross-attention query projection of the DiT block (dit:296) runs this way."""
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    if bias is not None:
+        bias = _chk(bias, "bias")
+    M, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    ss = torch.empty((N // 64, M), dtype=torch.float32, device=x.device)
+    rs = torch.empty((M,), dtype=torch.float32, device=x.device)
+    L.check(L.lib().svi_linear_row_stats(L.ptr(x), K, L.ptr(weight), K, L.ptr(y), N, M, N, K, L.ptr(bias), float(eps), L.ptr(ss), M, L.ptr(rs),
+                                         L.current_stream()), "linear_row_stats")
+    return y, rs, ss
+
+
+def cross_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads: int, s_kv: Optional[int] = None, q_rs: Optional[torch.Tensor] = None,
+                    q_gain: Optional[torch.Tensor] = None, q_out_scale: float = 1.0, key_tail: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The DiT block's cross-attention over the prompt's (short) key axis (svi_cross_attention_fwd): q bf16 [Lq, n*128] — with q_rs / q_gain the RAW
+    projection output, RMS-normalised and scaled as it is read; without them used as it is (it must carry softmax_scale*log2e) — k bf16 [Lk, n*128]
+    normalised, vt bf16 [n*128, ldvt] = V transposed (columns >= Lk up to a multiple of 8 readable)."""
+    q, k, vt = _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
+    Lq, Lk = q.shape[0], (s_kv if s_kv is not None else k.shape[0])
+    out = torch.empty((Lq, num_heads * 128), dtype=torch.bfloat16, device=q.device)
+    if q_rs is not None:
+        q_rs, q_gain = _chk(q_rs, "q_rs", torch.float32), _chk(q_gain, "q_gain")
+    if key_tail is not None:
+        key_tail = _chk(key_tail, "key_tail", torch.int32)
+    L.check(L.lib().svi_cross_attention_fwd(L.ptr(q), q.shape[1], L.ptr(k), k.shape[1], L.ptr(vt), vt.shape[1], L.ptr(out), out.shape[1], Lq, Lk, num_heads,
+                                            L.ptr(key_tail), L.ptr(q_rs), L.ptr(q_gain), float(q_out_scale), L.current_stream()), "cross_attention")
+    return out

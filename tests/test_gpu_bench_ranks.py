@@ -69,7 +69,7 @@ def test_rolling_window_and_full_clips_two_ranks():
     assert "rolling window of 3 clips" in line["config"]["workload"]
     c = line["config"]
     assert c["full_clip_s"] > 0 and c["full_clip_steady_s"] > 0 and c["full_clip_breakdown"]["step_graph_captures_over_both_clips"] == 1
-    assert abs(c["value_full_clip"] - 2 * 5 / c["full_clip_s"]) < 1e-3 * c["value_full_clip"]
+    assert abs(c["value_full_clip"] - 2 * 5 / c["full_clip_s"]) < 1e-2 * c["value_full_clip"]          # (full_clip_s is printed to the millisecond)
 
 
 def test_full_clip_single_rank():

@@ -177,6 +177,102 @@ def test_rmsnorm_rope(hip, grid, heads):
     assert r0 < 2e-3 and r1 < 2e-3, (r0, r1)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1000, 1536, 256), (8190, 1536, 1536), (2049, 5120, 128), (130, 192, 72)])
+def test_linear_row_stats_is_one_tree_in_every_tile_kernel(hip, M, N, K):
+    """svi_linear_row_stats: the q projection whose epilogue also leaves RMSNorm's statistic.  (a) C is bit for bit svi_gemm_bf16's; (b) the per-64-column
+    sums of squares and rs are BITWISE the same whichever tile kernel ran (128^2, 256 x 192, 256^2 in both schedules: one summation tree), and whether
+    the rows came as one launch or as shards (a sequence-parallel rank's rows); (c) against fp64 on the rounded outputs: rel 1e-6."""
+    L = hip._lib
+    x = dev(synth.randn(61, M, K)); w = dev(synth.randn(62, N, K) / math.sqrt(K)); b = dev(synth.randn(63, N))
+    outs = {}
+    try:
+        for kind in (128, 192, 259, 260):
+            L.set_switch("SVI_GEMM_KERNEL", kind)
+            outs[kind] = hip.ops.linear_row_stats(x, w, b, eps=1e-6)
+    finally:
+        L.set_switch("SVI_GEMM_KERNEL", None)
+    y, rs, ss = outs[128]
+    assert torch.equal(y, hip.linear(x, w, b))
+    for kind in (192, 259, 260):
+        assert torch.equal(outs[kind][0], y) and torch.equal(outs[kind][2], ss) and torch.equal(outs[kind][1], rs), kind
+    h = M // 2 + 3
+    top, bot = hip.ops.linear_row_stats(x[:h].contiguous(), w, b), hip.ops.linear_row_stats(x[h:].contiguous(), w, b)
+    assert torch.equal(torch.cat([top[1], bot[1]]), rs)
+    y64 = y.double().cpu()
+    want_ss = (y64 * y64).reshape(M, N // 64, 64).sum(-1).t()
+    want_rs = 1.0 / torch.sqrt((y64 * y64).mean(-1) + 1e-6)
+    r_ss, r_rs = errs(ss, want_ss.float())[0], errs(rs, want_rs.float())[0]
+    report("linear_row_stats", M=M, N=N, K=K, rel_sumsq=r_ss, rel_rs=r_rs)
+    assert r_ss < 1e-6 and r_rs < 1e-6, (r_ss, r_rs)
+
+
+@pytest.mark.parametrize("Lq,Lk,heads,tail", [(128, 64, 1, None), (1000, 512, 2, (65, 448)), (333, 257, 3, None), (4100, 512, 12, (33, 480)), (77, 512, 2, None), (2050, 33, 12, (33, 1)),
+                                                  (700, 512, 2, (200, 313)), (300, 96, 1, None), (513, 128, 2, (128, 1)), (260, 130, 1, (129, 2))])
+def test_cross_attention_normalises_q_as_it_reads_it(hip, Lq, Lk, heads, tail):
+    """svi_cross_attention_fwd (up to 128 walked keys: flash_cross_resident_kernel, K / V^T resident in LDS; more: flash_fwd_kernel<1, STAGED>; with a device-side
+    key_tail both are launched and gate themselves): (a) without the normalisation it gives the plain short-key kernel's result on the same operands; (b) with it — q raw, rs from svi_linear_row_stats' arithmetic — it equals normalising q first
+    with svi_rmsnorm_rope's rounding points and then attending: bit for bit when the two statistics agree, and they are compared here (the standalone
+    kernel sums a row's squares in another order: the fp32 statistic may differ in the last bit, which moves a bf16 rounding of q on rare elements;
+    measured rate reported, bound 2e-3 of the elements, output rel-L2 <= 1e-3); (c) against fp64 attention on the normalised q: rel-L2 <= 6e-3."""
+    D = heads * 128
+    qraw = dev(2.0 * synth.randn(71, Lq, D))
+    gain = dev(1 + 0.1 * synth.randn(72, D))
+    k = dev(synth.randn(73, Lk, D))
+    v = bf16r(torch.from_numpy(synth.randn(74, Lk, D)))
+    ldvt = (Lk + 7) // 8 * 8
+    vt = torch.zeros((D, ldvt), dtype=torch.bfloat16, device="cuda")
+    vt[:, :Lk] = dev(v).t()
+    SC = 0.12751743          # softmax_scale * log2(e) for head_dim 128 (SVI_QK_SCALE_LOG2E)
+    kt = None
+    if tail is not None:     # keys n-1 .. Lk-1 identical: make them so
+        n, m = tail
+        k[n - 1:] = k[n - 1]
+        vt[:, n - 1:Lk] = vt[:, n - 1:n]
+        kt = torch.tensor([n, m], dtype=torch.int32, device="cuda")
+        assert n - 1 + m == Lk
+    # the two-kernel path: RMSNorm in place (out_scale folded in by the library's own call) then the short-key attention
+    lib = hip._lib
+    qn = qraw.clone()
+    lib.check(lib.lib().svi_rmsnorm_rope(qn.data_ptr(), D, Lq, D, gain.data_ptr(), 1e-6, 0, 0, 0, 0, 0, lib.current_stream()))
+    qn_scaled = (qn.float() * SC).to(torch.bfloat16)          # the DiT folds SC into the same final rounding; here it is one more rounding, so (b) compares against the fused kernel fed the same way
+    plain = hip.ops.cross_attention(qn_scaled, k, vt, heads, s_kv=Lk, key_tail=kt)
+    ref_kernel = torch.empty_like(plain)
+    lib.check(lib.lib().svi_attention_vt_fwd(qn_scaled.data_ptr(), D, k.data_ptr(), D, vt.data_ptr(), ldvt, ref_kernel.data_ptr(), D, Lq, Lk if tail is None else tail[0],
+                                             heads, 1, lib.current_stream()))
+    if tail is None:                                          # (a)
+        if Lk <= 64 or Lk > 128:      # one key tile, or the streaming kernel itself: the very same arithmetic
+            assert torch.equal(plain, ref_kernel)
+        else:                         # 65 .. 128 keys: the resident kernel's softmax is exact in one sweep, the streaming kernel's online (one rescale): same to rounding
+            assert errs(plain, ref_kernel)[0] < 2e-3
+    # (b): statistic in the projection-epilogue's tree — feed the raw q through an identity "projection" to get rs
+    eye = torch.eye(D, dtype=torch.bfloat16, device="cuda")
+    y, rs, _ = hip.ops.linear_row_stats(qraw, eye, None, eps=1e-6)
+    assert torch.equal(y, qraw)
+    rs_ref = 1.0 / torch.sqrt((qraw.double() ** 2).mean(-1) + 1e-6)
+    assert float(((rs.double() - rs_ref).abs() / rs_ref).max()) < 1e-6
+    fused1 = hip.ops.cross_attention(qraw, k, vt, heads, s_kv=Lk, q_rs=rs, q_gain=gain, q_out_scale=1.0, key_tail=kt)      # q' = norm(q), no extra scale
+    two = hip.ops.cross_attention(qn, k, vt, heads, s_kv=Lk, key_tail=kt)
+    frac = float((fused1 != two).float().mean())
+    r_b = errs(fused1, two)[0]
+    # (c)
+    vv = v.double().clone()
+    if tail is not None:
+        vv[tail[0] - 1:] = vv[tail[0] - 1]
+    # fp64 softmax(q'.k^T) v over ALL Lk keys, q' carrying the scale in base-2 units (the kernel's convention): p = 2^(q'.k - max)
+    qh = qn.double().cpu().reshape(Lq, heads, 128).transpose(0, 1)
+    kh = k.double().cpu().reshape(Lk, heads, 128).transpose(0, 1)
+    vh = vv.reshape(Lk, heads, 128).transpose(0, 1)
+    sc = qh @ kh.transpose(1, 2)
+    p = torch.exp2(sc - sc.max(-1, keepdim=True).values)
+    want = ((p / p.sum(-1, keepdim=True)) @ vh).transpose(0, 1).reshape(Lq, D).float()
+    r_c = errs(two, want)[0]
+    r_cf = errs(fused1, want)[0]
+    report("cross_attention_fused", Lq=Lq, Lk=Lk, heads=heads, tail=list(tail) if tail else None, frac_elements_differ=frac, rel_l2_fused_vs_two_kernel=r_b,
+           rel_l2_two_kernel_vs_fp64=r_c, rel_l2_fused_vs_fp64=r_cf)
+    assert frac < 2e-3 and r_b < 1e-3, (frac, r_b)
+    assert r_c < 6e-3 and r_cf < 6e-3, (r_c, r_cf)
+
+
 def test_rmsnorm_strided_view(hip):
     """The block normalises q and k in place inside the [L, 2D] q|k buffer (ld = 2D)."""
     L_, D = 50, 256
