@@ -251,6 +251,31 @@ def dit_block(sd: Dict[str, Tensor], prefix: str, x: Tensor, context: Tensor, t_
     return x
 
 
+def dit_block_rows(sd: Dict[str, Tensor], prefix: str, x: Tensor, context: Tensor, t_mod: Tensor, rope: Tensor, cfg: DiTConfig,
+                   rows, rounding: Optional[str] = None) -> Tensor:
+    """dit_block's output at the token rows `rows` only — exactly those rows of dit_block(...) (the same statements on fewer rows): self-attention
+    needs K and V of every token, everything else of a block is row-local.  What makes a block at sizes beyond the host's reach for the whole
+    score matrix checkable (81f@1280x720: 75600 tokens)."""
+    rnd = _rounder(rounding)
+    rows = torch.as_tensor(rows, dtype=torch.long)
+    mod = rnd(sd[prefix + "modulation"] + t_mod)
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = [mod[:, i:i + 1] for i in range(6)]
+    h = modulated_norm(x, sh_a, sc_a, cfg.eps, rnd)
+    p = prefix + "self_attn."
+    k = rms_norm_full(rnd(linear(h, sd[p + "k.weight"], sd[p + "k.bias"])), sd[p + "norm_k.weight"], cfg.eps, rnd)
+    k = rnd(apply_rope(k, rope, cfg.num_heads))
+    v = rnd(linear(h, sd[p + "v.weight"], sd[p + "v.bias"]))
+    q = rms_norm_full(rnd(linear(h[:, rows], sd[p + "q.weight"], sd[p + "q.bias"])), sd[p + "norm_q.weight"], cfg.eps, rnd)
+    q = rnd(apply_rope(q, rope[rows], cfg.num_heads))
+    a = rnd(attention(q, k, v, cfg.num_heads))
+    xr = rnd(x[:, rows] + rnd(g_a * rnd(linear(a, sd[p + "o.weight"], sd[p + "o.bias"]))))
+    h = rnd(layer_norm(xr, cfg.eps, sd[prefix + "norm3.weight"], sd[prefix + "norm3.bias"]))
+    xr = rnd(xr + cross_attention(sd, prefix + "cross_attn.", h, context, cfg, rnd))
+    h = modulated_norm(xr, sh_m, sc_m, cfg.eps, rnd)
+    u = rnd(gelu_tanh(rnd(linear(h, sd[prefix + "ffn.0.weight"], sd[prefix + "ffn.0.bias"]))))
+    return rnd(xr + rnd(g_m * rnd(linear(u, sd[prefix + "ffn.2.weight"], sd[prefix + "ffn.2.bias"]))))
+
+
 # --------------------------------------------------------------------------------------
 # whole forward
 # --------------------------------------------------------------------------------------

@@ -1656,6 +1656,15 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
     SVI_TRY((svi_status)flash_device_cus(&ncu));
     int kernel = 0;
     const SviFlashSplit sp = svi_flash_plan(Lq, Lk, num_heads, ncu, &kernel);          // the one place that decides kernel and split (svi_attention_plan shows it)
+    // The long-sequence kernel addresses its operands through buffer descriptors with 32-bit BYTE offsets (and the V^T row stride times a channel index as
+    // an int): an operand that reaches 2 GiB is refused here with a message rather than wrapped.  (The DiT stays far below: 75600 tokens x [L, 2D] bf16 at
+    // the 14B width is 1.5 GiB; the stacked CFG pair is only taken where 2 L rows of the widest activation stay under 2 GiB, csrc/svi_dit.hip forward_pair.)
+    if (kernel == 2) {
+        const long lim = 1L << 31;
+        SVI_REQUIRE(((long)(Lq - 1) * ldq + (long)num_heads * DH) * 2 < lim && ((long)(Lk - 1) * ldk + (long)num_heads * DH) * 2 < lim &&
+                        (long)num_heads * DH * ldvt * 2 < lim && ((long)(Lq - 1) * ldo + (long)num_heads * DH) * 2 < lim,
+                    "attention: an operand of the long-sequence kernel reaches 2 GiB (Lq=%d ldq=%d, Lk=%d ldk=%d, ldvt=%d, ldo=%d): split the call", Lq, ldq, Lk, ldk, ldvt, ldo);
+    }
     if (kernel == 2) {
         typedef void (*kern_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*, float*, float2*, SviFlashSplit, const unsigned*,
                                const unsigned*, int, int);

@@ -1005,6 +1005,8 @@ int svi_gemm_choose(const SviGemmArgs& g, int ncu) {
     if (ncu <= 0) ncu = 256;
     const int selM = g.sel_m > 0 ? g.sel_m : g.M, selN = g.sel_n > 0 ? g.sel_n : g.N;
     const long t256 = (long)((selM + TM - 1) / TM) * ((selN + TN - 1) / TN);
+    // The 256-row kernels reach A and W through buffer descriptors with 32-bit byte offsets: an operand of 2^31 elements (4 GiB) or more takes the 128^2
+    // kernel, whose loads use 64-bit pointers; C, the residual and the bias are addressed with 64-bit pointers in every kernel (tests/test_plans.py).
     const bool fits32 = (long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31);
     const SviSwitches& sw = svi_switches();
     const bool want256 = sw.gemm_kernel ? sw.gemm_kernel >= 192 : (t256 >= ncu / 2);      // 256-row tiles when the problem fills at least half the chip with them

@@ -231,3 +231,50 @@ def test_fused_q_k_projection_is_bit_identical(hip, grid):
     assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1])
     if sa is not None:
         assert torch.equal(sa, sb)
+
+
+def test_block_and_unstacked_pair_at_75600_tokens_720p(hip):
+    """A size ABOVE the headline: 81 frames at 1280x720 -> latent 21x90x160 -> 75600 tokens, Wan2.1-1.3B widths.
+      * one DiT block (svi_dit_block_forward: 256^2 GEMMs with 296 row panels, the long-sequence attention over 75600 keys, the fused cross-attention
+        on 75600 rows) against oracle.dit_block_rows — the oracle's own block statements on sampled rows (self-attention against the K / V of every
+        token) with the bf16 rounding statement: rel-L2 <= 8e-3, as the C2-size block;
+      * the CFG pair at this size: 2 x 75600 rows of the widest activation pass 2 GiB, so forward_pair takes its UNSTACKED fallback
+        (csrc/svi_dit.hip forward_pair) — outputs bit-identical to two separate forwards, finite."""
+    import numpy as np
+    import synth
+    from oracle import wan_dit_oracle as wdo
+    grid = (21, 45, 80)
+    f, h, w = grid
+    L = f * h * w
+    assert L == 75600
+    c = dict(synth.WAN_1_3B, num_layers=1)
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(990, **c).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=12, **c)
+    x = torch.from_numpy(synth.randn(991, 1, L, D))
+    ctx = torch.from_numpy(synth.randn(992, 1, 512, D))
+    ctx[:, 70:] = 0
+    tm = torch.from_numpy(0.5 * synth.randn(993, 1, 6, D))
+    got = m.block_forward(0, x.cuda(), ctx.cuda(), tm.cuda(), grid)
+    assert torch.isfinite(got.float()).all() and torch.equal(got, m.block_forward(0, x.cuda(), ctx.cuda(), tm.cuda(), grid))
+    rows = sorted(set([0, 1, 255, 256, 32759, 32760, 65535, 65536, L - 257, L - 2, L - 1] + list(range(11, L, L // 37))))
+    sdb = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    cfg = wdo.DiTConfig(dim=D, in_dim=16, ffn_dim=F, out_dim=16, text_dim=4096, freq_dim=256, patch_size=(1, 2, 2), num_heads=12, num_layers=1, has_image_input=False)
+    b16 = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
+    with torch.no_grad():
+        want = wdo.dit_block_rows(sdb, "blocks.0.", b16(x), b16(ctx), b16(tm), wdo.rope_table_3d(128, grid), cfg, rows, rounding="bf16")
+    r = _rel(got[0, rows].cpu(), want[0])
+    from gpu_util import report
+    report("dit_block_720p_75600_tokens", rel_l2_vs_oracle_bf16=r, rows=len(rows), tokens=L)
+    assert r < 8e-3, r
+    # the CFG pair at this size: unstacked fallback, same bits as two forwards
+    lat = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=3, device="cpu", dtype=torch.float32).to("cuda", torch.bfloat16)
+    cp = torch.from_numpy(synth.text_context(994, 512, 4096, 64)).to("cuda", torch.bfloat16)
+    cn = torch.from_numpy(synth.text_context(995, 512, 4096, 32)).to("cuda", torch.bfloat16)
+    ts = torch.tensor([700.0])
+    m.context_cache(True)
+    try:
+        a, b = m.forward_cfg_pair(lat, ts, cp, cn)
+        assert torch.isfinite(a.float()).all() and torch.isfinite(b.float()).all()
+        assert torch.equal(a, m.forward(lat, ts, cp)) and torch.equal(b, m.forward(lat, ts, cn))
+    finally:
+        m.context_cache(False)

@@ -174,3 +174,20 @@ def test_talk_variant_matches_reference(golden):
         plain = wdo.dit_forward(sd, cfg, x, torch.tensor([637.5]), ctx, **kw)
         assert rel_l2(plain.numpy(), g["out_fp32_no_audio"]) < 2e-5
     assert rel_l2(g["out_fp32"], g["out_fp32_no_audio"]) > 0.1
+
+
+def test_block_rows_is_the_block_on_those_rows():
+    """oracle.dit_block_rows (what checks a block at 75600 tokens, tests/test_gpu_fullsize.py) gives exactly the rows of dit_block."""
+    c = dict(synth.TINY_DIT)
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(5, **c).items()}
+    cfg = make_cfg(c)
+    grid, L = (3, 4, 6), 72
+    x = torch.from_numpy(synth.randn(1, 1, L, c["dim"]))
+    ctx = torch.from_numpy(synth.randn(2, 1, 20, c["dim"]))
+    tm = torch.from_numpy(0.3 * synth.randn(3, 1, 6, c["dim"]))
+    rope = wdo.rope_table_3d(128, grid)
+    rows = [0, 5, 17, 71]
+    for rounding, tol in ((None, 1e-6), ("bf16", 0.0)):
+        full = wdo.dit_block(sd, "blocks.0.", x, ctx, tm, rope, cfg, rounding=rounding)
+        part = wdo.dit_block_rows(sd, "blocks.0.", x, ctx, tm, rope, cfg, rows, rounding=rounding)
+        assert float((full[:, rows] - part).abs().max()) <= tol

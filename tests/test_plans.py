@@ -76,3 +76,19 @@ def test_attention_plan_follows_the_switches():
     L.set_switch("SVI_FLASH_KERNEL", None)
     # another chip (304 compute units): 1536 = 5 x 304 + 16 -> the 16 items left over are cut in four
     assert L.attention_plan(L_TOK, L_TOK, 12, compute_units=304) == dict(kernel=2, whole=1520, pieces=4, workgroups=1584)
+
+
+def test_gemm_operands_of_4_gib_take_the_kernel_with_64_bit_addresses():
+    """Guards: the 256-row kernels reach A and W through buffer descriptors with 32-bit byte offsets; a problem whose A or W holds
+    2^31 elements or more must never run on them (it would read zeros past the wrap) — the planner sends it to the 128^2 kernel (64-bit pointers)."""
+    M = 75600 * 2                                          # a stacked CFG pair at 720p
+    assert L.gemm_plan(M, D, F) != 128 and M * F < 2 ** 31     # A = [151200, 8960]: 1.35e9 elements, still a 256-row tile
+    big_m = 2 ** 31 // F + 1
+    assert big_m * F >= 2 ** 31 and L.gemm_plan(big_m, D, F) == 128
+    assert L.gemm_plan(1024, 2 ** 31 // 4096 + 1, 4096) == 128    # ... and the same for the weight operand
+    for forced in (192, 259, 260):
+        L.set_switch("SVI_GEMM_KERNEL", forced)
+        try:
+            assert L.gemm_plan(big_m, D, F) == 128                 # a forced 256-row kernel does not override the guard
+        finally:
+            L.set_switch("SVI_GEMM_KERNEL", None)
