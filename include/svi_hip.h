@@ -181,6 +181,14 @@ svi_status svi_dit_context_refill(svi_dit* h, const void* context, const void* c
 svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* timestep, const void* context, const void* clip_feature,
                             const void* y, const void* add_condition, int32_t T, int32_t H, int32_t W, int32_t Lc,
                             int32_t row0, int32_t nrows, svi_stream stream);
+/* Both forwards of a CFG step on one shard, STACKED (svi_dit_forward_cfg_pair's form on a rank's rows; needs svi_dit_context_cache(h, 1)): the shard's
+ * rows of the conditional branch on top of the unconditional branch's.  The calls that follow act on 2 nrows rows: svi_dit_sp_block_qkv stores
+ * q_send / k_send as [branch][G][P][nrows][Dg] and V^T as [dim, ldvt >= 2 nrows] (columns [0, nrows) conditional, [nrows, 2 nrows) unconditional);
+ * svi_dit_sp_block_rest takes attn [2 nrows, dim]; svi_dit_sp_head writes [2 nrows, svi_dit_head_ld].  Attention is run per branch by the caller.
+ * No CFG exchange between ranks; each row-local launch of a shard is twice as long.  Bit-identical to two svi_dit_sp_begin forwards. */
+svi_status svi_dit_sp_begin_pair(svi_dit* h, const void* x, const float* timestep, const void* context_cond, const void* context_uncond,
+                                 const void* clip_feature, const void* y, const void* add_condition, int32_t T, int32_t H, int32_t W, int32_t Lc,
+                                 int32_t row0, int32_t nrows, svi_stream stream);
 /* svi_dit_sp_block_qkv_part: the same in two pieces — part 1 = LN + modulate and the V^T projection, part 2 = the q | k projection with RMSNorm + RoPE
  * (0 = both: svi_dit_sp_block_qkv) — so that V^T can be on the wire while q | k are still being made (the gather mode of sequence_parallel.py). */
 svi_status svi_dit_sp_block_qkv_part(svi_dit* h, int32_t layer, void* q_send, void* k_send, void* vt_out, int32_t ldvt, int32_t P, int32_t G,

@@ -270,13 +270,16 @@ struct SviRope {                // device tables of (cos,sin) pairs, fp32
     int npf, nph, npw;          // complex pairs per head owned by the frame / height / width axis
     int f, h, w;
     int row0;                   // token index of row 0 of the launch (sequence-parallel shards start mid-grid)
-    int period;                 // > 0: rows are `rows / period` samples stacked one under the other; token = (row0 + row) % period
+    int period;                 // > 0: rows are `rows / period` samples of `period` rows stacked one under the other; token = row0 + row % period
+                                // (the stacked CFG pair: period = L on one rank, = the shard's row count on a sequence-parallel rank)
     const float2* tab_tok;      // optional: [f*h*w][64] — every token's 64 pairs gathered from the axis tables (16-byte aligned); the DiT builds it once per grid
 };
 // Sequence-parallel send layout (svi_hip/sequence_parallel.py): instead of in place, operand p of the q | k launch is stored as
 // out[p][g][j][row][cg] — destination rank j = col / Dp owns head-channel block [j*Dp, (j+1)*Dp), inside it head group g = (col % Dp) / Dg,
 // cg = col % Dg — so that every (operand, head group)'s all-to-all input is one contiguous [P][rows * Dg] tensor.
-struct SviScatter { bf16* out0; bf16* out1; int P, Dp, Dg; };
+// rows_per_sample > 0 (the stacked CFG pair on a shard): the launch's rows are samples of that many rows one under the other, and sample b's block
+// starts sample_stride elements behind sample b - 1's: out[p] + b * sample_stride + [g][j][row % rows_per_sample][cg] — each branch's exchange input stays contiguous.
+struct SviScatter { bf16* out0; bf16* out1; int P, Dp, Dg; int rows_per_sample; long sample_stride; };
 // out_scale multiplies the result before its single final rounding (the DiT folds the attention scale into q there)
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
                                    const SviRope* rope, float out_scale, hipStream_t st);

@@ -117,9 +117,11 @@ struct svi_dit {
     int ldavt = 0;
     // sequence-parallel shard in flight (svi_dit_sp_begin .. svi_dit_sp_head)
     int sp_rows = 0, sp_row0 = 0, sp_Lc = 0;
+    int sp_nb = 1;                    // 2: the shard carries both CFG branches stacked (svi_dit_sp_begin_pair): X = [cond rows | uncond rows]
     bool sp_active = false;
     const bf16* sp_ctxp = nullptr;
-    std::vector<CtxKV> sp_kv;
+    const bf16* sp_ctxp_b = nullptr;
+    std::vector<CtxKV> sp_kv, sp_kv_b;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1198,9 +1200,51 @@ extern "C" svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* t
                           reinterpret_cast<const bf16*>(y), Lc, &cu, st));
     SVI_TRY(stage_embed(h, reinterpret_cast<const bf16*>(x), reinterpret_cast<const bf16*>(y), reinterpret_cast<const bf16*>(add_condition),
                         T, H, W, nrows, st, row0));
-    h->sp_rows = nrows; h->sp_row0 = row0; h->sp_Lc = Lc; h->sp_active = true; h->sp_ctxp = cu.CTXp;
+    h->sp_rows = nrows; h->sp_row0 = row0; h->sp_Lc = Lc; h->sp_active = true; h->sp_ctxp = cu.CTXp; h->sp_nb = 1;
     h->sp_kv.clear();
     for (int l = 0; l < c.num_layers; ++l) h->sp_kv.push_back(kv_of(h, cu, l));
+    return SVI_OK;
+}
+
+// Both forwards of a CFG step on ONE sequence shard, stacked (the single-rank forward_pair's form on a rank's rows): X holds the conditional branch's
+// nrows rows on top of the unconditional branch's; every row-local kernel of a block (norms, projections, MLP, head) then runs once over 2 nrows rows —
+// a quarter-size shard's launches are half-size again — and the exchange moves each branch's q | k / output pieces as their own contiguous blocks
+// (SviScatter::rows_per_sample).  No CFG exchange between ranks: a rank ends with both branches' head rows.  Needs the context cache (each prompt's
+// projected context and K / V in buffers of its own).  The results are bit-identical to two svi_dit_sp_begin forwards.
+extern "C" svi_status svi_dit_sp_begin_pair(svi_dit* h, const void* x, const float* timestep, const void* context_cond, const void* context_uncond,
+                                            const void* clip_feature, const void* y, const void* add_condition, int32_t T, int32_t H,
+                                            int32_t W, int32_t Lc, int32_t row0, int32_t nrows, svi_stream stream) {
+    SVI_REQUIRE(h && x && timestep && context_cond && context_uncond && context_cond != context_uncond, "svi_dit_sp_begin_pair: null argument (or one prompt given twice)");
+    SVI_REQUIRE_DEVICE(h);
+    const svi_dit_config& c = h->cfg;
+    SVI_REQUIRE(h->ctx_cache_on, "svi_dit_sp_begin_pair: the stacked CFG pair needs the context cache (svi_dit_context_cache(h, 1))");
+    SVI_REQUIRE(T > 0 && H > 0 && W > 0 && Lc > 0 && T % c.patch_t == 0 && H % c.patch_h == 0 && W % c.patch_w == 0, "svi_dit_sp_begin_pair: bad sizes");
+    if (h->aud_first) { svi_set_error("svi_dit_sp_begin_pair: the talk variant's per-frame audio attention is not served on sequence shards"); return SVI_ERR_UNSUPPORTED; }
+    SVI_REQUIRE(y || c.in_dim == 16, "this model takes %d extra input channels: y must be given", c.in_dim - 16);
+    SVI_REQUIRE(!c.has_image_input || clip_feature, "has_image_input model needs clip_feature");
+    const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w, L = f * hh * ww;
+    SVI_REQUIRE(row0 >= 0 && nrows > 0 && row0 + nrows <= L, "svi_dit_sp_begin_pair: rows [%d, %d) outside the %d-token sequence", row0, row0 + nrows, L);
+    const size_t widest = (size_t)std::max(c.ffn_dim, 2 * c.dim);
+    SVI_REQUIRE((size_t)2 * nrows * widest * 2 < ((size_t)1 << 31), "svi_dit_sp_begin_pair: 2 x %d rows of the widest activation reach 2 GiB: run the branches separately", nrows);
+    SVI_TRY(svi_dit_check_bound(h));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SVI_TRY(ensure_workspace(h, 2 * nrows, Lc, st));
+    SVI_TRY(ensure_rope(h, f, hh, ww));
+    SVI_TRY(stage_time(h, timestep, st));
+    Workspace& w = h->ws;
+    SVI_TRY(stage_embed(h, reinterpret_cast<const bf16*>(x), reinterpret_cast<const bf16*>(y), reinterpret_cast<const bf16*>(add_condition),
+                        T, H, W, nrows, st, row0));
+    SVI_CHECK_HIP(hipMemcpyAsync(w.X + (size_t)nrows * c.dim, w.X, (size_t)nrows * c.dim * 2, hipMemcpyDeviceToDevice, st));
+    CtxUse cu[2]{};
+    const bf16* ctxs[2] = {reinterpret_cast<const bf16*>(context_cond), reinterpret_cast<const bf16*>(context_uncond)};
+    for (int k = 0; k < 2; ++k) {
+        SVI_TRY(stage_context(h, ctxs[k], reinterpret_cast<const bf16*>(clip_feature), reinterpret_cast<const bf16*>(y), Lc, &cu[k], st));
+        SVI_REQUIRE(cu[k].ce != nullptr, "svi_dit_sp_begin_pair: no cache entry");
+    }
+    h->sp_rows = nrows; h->sp_row0 = row0; h->sp_Lc = Lc; h->sp_active = true; h->sp_nb = 2;
+    h->sp_ctxp = cu[0].CTXp; h->sp_ctxp_b = cu[1].CTXp;
+    h->sp_kv.clear(); h->sp_kv_b.clear();
+    for (int l = 0; l < c.num_layers; ++l) { h->sp_kv.push_back(kv_of(h, cu[0], l)); h->sp_kv_b.push_back(kv_of(h, cu[1], l)); }
     return SVI_OK;
 }
 
@@ -1213,11 +1257,13 @@ extern "C" svi_status svi_dit_sp_block_qkv_part(svi_dit* h, int32_t layer, void*
     SVI_REQUIRE(h && h->sp_active && q_send && k_send && vt_out && part >= 0 && part <= 2, "svi_dit_sp_block_qkv: no shard in flight (svi_dit_sp_begin), null buffer or bad part");
     SVI_REQUIRE_DEVICE(h);
     const int D = h->cfg.dim;
-    SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && ldvt >= h->sp_rows && ldvt % 8 == 0, "svi_dit_sp_block_qkv: bad layer / ldvt");
+    const int nb = h->sp_nb, rows = nb * h->sp_rows;
+    SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && ldvt >= rows && ldvt % 8 == 0, "svi_dit_sp_block_qkv: bad layer / ldvt");
     SVI_REQUIRE(P > 0 && G > 0 && h->cfg.num_heads % (P * G) == 0, "svi_dit_sp_block_qkv: %d heads do not split into %d ranks x %d head groups", h->cfg.num_heads, P, G);
-    SviScatter sc{reinterpret_cast<bf16*>(q_send), reinterpret_cast<bf16*>(k_send), P, D / P, D / P / G};
-    return block_qkv(h, layer, h->ws.X, h->ws.modf + (size_t)layer * 6 * D, h->sp_rows, h->sp_row0, h->ws.QK, reinterpret_cast<bf16*>(vt_out), ldvt,
-                     reinterpret_cast<hipStream_t>(stream), &sc, 1, part);
+    // stacked pair: each branch's send block [G][P][nrows][Dg] stands alone, the unconditional one right behind the conditional one
+    SviScatter sc{reinterpret_cast<bf16*>(q_send), reinterpret_cast<bf16*>(k_send), P, D / P, D / P / G, nb > 1 ? h->sp_rows : 0, (long)h->sp_rows * D};
+    return block_qkv(h, layer, h->ws.X, h->ws.modf + (size_t)layer * 6 * D, rows, h->sp_row0, h->ws.QK, reinterpret_cast<bf16*>(vt_out), ldvt,
+                     reinterpret_cast<hipStream_t>(stream), &sc, nb, part);
 }
 
 extern "C" svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, svi_stream stream) {
@@ -1237,7 +1283,7 @@ extern "C" svi_status svi_dit_sp_tea(svi_dit* h, int32_t mode, void* residual, s
     SVI_REQUIRE_DEVICE(h);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     Workspace& w = h->ws;
-    const int64_t n = (int64_t)h->sp_rows * h->cfg.dim;
+    const int64_t n = (int64_t)h->sp_nb * h->sp_rows * h->cfg.dim;
     if (mode == 0) { SVI_CHECK_HIP(hipMemcpyAsync(w.X2, w.X, (size_t)n * 2, hipMemcpyDeviceToDevice, st)); return SVI_OK; }
     if (mode == 1) return svi_launch_sub_bf16(reinterpret_cast<bf16*>(residual), w.X, w.X2, n, st);
     return svi_launch_add_bf16(w.X, reinterpret_cast<const bf16*>(residual), n, st);
@@ -1249,6 +1295,12 @@ extern "C" svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const voi
     SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers, "svi_dit_sp_block_rest: bad layer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float* modf = h->ws.modf + (size_t)layer * 6 * h->cfg.dim;
+    if (h->sp_nb == 2) {
+        SVI_TRY(block_attn_out(h, layer, h->ws.X, reinterpret_cast<const bf16*>(attn), modf, 2 * h->sp_rows, st, 2));
+        const bf16* CTXs[2] = {h->sp_ctxp, h->sp_ctxp_b};
+        CtxKV kvs[2] = {h->sp_kv[layer], h->sp_kv_b[layer]};
+        return run_block_rest_n(h, layer, h->ws.X, CTXs, modf, h->sp_rows, h->sp_Lc, kvs, 2, st);
+    }
     SVI_TRY(block_attn_out(h, layer, h->ws.X, reinterpret_cast<const bf16*>(attn), modf, h->sp_rows, st));
     return run_block_rest(h, layer, h->ws.X, h->sp_ctxp, modf, h->sp_rows, h->sp_Lc, h->sp_kv[layer], st);
 }
@@ -1257,7 +1309,7 @@ extern "C" svi_status svi_dit_sp_head(svi_dit* h, void* head_rows_out, svi_strea
     SVI_REQUIRE(h && h->sp_active && head_rows_out, "svi_dit_sp_head: no shard in flight or null buffer");
     SVI_REQUIRE_DEVICE(h);
     h->sp_active = false;
-    return stage_head_rows(h, reinterpret_cast<bf16*>(head_rows_out), h->sp_rows, reinterpret_cast<hipStream_t>(stream));
+    return stage_head_rows(h, reinterpret_cast<bf16*>(head_rows_out), h->sp_nb * h->sp_rows, reinterpret_cast<hipStream_t>(stream), h->sp_nb);
 }
 
 extern "C" svi_status svi_dit_unpatchify(svi_dit* h, const void* head_rows, void* out, int32_t T, int32_t H, int32_t W, svi_stream stream) {

@@ -228,8 +228,9 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
     const float2* tt = nullptr;                  // this token's 64 pairs, when the caller gathered them (SviRope::tab_tok)
     if (use_rope) {
         const int hw = r.h * r.w;
-        int tok = row + r.row0;
+        int tok = row;
         if (r.period > 0) tok %= r.period;
+        tok += r.row0;
         if (r.tab_tok) tt = r.tab_tok + (size_t)tok * 64;
         pf = tok / hw;
         const int rem = tok - pf * hw;
@@ -272,7 +273,9 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
             if constexpr (SCATTER) {
                 const int j = col / sc.Dp, cl = col - j * sc.Dp, gq = cl / sc.Dg, cg = cl - gq * sc.Dg;
                 bf16* ob = blockIdx.y ? sc.out1 : sc.out0;
-                st_bf16x8(ob + ((size_t)(gq * sc.P + j) * rows + row) * sc.Dg + cg, o);
+                int rps = rows, rr = row;
+                if (sc.rows_per_sample > 0) { rps = sc.rows_per_sample; const int smp = row / rps; rr = row - smp * rps; ob += (size_t)smp * sc.sample_stride; }
+                st_bf16x8(ob + ((size_t)(gq * sc.P + j) * rps + rr) * sc.Dg + cg, o);
             } else {
                 st_bf16x8(xr + col, o);
             }
@@ -316,8 +319,9 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_rows_kernel(bf16* __restrict
         const float rs = rsqrtf(wave_sum(ss) / (float)dim + eps);
         const float2* tt = nullptr;
         if (ROPE) {
-            int tok = row + r.row0;
+            int tok = row;
             if (r.period > 0) tok %= r.period;
+            tok += r.row0;
             tt = r.tab_tok + (size_t)tok * 64;
         }
         bf16* xr = xb + (size_t)row * ld;
@@ -388,7 +392,7 @@ svi_status svi_launch_rmsnorm_rope2_q8(bf16* x, int ld, int rows, int dim, const
                                        float out_scale1, hipStream_t st, const SviQk8& out) {
     SVI_REQUIRE(svi_rmsnorm_rope_q8_ok(dim, rope) && weight1 && ld >= 2 * dim && ld % 8 == 0, "rmsnorm -> e4m3: only the DiT's q | k launch (dim %d)", dim);
     SVI_REQUIRE(out.q8 && out.k8 && out.qs && out.ks && out.ld8 >= dim && out.ld8 % 8 == 0 && out.qs_rows >= rows && out.ks_rows >= rows, "rmsnorm -> e4m3: bad output buffers");
-    SVI_REQUIRE(rope->npf + rope->nph + rope->npw == 64 && rope->row0 >= 0 && (rope->period > 0 ? rope->period == rope->f * rope->h * rope->w : rope->row0 + rows <= rope->f * rope->h * rope->w),
+    SVI_REQUIRE(rope->npf + rope->nph + rope->npw == 64 && rope->row0 >= 0 && (rope->period > 0 ? (rope->row0 + rope->period <= rope->f * rope->h * rope->w && rows % rope->period == 0) : rope->row0 + rows <= rope->f * rope->h * rope->w),
                 "rope grid %dx%dx%d does not cover rows [%d, %d)", rope->f, rope->h, rope->w, rope->row0, rope->row0 + rows);
     if (rows <= 0) return SVI_OK;
     constexpr int RPW = 4;
@@ -414,7 +418,7 @@ svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf
     if (rope) {
         r = *rope;
         SVI_REQUIRE(dim % 128 == 0 && r.npf + r.nph + r.npw == 64, "rope needs head_dim 128");
-        SVI_REQUIRE(r.row0 >= 0 && (r.period > 0 ? r.period == r.f * r.h * r.w : r.row0 + rows <= r.f * r.h * r.w),
+        SVI_REQUIRE(r.row0 >= 0 && (r.period > 0 ? (r.row0 + r.period <= r.f * r.h * r.w && rows % r.period == 0) : r.row0 + rows <= r.f * r.h * r.w),
                     "rope grid %dx%dx%d does not cover rows [%d, %d)", r.f, r.h, r.w, r.row0, r.row0 + rows);
     }
     SVI_REQUIRE(!weight1 || ld >= 2 * dim, "rmsnorm: a second operand needs ld >= 2 dim");
@@ -426,6 +430,8 @@ svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf
         sc = *scatter;
         SVI_REQUIRE(sc.out0 && (!weight1 || sc.out1) && sc.P > 0 && sc.Dp > 0 && sc.Dg > 0 && sc.P * sc.Dp == dim && sc.Dp % sc.Dg == 0 && sc.Dg % 8 == 0,
                     "rmsnorm: bad send layout (P=%d Dp=%d Dg=%d for dim %d)", sc.P, sc.Dp, sc.Dg, dim);
+        SVI_REQUIRE(sc.rows_per_sample == 0 || (sc.rows_per_sample > 0 && rows % sc.rows_per_sample == 0 && sc.sample_stride % 8 == 0),
+                    "rmsnorm: %d rows are not whole samples of %d rows", rows, sc.rows_per_sample);
     }
 #define SVI_RMS_LAUNCH(MAXC)                                                                                                             \
     do {                                                                                                                                 \

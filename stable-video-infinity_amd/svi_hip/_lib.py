@@ -46,6 +46,7 @@ SYMBOLS = [
     ("svi_dit_check_bound", _i32, [_vp]),
     ("svi_dit_forward", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_sp_begin", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_dit_sp_begin_pair", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_sp_block_qkv", _i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_dit_sp_block_qkv_part", _i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     ("svi_sp_unpack_vt", _i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -68,6 +68,7 @@ class DenoiseLoop:
         self.resident = bool(resident) and self.graph
         self._slots: Dict[str, torch.Tensor] = {}      # resident: name -> the loop's own tensor of that input
         self._slot_src: Dict[str, tuple] = {}          # name -> (the tensor last copied in — kept alive so that its address cannot return as another's —, its version)
+        self.last_sp_form = None      # sequence-parallel steps: "stacked pair" (forward_distributed_pair) or "two forwards"
         self.captures = 0             # how many times a step was captured (a resident stream of equal-shaped clips: once)
         self._graph = None            # dict(key, graph, ts, pins, generation) of the captured step, see _forwards_graphed
         self._capture_stream = None   # ONE side stream per loop, reused by every re-capture: the library keeps per-stream scratch (flag words,
@@ -237,8 +238,18 @@ class DenoiseLoop:
             return self.cfg_pair.step(fwd, ops.cfg_step_, latents, timestep, dsigma, ctx_pos, ctx_neg, cfg_scale,
                                       uncond_overrides=dict(add_condition=None) if split else None, **cond)
         if self.sequence_parallel:
-            cpred = fwd(latents, timestep, ctx_pos, **cond)
-            upred = fwd(latents, timestep, ctx_neg, **ucond) if cfg_scale != 1.0 else None
+            import torch.distributed as dist
+            from .sequence_parallel import forward_distributed_pair
+            stackable = (cfg_scale != 1.0 and not split and self.dit._ctx_cache_on and ctx_neg is not None and ctx_neg.shape == ctx_pos.shape
+                         and ctx_neg is not ctx_pos and self.dit.num_heads % dist.get_world_size(self.sp_group) == 0)
+            if stackable:
+                # both branches stacked on this rank's rows: half the launches of two shard forwards, each twice as long; no CFG exchange
+                cpred, upred = forward_distributed_pair(self.dit, latents, timestep, ctx_pos, ctx_neg, group=self.sp_group, **cond)
+                self.last_sp_form = "stacked pair"
+            else:
+                cpred = fwd(latents, timestep, ctx_pos, **cond)
+                upred = fwd(latents, timestep, ctx_neg, **ucond) if cfg_scale != 1.0 else None
+                self.last_sp_form = "two forwards"
             ops.cfg_step_(latents, cpred, upred, cfg_scale if upred is not None else 1.0, dsigma)
             return latents
         if self._cond is None or self._cond.shape != latents.shape:

@@ -119,19 +119,22 @@ def all_to_all_local(sends: Sequence[torch.Tensor]) -> List[torch.Tensor]:
 class _Buffers:
     """Exchange buffers of one (rank, world, tokens, head groups) configuration; allocated once, reused by every block."""
 
-    def __init__(self, d: WanDiT, world: int, Ls: int, G: int, dev):
+    def __init__(self, d: WanDiT, world: int, Ls: int, G: int, dev, nb: int = 1):
+        """nb = 2: the stacked CFG pair (SequenceShard.begin_pair) — a leading branch axis on every q | k / output block (each branch's exchange pieces
+        stay contiguous), V^T with both branches' rows side by side along the token axis (one exchange), attn with the unconditional rows below."""
         D, Dp = d.dim, d.dim // world
         Dg, Lfull = Dp // G, Ls * world
-        self.ldvt, self.L8 = (Ls + 7) // 8 * 8, (Lfull + 7) // 8 * 8
+        self.nb = nb
+        self.ldvt, self.L8 = (nb * Ls + 7) // 8 * 8, (Lfull + 7) // 8 * 8
         bf = dict(dtype=torch.bfloat16, device=dev)
-        self.qk_send = torch.empty((2, G, world, Ls * Dg), **bf)       # [q|k][group][dest][rows of this rank]
-        self.qk_recv = torch.empty((2, G, world, Ls * Dg), **bf)       # [q|k][group][src] = [q|k][group] x token-major [L, Dg]
+        self.qk_send = torch.empty((2, nb, G, world, Ls * Dg), **bf)   # [q|k][branch][group][dest][rows of this rank]
+        self.qk_recv = torch.empty((2, nb, G, world, Ls * Dg), **bf)   # [q|k][branch][group][src] = token-major [L, Dg] per (operand, branch, group)
         self.vt_send = torch.zeros((world, Dp, self.ldvt), **bf)       # = V^T [D, ldvt] of this rank's rows (pad columns stay zero)
         self.vt_recv = torch.empty((world, Dp, self.ldvt), **bf)
-        self.vt_full = torch.zeros((Dp, self.L8), **bf)                # V^T of this rank's head block over all tokens (pad stays zero)
-        self.o_send = torch.empty((G, world, Ls * Dg), **bf)           # attention output [group][L, Dg] = [group][dest][Ls*Dg]
-        self.o_recv = torch.empty((G, world, Ls * Dg), **bf)
-        self.attn = torch.empty((Ls, D), **bf)
+        self.vt_full = torch.zeros((nb, Dp, self.L8), **bf)            # V^T of this rank's head block over all tokens, per branch (pad stays zero)
+        self.o_send = torch.empty((nb, G, world, Ls * Dg), **bf)       # attention output [branch][group][L, Dg] = [branch][group][dest][Ls*Dg]
+        self.o_recv = torch.empty((nb, G, world, Ls * Dg), **bf)
+        self.attn = torch.empty((nb * Ls, D), **bf)
         self.head_rows = None
 
 
@@ -171,11 +174,9 @@ class SequenceShard:
             raise ValueError(f"{self.heads_local} heads per rank do not split into {groups} head groups")
         self._groups = groups
 
-    def begin(self, x, timestep, context, clip_feature=None, y=None, add_condition=None):
+    def _setup(self, x, contexts, clip_feature, y, add_condition, nb: int):
         d = self.dit
-        d.check_inputs(x, (context,), clip_feature, y, add_condition)
-        if not d.has_image_input:
-            clip_feature = None
+        d.check_inputs(x, contexts, clip_feature, y, add_condition)
         x = x.to(torch.bfloat16).contiguous()
         B, _, T, H, W = x.shape
         if B != 1:
@@ -185,15 +186,24 @@ class SequenceShard:
         if self.L % self.world:
             raise ValueError(f"{self.L} tokens do not divide over {self.world} ranks")
         self.Ls = self.L // self.world
+        self.nb = nb
         self.G = self._groups if self._groups is not None else head_groups(self.heads_local, self.L)
         self.Dg = self.Dp // self.G
         cache = d.__dict__.setdefault("_sp_buffers", {})
-        key = (self.rank, self.world, self.L, self.G if self.mode == "ulysses" else "gather", x.device)
+        key = (self.rank, self.world, self.L, self.G if self.mode == "ulysses" else "gather", x.device, nb)
         if key not in cache:
             if len(cache) >= 4:
                 cache.clear()
-            cache[key] = _Buffers(d, self.world, self.Ls, self.G, x.device) if self.mode == "ulysses" else _GatherBuffers(d, self.world, self.Ls, x.device)
+            cache[key] = _Buffers(d, self.world, self.Ls, self.G, x.device, nb) if self.mode == "ulysses" else _GatherBuffers(d, self.world, self.Ls, x.device)
         self.buf = cache[key]
+        return x
+
+    def begin(self, x, timestep, context, clip_feature=None, y=None, add_condition=None):
+        d = self.dit
+        if not d.has_image_input:
+            clip_feature = None
+        x = self._setup(x, (context,), clip_feature, y, add_condition, 1)
+        T, H, W = self.T, self.H, self.W
         context, clip_feature = d._prompt_args(context, clip_feature)
         self._keep = [x, context, timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(), clip_feature,
                       None if y is None else y.to(torch.bfloat16).contiguous(),
@@ -201,6 +211,28 @@ class SequenceShard:
         x, context, ts, clip, yy, addc = self._keep
         L.check(L.lib().svi_dit_sp_begin(d._h, L.ptr(x), L.ptr(ts), L.ptr(context), L.ptr(clip), L.ptr(yy), L.ptr(addc), T, H, W,
                                          context.shape[1], self.rank * self.Ls, self.Ls, L.current_stream()), "svi_dit_sp_begin")
+
+    def begin_pair(self, x, timestep, context_cond, context_uncond, clip_feature=None, y=None, add_condition=None):
+        """Both forwards of a CFG step on this shard, stacked (svi_dit_sp_begin_pair): the calls that follow act on 2 Ls rows — the conditional
+        branch's on top — and every exchange block carries a leading branch axis.  Ulysses mode, context cache on."""
+        d = self.dit
+        if self.mode != "ulysses":
+            raise ValueError("the stacked CFG pair is served in ulysses mode (heads divide over the ranks)")
+        if not d._ctx_cache_on:
+            raise RuntimeError("the stacked CFG pair needs the context cache (WanDiT.context_cache(True)): each prompt's K / V live in buffers of their own")
+        if context_cond.shape != context_uncond.shape:
+            raise ValueError("the two prompt embeddings of a CFG pair must have the same shape")
+        if not d.has_image_input:
+            clip_feature = None
+        x = self._setup(x, (context_cond, context_uncond), clip_feature, y, add_condition, 2)
+        T, H, W = self.T, self.H, self.W
+        context_cond, context_uncond, clip_feature = d._prompt_args(context_cond, context_uncond, clip_feature)
+        self._keep = [x, context_cond, context_uncond, timestep.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(), clip_feature,
+                      None if y is None else y.to(torch.bfloat16).contiguous(),
+                      None if add_condition is None else add_condition.to(torch.bfloat16).contiguous()]
+        x, ca, cb, ts, clip, yy, addc = self._keep
+        L.check(L.lib().svi_dit_sp_begin_pair(d._h, L.ptr(x), L.ptr(ts), L.ptr(ca), L.ptr(cb), L.ptr(clip), L.ptr(yy), L.ptr(addc), T, H, W,
+                                              ca.shape[1], self.rank * self.Ls, self.Ls, L.current_stream()), "svi_dit_sp_begin_pair")
 
     # ---- gather mode: q stays, K / V^T of all ranks are gathered ---------------------------------------------------------------
     def block_qkv_rows(self, layer: int) -> None:
@@ -232,24 +264,29 @@ class SequenceShard:
 
     # ---- ulysses mode ----------------------------------------------------------------------------------------------------------------
     def block_qkv(self, layer: int) -> None:
-        """-> buf.qk_send (q | k in send order), buf.vt_send (V^T, row block j = rank j's piece)."""
+        """-> buf.qk_send (q | k in send order, per branch), buf.vt_send (V^T, row block j = rank j's piece; a stacked pair's branches side by side
+        along the token axis)."""
         b = self.buf
         L.check(L.lib().svi_dit_sp_block_qkv(self.dit._h, layer, L.ptr(b.qk_send[0]), L.ptr(b.qk_send[1]), L.ptr(b.vt_send), b.ldvt,
                                              self.world, self.G, L.current_stream()), "svi_dit_sp_block_qkv")
 
     def unpack_v(self) -> None:
         b = self.buf
-        L.check(L.lib().svi_sp_unpack_vt(L.ptr(b.vt_recv), L.ptr(b.vt_full), self.world, self.Dp, self.Ls, b.ldvt, b.L8, L.current_stream()), "svi_sp_unpack_vt")
+        for br in range(self.nb):          # branch br's tokens are columns [br * Ls, (br + 1) * Ls) of every received piece
+            L.check(L.lib().svi_sp_unpack_vt(b.vt_recv.data_ptr() + br * self.Ls * 2, L.ptr(b.vt_full[br]), self.world, self.Dp, self.Ls, b.ldvt, b.L8,
+                                             L.current_stream()), "svi_sp_unpack_vt")
 
-    def attention(self, g: int) -> None:
-        """Attention of head group g on the received operands -> buf.o_send[g] ([L, Dg], contiguous per destination)."""
+    def attention(self, g: int, branch: int = 0) -> None:
+        """Attention of head group g (of CFG branch `branch`) on the received operands -> buf.o_send[branch, g] ([L, Dg], contiguous per destination)."""
         b = self.buf
-        L.check(L.lib().svi_attention_vt_fwd(L.ptr(b.qk_recv[0, g]), self.Dg, L.ptr(b.qk_recv[1, g]), self.Dg, L.ptr(b.vt_full[g * self.Dg:]), b.L8,
-                                             L.ptr(b.o_send[g]), self.Dg, self.L, self.L, self.heads_local // self.G, 1, L.current_stream()), "svi_attention_vt_fwd")
+        L.check(L.lib().svi_attention_vt_fwd(L.ptr(b.qk_recv[0, branch, g]), self.Dg, L.ptr(b.qk_recv[1, branch, g]), self.Dg,
+                                             L.ptr(b.vt_full[branch, g * self.Dg:]), b.L8, L.ptr(b.o_send[branch, g]), self.Dg, self.L, self.L,
+                                             self.heads_local // self.G, 1, L.current_stream()), "svi_attention_vt_fwd")
 
     def block_rest(self, layer: int) -> None:
         b = self.buf
-        L.check(L.lib().svi_sp_unpack_out(L.ptr(b.o_recv), L.ptr(b.attn), self.world, self.G, self.Ls, self.Dg, L.current_stream()), "svi_sp_unpack_out")
+        for br in range(self.nb):
+            L.check(L.lib().svi_sp_unpack_out(L.ptr(b.o_recv[br]), L.ptr(b.attn[br * self.Ls:]), self.world, self.G, self.Ls, self.Dg, L.current_stream()), "svi_sp_unpack_out")
         L.check(L.lib().svi_dit_sp_block_rest(self.dit._h, layer, L.ptr(b.attn), L.current_stream()), "svi_dit_sp_block_rest")
 
     def tea(self, mode: int, residual: Optional[torch.Tensor] = None) -> None:
@@ -259,10 +296,11 @@ class SequenceShard:
         L.check(L.lib().svi_dit_sp_tea(self.dit._h, mode, L.ptr(residual), L.current_stream()), "svi_dit_sp_tea")
 
     def head(self) -> torch.Tensor:
+        """-> head rows of this shard [nb * Ls, ld] (a stacked pair: the unconditional branch's rows below the conditional one's)."""
         ld = L.lib().svi_dit_head_ld(self.dit._h)
         b = self.buf
-        if b.head_rows is None or tuple(b.head_rows.shape) != (self.Ls, ld):
-            b.head_rows = torch.empty((self.Ls, ld), dtype=torch.bfloat16, device=b.attn.device)
+        if b.head_rows is None or tuple(b.head_rows.shape) != (self.nb * self.Ls, ld):
+            b.head_rows = torch.empty((self.nb * self.Ls, ld), dtype=torch.bfloat16, device=b.attn.device)
         L.check(L.lib().svi_dit_sp_head(self.dit._h, L.ptr(b.head_rows), L.current_stream()), "svi_dit_sp_head")
         return b.head_rows
 
@@ -331,7 +369,7 @@ def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: O
     for layer in range(dit.num_layers):
         sh.block_qkv(layer)
         wv = _exchange(b.vt_recv, b.vt_send, group, True)
-        wq = [(_exchange(b.qk_recv[0, g], b.qk_send[0, g], group, True), _exchange(b.qk_recv[1, g], b.qk_send[1, g], group, True)) for g in range(G)]
+        wq = [(_exchange(b.qk_recv[0, 0, g], b.qk_send[0, 0, g], group, True), _exchange(b.qk_recv[1, 0, g], b.qk_send[1, 0, g], group, True)) for g in range(G)]
         if wv is not None:
             wv.wait()
         sh.unpack_v()
@@ -341,7 +379,7 @@ def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: O
                 if w_ is not None:
                     w_.wait()
             sh.attention(g)
-            wo.append(_exchange(b.o_recv[g], b.o_send[g], group, True))
+            wo.append(_exchange(b.o_recv[0, g], b.o_send[0, g], group, True))
         for w_ in wo:
             if w_ is not None:
                 w_.wait()
@@ -380,15 +418,83 @@ def forward_local(dits: Sequence[WanDiT], x, timestep, context, groups: Optional
         for j, sj in enumerate(shards):                 # rank j receives piece j of every rank i
             for i, si in enumerate(shards):
                 sj.buf.vt_recv[i].copy_(si.buf.vt_send[j])
-                sj.buf.qk_recv[:, :, i].copy_(si.buf.qk_send[:, :, j])
+                sj.buf.qk_recv[:, :, :, i].copy_(si.buf.qk_send[:, :, :, j])
         for sh in shards:
             sh.unpack_v()
             for g in range(G):
                 sh.attention(g)
         for j, sj in enumerate(shards):
             for i, si in enumerate(shards):
-                sj.buf.o_recv[:, i].copy_(si.buf.o_send[:, j])
+                sj.buf.o_recv[:, :, i].copy_(si.buf.o_send[:, :, j])
         for sh in shards:
             sh.block_rest(layer)
     rows = torch.cat([sh.head() for sh in shards], dim=0)
     return shards[0].unpatchify(rows)
+
+
+def _pair_outputs(sh: SequenceShard, rows_all: torch.Tensor):
+    """rows_all [P, 2 Ls, ld] (every rank's stacked head rows, rank-major) -> (cond, uncond) latents."""
+    P, Ls = rows_all.shape[0], sh.Ls
+    return tuple(sh.unpatchify(rows_all[:, br * Ls:(br + 1) * Ls].reshape(P * Ls, -1)) for br in range(2))
+
+
+def forward_distributed_pair(dit: WanDiT, x, timestep, context_cond, context_uncond, group=None, groups: Optional[int] = None, **cond):
+    """Both forwards of a CFG step (svi_video.py:401-408) for this rank of `group`, STACKED on the rank's rows: every row-local launch runs once over
+    2 L / P rows (the conditional branch's on top), attention and the exchanges run per branch, and no rank waits for another's noise prediction —
+    each rank ends with both.  Returns (noise_pred_cond, noise_pred_uncond), full latents on every rank; bit-identical to two forward_distributed
+    calls and, with the key axis never cut (SVI_FLASH_SPLIT=1), to WanDiT.forward_cfg_pair on one rank.  Ulysses mode; context cache on."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    sh = SequenceShard(dit, rank, world, groups, "ulysses")
+    sh.begin_pair(x, timestep, context_cond, context_uncond, **cond)
+    b, G = sh.buf, sh.G
+    for layer in range(dit.num_layers):
+        sh.block_qkv(layer)
+        wv = _exchange(b.vt_recv, b.vt_send, group, True)                  # both branches' V^T pieces in one exchange
+        wq = [[(_exchange(b.qk_recv[0, br, g], b.qk_send[0, br, g], group, True), _exchange(b.qk_recv[1, br, g], b.qk_send[1, br, g], group, True))
+               for g in range(G)] for br in range(2)]
+        if wv is not None:
+            wv.wait()
+        sh.unpack_v()
+        wo = []
+        for br in range(2):
+            for g in range(G):
+                for w_ in wq[br][g]:
+                    if w_ is not None:
+                        w_.wait()
+                sh.attention(g, br)
+                wo.append(_exchange(b.o_recv[br, g], b.o_send[br, g], group, True))
+        for w_ in wo:
+            if w_ is not None:
+                w_.wait()
+        sh.block_rest(layer)
+    rows = sh.head()
+    gathered = all_gather_rows(rows, group).reshape(world, 2 * sh.Ls, -1)
+    return _pair_outputs(sh, gathered)
+
+
+def forward_local_pair(dits: Sequence[WanDiT], x, timestep, context_cond, context_uncond, groups: Optional[int] = None, **cond):
+    """forward_distributed_pair's schedule with P = len(dits) shards in ONE process (device copies for the exchanges): tests, tools/sp_overhead.py."""
+    P = len(dits)
+    shards = [SequenceShard(d, r, P, groups, "ulysses") for r, d in enumerate(dits)]
+    for sh in shards:
+        sh.begin_pair(x, timestep, context_cond, context_uncond, **cond)
+    G = shards[0].G
+    for layer in range(dits[0].num_layers):
+        for sh in shards:
+            sh.block_qkv(layer)
+        for j, sj in enumerate(shards):
+            for i, si in enumerate(shards):
+                sj.buf.vt_recv[i].copy_(si.buf.vt_send[j])
+                sj.buf.qk_recv[:, :, :, i].copy_(si.buf.qk_send[:, :, :, j])
+        for sh in shards:
+            sh.unpack_v()
+            for br in range(2):
+                for g in range(G):
+                    sh.attention(g, br)
+        for j, sj in enumerate(shards):
+            for i, si in enumerate(shards):
+                sj.buf.o_recv[:, :, i].copy_(si.buf.o_send[:, :, j])
+        for sh in shards:
+            sh.block_rest(layer)
+    rows = torch.stack([sh.head() for sh in shards], dim=0)
+    return _pair_outputs(shards[0], rows)

@@ -90,6 +90,38 @@ def test_1_3b_30_layers_at_32760_tokens_vs_reference(hip, golden):
     assert r16 < 2e-2 and r32 < max(2e-2, 2 * gap), (r32, r16, gap)
 
 
+def test_1_3b_two_step_cfg_loop_at_32760_tokens_vs_reference(hip, golden):
+    """The LOOP at the headline size: golden/dit_c2_loop.npz = the reference's own 2-step CFG-5 flow-match loop (svi_video.py:392-421:
+    cond forward, uncond forward, u + 5 (c - u), scheduler.step) of its 30-layer 1.3B WanModel on the full C2 latent — 4 forwards at 32760 tokens, fp32 and
+    bf16 — against DenoiseLoop.sample (the path bench.py times: stacked CFG pair, block-0 self-attention shared, fused cross-attention, CFG + Euler kernel,
+    step 2 a hipGraph replay).  The negative prompt has 32 valid rows, the positive 64: the two branches walk different key counts.  Bounds as the
+    7800-token loop (test_gpu_depth.py): rel-L2 <= 5e-2 vs the reference's fp32 latents; reported beside the reference's own bf16-vs-fp32 gap."""
+    g = golden("dit_c2_loop.npz")
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    f, h, w = synth.C2_GRID
+    k = synth.C2_FULL_STRIDE
+    sd = {n: torch.from_numpy(v) for n, v in synth.dit_state_dict(seed, **cfg).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=12, **cfg)
+    del sd
+    noise = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=2, device="cpu", dtype=torch.float32)
+    pos = dev(torch.from_numpy(synth.text_context(seed + 1, 512, cfg["text_dim"], 64)))
+    neg = dev(torch.from_numpy(synth.text_context(seed + 2, 512, cfg["text_dim"], 32)))
+    loop = hip.DenoiseLoop(m)
+    lat = loop.sample(dev(noise), pos, neg, num_inference_steps=synth.C2_LOOP_STEPS, cfg_scale=5.0, sigma_shift=5.0)
+    assert tuple(lat.shape) == (1, 16, f, 2 * h, 2 * w) and torch.isfinite(lat.float()).all()
+    got = lat[0, :, :, ::k, ::k]
+    ref16 = synth.bf16_from_bits(g["lat_bf16_bits"])
+    gap = rel_l2(ref16, g["lat_fp32"])
+    l32, mx, _ = errs(got, g["lat_fp32"])
+    l16 = errs(got, ref16)[0]
+    report("dit_c2_loop_2_steps", loop_vs_ref_fp32=l32, loop_vs_ref_bf16=l16, ref_bf16_vs_fp32_on_lattice=gap, ref_bf16_vs_fp32_whole=float(g["full_rel_bf16_vs_fp32"]),
+           max_abs=mx, tokens=f * h * w, forwards=2 * synth.C2_LOOP_STEPS)
+    assert l32 < 5e-2 and l16 < 5e-2, (l32, l16, gap)
+    # and the eager, unstacked-launch loop gives the same bits as the graphed one
+    again = hip.DenoiseLoop(m, graph=False).sample(dev(noise), pos, neg, num_inference_steps=synth.C2_LOOP_STEPS, cfg_scale=5.0, sigma_shift=5.0)
+    assert torch.equal(lat, again)
+
+
 @pytest.mark.skipif(os.environ.get("SVI_SLOW_ORACLE") != "1", reason="about 8 minutes of host time on the GPU box: SVI_SLOW_ORACLE=1 (the reference-run fixture above is the same check, stronger)")
 def test_1_3b_30_layers_at_32760_tokens_vs_oracle_on_this_box(hip):
     """The same forward against oracle.wan_dit_oracle.dit_forward (fp32) computed here on the box's host threads."""

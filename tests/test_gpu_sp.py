@@ -44,6 +44,60 @@ def test_sequence_parallel_is_bit_identical_t2v(P, G, grid):
     assert torch.equal(again, want) and len(ms[0]._sp_buffers) == 1
 
 
+@pytest.mark.parametrize("P,G,grid", [(P, G, g) for g in [(2, 4, 6), (4, 16, 32), (3, 5, 14)]
+                                      for P, G in [(1, 1), (2, 1), (2, 2), (4, 1)] if (g[0] * g[1] * g[2]) % P == 0])
+def test_stacked_cfg_pair_on_sequence_shards_is_bit_identical(P, G, grid):
+    """The CFG pair STACKED inside every sequence shard (svi_dit_sp_begin_pair / forward_local_pair: 2 L / P rows per rank, the conditional branch's on
+    top; attention and the exchange blocks per branch; no CFG exchange between ranks) against the single-rank WanDiT.forward_cfg_pair and against two
+    separate single-rank forwards: the same bits.  Shard lengths that are multiples of 8 (2048 / P), even (48 / P = 12 at P = 4) and odd (210 / 2 = 105:
+    the unconditional branch's V^T columns then start at an odd column of the piece); RoPE positions of the lower half = the shard's own rows."""
+    import svi_hip
+    from svi_hip import sequence_parallel as sp
+    f, h, w = grid
+    ms = handles(svi_hip, WIDE_T2V, 900, P + 1)
+    x = dev(synth.randn(901, 1, 16, f, 2 * h, 2 * w))
+    ca, cb = dev(synth.text_context(902, 24, 64, 17)), dev(synth.text_context(903, 24, 64, 9))
+    t = torch.tensor([712.5])
+    want_a, want_b = ms[-1].forward(x, t, ca).clone(), ms[-1].forward(x, t, cb).clone()
+    for m in ms:
+        m.context_cache(True)
+    try:
+        one_a, one_b = ms[-1].forward_cfg_pair(x, t, ca, cb)
+        assert torch.equal(one_a, want_a) and torch.equal(one_b, want_b)
+        got_a, got_b = sp.forward_local_pair(ms[:P], x, t, ca, cb, groups=G)
+        assert got_a.shape == want_a.shape and torch.isfinite(got_a.float()).all() and torch.isfinite(got_b.float()).all()
+        assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
+        again = sp.forward_local_pair(ms[:P], x, t, ca, cb, groups=G)          # second step: cached prompts, reused buffers
+        assert torch.equal(again[0], want_a) and torch.equal(again[1], want_b)
+        assert torch.equal(sp.forward_local(ms[:P], x, t, ca, groups=G), want_a)      # the unstacked shard forward beside it (own buffers) is undisturbed
+    finally:
+        for m in ms:
+            m.context_cache(False)
+    with pytest.raises(RuntimeError):                     # without the context cache the stacked pair is refused, not silently run some other way
+        sp.forward_local_pair(ms[:P], x, t, ca, cb, groups=G)
+
+
+def test_stacked_cfg_pair_on_shards_i2v():
+    import svi_hip
+    from svi_hip import sequence_parallel as sp
+    f, h, w = 3, 4, 4
+    ms = handles(svi_hip, WIDE_I2V, 910, 3)
+    x = dev(synth.randn(911, 1, 16, f, 2 * h, 2 * w))
+    y = dev(synth.randn(912, 1, 20, f, 2 * h, 2 * w))
+    clip = dev(synth.randn(913, 1, 257, 1280))
+    ca, cb = dev(synth.text_context(915, 16, 64, 9)), dev(synth.text_context(916, 16, 64, 4))
+    t = torch.tensor([92.5926])
+    want = [ms[-1].forward(x, t, c, clip_feature=clip, y=y).clone() for c in (ca, cb)]
+    for m in ms:
+        m.context_cache(True)
+    try:
+        got = sp.forward_local_pair(ms[:2], x, t, ca, cb, clip_feature=clip, y=y)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    finally:
+        for m in ms:
+            m.context_cache(False)
+
+
 @pytest.mark.parametrize("P,Dp,Ls", [(2, 128, 24), (4, 256, 105), (3, 128, 7), (2, 384, 8190)])
 def test_unpack_kernels_follow_the_layout_algebra(P, Dp, Ls):
     """svi_sp_unpack_vt / svi_sp_unpack_out against their statement in tensor algebra (sequence_parallel.unpack_vt / unpack_out):
@@ -132,6 +186,16 @@ def _dist_worker(rank, world, port, queue):
         loop.step(lat, t.cuda(), -0.05, ctx, dev(synth.text_context(903, 24, 64, 11)), 5.0)
         ref = x.clone()
         svi_hip.DenoiseLoop(m).step(ref, t.cuda(), -0.05, ctx, dev(synth.text_context(903, 24, 64, 11)), 5.0)
+        # with the context cache on (as DenoiseLoop.sample leaves it) the sequence-parallel step STACKS the CFG pair on every rank
+        # (forward_distributed_pair: no second forward, no CFG exchange): still the single-rank bits
+        neg = dev(synth.text_context(903, 24, 64, 11))
+        m.context_cache(True)
+        try:
+            lat2 = x.clone()
+            loop.step(lat2, t.cuda(), -0.05, ctx, neg, 5.0)
+            stacked_ok = bool(torch.equal(lat2, ref)) and loop.last_sp_form == "stacked pair"
+        finally:
+            m.context_cache(False)
         # TeaCache + sequence parallelism (allowed by the reference, svi_video.py:112-131): same skip pattern and the same bits as the
         # single-rank TeaCache loop; a huge threshold makes every middle step a skip, step 0 and the last step compute
         outs = {}
@@ -144,7 +208,7 @@ def _dist_worker(rank, world, port, queue):
                 xs = (xs.float() + 0.05 * o.float()).to(torch.bfloat16)
             outs[usp] = (xs, tuple(pattern))
         ok_tea = bool(torch.equal(outs[False][0], outs[True][0])) and outs[True][1] == (x.shape[2] * (x.shape[3] // 2) * (x.shape[4] // 2) // world,) * 5
-        queue.put((rank, bool(torch.equal(got, want)) and ok_tea, bool(torch.equal(lat, ref))))
+        queue.put((rank, bool(torch.equal(got, want)) and ok_tea, bool(torch.equal(lat, ref)) and stacked_ok))
     finally:
         dist.destroy_process_group()
 

@@ -1,7 +1,9 @@
 """What the sequence-parallel schedule costs besides the transport, on ONE GPU: P shards run back to back with the exchange
 simulated by device copies (svi_hip.sequence_parallel.forward_local) vs the plain forward, Wan2.1-1.3B widths, C2 geometry.
 With P ranks on P GPUs the shard work runs concurrently, so  (local time / P)  is the per-rank compute + packing time that the
-all-to-all transport is added to.   python tools/sp_overhead.py [layers] [tags]"""
+all-to-all transport is added to.   python tools/sp_overhead.py [layers] [tags] [pair]
+`pair`: the CFG PAIR per step instead — the single-rank stacked pair (WanDiT.forward_cfg_pair) against (a) two plain shard forwards per rank
+(forward_local twice: what a sequence-parallel rank ran before round 5) and (b) the stacked pair on every shard (forward_local_pair)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-video-infinity_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -39,6 +41,34 @@ def tags(fn):
     _lib.prof_enable(False)
     return out
 base_tags = tags(lambda: plain.forward(x, t, ctx))
+if "pair" in sys.argv[1:]:
+    ctx2 = torch.randn((1, 512, 4096), generator=g, device=dev).to(torch.bfloat16)
+    ctx[:, 64:] = 0; ctx2[:, 32:] = 0
+    pair_base = timeit(lambda: plain.forward_cfg_pair(x, t, ctx, ctx2))
+    pair_tags = tags(lambda: plain.forward_cfg_pair(x, t, ctx, ctx2))
+    print(f"single rank, stacked CFG pair, {layers} blocks: {pair_base:.1f} ms per step (two plain forwards: {2 * base:.1f} ms)")
+    for P in (2, 4, 6):
+        hs = [handle() for _ in range(P)]
+        for m in hs: m.context_cache(True)
+        G = sp.head_groups(12 // P, 32760)
+        def two(): sp.forward_local(hs, x, t, ctx, groups=G); sp.forward_local(hs, x, t, ctx2, groups=G)
+        ms2 = timeit(two)
+        msp = timeit(lambda: sp.forward_local_pair(hs, x, t, ctx, ctx2, groups=G))
+        def copies(nb):
+            bufs = [m._sp_buffers[k] for m in hs for k in m._sp_buffers if k[3] == G and k[5] == nb]
+            for _ in range(layers):
+                for j, bj in enumerate(bufs):
+                    for i, bi in enumerate(bufs):
+                        bj.vt_recv[i].copy_(bi.vt_send[j]); bj.qk_recv[:, :, :, i].copy_(bi.qk_send[:, :, :, j]); bj.o_recv[:, :, i].copy_(bi.o_send[:, :, j])
+        cp1, cp2 = timeit(lambda: copies(1)), timeit(lambda: copies(2))
+        r_two, r_pair = (ms2 - 2 * cp1) / P, (msp - cp2) / P
+        print(f"P={P} G={G}: per rank compute + unpack per STEP: two shard forwards {r_two:.1f} ms ({r_two / (pair_base / P) - 1:+.1%} over the ideal 1/P of the single-rank "
+              f"stacked pair), stacked pair on the shard {r_pair:.1f} ms ({r_pair / (pair_base / P) - 1:+.1%}); simulated transport {2 * cp1:.1f} / {cp2:.1f} ms")
+        if "tags" in sys.argv[1:]:
+            tg = tags(lambda: sp.forward_local_pair(hs, x, t, ctx, ctx2, groups=G))
+            print("      per tag, all shards (stacked) / single-rank stacked pair: " + "  ".join(f"{k} {tg.get(k, 0.0):.2f}/{v:.2f} ({tg.get(k, 0.0) / v - 1:+.0%})" for k, v in pair_tags.items()))
+        del hs
+    sys.exit(0)
 for P in (2, 4, 6):
     hs = [handle() for _ in range(P)]
     for m in hs: m.context_cache(True)
@@ -50,7 +80,7 @@ for P in (2, 4, 6):
             for _ in range(layers):
                 for j, bj in enumerate(bufs):
                     for i, bi in enumerate(bufs):
-                        bj.vt_recv[i].copy_(bi.vt_send[j]); bj.qk_recv[:, :, i].copy_(bi.qk_send[:, :, j]); bj.o_recv[:, i].copy_(bi.o_send[:, j])
+                        bj.vt_recv[i].copy_(bi.vt_send[j]); bj.qk_recv[:, :, :, i].copy_(bi.qk_send[:, :, :, j]); bj.o_recv[:, :, i].copy_(bi.o_send[:, :, j])
         cp = timeit(copies)
         per_rank = (ms - cp) / P
         print(f"P={P} G={G}: all shards back to back {ms:.1f} ms, of which simulated transport {cp:.1f} ms -> per rank compute + unpack {per_rank:.1f} ms "
