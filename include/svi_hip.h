@@ -87,6 +87,9 @@ int32_t svi_device_count(void);
  * backend as interchangeable — with its own oracle and stated tolerance (tests/test_gpu_attn_qk8.py) and its own bench line (bench.py --fp8-attn).
  * In that mode the DiT's RMSNorm + RoPE launch writes the e4m3 rows and block scales itself (SVI_QK8_FUSED=0: bf16 q | k + two quantiser launches; same bits). */
 svi_status svi_switches_reload(void);
+/* The value the library PARSED for a switch at its last (re)load — SVI_ATTN_QK8, SVI_CROSS_FUSED, SVI_CROSS_DEDUP, SVI_QK_FUSED, SVI_FLASH_TWO_PASS:
+ * 1 / 0 — or -1 for any other name.  What the kernels do follows this, not the process environment of the moment. */
+int32_t svi_switch_state(const char* name);
 
 /* ------------------------------------------------------------------ DiT: whole model ------ */
 /* WanModel(...) construction (weights are bound afterwards, by reference state-dict key). */

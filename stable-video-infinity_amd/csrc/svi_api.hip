@@ -1,6 +1,7 @@
 // svi_api.hip — C-ABI glue of libsvi_hip.so: error plumbing and the operator-level entry points
 // (the seams the reference exposes: flash_attention, LayerNorm+modulate, RMSNorm+RoPE, Linear, CFG step).
 #include <algorithm>
+#include <string>
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -34,7 +35,11 @@ static SviSwitches parse_switches() {
     s.flash_kernel = env_int("SVI_FLASH_KERNEL", 1, 0);
     if (s.flash_kernel > 2) s.flash_kernel = 0;
     s.gemm_kernel = env_int("SVI_GEMM_KERNEL", 128, 0);
-    if (s.gemm_kernel != 128 && s.gemm_kernel != 192 && s.gemm_kernel != 259 && s.gemm_kernel != 260) s.gemm_kernel = 0;
+    if (s.gemm_kernel != 128 && s.gemm_kernel != 192 && s.gemm_kernel != 259 && s.gemm_kernel != 260) {
+        if (s.gemm_kernel != 0)      // 256 / 257 / 258 were kernels of rounds 1-3: an old A/B script must not silently measure "auto" instead
+            fprintf(stderr, "libsvi_hip: ignoring SVI_GEMM_KERNEL=%d (kernels: 128, 192, 259 = 256^2 four phases, 260 = 256^2 two phases; 256 / 257 / 258 are retired)\n", s.gemm_kernel);
+        s.gemm_kernel = 0;
+    }
     s.gemm_gm = env_int("SVI_GEMM_GM", 1, 0);
     s.vae_exact_fp32 = getenv("SVI_VAE_EXACT_FP32") != nullptr;
     s.flash_two_pass = env_int("SVI_FLASH_TWO_PASS", 0, 1);
@@ -60,18 +65,33 @@ static SviSwitches parse_switches() {
 #endif
     return s;
 }
-static SviSwitches& switches_storage() {
-    static SviSwitches sw = parse_switches();
-    return sw;
+// The parsed switches live behind an atomic pointer: a reload publishes a NEW immutable struct (the old ones are kept — a few hundred bytes per reload, A/B
+// tooling only), so a launcher on another thread reads either the old set or the new one, never a half-written struct.
+static std::atomic<const SviSwitches*>& switches_ptr() {
+    static std::atomic<const SviSwitches*> p{new SviSwitches(parse_switches())};
+    return p;
 }
-const SviSwitches& svi_switches() { return switches_storage(); }
+const SviSwitches& svi_switches() { return *switches_ptr().load(std::memory_order_acquire); }
 static std::atomic<unsigned long long> g_stream_buffer_generation{0};      // moves whenever a per-stream library buffer is freed or the switches are re-read
 extern "C" svi_status svi_switches_reload(void) {
-    switches_storage() = parse_switches();
+    switches_ptr().store(new SviSwitches(parse_switches()), std::memory_order_release);
     // what a captured step graph has baked in includes the kernels the switches selected (and, with SVI_ATTN_QK8, the arithmetic): move the
     // generation svi_dit_generation reports so that every DenoiseLoop re-captures
     g_stream_buffer_generation.fetch_add(1, std::memory_order_relaxed);
     return SVI_OK;
+}
+
+// What the library PARSED for a switch (not what the environment says now): 1 / 0, or -1 for a name this query does not know.
+extern "C" int32_t svi_switch_state(const char* name) {
+    if (!name) return -1;
+    const SviSwitches& sw = svi_switches();
+    const std::string n(name);
+    if (n == "SVI_ATTN_QK8") return sw.attn_qk8 ? 1 : 0;
+    if (n == "SVI_CROSS_FUSED") return sw.cross_fused ? 1 : 0;
+    if (n == "SVI_CROSS_DEDUP") return sw.cross_dedup ? 1 : 0;
+    if (n == "SVI_QK_FUSED") return sw.qk_fused ? 1 : 0;
+    if (n == "SVI_FLASH_TWO_PASS") return sw.flash_two_pass ? 1 : 0;
+    return -1;
 }
 
 int svi_current_device() {
@@ -206,13 +226,22 @@ hipEvent_t prof_event() {
     return e;
 }
 }  // namespace
+// A stream that is being captured takes no event pairs (they would be recorded INTO the graph and read back as garbage): the scope is a
+// no-op there — bench.py times graphed steps as wholes and takes the per-kernel figures from eager steps.
+static bool prof_stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
 void svi_prof_begin_impl(int tag, hipStream_t st) {
+    if (prof_stream_capturing(st)) return;
     std::lock_guard<std::mutex> lock(table_mutex());
     hipEvent_t e = prof_event();
     (void)hipEventRecord(e, st);
     g_prof_open.push_back(ProfOpen{tag, st, e});
 }
 void svi_prof_end_impl(int tag, hipStream_t st) {
+    if (prof_stream_capturing(st)) return;
     std::lock_guard<std::mutex> lock(table_mutex());
     for (size_t i = g_prof_open.size(); i-- > 0;) {
         if (g_prof_open[i].tag != tag || g_prof_open[i].st != st) continue;

@@ -977,8 +977,17 @@ static svi_status forward_pair(svi_dit* h, const bf16* x, const float* timestep,
     const int f = T / c.patch_t, hh = H / c.patch_h, ww = W / c.patch_w;
     const int L = f * hh * ww;
     const size_t widest = (size_t)std::max(c.ffn_dim, 2 * D);
-    const bool stacked = h->ctx_cache_on && L <= SVI_PAIR_STACK_MAX && L % 8 == 0 && ctx_a != ctx_b && (size_t)2 * L * widest * 2 < ((size_t)1 << 31);
-    SVI_TRY(ensure_workspace(h, stacked ? 2 * L : L, Lc, st));
+    // The 2 GiB bound covers every buffer the stacked form addresses with 32-bit byte offsets: the widest activation [2 L, max(ffn_dim, 2 dim)] (the GEMMs'
+    // buffer descriptors; the q | k buffer is [2 L, 2 dim]) and V^T [dim, ldvt >= 2 L] (the attention kernel's int row offsets: dim * 2 L * 2 bytes, never
+    // more than the q | k buffer's).  The MX-fp8 scale tables are smaller than either.
+    bool stacked = h->ctx_cache_on && L <= SVI_PAIR_STACK_MAX && L % 8 == 0 && ctx_a != ctx_b && (size_t)2 * L * widest * 2 < ((size_t)1 << 31);
+    svi_status ws = ensure_workspace(h, stacked ? 2 * L : L, Lc, st);
+    if (ws == SVI_ERR_OOM && stacked) {          // the doubled workspace does not fit (about 5 GB more at the 14B widths): the unstacked form gives the same bits
+        (void)hipGetLastError();
+        stacked = false;
+        ws = ensure_workspace(h, L, Lc, st);
+    }
+    SVI_TRY(ws);
     SVI_TRY(ensure_rope(h, f, hh, ww));
     Workspace& w = h->ws;
     SVI_TRY(stage_time(h, timestep, st));

@@ -1056,10 +1056,13 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
                     "gemm: row statistics need a tiled kernel, N %% 64 == 0 (N = %d), the plain bias epilogue and ldss >= M", g.N);
     if (g.W2) {        // two weight matrices side by side: one launch when the split falls on a tile boundary of the kernel that runs, else two
         SVI_REQUIRE(g.n_split > 0 && g.n_split < g.N && !g.bias_along_m && ((uintptr_t)g.W2 % 16) == 0, "gemm: bad weight pair (n_split %d of N %d)", g.n_split, g.N);
+        // tiles of the second half read rows n - n_split of W2 through a base moved back by n_split rows and a descriptor sized for N rows from there: the
+        // second matrix must hold N - n_split rows of the same stride (the DiT's q | k: two [D, D] weights), and its own 2^31-element bound holds with A / W's
+        SVI_REQUIRE((long)(g.N - g.n_split) * g.ldw < (1L << 31), "gemm: second weight matrix of 2^31 elements or more");
         const int tw = kind == 0 ? 0 : kind == 128 ? BN : kind == 192 ? 192 : TN;
         if (tw == 0 || g.n_split % tw != 0) {
             SviGemmArgs a = g, b = g;
-            a.W2 = nullptr; a.bias2 = nullptr; a.n_split = 0; a.N = g.n_split; a.sel_n = g.sel_n > 0 ? g.sel_n : g.N;
+            a.W2 = nullptr; a.bias2 = nullptr; a.n_split = 0; a.N = g.n_split; a.sel_n = g.sel_n > 0 ? g.sel_n : g.n_split;      // (the per-projection shape: the same kernel, and bits, as two separate launches)
             b.W2 = nullptr; b.bias2 = nullptr; b.n_split = 0; b.W = g.W2; b.bias = g.bias2; b.N = g.N - g.n_split; b.C = g.C + g.n_split;
             b.res = g.res ? g.res + g.n_split : nullptr; b.gate = g.gate ? g.gate + g.n_split : nullptr; b.sel_n = a.sel_n;
             SVI_TRY(svi_launch_gemm(a, st));

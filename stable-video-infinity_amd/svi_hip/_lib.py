@@ -40,6 +40,7 @@ SYMBOLS = [
     ("svi_abi_version", _i32, []),
     ("svi_device_count", _i32, []),
     ("svi_switches_reload", _i32, []),
+    ("svi_switch_state", _i32, [C.c_char_p]),
     ("svi_dit_create", _i32, [C.POINTER(DitConfig), C.POINTER(_vp)]),
     ("svi_dit_destroy", _i32, [_vp]),
     ("svi_dit_bind_weight", _i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
@@ -185,7 +186,8 @@ def prof_enable(on: bool) -> None:
 
 
 def gemm_plan(M: int, N: int, K: int, epilogue: int = 0, skinny: bool = False, compute_units: int = 256) -> int:
-    """The kernel svi_gemm_bf16 would take on a part with `compute_units` CUs: 0 skinny, 128, 192, 257 / 259 (see include/svi_hip.h)."""
+    """The kernel svi_gemm_bf16 would take on a part with `compute_units` CUs: 0 = weight-streaming skinny kernel, 128 = 128^2 tile, 192 = 256 x 192 tile,
+    259 / 260 = the 256^2 tile with four / two phases per K tile (see include/svi_hip.h; ids 256-258 of rounds 1-3 are retired and refused with a warning)."""
     out = _i32(0)
     check(lib().svi_gemm_plan(M, N, K, epilogue, 1 if skinny else 0, compute_units, C.byref(out)), "svi_gemm_plan")
     return out.value

@@ -49,8 +49,8 @@ def fp8_attention(enable: bool = True) -> None:
 
 
 def fp8_attention_enabled() -> bool:
-    import os
-    return os.environ.get("SVI_ATTN_QK8", "0") not in ("", "0")
+    """What the LIBRARY parsed (svi_switch_state), not the environment of the moment: an environment edit without a reload changes nothing the kernels do."""
+    return L.lib().svi_switch_state(b"SVI_ATTN_QK8") == 1
 
 
 def layernorm_modulate(x: torch.Tensor, eps: float = 1e-6, weight: Optional[torch.Tensor] = None,

@@ -8,7 +8,6 @@ One object per CFG branch, as in the reference (tea_cache_posi / tea_cache_nega)
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 COEFFICIENTS = {      # svi_video.py:35-40, fitted by the TeaCache authors per checkpoint
@@ -19,7 +18,21 @@ COEFFICIENTS = {      # svi_video.py:35-40, fitted by the TeaCache authors per c
 }
 
 
+def _rescaled_drift(coefficients, previous: torch.Tensor, current: torch.Tensor) -> float:
+    """The fitted polynomial (Horner form, double precision — what numpy.poly1d evaluates) of the mean absolute change of the modulation input
+    relative to its previous mean magnitude; the tensor arithmetic stays in the tensors' dtype, as in the reference (svi_video.py:51)."""
+    rel = ((current - previous).abs().mean() / previous.abs().mean()).cpu().item()
+    acc = 0.0
+    for c in coefficients:
+        acc = acc * rel + c
+    return acc
+
+
 class TeaCache:
+    """A drift budget: every step adds its rescaled drift to a running sum; the step is skipped while the sum stays under `rel_l1_thresh`, and a computed
+    step empties the sum.  The first and the last step of a clip always compute.  Attribute names are the reference's (its own object and this one are
+    interchangeable in model_fn_wan_video): step, accumulated_rel_l1_distance, previous_modulated_input, previous_residual, previous_hidden_states."""
+
     def __init__(self, num_inference_steps: int, rel_l1_thresh: float, model_id: str):
         if model_id not in COEFFICIENTS:
             raise ValueError(f"{model_id} is not a supported TeaCache model id. Please choose a valid model id in ({', '.join(COEFFICIENTS)}).")
@@ -32,18 +45,18 @@ class TeaCache:
         self.previous_residual = None
         self.previous_hidden_states = None
 
+    def _must_compute(self, current: torch.Tensor) -> bool:
+        if self.step in (0, self.num_inference_steps - 1):
+            return True
+        self.accumulated_rel_l1_distance += _rescaled_drift(self.coefficients, self.previous_modulated_input, current)
+        return not (self.accumulated_rel_l1_distance < self.rel_l1_thresh)
+
     def check(self, dit, x, t_mod) -> bool:
-        """True = skip the blocks this step (svi_video.py:43-62; the arithmetic runs in t_mod's dtype, as there)."""
-        modulated_inp = t_mod.clone()
-        if self.step == 0 or self.step == self.num_inference_steps - 1:
-            should_calc = True
+        """True = skip the blocks this step (the decision of svi_video.py:43-62).  `x` is not kept: the HIP forward forms the residual on the device."""
+        current = t_mod.clone()
+        compute = self._must_compute(current)
+        if compute:
             self.accumulated_rel_l1_distance = 0
-        else:
-            rel = ((modulated_inp - self.previous_modulated_input).abs().mean() / self.previous_modulated_input.abs().mean()).cpu().item()
-            self.accumulated_rel_l1_distance += np.poly1d(self.coefficients)(rel)
-            should_calc = not (self.accumulated_rel_l1_distance < self.rel_l1_thresh)
-            if should_calc:
-                self.accumulated_rel_l1_distance = 0
-        self.previous_modulated_input = modulated_inp
+        self.previous_modulated_input = current
         self.step = (self.step + 1) % self.num_inference_steps
-        return not should_calc
+        return not compute
