@@ -333,19 +333,17 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
     char* QO = smem + 2 * CR_KEYS * 256;
     const int sc = tid & 15, sr = tid >> 4;          // staging: this thread's 16-byte chunk and first row (+ 32 per j)
 
-    {   // the head's K / V^T, once.  Rows / columns past the last key are clamped to it: finite duplicates that the -inf mask removes
+    // the head's K / V^T, once.  Rows / columns past the last key are clamped to it: finite duplicates that the -inf mask removes.  (Requested here, put
+    // into LDS behind the request for the first query rows below: both are in flight together.)
+    u32x4 kreg[NKB], vreg[4];
+    {
         const int last_key = Lk - 1, last_chunk = (Lk - 1) & ~7;
         const bf16* kb = K + head * DH + sc * 8;
         const bf16* vb = VT + (size_t)(head * DH) * ldvt + min(sc * 8, last_chunk);
-        u32x4 a[NKB], b[4];
 #pragma unroll
-        for (int j = 0; j < NKB; ++j) a[j] = *reinterpret_cast<const u32x4*>(kb + (size_t)min(sr + 32 * j, last_key) * ldk);
+        for (int j = 0; j < NKB; ++j) kreg[j] = *reinterpret_cast<const u32x4*>(kb + (size_t)min(sr + 32 * j, last_key) * ldk);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u32x4*>(vb + (size_t)(sr + 32 * j) * ldvt);
-#pragma unroll
-        for (int j = 0; j < NKB; ++j) *reinterpret_cast<u32x4*>(Ks + k_off(sr + 32 * j, sc)) = a[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(Vs + k_off(sr + 32 * j, sc)) = b[j];
+        for (int j = 0; j < 4; ++j) vreg[j] = *reinterpret_cast<const u32x4*>(vb + (size_t)(sr + 32 * j) * ldvt);
     }
     const int krow = perm23(l31);
     bf16x8 wv;
@@ -450,6 +448,10 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
             }
     };
     issue(r_begin);
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) *reinterpret_cast<u32x4*>(Ks + k_off(sr + 32 * j, sc)) = kreg[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(Vs + k_off(sr + 32 * j, sc)) = vreg[j];
     for (int base = r_begin; base < r_end; base += CR_ROWS) {
         // ---- this iteration's query rows, normalised (the wait for them is here)
         u32x4 outv[8];
@@ -465,12 +467,13 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (base + CR_ROWS < r_end) issue(base + CR_ROWS);          // the next iteration's rows are on their way while this one computes
-        __builtin_amdgcn_sched_barrier(0);
         if (base > r_begin) flush(base - CR_ROWS);                    // the previous iteration's output rows leave the cells ...
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(QO + k_off(sr + 32 * j, sc)) = outv[j];      // ... that this iteration's query rows take
+        // the next iteration's rows are on their way while this one computes (requested BEHIND the stores: with the requests first the kernel measured
+        // 8 us slower per launch, profiles/r5g_kernel_stats.md vs r5h)
+        if (base + CR_ROWS < r_end) issue(base + CR_ROWS);
         __syncthreads();
         compute();
         __syncthreads();

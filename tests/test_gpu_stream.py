@@ -128,3 +128,22 @@ def test_stream_against_the_reference_clip_loop(case, golden):
            stream_max_levels=int(d.max()), stream_frac_equal=float((d == 0).mean()))
     assert worst_mean <= 0.75 and worst_max <= 6, (worst_mean, worst_max)
     assert float(d.mean()) <= 0.75 and int(d.max()) <= 6, (float(d.mean()), int(d.max()))
+
+
+def test_example_launcher_runs_a_synthetic_window(tmp_path):
+    """examples/test_svi_hip.py --synthetic: the reference CLI's surface over the whole HIP chain — random-init I2V model, seeded prompt embeddings, a
+    synthetic image, StreamLoop (conditioning encode, CFG denoise on one captured step graph, decode, 8-bit hand-off, stitching) — on a box
+    with no weights: 3 clips of 9 frames, motion hand-off of 1 frame -> 8 + 8 + 9 stitched frames, seeds 0 / 42 / 84, one graph capture."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "test_svi_hip.py"), "--synthetic", "--synthetic_model", "tiny-i2v", "--num_clips", "3",
+                        "--num_steps", "3", "--height", "32", "--width", "48", "--max_frames", "9", "--output", str(tmp_path), "--ref_pad_num", "-1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"test_svi_hip"')][-1])["test_svi_hip"][0]
+    assert rec["clips"] == 3 and rec["frames"] == 8 + 8 + 9 and rec["seeds"] == [0, 42, 84] and rec["step_graph_captures"] == 1
+    vid = np.load(os.path.join(rec["out"], "video_u8.npy"))
+    assert vid.shape == (25, 32, 48, 3) and vid.dtype == np.uint8 and vid.std() > 0

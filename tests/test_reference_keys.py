@@ -446,3 +446,32 @@ def test_enable_vram_management_is_harmless_before_and_after_install(ref, capsys
             pipeline._assert_resident(pipe, None)
     finally:
         sys.modules.pop("svi_video_offload", None)
+
+
+def test_example_launcher_has_the_reference_cli_surface():
+    """examples/test_svi_hip.py takes every argument the reference's test_svi.py defines (names and defaults read out of its parse_args with ast), so a
+    command line written for the reference runs the HIP launcher unchanged (+ --synthetic for boxes without weights)."""
+    import ast
+    import importlib.util
+    tree = ast.parse(open(os.path.join(REF, "test_svi.py")).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "parse_args")
+    ref_args = {}
+    for node in ast.walk(fn):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument":
+            name = node.args[0].value
+            kw = {k.arg: k.value for k in node.keywords}
+            default = ast.literal_eval(kw["default"]) if "default" in kw and not isinstance(kw["default"], ast.BinOp) else None
+            ref_args[name.lstrip("-")] = default
+    assert len(ref_args) >= 25 and "num_motion_frames" in ref_args and "seed_times" in ref_args
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("test_svi_hip_example", os.path.join(root, "examples", "test_svi_hip.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ours = vars(mod.parse_args([]))
+    missing = sorted(set(ref_args) - set(ours))
+    assert not missing, missing
+    for name, default in ref_args.items():
+        if default is not None and name != "num_persistent_param_in_dit":
+            assert ours[name] == default, (name, ours[name], default)
+    assert mod.COMMON_NEGATIVE_PROMPT in open(os.path.join(REF, "test_svi.py")).read()       # the negative prompt is the reference's string
+    assert mod.calculate_dimensions(1920, 1080, 832) == (464, 832) and mod.calculate_dimensions(640, 480, 832) == (480, 640)
