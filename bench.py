@@ -833,7 +833,9 @@ def main() -> None:
                    f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
                    "cfg_pair_stacked": bool(stacked),       # behind the shared block-0 self-attention, every row-local kernel runs once over both branches' rows (2 L); bit-identical
                    "steps_per_clip": spc, "tokens": L, "clips_per_gpu": round(units / world, 4),
-                   "parallelism": (f"one clip: {'cfg-pair x ' if pair else ''}sequence-parallel over {world} ranks" if args.seq_parallel else
+                   "sp_cfg_pair": getattr(loop, "last_sp_form", None),      # sequence-parallel steps: "stacked pair" = both CFG branches stacked on every rank's rows
+                   "parallelism": (f"one clip: {'cfg-pair x ' if pair else ''}sequence-parallel over {world} ranks" +
+                                   (" (CFG pair stacked on every rank's rows: no CFG exchange)" if getattr(loop, "last_sp_form", None) == "stacked pair" else "") if args.seq_parallel else
                                    f"cfg-pair x{units} clips" if pair else f"clip-per-rank x{world}"),
                    "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
                    "vae_condition_encode_ms": None if enc_ms is None else round(enc_ms, 2),

@@ -186,8 +186,9 @@ svi_status svi_dit_sp_begin(svi_dit* h, const void* x, const float* timestep, co
                             int32_t row0, int32_t nrows, svi_stream stream);
 /* Both forwards of a CFG step on one shard, STACKED (svi_dit_forward_cfg_pair's form on a rank's rows; needs svi_dit_context_cache(h, 1)): the shard's
  * rows of the conditional branch on top of the unconditional branch's.  The calls that follow act on 2 nrows rows: svi_dit_sp_block_qkv stores
- * q_send / k_send as [branch][G][P][nrows][Dg] and V^T as [dim, ldvt >= 2 nrows] (columns [0, nrows) conditional, [nrows, 2 nrows) unconditional);
- * svi_dit_sp_block_rest takes attn [2 nrows, dim]; svi_dit_sp_head writes [2 nrows, svi_dit_head_ld].  Attention is run per branch by the caller.
+ * q_send / k_send as [G][P][nrows][branch][Dg] and V^T as [dim, ldvt >= 2 nrows] (columns [0, nrows) conditional, [nrows, 2 nrows) unconditional);
+ * svi_dit_sp_block_rest takes attn [2 nrows, dim]; svi_dit_sp_head writes [2 nrows, svi_dit_head_ld].  After the exchange the two branches are twice as
+ * many heads of one svi_attention_vt_fwd call per head group (row stride 2 Dg).
  * No CFG exchange between ranks; each row-local launch of a shard is twice as long.  Bit-identical to two svi_dit_sp_begin forwards. */
 svi_status svi_dit_sp_begin_pair(svi_dit* h, const void* x, const float* timestep, const void* context_cond, const void* context_uncond,
                                  const void* clip_feature, const void* y, const void* add_condition, int32_t T, int32_t H, int32_t W, int32_t Lc,
@@ -198,8 +199,12 @@ svi_status svi_dit_sp_block_qkv_part(svi_dit* h, int32_t layer, void* q_send, vo
                                      int32_t part, svi_stream stream);
 svi_status svi_dit_sp_block_qkv(svi_dit* h, int32_t layer, void* q_send, void* k_send, void* vt_out, int32_t ldvt, int32_t P, int32_t G,
                                 svi_stream stream);
-svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, svi_stream stream);
-svi_status svi_sp_unpack_out(const void* recv, void* out, int32_t P, int32_t G, int32_t Ls, int32_t Dg, svi_stream stream);
+/* nb = CFG branches stacked on the shard (1, or 2 after svi_dit_sp_begin_pair): a token's branches travel side by side, so what a rank receives per head
+ * group is token-major [L, nb * Dg] and the branches' heads are nb x as many heads of ONE attention launch.  svi_sp_unpack_vt: a piece's columns hold branch b's
+ * tokens at [b * Ls, (b + 1) * Ls); channel g * Dg + cg goes to row (g * nb + b) * Dg + cg of out [G * nb * Dg][L8] (Dg = channels per head group; nb = 1:
+ * row = channel).  svi_sp_unpack_out: pieces [G][P(src)][Ls][nb][Dg] -> attn [nb * Ls][dim], branch b's rows at [b * Ls, (b + 1) * Ls). */
+svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, int32_t nb, int32_t Dg, svi_stream stream);
+svi_status svi_sp_unpack_out(const void* recv, void* out, int32_t P, int32_t G, int32_t Ls, int32_t Dg, int32_t nb, svi_stream stream);
 svi_status svi_dit_sp_block_rest(svi_dit* h, int32_t layer, const void* attn, svi_stream stream);
 /* TeaCache on a shard's rows (the reference combines TeaCache and USP, pipelines/svi_video.py:112-131): mode 0 snapshot before the blocks,
  * 1 residual bf16 [nrows, dim] = x_after - x_before, 2 x += residual in place of the blocks. */

@@ -277,9 +277,10 @@ struct SviRope {                // device tables of (cos,sin) pairs, fp32
 // Sequence-parallel send layout (svi_hip/sequence_parallel.py): instead of in place, operand p of the q | k launch is stored as
 // out[p][g][j][row][cg] — destination rank j = col / Dp owns head-channel block [j*Dp, (j+1)*Dp), inside it head group g = (col % Dp) / Dg,
 // cg = col % Dg — so that every (operand, head group)'s all-to-all input is one contiguous [P][rows * Dg] tensor.
-// rows_per_sample > 0 (the stacked CFG pair on a shard): the launch's rows are samples of that many rows one under the other, and sample b's block
-// starts sample_stride elements behind sample b - 1's: out[p] + b * sample_stride + [g][j][row % rows_per_sample][cg] — each branch's exchange input stays contiguous.
-struct SviScatter { bf16* out0; bf16* out1; int P, Dp, Dg; int rows_per_sample; long sample_stride; };
+// rows_per_sample > 0 (the stacked CFG pair on a shard): the launch's rows are nb = rows / rows_per_sample samples (CFG branches) of that many rows one under
+// the other, and a token's nb branches sit side by side: out[p][g][j][row % rows_per_sample][branch][cg].  What a destination receives from all sources is
+// then token-major [L, nb * Dg] per (operand, head group): the two branches' heads are 2 x as many heads of ONE attention launch.
+struct SviScatter { bf16* out0; bf16* out1; int P, Dp, Dg; int rows_per_sample; };
 // out_scale multiplies the result before its single final rounding (the DiT folds the attention scale into q there)
 svi_status svi_launch_rmsnorm_rope(bf16* x, int ld, int rows, int dim, const bf16* weight, float eps,
                                    const SviRope* rope, float out_scale, hipStream_t st);
@@ -292,8 +293,8 @@ svi_status svi_launch_rmsnorm_rope2_q8(bf16* x, int ld, int rows, int dim, const
                                        float out_scale1, hipStream_t st, const SviQk8& out);
 // receive side of the two exchanges: V^T pieces [P(src)][Dp][lds] -> [Dp][L8] (token axis = source-major), attention output pieces
 // [G][P(src = owner of head block)][Ls][Dg] -> [Ls][P*Dp] token rows
-svi_status svi_launch_sp_unpack_vt(const bf16* recv, bf16* out, int P, int Dp, int Ls, int lds, int L8, hipStream_t st);
-svi_status svi_launch_sp_unpack_out(const bf16* recv, bf16* out, int P, int G, int Ls, int Dg, hipStream_t st);
+svi_status svi_launch_sp_unpack_vt(const bf16* recv, bf16* out, int P, int Dp, int Ls, int lds, int L8, hipStream_t st, int nb = 1, int Dg = 0);
+svi_status svi_launch_sp_unpack_out(const bf16* recv, bf16* out, int P, int G, int Ls, int Dg, hipStream_t st, int nb = 1);
 svi_status svi_launch_transpose(const bf16* in, int ldi, bf16* out, int ldo, int rows, int cols, hipStream_t st);
 svi_status svi_launch_cfg_step(bf16* lat, const bf16* cond, const bf16* uncond, int64_t n, float s, float dsigma,
                                hipStream_t st);

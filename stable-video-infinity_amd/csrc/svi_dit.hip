@@ -1269,19 +1269,19 @@ extern "C" svi_status svi_dit_sp_block_qkv_part(svi_dit* h, int32_t layer, void*
     const int nb = h->sp_nb, rows = nb * h->sp_rows;
     SVI_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && ldvt >= rows && ldvt % 8 == 0, "svi_dit_sp_block_qkv: bad layer / ldvt");
     SVI_REQUIRE(P > 0 && G > 0 && h->cfg.num_heads % (P * G) == 0, "svi_dit_sp_block_qkv: %d heads do not split into %d ranks x %d head groups", h->cfg.num_heads, P, G);
-    // stacked pair: each branch's send block [G][P][nrows][Dg] stands alone, the unconditional one right behind the conditional one
-    SviScatter sc{reinterpret_cast<bf16*>(q_send), reinterpret_cast<bf16*>(k_send), P, D / P, D / P / G, nb > 1 ? h->sp_rows : 0, (long)h->sp_rows * D};
+    // stacked pair: a token's two branches side by side in the send block, [G][P][nrows][2][Dg] (SviScatter)
+    SviScatter sc{reinterpret_cast<bf16*>(q_send), reinterpret_cast<bf16*>(k_send), P, D / P, D / P / G, nb > 1 ? h->sp_rows : 0};
     return block_qkv(h, layer, h->ws.X, h->ws.modf + (size_t)layer * 6 * D, rows, h->sp_row0, h->ws.QK, reinterpret_cast<bf16*>(vt_out), ldvt,
                      reinterpret_cast<hipStream_t>(stream), &sc, nb, part);
 }
 
-extern "C" svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, svi_stream stream) {
+extern "C" svi_status svi_sp_unpack_vt(const void* recv, void* out, int32_t P, int32_t Dp, int32_t Ls, int32_t lds, int32_t L8, int32_t nb, int32_t Dg, svi_stream stream) {
     SVI_REQUIRE(recv && out, "svi_sp_unpack_vt: null argument");
-    return svi_launch_sp_unpack_vt(reinterpret_cast<const bf16*>(recv), reinterpret_cast<bf16*>(out), P, Dp, Ls, lds, L8, reinterpret_cast<hipStream_t>(stream));
+    return svi_launch_sp_unpack_vt(reinterpret_cast<const bf16*>(recv), reinterpret_cast<bf16*>(out), P, Dp, Ls, lds, L8, reinterpret_cast<hipStream_t>(stream), nb, Dg);
 }
-extern "C" svi_status svi_sp_unpack_out(const void* recv, void* out, int32_t P, int32_t G, int32_t Ls, int32_t Dg, svi_stream stream) {
+extern "C" svi_status svi_sp_unpack_out(const void* recv, void* out, int32_t P, int32_t G, int32_t Ls, int32_t Dg, int32_t nb, svi_stream stream) {
     SVI_REQUIRE(recv && out, "svi_sp_unpack_out: null argument");
-    return svi_launch_sp_unpack_out(reinterpret_cast<const bf16*>(recv), reinterpret_cast<bf16*>(out), P, G, Ls, Dg, reinterpret_cast<hipStream_t>(stream));
+    return svi_launch_sp_unpack_out(reinterpret_cast<const bf16*>(recv), reinterpret_cast<bf16*>(out), P, G, Ls, Dg, reinterpret_cast<hipStream_t>(stream), nb);
 }
 
 // TeaCache inside a sequence-parallel forward (the reference allows the combination: svi_video.py:112-131 checks on the full x, then

@@ -273,9 +273,9 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
             if constexpr (SCATTER) {
                 const int j = col / sc.Dp, cl = col - j * sc.Dp, gq = cl / sc.Dg, cg = cl - gq * sc.Dg;
                 bf16* ob = blockIdx.y ? sc.out1 : sc.out0;
-                int rps = rows, rr = row;
-                if (sc.rows_per_sample > 0) { rps = sc.rows_per_sample; const int smp = row / rps; rr = row - smp * rps; ob += (size_t)smp * sc.sample_stride; }
-                st_bf16x8(ob + ((size_t)(gq * sc.P + j) * rps + rr) * sc.Dg + cg, o);
+                int rps = rows, rr = row, nbr = 1, smp = 0;
+                if (sc.rows_per_sample > 0) { rps = sc.rows_per_sample; nbr = rows / rps; smp = row / rps; rr = row - smp * rps; }
+                st_bf16x8(ob + (((size_t)(gq * sc.P + j) * rps + rr) * nbr + smp) * sc.Dg + cg, o);
             } else {
                 st_bf16x8(xr + col, o);
             }
@@ -430,7 +430,7 @@ svi_status svi_launch_rmsnorm_rope2(bf16* x, int ld, int rows, int dim, const bf
         sc = *scatter;
         SVI_REQUIRE(sc.out0 && (!weight1 || sc.out1) && sc.P > 0 && sc.Dp > 0 && sc.Dg > 0 && sc.P * sc.Dp == dim && sc.Dp % sc.Dg == 0 && sc.Dg % 8 == 0,
                     "rmsnorm: bad send layout (P=%d Dp=%d Dg=%d for dim %d)", sc.P, sc.Dp, sc.Dg, dim);
-        SVI_REQUIRE(sc.rows_per_sample == 0 || (sc.rows_per_sample > 0 && rows % sc.rows_per_sample == 0 && sc.sample_stride % 8 == 0),
+        SVI_REQUIRE(sc.rows_per_sample == 0 || (sc.rows_per_sample > 0 && rows % sc.rows_per_sample == 0),
                     "rmsnorm: %d rows are not whole samples of %d rows", rows, sc.rows_per_sample);
     }
 #define SVI_RMS_LAUNCH(MAXC)                                                                                                             \
@@ -621,50 +621,58 @@ svi_status svi_launch_fp8_e4m3_to_bf16(const unsigned char* in, bf16* out, int64
 // Sequence-parallel exchanges, receive side (svi_hip/sequence_parallel.py).  The send side needs no kernel: q | k leave the
 // RMSNorm+RoPE launch in send order (SviScatter), V^T [D, ldvt] and the attention output [G][L][Dg] already are contiguous per peer.
 // ------------------------------------------------------------------------------------------------
-// V^T pieces [P(src)][Dp][lds] (columns >= Ls of a piece are padding) -> out [Dp][L8], column src*Ls + i.  VEC elements per thread.
+// V^T pieces [P(src)][Dp][lds] -> out.  A piece's columns are the source's token rows, branch b (of nb stacked CFG branches) at columns
+// [b * Ls, (b + 1) * Ls) (columns past nb * Ls are padding); channel c = g * Dg + cg of the piece goes to row (g * nb + b) * Dg + cg of out
+// [G * nb * Dg][L8], column src * Ls + i: per head group the branches' channels are adjacent — 2 x as many heads of one attention launch.
+// nb = 1: out [Dp][L8], row c.  VEC elements per thread.
 template <int VEC>
-__global__ __launch_bounds__(256) void sp_unpack_vt_kernel(const bf16* __restrict__ recv, bf16* __restrict__ out, int P, int Dp, int Ls, int lds, int L8) {
+__global__ __launch_bounds__(256) void sp_unpack_vt_kernel(const bf16* __restrict__ recv, bf16* __restrict__ out, int P, int Dp, int Ls, int lds, int L8, int nb, int Dg) {
     const int per_row = Ls / VEC;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)P * Dp * per_row;
+    const int64_t n = (int64_t)P * Dp * nb * per_row;
     if (idx >= n) return;
     const int i = (int)(idx % per_row) * VEC;
-    const int64_t rc = idx / per_row;
+    int64_t rc = idx / per_row;
+    const int b = (int)(rc % nb); rc /= nb;
     const int c = (int)(rc % Dp), src = (int)(rc / Dp);
-    const bf16* ip = recv + ((size_t)src * Dp + c) * lds + i;
-    bf16* op = out + (size_t)c * L8 + (size_t)src * Ls + i;
+    const int g = c / Dg, cg = c - g * Dg;
+    const bf16* ip = recv + ((size_t)src * Dp + c) * lds + (size_t)b * Ls + i;
+    bf16* op = out + ((size_t)(g * nb + b) * Dg + cg) * L8 + (size_t)src * Ls + i;
     if constexpr (VEC == 8) st_bf16x8(op, ld_bf16x8(ip));
     else if constexpr (VEC == 2) *reinterpret_cast<unsigned*>(op) = *reinterpret_cast<const unsigned*>(ip);
     else *op = *ip;
 }
-svi_status svi_launch_sp_unpack_vt(const bf16* recv, bf16* out, int P, int Dp, int Ls, int lds, int L8, hipStream_t st) {
-    SVI_REQUIRE(P > 0 && Dp > 0 && Ls > 0 && lds >= Ls && L8 >= P * Ls, "sp_unpack_vt: bad sizes");
+svi_status svi_launch_sp_unpack_vt(const bf16* recv, bf16* out, int P, int Dp, int Ls, int lds, int L8, hipStream_t st, int nb, int Dg) {
+    if (Dg <= 0) Dg = Dp;
+    SVI_REQUIRE(P > 0 && Dp > 0 && Ls > 0 && nb >= 1 && lds >= nb * Ls && L8 >= P * Ls && Dp % Dg == 0, "sp_unpack_vt: bad sizes");
     const int vec = (Ls % 8 == 0 && lds % 8 == 0 && L8 % 8 == 0) ? 8 : (Ls % 2 == 0 && lds % 2 == 0 && L8 % 2 == 0) ? 2 : 1;
-    const int64_t n = (int64_t)P * Dp * (Ls / vec);
+    const int64_t n = (int64_t)P * Dp * nb * (Ls / vec);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (vec == 8) hipLaunchKernelGGL(sp_unpack_vt_kernel<8>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8);
-    else if (vec == 2) hipLaunchKernelGGL(sp_unpack_vt_kernel<2>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8);
-    else hipLaunchKernelGGL(sp_unpack_vt_kernel<1>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8);
+    if (vec == 8) hipLaunchKernelGGL(sp_unpack_vt_kernel<8>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8, nb, Dg);
+    else if (vec == 2) hipLaunchKernelGGL(sp_unpack_vt_kernel<2>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8, nb, Dg);
+    else hipLaunchKernelGGL(sp_unpack_vt_kernel<1>, grid, block, 0, st, recv, out, P, Dp, Ls, lds, L8, nb, Dg);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
-// attention output pieces [G][P(src)][Ls][Dg] -> out [Ls][P * G * Dg]: source j's head block at columns [j*Dp, (j+1)*Dp), Dp = G*Dg
-__global__ __launch_bounds__(256) void sp_unpack_out_kernel(const bf16* __restrict__ recv, bf16* __restrict__ out, int P, int G, int Ls, int Dg) {
+// attention output pieces [G][P(src)][Ls][nb][Dg] -> out [nb * Ls][P * G * Dg]: branch b's token rows at [b * Ls, (b + 1) * Ls), source j's head block at
+// columns [j*Dp, (j+1)*Dp), Dp = G*Dg
+__global__ __launch_bounds__(256) void sp_unpack_out_kernel(const bf16* __restrict__ recv, bf16* __restrict__ out, int P, int G, int Ls, int Dg, int nb) {
     const int cpr = Dg >> 3;                                            // 16-byte chunks per piece row
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)G * P * Ls * cpr;
+    const int64_t n = (int64_t)G * P * Ls * nb * cpr;
     if (idx >= n) return;
     const int ch = (int)(idx % cpr);
     int64_t t = idx / cpr;
+    const int b = (int)(t % nb); t /= nb;
     const int row = (int)(t % Ls); t /= Ls;
     const int j = (int)(t % P), g = (int)(t / P);
     const int D = P * G * Dg;
-    st_bf16x8(out + (size_t)row * D + (size_t)j * G * Dg + (size_t)g * Dg + ch * 8, ld_bf16x8(recv + idx * 8));
+    st_bf16x8(out + ((size_t)b * Ls + row) * D + (size_t)j * G * Dg + (size_t)g * Dg + ch * 8, ld_bf16x8(recv + idx * 8));
 }
-svi_status svi_launch_sp_unpack_out(const bf16* recv, bf16* out, int P, int G, int Ls, int Dg, hipStream_t st) {
-    SVI_REQUIRE(P > 0 && G > 0 && Ls > 0 && Dg > 0 && Dg % 8 == 0, "sp_unpack_out: bad sizes");
-    const int64_t n = (int64_t)G * P * Ls * (Dg / 8);
-    hipLaunchKernelGGL(sp_unpack_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, recv, out, P, G, Ls, Dg);
+svi_status svi_launch_sp_unpack_out(const bf16* recv, bf16* out, int P, int G, int Ls, int Dg, hipStream_t st, int nb) {
+    SVI_REQUIRE(P > 0 && G > 0 && Ls > 0 && Dg > 0 && Dg % 8 == 0 && nb >= 1, "sp_unpack_out: bad sizes");
+    const int64_t n = (int64_t)G * P * Ls * nb * (Dg / 8);
+    hipLaunchKernelGGL(sp_unpack_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, recv, out, P, G, Ls, Dg, nb);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }

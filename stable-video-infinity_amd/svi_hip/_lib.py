@@ -50,8 +50,8 @@ SYMBOLS = [
     ("svi_dit_sp_begin_pair", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_sp_block_qkv", _i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("svi_dit_sp_block_qkv_part", _i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    ("svi_sp_unpack_vt", _i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    ("svi_sp_unpack_out", _i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_sp_unpack_vt", _i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("svi_sp_unpack_out", _i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("svi_dit_sp_block_rest", _i32, [_vp, _i32, _vp, _vp]),
     ("svi_dit_sp_tea", _i32, [_vp, _i32, _vp, _vp]),
     ("svi_dit_sp_head", _i32, [_vp, _vp, _vp]),

@@ -72,13 +72,13 @@ def unpack_out(recv: torch.Tensor, Ls: int) -> torch.Tensor:
     return recv.reshape(G, P, Ls, Dg).permute(2, 1, 0, 3).reshape(Ls, P * G * Dg).contiguous()
 
 
-def head_groups(heads_local: int, tokens: int) -> int:
+def head_groups(heads_local: int, tokens: int, nb: int = 1) -> int:
     """Number of head groups the exchange is pipelined in: as many as possible while one group's attention still fills the chip
-    (256 CUs x one 256-row query block each) and divides the rank's heads."""
+    (256 CUs x one 256-row query block each) and divides the rank's heads.  nb = 2 (stacked CFG pair): a group's launch carries both branches' heads."""
     blocks_per_head = (tokens + 255) // 256
     best = 1
     for g in range(1, heads_local + 1):
-        if heads_local % g == 0 and (heads_local // g) * blocks_per_head >= 256:
+        if heads_local % g == 0 and nb * (heads_local // g) * blocks_per_head >= 256:
             best = g
     return best
 
@@ -120,20 +120,22 @@ class _Buffers:
     """Exchange buffers of one (rank, world, tokens, head groups) configuration; allocated once, reused by every block."""
 
     def __init__(self, d: WanDiT, world: int, Ls: int, G: int, dev, nb: int = 1):
-        """nb = 2: the stacked CFG pair (SequenceShard.begin_pair) — a leading branch axis on every q | k / output block (each branch's exchange pieces
-        stay contiguous), V^T with both branches' rows side by side along the token axis (one exchange), attn with the unconditional rows below."""
+        """nb = 2: the stacked CFG pair (SequenceShard.begin_pair).  A token's two branches travel side by side: every q | k / output piece row is
+        [branch][Dg], so what arrives per head group is token-major [L, nb * Dg] and the two branches are nb x as many heads of ONE attention launch
+        (P = 4 of the 1.3B model: 6 head-equivalents x 128 query blocks = 768 work items = three whole rounds of 256 CUs, where one branch's 384 are one
+        and a half); V^T carries both branches' token rows side by side along the token axis; attn has the unconditional rows below the conditional."""
         D, Dp = d.dim, d.dim // world
         Dg, Lfull = Dp // G, Ls * world
         self.nb = nb
         self.ldvt, self.L8 = (nb * Ls + 7) // 8 * 8, (Lfull + 7) // 8 * 8
         bf = dict(dtype=torch.bfloat16, device=dev)
-        self.qk_send = torch.empty((2, nb, G, world, Ls * Dg), **bf)   # [q|k][branch][group][dest][rows of this rank]
-        self.qk_recv = torch.empty((2, nb, G, world, Ls * Dg), **bf)   # [q|k][branch][group][src] = token-major [L, Dg] per (operand, branch, group)
+        self.qk_send = torch.empty((2, G, world, Ls * nb * Dg), **bf)  # [q|k][group][dest][rows of this rank x branch x Dg]
+        self.qk_recv = torch.empty((2, G, world, Ls * nb * Dg), **bf)  # [q|k][group][src] = [q|k][group] x token-major [L, nb * Dg]
         self.vt_send = torch.zeros((world, Dp, self.ldvt), **bf)       # = V^T [D, ldvt] of this rank's rows (pad columns stay zero)
         self.vt_recv = torch.empty((world, Dp, self.ldvt), **bf)
-        self.vt_full = torch.zeros((nb, Dp, self.L8), **bf)            # V^T of this rank's head block over all tokens, per branch (pad stays zero)
-        self.o_send = torch.empty((nb, G, world, Ls * Dg), **bf)       # attention output [branch][group][L, Dg] = [branch][group][dest][Ls*Dg]
-        self.o_recv = torch.empty((nb, G, world, Ls * Dg), **bf)
+        self.vt_full = torch.zeros((G, nb * Dg, self.L8), **bf)        # V^T of this rank's head block over all tokens: per group [branch][Dg] channel rows (pad stays zero)
+        self.o_send = torch.empty((G, world, Ls * nb * Dg), **bf)      # attention output [group][L, nb * Dg] = [group][dest][Ls * nb * Dg]
+        self.o_recv = torch.empty((G, world, Ls * nb * Dg), **bf)
         self.attn = torch.empty((nb * Ls, D), **bf)
         self.head_rows = None
 
@@ -187,7 +189,7 @@ class SequenceShard:
             raise ValueError(f"{self.L} tokens do not divide over {self.world} ranks")
         self.Ls = self.L // self.world
         self.nb = nb
-        self.G = self._groups if self._groups is not None else head_groups(self.heads_local, self.L)
+        self.G = self._groups if self._groups is not None else head_groups(self.heads_local, self.L, nb)
         self.Dg = self.Dp // self.G
         cache = d.__dict__.setdefault("_sp_buffers", {})
         key = (self.rank, self.world, self.L, self.G if self.mode == "ulysses" else "gather", x.device, nb)
@@ -255,7 +257,7 @@ class SequenceShard:
     def attention_rows(self) -> None:
         """This rank's query rows against the gathered K (buf.k_all = [L, dim]) and V^T (buf.vt_all -> buf.vt_full) -> buf.attn [Ls, dim]."""
         b = self.buf
-        L.check(L.lib().svi_sp_unpack_vt(L.ptr(b.vt_all), L.ptr(b.vt_full), self.world, self.dit.dim, self.Ls, b.ldvt, b.L8, L.current_stream()), "svi_sp_unpack_vt")
+        L.check(L.lib().svi_sp_unpack_vt(L.ptr(b.vt_all), L.ptr(b.vt_full), self.world, self.dit.dim, self.Ls, b.ldvt, b.L8, 1, self.dit.dim, L.current_stream()), "svi_sp_unpack_vt")
         L.check(L.lib().svi_attention_vt_fwd(L.ptr(b.q), self.dit.dim, L.ptr(b.k_all), self.dit.dim, L.ptr(b.vt_full), b.L8, L.ptr(b.attn), self.dit.dim,
                                              self.Ls, self.L, self.dit.num_heads, 1, L.current_stream()), "svi_attention_vt_fwd")
 
@@ -272,21 +274,20 @@ class SequenceShard:
 
     def unpack_v(self) -> None:
         b = self.buf
-        for br in range(self.nb):          # branch br's tokens are columns [br * Ls, (br + 1) * Ls) of every received piece
-            L.check(L.lib().svi_sp_unpack_vt(b.vt_recv.data_ptr() + br * self.Ls * 2, L.ptr(b.vt_full[br]), self.world, self.Dp, self.Ls, b.ldvt, b.L8,
-                                             L.current_stream()), "svi_sp_unpack_vt")
+        L.check(L.lib().svi_sp_unpack_vt(L.ptr(b.vt_recv), L.ptr(b.vt_full), self.world, self.Dp, self.Ls, b.ldvt, b.L8, self.nb, self.Dg,
+                                         L.current_stream()), "svi_sp_unpack_vt")
 
-    def attention(self, g: int, branch: int = 0) -> None:
-        """Attention of head group g (of CFG branch `branch`) on the received operands -> buf.o_send[branch, g] ([L, Dg], contiguous per destination)."""
+    def attention(self, g: int) -> None:
+        """Attention of head group g on the received operands -> buf.o_send[g] ([L, nb * Dg], contiguous per destination).  A stacked pair's two branches
+        are 2 x as many heads of this one launch."""
         b = self.buf
-        L.check(L.lib().svi_attention_vt_fwd(L.ptr(b.qk_recv[0, branch, g]), self.Dg, L.ptr(b.qk_recv[1, branch, g]), self.Dg,
-                                             L.ptr(b.vt_full[branch, g * self.Dg:]), b.L8, L.ptr(b.o_send[branch, g]), self.Dg, self.L, self.L,
-                                             self.heads_local // self.G, 1, L.current_stream()), "svi_attention_vt_fwd")
+        ld = self.nb * self.Dg
+        L.check(L.lib().svi_attention_vt_fwd(L.ptr(b.qk_recv[0, g]), ld, L.ptr(b.qk_recv[1, g]), ld, L.ptr(b.vt_full[g]), b.L8,
+                                             L.ptr(b.o_send[g]), ld, self.L, self.L, self.nb * self.heads_local // self.G, 1, L.current_stream()), "svi_attention_vt_fwd")
 
     def block_rest(self, layer: int) -> None:
         b = self.buf
-        for br in range(self.nb):
-            L.check(L.lib().svi_sp_unpack_out(L.ptr(b.o_recv[br]), L.ptr(b.attn[br * self.Ls:]), self.world, self.G, self.Ls, self.Dg, L.current_stream()), "svi_sp_unpack_out")
+        L.check(L.lib().svi_sp_unpack_out(L.ptr(b.o_recv), L.ptr(b.attn), self.world, self.G, self.Ls, self.Dg, self.nb, L.current_stream()), "svi_sp_unpack_out")
         L.check(L.lib().svi_dit_sp_block_rest(self.dit._h, layer, L.ptr(b.attn), L.current_stream()), "svi_dit_sp_block_rest")
 
     def tea(self, mode: int, residual: Optional[torch.Tensor] = None) -> None:
@@ -366,24 +367,7 @@ def forward_distributed(dit: WanDiT, x, timestep, context, group=None, groups: O
         if tea_mode == 1:
             sh.tea(1, residual)
         return sh.unpatchify(all_gather_rows(sh.head(), group))
-    for layer in range(dit.num_layers):
-        sh.block_qkv(layer)
-        wv = _exchange(b.vt_recv, b.vt_send, group, True)
-        wq = [(_exchange(b.qk_recv[0, 0, g], b.qk_send[0, 0, g], group, True), _exchange(b.qk_recv[1, 0, g], b.qk_send[1, 0, g], group, True)) for g in range(G)]
-        if wv is not None:
-            wv.wait()
-        sh.unpack_v()
-        wo = []
-        for g in range(G):
-            for w_ in wq[g]:
-                if w_ is not None:
-                    w_.wait()
-            sh.attention(g)
-            wo.append(_exchange(b.o_recv[0, g], b.o_send[0, g], group, True))
-        for w_ in wo:
-            if w_ is not None:
-                w_.wait()
-        sh.block_rest(layer)
+    _blocks_distributed(sh, group)
     if tea_mode == 1:
         sh.tea(1, residual)
     return sh.unpatchify(all_gather_rows(sh.head(), group))
@@ -418,14 +402,14 @@ def forward_local(dits: Sequence[WanDiT], x, timestep, context, groups: Optional
         for j, sj in enumerate(shards):                 # rank j receives piece j of every rank i
             for i, si in enumerate(shards):
                 sj.buf.vt_recv[i].copy_(si.buf.vt_send[j])
-                sj.buf.qk_recv[:, :, :, i].copy_(si.buf.qk_send[:, :, :, j])
+                sj.buf.qk_recv[:, :, i].copy_(si.buf.qk_send[:, :, j])
         for sh in shards:
             sh.unpack_v()
             for g in range(G):
                 sh.attention(g)
         for j, sj in enumerate(shards):
             for i, si in enumerate(shards):
-                sj.buf.o_recv[:, :, i].copy_(si.buf.o_send[:, :, j])
+                sj.buf.o_recv[:, i].copy_(si.buf.o_send[:, j])
         for sh in shards:
             sh.block_rest(layer)
     rows = torch.cat([sh.head() for sh in shards], dim=0)
@@ -438,35 +422,39 @@ def _pair_outputs(sh: SequenceShard, rows_all: torch.Tensor):
     return tuple(sh.unpatchify(rows_all[:, br * Ls:(br + 1) * Ls].reshape(P * Ls, -1)) for br in range(2))
 
 
-def forward_distributed_pair(dit: WanDiT, x, timestep, context_cond, context_uncond, group=None, groups: Optional[int] = None, **cond):
-    """Both forwards of a CFG step (svi_video.py:401-408) for this rank of `group`, STACKED on the rank's rows: every row-local launch runs once over
-    2 L / P rows (the conditional branch's on top), attention and the exchanges run per branch, and no rank waits for another's noise prediction —
-    each rank ends with both.  Returns (noise_pred_cond, noise_pred_uncond), full latents on every rank; bit-identical to two forward_distributed
-    calls and, with the key axis never cut (SVI_FLASH_SPLIT=1), to WanDiT.forward_cfg_pair on one rank.  Ulysses mode; context cache on."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    sh = SequenceShard(dit, rank, world, groups, "ulysses")
-    sh.begin_pair(x, timestep, context_cond, context_uncond, **cond)
+def _blocks_distributed(sh: SequenceShard, group) -> None:
+    """The block loop of the Ulysses mode for this rank (one branch or a stacked pair: the same exchanges, pieces nb x as long)."""
     b, G = sh.buf, sh.G
-    for layer in range(dit.num_layers):
+    for layer in range(sh.dit.num_layers):
         sh.block_qkv(layer)
-        wv = _exchange(b.vt_recv, b.vt_send, group, True)                  # both branches' V^T pieces in one exchange
-        wq = [[(_exchange(b.qk_recv[0, br, g], b.qk_send[0, br, g], group, True), _exchange(b.qk_recv[1, br, g], b.qk_send[1, br, g], group, True))
-               for g in range(G)] for br in range(2)]
+        wv = _exchange(b.vt_recv, b.vt_send, group, True)
+        wq = [(_exchange(b.qk_recv[0, g], b.qk_send[0, g], group, True), _exchange(b.qk_recv[1, g], b.qk_send[1, g], group, True)) for g in range(G)]
         if wv is not None:
             wv.wait()
         sh.unpack_v()
         wo = []
-        for br in range(2):
-            for g in range(G):
-                for w_ in wq[br][g]:
-                    if w_ is not None:
-                        w_.wait()
-                sh.attention(g, br)
-                wo.append(_exchange(b.o_recv[br, g], b.o_send[br, g], group, True))
+        for g in range(G):
+            for w_ in wq[g]:
+                if w_ is not None:
+                    w_.wait()
+            sh.attention(g)
+            wo.append(_exchange(b.o_recv[g], b.o_send[g], group, True))
         for w_ in wo:
             if w_ is not None:
                 w_.wait()
         sh.block_rest(layer)
+
+
+def forward_distributed_pair(dit: WanDiT, x, timestep, context_cond, context_uncond, group=None, groups: Optional[int] = None, **cond):
+    """Both forwards of a CFG step (svi_video.py:401-408) for this rank of `group`, STACKED on the rank's rows: every row-local launch runs once over
+    2 L / P rows (the conditional branch's on top), the two branches are twice as many heads of each attention launch and ride in the same exchange
+    pieces, and no rank waits for another's noise prediction — each rank ends with both.  Returns (noise_pred_cond, noise_pred_uncond), full latents on
+    every rank; bit-identical to two forward_distributed calls with the key axis in one piece and to WanDiT.forward_cfg_pair on one rank (at P = 4 of the
+    1.3B model the doubled head count makes the attention's rounds whole, so no key-axis cut is taken at all).  Ulysses mode; context cache on."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    sh = SequenceShard(dit, rank, world, groups, "ulysses")
+    sh.begin_pair(x, timestep, context_cond, context_uncond, **cond)
+    _blocks_distributed(sh, group)
     rows = sh.head()
     gathered = all_gather_rows(rows, group).reshape(world, 2 * sh.Ls, -1)
     return _pair_outputs(sh, gathered)
@@ -485,15 +473,14 @@ def forward_local_pair(dits: Sequence[WanDiT], x, timestep, context_cond, contex
         for j, sj in enumerate(shards):
             for i, si in enumerate(shards):
                 sj.buf.vt_recv[i].copy_(si.buf.vt_send[j])
-                sj.buf.qk_recv[:, :, :, i].copy_(si.buf.qk_send[:, :, :, j])
+                sj.buf.qk_recv[:, :, i].copy_(si.buf.qk_send[:, :, j])
         for sh in shards:
             sh.unpack_v()
-            for br in range(2):
-                for g in range(G):
-                    sh.attention(g, br)
+            for g in range(G):
+                sh.attention(g)
         for j, sj in enumerate(shards):
             for i, si in enumerate(shards):
-                sj.buf.o_recv[:, :, i].copy_(si.buf.o_send[:, :, j])
+                sj.buf.o_recv[:, i].copy_(si.buf.o_send[:, j])
         for sh in shards:
             sh.block_rest(layer)
     rows = torch.stack([sh.head() for sh in shards], dim=0)

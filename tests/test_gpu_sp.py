@@ -107,14 +107,29 @@ def test_unpack_kernels_follow_the_layout_algebra(P, Dp, Ls):
     lds, L8 = (Ls + 7) // 8 * 8, (P * Ls + 7) // 8 * 8
     recv = dev(synth.randn(7, P, Dp, lds))
     out = torch.zeros((Dp, L8), dtype=torch.bfloat16, device="cuda")
-    L.check(L.lib().svi_sp_unpack_vt(recv.data_ptr(), out.data_ptr(), P, Dp, Ls, lds, L8, L.current_stream()))
+    L.check(L.lib().svi_sp_unpack_vt(recv.data_ptr(), out.data_ptr(), P, Dp, Ls, lds, L8, 1, Dp, L.current_stream()))
     assert torch.equal(out, sp.unpack_vt(recv, Ls))
     for G in (1, 2):
         Dg = Dp // G
         r2 = dev(synth.randn(8, G, P, Ls * Dg))
         o2 = torch.empty((Ls, P * Dp), dtype=torch.bfloat16, device="cuda")
-        L.check(L.lib().svi_sp_unpack_out(r2.data_ptr(), o2.data_ptr(), P, G, Ls, Dg, L.current_stream()))
+        L.check(L.lib().svi_sp_unpack_out(r2.data_ptr(), o2.data_ptr(), P, G, Ls, Dg, 1, L.current_stream()))
         assert torch.equal(o2, sp.unpack_out(r2, Ls))
+        # the stacked CFG pair (nb = 2): a piece's columns hold branch b's tokens at [b Ls, (b + 1) Ls); out rows are [group][branch][Dg]; output pieces
+        # [G][P][Ls][2][Dg] -> attn with the unconditional rows below the conditional ones
+        lds2 = (2 * Ls + 7) // 8 * 8
+        rv = dev(synth.randn(9, P, Dp, lds2))
+        ov = torch.zeros((G * 2 * Dg, L8), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().svi_sp_unpack_vt(rv.data_ptr(), ov.data_ptr(), P, Dp, Ls, lds2, L8, 2, Dg, L.current_stream()))
+        want = torch.zeros_like(ov).view(G, 2, Dg, L8)
+        for b in range(2):
+            want[:, b, :, :P * Ls] = rv[:, :, b * Ls:(b + 1) * Ls].reshape(P, G, Dg, Ls).permute(1, 2, 0, 3).reshape(G, Dg, P * Ls)
+        assert torch.equal(ov.view(G, 2, Dg, L8), want)
+        r3 = dev(synth.randn(10, G, P, Ls * 2 * Dg))
+        o3 = torch.empty((2 * Ls, P * Dp), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().svi_sp_unpack_out(r3.data_ptr(), o3.data_ptr(), P, G, Ls, Dg, 2, L.current_stream()))
+        w3 = r3.view(G, P, Ls, 2, Dg).permute(3, 2, 1, 0, 4).reshape(2 * Ls, P * Dp)          # [b][row][src][g][c]
+        assert torch.equal(o3, w3)
 
 
 def test_sequence_parallel_i2v_and_add_condition():

@@ -50,23 +50,24 @@ if "pair" in sys.argv[1:]:
     for P in (2, 4, 6):
         hs = [handle() for _ in range(P)]
         for m in hs: m.context_cache(True)
-        G = sp.head_groups(12 // P, 32760)
-        def two(): sp.forward_local(hs, x, t, ctx, groups=G); sp.forward_local(hs, x, t, ctx2, groups=G)
+        G1 = sp.head_groups(12 // P, 32760, 1)
+        def two(): sp.forward_local(hs, x, t, ctx, groups=G1); sp.forward_local(hs, x, t, ctx2, groups=G1)
         ms2 = timeit(two)
-        msp = timeit(lambda: sp.forward_local_pair(hs, x, t, ctx, ctx2, groups=G))
-        def copies(nb):
-            bufs = [m._sp_buffers[k] for m in hs for k in m._sp_buffers if k[3] == G and k[5] == nb]
-            for _ in range(layers):
-                for j, bj in enumerate(bufs):
-                    for i, bi in enumerate(bufs):
-                        bj.vt_recv[i].copy_(bi.vt_send[j]); bj.qk_recv[:, :, :, i].copy_(bi.qk_send[:, :, :, j]); bj.o_recv[:, :, i].copy_(bi.o_send[:, :, j])
-        cp1, cp2 = timeit(lambda: copies(1)), timeit(lambda: copies(2))
-        r_two, r_pair = (ms2 - 2 * cp1) / P, (msp - cp2) / P
-        print(f"P={P} G={G}: per rank compute + unpack per STEP: two shard forwards {r_two:.1f} ms ({r_two / (pair_base / P) - 1:+.1%} over the ideal 1/P of the single-rank "
-              f"stacked pair), stacked pair on the shard {r_pair:.1f} ms ({r_pair / (pair_base / P) - 1:+.1%}); simulated transport {2 * cp1:.1f} / {cp2:.1f} ms")
-        if "tags" in sys.argv[1:]:
-            tg = tags(lambda: sp.forward_local_pair(hs, x, t, ctx, ctx2, groups=G))
-            print("      per tag, all shards (stacked) / single-rank stacked pair: " + "  ".join(f"{k} {tg.get(k, 0.0):.2f}/{v:.2f} ({tg.get(k, 0.0) / v - 1:+.0%})" for k, v in pair_tags.items()))
+        for G in sorted({1, sp.head_groups(12 // P, 32760, 2)}):
+            msp = timeit(lambda: sp.forward_local_pair(hs, x, t, ctx, ctx2, groups=G))
+            def copies(nb):
+                bufs = [m._sp_buffers[k] for m in hs for k in m._sp_buffers if k[3] == (G if nb == 2 else G1) and k[5] == nb]
+                for _ in range(layers):
+                    for j, bj in enumerate(bufs):
+                        for i, bi in enumerate(bufs):
+                            bj.vt_recv[i].copy_(bi.vt_send[j]); bj.qk_recv[:, :, i].copy_(bi.qk_send[:, :, j]); bj.o_recv[:, i].copy_(bi.o_send[:, j])
+            cp1, cp2 = timeit(lambda: copies(1)), timeit(lambda: copies(2))
+            r_two, r_pair = (ms2 - 2 * cp1) / P, (msp - cp2) / P
+            print(f"P={P} G={G}: per rank compute + unpack per STEP: two shard forwards {r_two:.1f} ms ({r_two / (pair_base / P) - 1:+.1%} over the ideal 1/P of the single-rank "
+                  f"stacked pair), stacked pair on the shard {r_pair:.1f} ms ({r_pair / (pair_base / P) - 1:+.1%}); simulated transport {2 * cp1:.1f} / {cp2:.1f} ms")
+            if "tags" in sys.argv[1:]:
+                tg = tags(lambda: sp.forward_local_pair(hs, x, t, ctx, ctx2, groups=G))
+                print("      per tag, all shards (stacked) / single-rank stacked pair: " + "  ".join(f"{k} {tg.get(k, 0.0):.2f}/{v:.2f} ({tg.get(k, 0.0) / v - 1:+.0%})" for k, v in pair_tags.items()))
         del hs
     sys.exit(0)
 for P in (2, 4, 6):
@@ -80,7 +81,7 @@ for P in (2, 4, 6):
             for _ in range(layers):
                 for j, bj in enumerate(bufs):
                     for i, bi in enumerate(bufs):
-                        bj.vt_recv[i].copy_(bi.vt_send[j]); bj.qk_recv[:, :, :, i].copy_(bi.qk_send[:, :, :, j]); bj.o_recv[:, :, i].copy_(bi.o_send[:, :, j])
+                        bj.vt_recv[i].copy_(bi.vt_send[j]); bj.qk_recv[:, :, i].copy_(bi.qk_send[:, :, j]); bj.o_recv[:, i].copy_(bi.o_send[:, j])
         cp = timeit(copies)
         per_rank = (ms - cp) / P
         print(f"P={P} G={G}: all shards back to back {ms:.1f} ms, of which simulated transport {cp:.1f} ms -> per rank compute + unpack {per_rank:.1f} ms "
