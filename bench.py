@@ -189,7 +189,7 @@ def pmc_summaries() -> dict:
                 continue
             tag = os.path.basename(f)[:-len("_source_hashes.json")]
             out = {"tag": tag}
-            for key in ("flash", "flash_qk8", "gemm_ffn1", "gemm_ffn2"):
+            for key in ("flash", "flash_qk8", "gemm_ffn1", "gemm_ffn2", "flash_cross", "vae_conv"):
                 p = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc.json")
                 if os.path.exists(p):
                     out[key] = json.load(open(p))
@@ -807,7 +807,7 @@ def main() -> None:
     roof_all = {k: v for k, v in roof_all.items() if v is not None}
     if args.workload == "c2" and not sp:
         pm = pmc_summaries()
-        for fam_name, key in (("flash_self", "flash"), ("gemm_ffn1", "gemm_ffn1"), ("gemm_ffn2", "gemm_ffn2")):
+        for fam_name, key in (("flash_self", "flash"), ("gemm_ffn1", "gemm_ffn1"), ("gemm_ffn2", "gemm_ffn2"), ("flash_cross", "flash_cross"), ("vae_decode", "vae_conv")):
             if fam_name in roof_all and pm.get(key):
                 roof_all[fam_name].update(traffic=pm[key].get("hbm_bytes"), mfma_busy_in_clock=pm[key].get("mfma_busy_in_clock"),
                                           l2_hit_rate=pm[key].get("l2_hit_rate"), pmc_source=pm.get(key + "_file"))

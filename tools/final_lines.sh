@@ -21,12 +21,20 @@ line() { # name, args...
 import json, sys
 try:
     j = json.load(open(sys.argv[2]))
-    print(sys.argv[1], j["ms_per_step"], j["value"], (j.get("roofline") or {}).get("frac"), (j.get("roofline") or {}).get("traffic"))
+    c = j["config"]
+    print(sys.argv[1], j["ms_per_step"], j["value"], (j.get("roofline") or {}).get("frac"), (j.get("roofline") or {}).get("traffic"),
+          {k: c.get(k) for k in ("full_clip_s", "value_full_clip", "full_clip_steady_s") if c.get(k) is not None}, (c.get("window") or {}).get("per_clip_fixed_cost_s"))
 except Exception as ex:
     print(sys.argv[1], "FAILED", ex)
 PY
 }
 line default --gpus 1 --steps 20 --warmup 5
+# the metric as defined, as a workload: BASELINE configs[2] on one GPU (3 clips, seeds k x 42, 2 prompts cycled, decode + 8-bit frames + stitch), resident loop
+# (one captured step graph for the window) against a loop that re-captures per clip; then the same window sharded over 2 ranks that share the GPU (gloo probe)
+line window --steps 5 --warmup 2 --window 3 --window-ab --no-cpu-baseline --no-full-clip
+line window_gloo_x2 --gpus 2 --transport gloo --steps 3 --warmup 1 --window 2 --no-cpu-baseline --no-full-clip
+line c1_window --workload c1 --steps 10 --warmup 3 --window 6 --window-ab --no-cpu-baseline --no-full-clip
+SVI_CROSS_FUSED=0 line cross_two_kernels --steps 10 --warmup 3 --no-cpu-baseline
 line no_graph --steps 10 --warmup 3 --no-graph --no-cpu-baseline
 line fp8_attn --steps 10 --warmup 3 --fp8-attn --no-cpu-baseline
 line fp8_mfma --steps 10 --warmup 3 --fp8-mfma --no-cpu-baseline

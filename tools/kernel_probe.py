@@ -3,6 +3,7 @@
     python tools/kernel_probe.py attn [iters]      self-attention flash kernel, L=32760, 12 heads
     python tools/kernel_probe.py gemm_ffn1|gemm_ffn2|gemm_qkv [iters]
     python tools/kernel_probe.py ln|rms [iters]
+    python tools/kernel_probe.py cross [iters]     the fused cross-attention (q RMS-normalised as it is read; 65 of 512 keys, resident in LDS) at L = 32760
     python tools/kernel_probe.py vae [iters]       VAE decode of 3 latent frames at 480x832 (every decoder layer at its C2 spatial size)
 Prints achieved TFLOP/s (or TB/s) from torch.cuda.Event timing on the launch stream.
 """
@@ -70,6 +71,14 @@ elif what == "ln":
 elif what == "rms":
     x = rnd(Ltok, D); wt = rnd(D)
     timeit(lambda: svi_hip.rmsnorm_rope_(x, wt, 1e-6, grid=(21, 30, 52), num_heads=12), bytes_=2.0 * Ltok * D * 2)
+elif what == "cross":
+    # the DiT block's cross-attention query path at the C2 size: q projection with the row statistics, then the fused attention (65 keys walked of 512)
+    x = rnd(Ltok, D); w = rnd(D, D, scale=D ** -0.5); b = rnd(D); gain = rnd(D)
+    k = rnd(512, D); vt = rnd(D, 512)
+    k[64:] = k[64]; vt[:, 64:] = vt[:, 64:65]
+    tail = torch.tensor([65, 448], dtype=torch.int32, device=dev)
+    y, rs, _ = svi_hip.ops.linear_row_stats(x, w, b, eps=1e-6)
+    timeit(lambda: svi_hip.ops.cross_attention(y, k, vt, H, s_kv=512, q_rs=rs, q_gain=gain, q_out_scale=0.12751743, key_tail=tail), bytes_=2.0 * Ltok * D * 2)
 elif what == "vae":
     from svi_hip.vae import WanVideoVAE, device_vae_weights
     vae = WanVideoVAE.from_state_dict(device_vae_weights(0, dev))

@@ -4,7 +4,7 @@ Per launch of the kernel: the raw counters, the HBM-side bytes corrected as MI35
 FETCH_SIZE tallies a wide coalesced read at half its bytes on gfx950 -> x2), the L2 hit rate, and the box-independent matrix-pipe figure
     mfma_busy_in_clock = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs)
 i.e. the share of the kernel's own shader clocks in which a SIMD's matrix pipe was busy, whatever clock the power cap allowed.
-Every JSON carries the sha256[:16] of every csrc/*.hip it was collected on; bench.py quotes it only when all of them equal the tree it times.
+Every JSON carries the sha256[:16] of every csrc/*.hip and of csrc/svi_common.h it was collected on; bench.py quotes it only when all of them equal the tree it times.
 """
 import hashlib
 import json
@@ -13,7 +13,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = ["svi_attention.hip", "svi_gemm.hip", "svi_dit.hip", "svi_elementwise.hip", "svi_vae.hip", "svi_api.hip", "svi_encoders.hip"]
+SRCS = ["svi_attention.hip", "svi_gemm.hip", "svi_dit.hip", "svi_elementwise.hip", "svi_vae.hip", "svi_api.hip", "svi_encoders.hip",
+        "svi_common.h"]          # the shared device code (MFMA fragment helpers, the MX quantiser, GELU) is part of every kernel: gated too
 
 
 def source_hashes():
@@ -91,6 +92,19 @@ def main(tag):
             name = max(ks, key=lambda k: ks[k]["SQ_INSTS_MFMA"])          # the GEMM launch itself
             vals = ks[name]
             out = {"kernel": f"{name} ({what})", "counters_per_launch": vals, "source_hashes": hashes, **derive(vals), "algorithmic_bytes": alg, "note": note}
+            json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_{key}_pmc.json"), "w"), indent=1)
+            print(json.dumps({k: out.get(k) for k in ("kernel", "hbm_bytes", "mfma_busy_in_clock", "l2_hit_rate")}))
+    # the fused cross-attention (flash_cross_resident_kernel: q read + o written, HBM-bound) and the VAE's strip convolution, when their passes were collected
+    for key, pat, what in (("flash_cross", "flash_cross_resident_kernel", "cross-attention, L = 32760 query rows, 12 heads, 65 keys resident in LDS, q RMS-normalised as it is read"),
+                           ("vae_conv", "conv_dma2h_kernel<3>", "the VAE decoder's residual-block convolution (fp16 two-term, plane-fed strips)")):
+        p = os.path.join(ROOT, "gpurun_out", f"{tag}_{key}_pmc.txt")
+        if not os.path.exists(p):
+            continue
+        ks = {k: v for k, v in parse(p).items() if pat in k and v.get("GRBM_GUI_ACTIVE")}
+        if ks:
+            name = max(ks, key=lambda k: ks[k].get("SQ_WAVE_CYCLES", 0.0))
+            vals = ks[name]
+            out = {"kernel": f"{name} ({what})", "counters_per_launch": vals, "source_hashes": hashes, **derive(vals), "note": note}
             json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_{key}_pmc.json"), "w"), indent=1)
             print(json.dumps({k: out.get(k) for k in ("kernel", "hbm_bytes", "mfma_busy_in_clock", "l2_hit_rate")}))
     json.dump(hashes, open(os.path.join(ROOT, "gpurun_out", f"{tag}_source_hashes.json"), "w"), indent=1)

@@ -34,5 +34,13 @@ rm -rf gpurun_out/pmch_$TAG/pass*/
 SVI_ATTN_QK8=1 tools/pmc_collect.sh attn gpurun_out/pmcq_$TAG > gpurun_out/pmcq_$TAG.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmcq_$TAG "flash|mx8_quantize" > gpurun_out/${TAG}_flash_qk8_pmc.txt
 rm -rf gpurun_out/pmcq_$TAG/pass*/
+# 3d. the fused cross-attention (q RMS-normalised as it is read, K / V^T resident in LDS): HBM-bound -> gpurun_out/<tag>_flash_cross_pmc.txt
+tools/pmc_collect.sh cross gpurun_out/pmcx_$TAG > gpurun_out/pmcx_$TAG.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmcx_$TAG "flash_cross|row_rs" > gpurun_out/${TAG}_flash_cross_pmc.txt
+rm -rf gpurun_out/pmcx_$TAG/pass*/
+# 3e. the VAE decoder's convolutions (3 latent frames at 480x832: every layer at its C2 spatial size) -> gpurun_out/<tag>_vae_conv_pmc.txt
+tools/pmc_collect.sh vae gpurun_out/pmcv_$TAG > gpurun_out/pmcv_$TAG.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmcv_$TAG "conv_dma2h" > gpurun_out/${TAG}_vae_conv_pmc.txt
+rm -rf gpurun_out/pmcv_$TAG/pass*/
 # 4. JSON summaries (per-launch HBM bytes, mfma_busy_in_clock, L2 hit rate) + the hashes of the sources they were collected on
 python tools/pmc_to_json.py $TAG
