@@ -780,7 +780,9 @@ def main() -> None:
         "flash_cross": fam("flash_cross", 4.0 * Ls * D, "hbm", f"q [L, D] bf16 read + o [L, D] bf16 written per launch; keys walked: {keys_walked} of {lc} context rows "
                            "(identical trailing rows of the zero-padded prompt count as one key)" +
                            ("; q is the raw projection, RMS-normalised as it is read; the tag also holds row_rs_kernel (the statistic): 2 launches per block and branch" if cross_fused else ""),
-                           total_fn=(lambda n: (4.0 * Ls * D + (D // 64 + 1) * 4.0 * Ls) * n / 2.0) if cross_fused else None),
+                           # fused: the tag holds the attention launches (one per block and branch) AND the statistic's launches (one per block where the pair is
+                           # stacked, else one per block and branch): the bytes are counted per (block, branch) unit, not per launch
+                           total_fn=(lambda n: (4.0 * Ls * D + (D // 64 + 1) * 4.0 * Ls) * n_cross_units) if cross_fused else None),
         # q | k are ONE N = 2D launch (4 L D^2 FLOP), V^T its own (2 L D^2): 3 L D^2 per launch on average; three 2 L D^2 launches with SVI_QK_FUSED=0
         "gemm_qkv": fam("gemm_qkv", (3.0 if os.environ.get("SVI_QK_FUSED", "1") != "0" else 2.0) * Ls * D * D, "mfma",
                         "q | k as one launch over the two weight matrices (4 L D^2 FLOP) + the V^T projection (2 L D^2)", third="self"),
@@ -814,7 +816,8 @@ def main() -> None:
     if "flash_cross" in roof_all:
         fc = roof_all["flash_cross"]
         mean_keys = sum(keys_walked) / len(keys_walked)
-        attn_launches = fc["launches_per_step"] / (2.0 if cross_fused else 1.0)
+        attn_launches = float(n_cross_units) if cross_fused else fc["launches_per_step"]
+        fc["attention_launches_per_step"] = attn_launches
         fc["executed_tflops"] = round(4.0 * Ls * mean_keys * D * attn_launches / (fc["ms_per_step"] * 1e-3) / 1e12, 1)
         fc["reference_algorithmic_tflops"] = round(4.0 * Ls * lc * D * attn_launches / (fc["ms_per_step"] * 1e-3) / 1e12, 1)
         fc["query_rmsnorm_fused"] = cross_fused

@@ -103,23 +103,33 @@ print(float((got - ref).norm() / ref.norm()))
 
 def test_committed_default_line_counts_stacked_launches_in_row_equivalents():
     """The CFG pair is stacked at the C2 size: a row-local launch covers both branches' rows.  bench.py must count such families in L-row launch
-    equivalents (59 self-attention thirds + 60 rest-thirds per step), or their roofline fractions halve.  Checked on the committed driver-shaped line."""
+    equivalents (59 self-attention thirds + 60 rest-thirds per step), or their roofline fractions halve; the fused cross-attention's bytes are counted per
+    (block, branch) unit (60 per step), not per launch (its tag also holds the statistic's launches).  Checked on the committed driver-shaped line, which
+    also carries the two TIMED complete clips beside the extrapolated value."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = os.path.join(root, "profiles", "r4z_bench_default.json")
+    p = os.path.join(root, "profiles", "r5z_bench_default.json")
     if not os.path.exists(p):
         import pytest
-        pytest.skip("no committed r4z line")
+        pytest.skip("no committed r5z line")
     j = json.load(open(p))
-    assert j["config"]["cfg_pair_stacked"] is True and j["config"]["hip_graph"] is True
+    c = j["config"]
+    assert c["cfg_pair_stacked"] is True and c["hip_graph"] is True
     ra = j["roofline_all"]
     want = {"gemm_qkv": 118, "gemm_attn_out": 59, "gemm_cross": 120, "gemm_ffn1": 60, "gemm_ffn2": 60, "ln_modulate": 179}
     for k, n in want.items():
         assert abs(ra[k]["launch_equivalents_per_step"] - n) < 0.01, (k, ra[k])
         assert ra[k]["launches_per_step"] < n
     assert 0.40 < ra["gemm_ffn1"]["frac"] < 0.60 and 0.45 < ra["gemm_ffn2"]["frac"] < 0.65 and 0.6 < ra["ln_modulate"]["frac"] < 0.9
+    fc = ra["flash_cross"]
+    assert fc["query_rmsnorm_fused"] is True and fc["attention_launches_per_step"] == 60 and fc["launches_per_step"] == 90
+    assert abs(fc["algorithmic_per_step"] - 60 * (4.0 * 32760 * 1536 + 25 * 4.0 * 32760)) < 1e6 and 0.35 < fc["frac"] < 0.7
+    assert fc["traffic"] and abs(fc["traffic"] - 4.0 * 32760 * 1536) < 0.1 * 4.0 * 32760 * 1536      # PMC: what crosses the fabric per launch IS the algorithmic q + o
     r = j["roofline"]
     assert r["traffic"] and r["mfma_busy_in_clock"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # the family sum is the step
     assert abs(sum(j["kernel_ms_per_step"].values()) - j["ms_per_step"]) < 0.03 * j["ms_per_step"]
+    # the metric as defined, timed: one complete clip as a stream starts, one as it continues — within 1 % of 50 x ms_per_step + the decode
+    assert abs(c["value_full_clip"] - 21.0 / c["full_clip_s"]) < 1e-3 and 0.99 < c["full_clip_vs_extrapolated"] < 1.01 and 0.99 < c["full_clip_steady_vs_extrapolated"] < 1.01
+    assert c["full_clip_breakdown"]["step_graph_captures_over_both_clips"] == 1
