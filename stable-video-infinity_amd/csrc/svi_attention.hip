@@ -303,15 +303,32 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
 // 128-row workgroup fetches K / V^T again, loads its q tile, computes and stores in sequence, two workgroups per CU).
 //   * ONE 512-thread workgroup per CU: head = blockIdx.x, a contiguous range of query rows = blockIdx.y (32-row units split evenly over gridDim.y);
 //     heads are the fast grid axis, so the 12 workgroups of a row range walk it together and a row's 3 KiB are touched while its DRAM pages are open.
-//   * up to 128 keys: K [key][128 ch] and V^T [ch][key] (32 KiB each, 16-byte chunks XOR-swizzled by row) are loaded once per workgroup;
-//   * the query rows stream through a 64 KiB tile, 256 rows per iteration: row-contiguous 16-byte loads for iteration i + 1 are in flight (registers)
-//     while iteration i computes; RMSNorm (NORM: rs[row] from the q projection's epilogue, rounding points of rmsnorm_rope_kernel) is applied on the way
-//     into LDS; the output tile leaves through the same LDS cells, row-contiguously.  Two barriers per iteration;
+//   * up to 128 keys: K [key][128 ch] and V^T [ch][key] (32 KiB each, 16-byte chunks XOR-swizzled by row) are loaded once per workgroup; ONE barrier
+//     behind that, and none afterwards:
+//   * every WAVE owns the 32-row units  wave, wave + 8, ...  of the workgroup's range and a private 8 KiB of LDS for them: row-contiguous 16-byte loads
+//     of unit i + 1 are in flight (registers) while unit i computes; RMSNorm (NORM: rs[row] from the q projection's epilogue, the rounding
+//     points of rmsnorm_rope_kernel) is applied on the way into LDS, where the rows change from the row-contiguous load layout to the MFMA operand
+//     layout; the output rows leave through the same cells, row-contiguously.  Eight unsynchronised instruction streams per CU: one wave's loads and
+//     stores run under another's arithmetic (the earlier form of this kernel staged 256 rows with the whole workgroup between two barriers per iteration,
+//     and ran every phase in lockstep: VALU-issue bound at 0.45 of the HBM rate, profiles/r5z_flash_cross_pmc.txt);
 //   * all keys are at hand, so the softmax is exact in one sweep (scores for every key block, the row maximum, exponentials, P V): no online rescaling.
+//     The mask of the keys past the last one and log2 of the count of the zero-padded tail key are ONE add per score of the last key block (a 32-float
+//     table in LDS, built once: 0 / log2 count / -inf) rather than compares and selects on every score;
+//   * the arithmetic, rounding point for rounding point, is flash_fwd_kernel<1, STAGED>'s on one key tile (q' = bf16(rbf(rbf(q rs) gain) scale), scores
+//     accumulated from zero, the tail key's bias added to the finished score, p = 2^(s - max), o = (P V) / l): up to 64 keys the two kernels agree bit for
+//     bit, which is what lets a step with the prompt's key count known on the host (this kernel) and one without (the streaming kernel) be compared with
+//     torch.equal (tests/test_gpu_attn_qk8.py, test_gpu_dit.py).
 // A prompt with more than 128 distinct keys returns at once; the streaming kernel launched beside it (long_keys_only) serves it.
 // =================================================================================================
-#define CR_ROWS 256
-#define CR_LDS (2 * CR_KEYS * 256 + CR_ROWS * 256)
+#define CR_ROWS 256       // rows a workgroup has in work at a time: 8 waves x 32
+#define CR_MASK_OFF (2 * CR_KEYS * 256 + CR_ROWS * 256)
+#define CR_LDS (CR_MASK_OFF + 128)
+__device__ __forceinline__ unsigned cr_pack_bf16(float a, float b) {           // {bf16(a), bf16(b)} in one word, round-to-nearest-even: (bf16)a and (bf16)b
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+typedef __attribute__((ext_vector_type(2))) float cr_f32x2;
 template <bool NORM, int NKB>
 __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16* __restrict__ Q, int ldq, const bf16* __restrict__ K, int ldk,
                                                                       const bf16* __restrict__ VT, int ldvt, bf16* __restrict__ O, int ldo, int Lq, int Lk_full,
@@ -321,7 +338,8 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
     // NKB = 32-key blocks walked, known to the launcher (the host's copy of key_tail[0]); the exact count is read here
     const int Lk = min(key_tail ? min(max(key_tail[0], 1), Lk_full) : Lk_full, 32 * NKB);
     const float tail_bias = (key_tail && key_tail[1] > 1) ? __builtin_amdgcn_logf((float)key_tail[1]) : 0.f;      // (q carries softmax_scale * log2e: scores are exponents)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform, and said so: the unit loop below is scalar control flow)
     const int l31 = lane & 31, hi = lane >> 5;
     const int head = blockIdx.x;
     const int units = (Lq + 31) >> 5;
@@ -330,13 +348,15 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
     if (r_begin >= r_end) return;
     char* Ks = smem;
     char* Vs = smem + CR_KEYS * 256;
-    char* QO = smem + 2 * CR_KEYS * 256;
-    const int sc = tid & 15, sr = tid >> 4;          // staging: this thread's 16-byte chunk and first row (+ 32 per j)
+    char* QO = smem + 2 * CR_KEYS * 256 + wave * (32 * 256);      // this wave's 32 rows
+    const int sc = tid & 15;                           // staging: this thread's 16-byte chunk of a row (K / V^T / q / o alike)
+    const int wr = lane >> 4;                          // q / o staging: row wr + 4 j of the wave's unit
 
-    // the head's K / V^T, once.  Rows / columns past the last key are clamped to it: finite duplicates that the -inf mask removes.  (Requested here, put
-    // into LDS behind the request for the first query rows below: both are in flight together.)
+    // the head's K / V^T, once, by the whole workgroup.  Rows / columns past the last key are clamped to it: finite duplicates that the -inf mask removes.
+    // (Requested here, put into LDS behind the request for the wave's first query rows below: both are in flight together.)
     u32x4 kreg[NKB], vreg[4];
     {
+        const int sr = tid >> 4;
         const int last_key = Lk - 1, last_chunk = (Lk - 1) & ~7;
         const bf16* kb = K + head * DH + sc * 8;
         const bf16* vb = VT + (size_t)(head * DH) * ldvt + min(sc * 8, last_chunk);
@@ -346,40 +366,53 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
         for (int j = 0; j < 4; ++j) vreg[j] = *reinterpret_cast<const u32x4*>(vb + (size_t)(sr + 32 * j) * ldvt);
     }
     const int krow = perm23(l31);
-    bf16x8 wv;
-    if constexpr (NORM) wv = ld_bf16x8(q_gain + head * DH + sc * 8);
-    u32x4 rq[8];
-    float rsv[8];
-    // Uniform base pointers + 32-bit per-lane element offsets (the launcher refuses tensors of 2^31 elements): one address register per access, nothing
-    // to precompute and keep.  Loads never branch: a row past the workgroup's range is clamped to its last row (finite, never stored).
+    cr_f32x2 gw[4];
+    if constexpr (NORM) {
+        const bf16x8 wv = ld_bf16x8(q_gain + head * DH + sc * 8);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gw[p] = cr_f32x2{(float)wv[2 * p], (float)wv[2 * p + 1]};
+    }
+    u32x4 rq[8];                             // the wave's next unit, on its way
+    float rsv = 0.f;                         // (its rows' statistics: lane l holds row l & 31's)
+    // A whole unit is addressed as a uniform pointer per group of four rows (scalar arithmetic) plus ONE per-lane offset that never changes; only the
+    // sequence's last, partial unit clamps its rows (to the last one: finite, never stored).  The launcher refuses tensors of 2^31 elements.
     const bf16* qh = Q + head * DH;
     bf16* oh = O + head * DH;
+    const unsigned q_lane = (unsigned)(wr * ldq + sc * 8), o_lane = (unsigned)(wr * ldo + sc * 8);
     auto issue = [&](int base) {
+        if (base + 32 <= r_end) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = min(base + sr + 32 * j, r_end - 1);
-            rq[j] = *reinterpret_cast<const u32x4*>(qh + (unsigned)(row * ldq + sc * 8));
-            if constexpr (NORM) rsv[j] = q_rs[row];
+            for (int j = 0; j < 8; ++j) rq[j] = *reinterpret_cast<const u32x4*>(qh + (size_t)(base + 4 * j) * ldq + q_lane);
+            if constexpr (NORM) rsv = (q_rs + base)[l31];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rq[j] = *reinterpret_cast<const u32x4*>(qh + (unsigned)(min(base + wr + 4 * j, r_end - 1) * ldq + sc * 8));
+            if constexpr (NORM) rsv = q_rs[min(base + l31, r_end - 1)];
         }
     };
-    // The output tile of iteration i stays in LDS (in the cells of its query tile) and goes to memory at the top of iteration i + 1, BEHIND that
-    // iteration's wait for its query rows and in front of the write of the new tile into the same cells.  (Loads and stores share one counter on this part
-    // and may retire out of order with respect to each other, so the compiler waits for everything outstanding whenever both kinds are: stores issued
-    // right in front of that wait would put their round trip on the critical path of every iteration; issued behind it they have an iteration's time.)
+    // The output rows of a unit stay in LDS (in the cells of its query rows) and go to memory at the top of the wave's next unit, behind that unit's
+    // wait for its query rows and in front of the write of the new rows into the same cells.
     auto flush = [&](int base) {
+        if (base + 32 <= r_end) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = base + sr + 32 * j;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(QO + k_off(sr + 32 * j, sc));
-            if (row < r_end) *reinterpret_cast<u32x4*>(oh + (unsigned)(row * ldo + sc * 8)) = v;
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<u32x4*>(oh + (size_t)(base + 4 * j) * ldo + o_lane) = *reinterpret_cast<const u32x4*>(QO + k_off(wr + 4 * j, sc));
+        } else {                                                         // the sequence's last, partial unit
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = base + wr + 4 * j;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(QO + k_off(wr + 4 * j, sc));
+                if (row < r_end) *reinterpret_cast<u32x4*>(oh + (unsigned)(row * ldo + sc * 8)) = v;
+            }
         }
     };
-    // One 32-row group of this wave against NKB key blocks: scores, exact softmax, P V, the output rows into the query rows' cells (this wave's own 32
-    // rows: nobody else read them).  Register r of s[kb] is key 32 kb + 16 (r >> 3) + 8 hi + (r & 7); lane holds O[row][32 d + 8 rg + 4 hi + e].
+    const bool last_half_live = 32 * (NKB - 1) + 16 < Lk;      // keys 16 .. 31 of the last block: any of them real?  (uniform)
+    // One unit against NKB key blocks: scores, exact softmax, P V, the output rows into the query rows' cells.
+    // Register r of s[kb] is key 32 kb + 16 (r >> 3) + 8 hi + (r & 7); lane holds O[row][32 d + 8 rg + 4 hi + e].
     auto compute = [&]() {
         bf16x8 qf[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(QO + k_off(wave * 32 + l31, 2 * kk + hi));
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(QO + k_off(l31, 2 * kk + hi));
         f32x16 s[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -392,15 +425,11 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
             for (int kk = 0; kk < 8; ++kk) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s[kb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);              // one key block's fragments in flight at a time
         }
-        // (opaque copies: the 16 x 4 select masks below are loop-invariant, and hoisted out of the row loop they cost more registers than the loop has)
-        int lk_here = Lk;
-        float bias_here = tail_bias;
-        asm volatile("" : "+s"(lk_here), "+v"(bias_here));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {                      // the last block holds the counted key and whatever lies past the last key
-            const int key = 32 * (NKB - 1) + 16 * (r >> 3) + 8 * hi + (r & 7);
-            const float biased = s[NKB - 1][r] + (key == lk_here - 1 ? bias_here : 0.f);
-            s[NKB - 1][r] = key >= lk_here ? -INFINITY : biased;
+        for (int g = 0; g < 4; ++g) {                       // the last block: + 0 / + log2(count) on the counted key / + -inf past the last key
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(smem + CR_MASK_OFF + hi * 64 + g * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[NKB - 1][4 * g + e] += m4[e];
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -409,14 +438,25 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));                 // (the other 16 keys of each block live in lane ^ 32)
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
-        bf16x8 pf[NKB][2];
+        unsigned pw[NKB][2][4];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] - mx);
-                ps[r & 3] += p;
-                pf[kb][r >> 3][r & 7] = (bf16)p;
+            for (int sb = 0; sb < 2; ++sb) {
+                if (kb == NKB - 1 && sb == 1 && !last_half_live) {        // every key of this half is masked: p = 0 without asking
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) pw[kb][sb][w] = 0u;
+                    continue;
+                }
+                float p[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = s[kb][8 * sb + e];
+                    p[e] = __builtin_amdgcn_exp2f(x - mx);
+                    ps[e & 3] += p[e];
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) pw[kb][sb][w] = cr_pack_bf16(p[2 * w], p[2 * w + 1]);
             }
         float l_tot = (ps[0] + ps[1]) + (ps[2] + ps[3]);
         l_tot += __shfl_xor(l_tot, 32);
@@ -429,56 +469,79 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
+                if (kb == NKB - 1 && sb == 1 && !last_half_live) continue;
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[kb][sb][0], pw[kb][sb][1], pw[kb][sb][2], pw[kb][sb][3]});
                 bf16x8 vf[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) vf[d] = *reinterpret_cast<const bf16x8*>(Vs + k_off(32 * d + l31, 4 * kb + 2 * sb + hi));
 #pragma unroll
-                for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d], pf[kb][sb], o[d], 0, 0, 0);
+                for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d], pf, o[d], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         const float inv = 1.0f / l_tot;
+        const cr_f32x2 inv2{inv, inv};
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                bf16x4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[d][rg * 4 + e] * inv);
-                *reinterpret_cast<bf16x4*>(QO + k_off(wave * 32 + l31, 4 * d + rg) + 8 * hi) = pk;
+                const cr_f32x2 a = cr_f32x2{o[d][rg * 4], o[d][rg * 4 + 1]} * inv2, b = cr_f32x2{o[d][rg * 4 + 2], o[d][rg * 4 + 3]} * inv2;
+                *reinterpret_cast<u32x2*>(QO + k_off(l31, 4 * d + rg) + 8 * hi) = u32x2{cr_pack_bf16(a[0], a[1]), cr_pack_bf16(b[0], b[1])};
             }
     };
-    issue(r_begin);
+    int base = r_begin + 32 * wave;
+    if (base < r_end) issue(base);
 #pragma unroll
-    for (int j = 0; j < NKB; ++j) *reinterpret_cast<u32x4*>(Ks + k_off(sr + 32 * j, sc)) = kreg[j];
+    for (int j = 0; j < NKB; ++j) *reinterpret_cast<u32x4*>(Ks + k_off((tid >> 4) + 32 * j, sc)) = kreg[j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(Vs + k_off(sr + 32 * j, sc)) = vreg[j];
-    for (int base = r_begin; base < r_end; base += CR_ROWS) {
-        // ---- this iteration's query rows, normalised (the wait for them is here)
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(Vs + k_off((tid >> 4) + 32 * j, sc)) = vreg[j];
+    if (tid < 32) {
+        const int key = 32 * (NKB - 1) + 16 * ((tid & 15) >> 3) + 8 * (tid >> 4) + (tid & 7);
+        *reinterpret_cast<float*>(smem + CR_MASK_OFF + tid * 4) = key >= Lk ? -INFINITY : (key == Lk - 1 ? tail_bias : 0.f);
+    }
+    __syncthreads();
+    int prev = -1;
+    for (; base < r_end; base += CR_ROWS) {
+        // ---- this unit's query rows, normalised (the wait for them is here)
         u32x4 outv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             outv[j] = rq[j];
             if constexpr (NORM) {
-                const bf16x8 t = __builtin_bit_cast(bf16x8, rq[j]);
-                bf16x8 o8;
+                const float rsj = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((wr + 4 * j) << 2, __builtin_bit_cast(int, rsv)));     // row wr + 4 j's, from its lane
+                const cr_f32x2 rs2{rsj, rsj}, sc2{q_out_scale, q_out_scale};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] = (bf16)(rbf(rbf((float)t[e] * rsv[j]) * (float)wv[e]) * q_out_scale);
-                outv[j] = __builtin_bit_cast(u32x4, o8);
+                for (int p = 0; p < 4; ++p) {             // bf16(rbf(rbf(q * rs) * gain) * scale), two elements per packed instruction
+                    const unsigned w0 = rq[j][p];
+                    const cr_f32x2 x = cr_f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)} * rs2;
+                    const unsigned w1 = cr_pack_bf16(x[0], x[1]);
+                    const cr_f32x2 y = cr_f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)} * gw[p];
+                    const unsigned w2 = cr_pack_bf16(y[0], y[1]);
+                    const cr_f32x2 z = cr_f32x2{__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u)} * sc2;
+                    outv[j][p] = cr_pack_bf16(z[0], z[1]);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (base > r_begin) flush(base - CR_ROWS);                    // the previous iteration's output rows leave the cells ...
+        if (prev >= 0) flush(prev);                                   // the wave's previous output rows leave the cells ...
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(QO + k_off(sr + 32 * j, sc)) = outv[j];      // ... that this iteration's query rows take
-        // the next iteration's rows are on their way while this one computes (requested BEHIND the stores: with the requests first the kernel measured
-        // 8 us slower per launch, profiles/r5g_kernel_stats.md vs r5h)
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(QO + k_off(wr + 4 * j, sc)) = outv[j];      // ... that this unit's query rows take
+        // the next unit's rows are on their way while this one computes (requested BEHIND the stores: with the requests first the kernel measured
+        // 8 us slower per launch, profiles/r5g_kernel_stats.md vs r5h; a second unit in flight — hand-issued requests, hand-counted waits — measured no
+        // faster: profiles/r5y_cross_ab.txt)
         if (base + CR_ROWS < r_end) issue(base + CR_ROWS);
-        __syncthreads();
+        // (the cells were written in the load layout and are read in the operand layout, by other lanes of this same wave: LDS serves a wave's
+        // accesses in order, the compiler is told not to reorder them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         compute();
-        __syncthreads();
-        if (base + CR_ROWS >= r_end) flush(base);                     // the last iteration's rows leave at once
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        prev = base;
     }
+    if (prev >= 0) flush(prev);
 }
 
 // =================================================================================================

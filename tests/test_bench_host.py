@@ -109,10 +109,10 @@ def test_committed_default_line_counts_stacked_launches_in_row_equivalents():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = os.path.join(root, "profiles", "r5z_bench_default.json")
+    p = os.path.join(root, "profiles", "r5zz_bench_default.json")
     if not os.path.exists(p):
         import pytest
-        pytest.skip("no committed r5z line")
+        pytest.skip("no committed r5zz line")
     j = json.load(open(p))
     c = j["config"]
     assert c["cfg_pair_stacked"] is True and c["hip_graph"] is True

@@ -271,6 +271,15 @@ def test_cross_attention_normalises_q_as_it_reads_it(hip, Lq, Lk, heads, tail):
            rel_l2_two_kernel_vs_fp64=r_c, rel_l2_fused_vs_fp64=r_cf)
     assert frac < 2e-3 and r_b < 1e-3, (frac, r_b)
     assert r_c < 6e-3 and r_cf < 6e-3, (r_c, r_cf)
+    # (d) the DiT's call: q_out_scale = softmax_scale * log2(e), folded into q' before its last rounding: softmax2(SC q'.k^T) v against fp64 on the normalised q.
+    fused_sc = hip.ops.cross_attention(qraw, k, vt, heads, s_kv=Lk, q_rs=rs, q_gain=gain, q_out_scale=SC, key_tail=kt)
+    sc2 = sc * SC
+    p2 = torch.exp2(sc2 - sc2.max(-1, keepdim=True).values)
+    want2 = ((p2 / p2.sum(-1, keepdim=True)) @ vh).transpose(0, 1).reshape(Lq, D).float()
+    r_d = errs(fused_sc, want2)[0]
+    r_d2 = errs(fused_sc, plain)[0]          # ... and against the two-kernel path fed q' * SC rounded once more
+    report("cross_attention_fused_scaled", Lq=Lq, Lk=Lk, heads=heads, tail=list(tail) if tail else None, rel_l2_vs_fp64=r_d, rel_l2_vs_two_kernel=r_d2)
+    assert r_d < 6e-3 and r_d2 < 6e-3, (r_d, r_d2)
 
 
 def test_rmsnorm_strided_view(hip):
