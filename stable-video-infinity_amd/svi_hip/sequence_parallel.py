@@ -72,6 +72,35 @@ def unpack_out(recv: torch.Tensor, Ls: int) -> torch.Tensor:
     return recv.reshape(G, P, Ls, Dg).permute(2, 1, 0, 3).reshape(Ls, P * G * Dg).contiguous()
 
 
+# The stacked CFG pair (svi_dit_sp_begin_pair): a rank's rows are [branch][Ls]; on the wire the two branches sit side by side per token, so that after the
+# first exchange a head group's operand is token-major [L, 2 Dg] — the unconditional branch's heads are simply MORE HEADS of the same attention launch.
+def send_layout_qk_pair(x2: torch.Tensor, P: int, G: int = 1) -> torch.Tensor:
+    """x2 [2 Ls, D] (q or k rows of this rank, conditional branch on top) -> [G, P, Ls*2*Dg] = [group][destination][row][branch][Dg]:
+    what svi_dit_sp_block_qkv_part stores for the pair."""
+    Ls, D = x2.shape[0] // 2, x2.shape[1]
+    Dg = D // P // G
+    return x2.reshape(2, Ls, P, G, Dg).permute(3, 2, 1, 0, 4).reshape(G, P, Ls * 2 * Dg).contiguous()
+
+
+def unpack_vt_pair(recv: torch.Tensor, Ls: int, G: int = 1) -> torch.Tensor:
+    """recv [P(src), Dp, lds2] (a source's V^T piece: branch b's tokens at columns [b Ls, (b + 1) Ls)) -> V^T [G, 2, Dg, L8] (zero beyond L),
+    rows ordered [group][branch][Dg] like the q | k columns: what svi_sp_unpack_vt writes with nb = 2."""
+    P, Dp, _ = recv.shape
+    Dg, Lfull = Dp // G, P * Ls
+    vt = torch.zeros((G, 2, Dg, (Lfull + 7) // 8 * 8), dtype=recv.dtype, device=recv.device)
+    for b in range(2):
+        vt[:, b, :, :Lfull] = recv[:, :, b * Ls:(b + 1) * Ls].reshape(P, G, Dg, Ls).permute(1, 2, 0, 3).reshape(G, Dg, Lfull)
+    return vt
+
+
+def unpack_out_pair(recv: torch.Tensor, Ls: int) -> torch.Tensor:
+    """recv [G, P(src), Ls*2*Dg] = [group][source][row][branch][Dg] -> attn [2 Ls, D] (unconditional rows below the conditional ones), source j's head
+    block at columns [j*Dp, (j+1)*Dp): what svi_sp_unpack_out writes with nb = 2."""
+    G, P, n = recv.shape
+    Dg = n // (2 * Ls)
+    return recv.reshape(G, P, Ls, 2, Dg).permute(3, 2, 1, 0, 4).reshape(2 * Ls, P * G * Dg).contiguous()
+
+
 def head_groups(heads_local: int, tokens: int, nb: int = 1) -> int:
     """Number of head groups the exchange is pipelined in: as many as possible while one group's attention still fills the chip
     (256 CUs x one 256-row query block each) and divides the rank's heads.  nb = 2 (stacked CFG pair): a group's launch carries both branches' heads."""

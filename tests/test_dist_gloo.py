@@ -157,6 +157,51 @@ def test_sequence_parallel_exchange_layout(world):
     assert all(a and b for _, a, b in res), res
 
 
+def _sp_pair_worker(rank, world, port, queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from svi_hip import sequence_parallel as sp
+        Lfull, D, G = 12 * world, 256 * world, 2
+        Ls, Dp = Lfull // world, D // world
+        Dg = Dp // G
+        g = torch.Generator("cpu").manual_seed(6)
+        Q, K, V = [[torch.randn((Lfull, D), generator=g).to(torch.bfloat16) for _ in range(2)] for _ in range(3)]     # [branch] global tensors, known to all
+        rows = slice(rank * Ls, (rank + 1) * Ls)
+        stack = lambda t: torch.cat([t[0][rows], t[1][rows]])                # noqa: E731  the rank's rows of the pair: conditional branch on top
+        lds2 = (2 * Ls + 7) // 8 * 8
+        vt = torch.zeros((D, lds2), dtype=torch.bfloat16)                     # what the rank's V projection leaves: V^T of its 2 Ls rows
+        vt[:, :2 * Ls] = stack(V).t()
+        qs, ks = sp.send_layout_qk_pair(stack(Q), world, G), sp.send_layout_qk_pair(stack(K), world, G)
+        a2a = lambda t: sp.all_to_all(t.contiguous())                        # noqa: E731
+        vt_full = sp.unpack_vt_pair(a2a(vt.reshape(world, Dp * lds2)).reshape(world, Dp, lds2), Ls, G)      # [G, 2, Dg, L8]
+        ok = bool((vt_full[..., Lfull:] == 0).all())
+        O = [(Q[b].float() * 0.5 + K[b].float()).to(torch.bfloat16) for b in range(2)]      # any [L, D] "attention" result per branch
+        o_send = []
+        for gi in range(G):
+            gc = slice(rank * Dp + gi * Dg, rank * Dp + (gi + 1) * Dg)
+            q, k = a2a(qs[gi]).reshape(Lfull, 2, Dg), a2a(ks[gi]).reshape(Lfull, 2, Dg)   # token-major [L, 2 Dg]: the branches are twice as many heads
+            for b in range(2):
+                ok = ok and torch.equal(q[:, b], Q[b][:, gc]) and torch.equal(k[:, b], K[b][:, gc]) and torch.equal(vt_full[gi, b, :, :Lfull], V[b][:, gc].t())
+            o_send.append(torch.stack([O[0][:, gc], O[1][:, gc]], dim=1).reshape(world, Ls * 2 * Dg))      # the launch's output [L, 2, Dg]: contiguous per destination
+        attn = sp.unpack_out_pair(torch.stack([a2a(o) for o in o_send]), Ls)
+        queue.put((rank, ok, torch.equal(attn, stack(O))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_stacked_cfg_pair_exchange_layout(world):
+    """The stacked CFG pair on sequence shards (forward_distributed_pair) over a real all-to-all (gloo): a rank sends its 2 Ls rows with the two branches side
+    by side per token, so after the first exchange it holds, per head group, ALL tokens as a token-major [L, 2 Dg] operand (the unconditional branch = more
+    heads of the same attention launch) and V^T as [group][branch][Dg] rows; after the second exchange its own rows of both branches, conditional on top.
+    No exchange BETWEEN the branches anywhere: the CFG combination needs none."""
+    res = _run_ranks(_sp_pair_worker, world)
+    assert sorted(r for r, _, _ in res) == list(range(world))
+    assert all(a and b for _, a, b in res), res
+
+
 def _groups_worker(rank, world, port, queue):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

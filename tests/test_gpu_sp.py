@@ -121,15 +121,11 @@ def test_unpack_kernels_follow_the_layout_algebra(P, Dp, Ls):
         rv = dev(synth.randn(9, P, Dp, lds2))
         ov = torch.zeros((G * 2 * Dg, L8), dtype=torch.bfloat16, device="cuda")
         L.check(L.lib().svi_sp_unpack_vt(rv.data_ptr(), ov.data_ptr(), P, Dp, Ls, lds2, L8, 2, Dg, L.current_stream()))
-        want = torch.zeros_like(ov).view(G, 2, Dg, L8)
-        for b in range(2):
-            want[:, b, :, :P * Ls] = rv[:, :, b * Ls:(b + 1) * Ls].reshape(P, G, Dg, Ls).permute(1, 2, 0, 3).reshape(G, Dg, P * Ls)
-        assert torch.equal(ov.view(G, 2, Dg, L8), want)
+        assert torch.equal(ov.view(G, 2, Dg, L8), sp.unpack_vt_pair(rv, Ls, G))
         r3 = dev(synth.randn(10, G, P, Ls * 2 * Dg))
         o3 = torch.empty((2 * Ls, P * Dp), dtype=torch.bfloat16, device="cuda")
         L.check(L.lib().svi_sp_unpack_out(r3.data_ptr(), o3.data_ptr(), P, G, Ls, Dg, 2, L.current_stream()))
-        w3 = r3.view(G, P, Ls, 2, Dg).permute(3, 2, 1, 0, 4).reshape(2 * Ls, P * Dp)          # [b][row][src][g][c]
-        assert torch.equal(o3, w3)
+        assert torch.equal(o3, sp.unpack_out_pair(r3, Ls))                                      # [b][row][src][g][c]
 
 
 def test_sequence_parallel_i2v_and_add_condition():
