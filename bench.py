@@ -50,6 +50,7 @@ for p in (ROOT, os.path.join(ROOT, "stable-video-infinity_amd"), os.path.join(RO
     if p not in sys.path:
         sys.path.insert(0, p)
 
+T_PROCESS_START = time.perf_counter()      # --budget-s and config.wall_s count from here (the interpreter's own start-up is ahead of it)
 import torch  # noqa: E402
 
 WORKLOADS = {
@@ -66,6 +67,30 @@ WORKLOADS = {
                     "FP8 weight storage (exact cast at bind, bf16 arithmetic), 81f@832x480 50-step CFG5; no Wan2.2-5B / fp8-MFMA exists in the reference"),
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def L_TOKENS(T: int, H: int, W: int) -> int:
+    return T * (H // 2) * (W // 2)
+
+
+def vendor_yardstick(timeout_s: int = 240):
+    """tools/yardstick.py in a child process on this box, this job: torch.matmul (hipBLASLt) and F.scaled_dot_product_attention on the step's six hot
+    shapes beside this repo's launches of the same shapes.  Measurement only — the product neither links nor calls a vendor kernel."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"svi_yardstick_{os.getpid()}.json")
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "yardstick.py"), "3", "--json", out], capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        return json.load(open(out))
+    except Exception as ex:  # noqa: BLE001
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    finally:
+        try:
+            os.remove(out)
+        except OSError:
+            pass
 
 
 def device_weights(cfg: dict, seed: int, device) -> dict:
@@ -338,6 +363,20 @@ def main() -> None:
                     "`value` is then the WINDOW's latent frames / s (wall clock over everything) and config.window holds the per-clip fixed cost")
     ap.add_argument("--window-ab", action="store_true", help="with --window: run the window a second time on a loop that re-captures its step graph for every clip "
                     "(the round 1-4 behaviour) and report the difference")
+    ap.add_argument("--attn-gain", type=float, default=1.0, metavar="G", help="multiply every block's self_attn.norm_q / norm_k weight by G: the logits of the self-attention scale "
+                    "with G^2 (random-init weights give diffuse attention, G = 1; a trained checkpoint's learned gains make it peaky).  The line reports the workgroups the "
+                    "optimistic attention pass flagged for its second pass (config.attention_second_pass); tools/attn_stats.py sweeps the kernel alone")
+    ap.add_argument("--prompt-tokens", type=int, default=64, metavar="N", help="valid (non-padded) tokens of the positive prompt (the negative prompt gets N // 2): the context's "
+                    "remaining rows are the prompter's zero padding = one more distinct key.  Default 64 / 32; beyond 127 valid tokens the cross-attention leaves "
+                    "flash_cross_resident_kernel (keys resident in LDS) for the streaming kernel")
+    ap.add_argument("--budget-s", type=float, default=600.0, metavar="S", help="wall-clock budget of this invocation, counted from process start.  The K timed steps are never "
+                    "trimmed; what is optional around them is: the two timed complete clips go when they would not fit, then the vendor yardstick.  The expected total is "
+                    "printed on stderr after the warm-up and reported as config.wall_s_expected beside config.wall_s")
+    ap.add_argument("--no-vendor", action="store_true", help="skip the vendor yardstick child (tools/yardstick.py: hipBLASLt / SDPA on the step's six hot shapes, same box, same "
+                    "job; N = 1, c2 only) whose figures stand beside every family of roofline_all as `vendor`")
+    ap.add_argument("--rccl-probe", action="store_true", help="N = 1 only: create the RCCL process group anyway (a one-rank communicator) so that the barrier, the tail all-gather and "
+                    "the MAX-reduce of the timed region go through RCCL and the step's hipGraph is captured beside a live communicator — the part of the multi-GPU path a "
+                    "one-GPU box can run on hardware")
     ap.add_argument("--rank-timeout", type=float, default=900.0, help="multi-rank runs: a rank that reaches no new stage (process group, join, warm-up, timed region, "
                     "clips) for this many seconds exits non-zero and names the rank(s) furthest behind; 0 = off")
     ap.add_argument("--selftest-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)      # --launcher-selftest: this rank never joins (tests the watchdog)
@@ -384,7 +423,11 @@ def main() -> None:
     dist, who = None, [{"rank": 0, "device": str(dev), "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
                         "name": torch.cuda.get_device_properties(dev).name}]
     rccl = None
-    if world > 1:
+    if args.rccl_probe and world == 1:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.rccl_probe:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         hb.mark("start", f"device cuda:{local}, initialising {args.transport}")
@@ -415,6 +458,10 @@ def main() -> None:
     if args.fp8_storage or wl.get("fp8_storage") or args.fp8_mfma:
         args.fp8_storage = True
         weights = {k: v.to(torch.float8_e4m3fn) for k, v in weights.items()}
+    if args.attn_gain != 1.0:
+        for name in weights:
+            if name.endswith("self_attn.norm_q.weight") or name.endswith("self_attn.norm_k.weight"):
+                weights[name] = (weights[name].float() * args.attn_gain).to(weights[name].dtype)
     dit.bind(weights)
     hb.mark("model-bound")
     if args.fp8_mfma:
@@ -433,11 +480,14 @@ def main() -> None:
         assert dist is not None and world % 2 == 0, "--cfg-pair needs an even number of ranks"
         from svi_hip.parallel import CfgPair
         pair, pair_idx, units = CfgPair.split_world()
+    graph_note = None
+    graph_try = False
     if args.graph is None:
-        # the single-rank step replays a hipGraph by default (DenoiseLoop's own default).  With an RCCL communicator in the process (--gpus N > 1) the
-        # default is eager launches: capture beside a live communicator has never run on hardware here (no multi-GPU node was available to any round),
-        # and a scaling run must not hinge on it; --graph turns it on (the gloo probe does: tests/test_gpu_bench_ranks.py)
-        args.graph = pair is None and not sp and (dist is None or args.transport == "gloo")
+        # the single-rank step replays a hipGraph by default (DenoiseLoop's own default).  Beside an RCCL communicator (--gpus N > 1) the graph is TRIED: one
+        # untimed probe step is captured and replayed inside a guard; the ranks then vote (MIN all-reduce) and either all keep the graph or all fall back to
+        # eager launches, and the line says which ran and why (config.hip_graph, config.hip_graph_note).  A scaling run does not hinge on the capture.
+        args.graph = pair is None and not sp
+        graph_try = bool(args.graph) and dist is not None and args.transport == "nccl"
     loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp, graph=args.graph)
     eager_loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp, graph=False) if args.graph else loop
     eager_loop.scheduler = loop.scheduler
@@ -449,8 +499,10 @@ def main() -> None:
     gen = torch.Generator(device=dev).manual_seed(1234)
     ctx_pos = torch.randn((1, wl["lc"], 4096), generator=gen, device=dev).to(torch.bfloat16)
     ctx_neg = torch.randn((1, wl["lc"], 4096), generator=gen, device=dev).to(torch.bfloat16)
-    ctx_pos[:, 64:] = 0
-    ctx_neg[:, 32:] = 0
+    if not 1 <= args.prompt_tokens <= wl["lc"]:
+        ap.error(f"--prompt-tokens must be within 1..{wl['lc']}")
+    ctx_pos[:, args.prompt_tokens:] = 0
+    ctx_neg[:, max(1, args.prompt_tokens // 2):] = 0
     ts_dev = loop.scheduler.timesteps.to(dev, torch.float32)
     cond = {}
     if cfg["has_image_input"]:      # I2V: y = mask(4) | VAE latent(16) as encode_images_adaptive builds it, CLIP tokens of the first frame
@@ -486,10 +538,69 @@ def main() -> None:
     # as DenoiseLoop.sample() does for a clip: the prompt embeddings are loop constants, their projection and the per-block
     # cross-attention K / V^T are computed in the first forward that sees them (inside the warm-up here, inside step 0 of a clip)
     dit.context_cache(True)
+    if graph_try:
+        ok, why = 1.0, ""
+        try:
+            one_step(0)                    # eager on the capture stream + capture
+            one_step(1)                    # a replay
+            torch.cuda.synchronize()
+        except Exception as ex:  # noqa: BLE001 — whatever the capture raised beside the communicator: say it, launch eagerly
+            ok, why = 0.0, f"{type(ex).__name__}: {str(ex).splitlines()[0][:160]}"
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+        vote = torch.tensor([ok], device=dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if vote.item() < 1.0:
+            graph_note = "hipGraph capture beside the RCCL communicator failed on " + ("this rank: " + why if not ok else "another rank") + " — every rank launches eagerly"
+            print(f"bench.py[rank {rank}]: {graph_note}", file=sys.stderr, flush=True)
+            args.graph = False
+            loop = eager_loop = svi_hip.DenoiseLoop(dit, cfg_pair=pair, sp_group=sp_group, sequence_parallel=sp, graph=False)
+            loop.scheduler.set_timesteps(spc, shift=5.0)
+        else:
+            graph_note = "captured and replayed beside the live RCCL communicator (probe step before the warm-up; all ranks agreed)"
     for i in range(args.warmup):
         one_step(i)
     sync()
     hb.mark("warmup-done", f"hip_graph={bool(args.graph)}")
+    # ---- wall-clock plan (--budget-s): what is still ahead, priced with a step time taken now --------------------------------------------------------
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_probe = time.perf_counter()
+    one_step(args.warmup)
+    torch.cuda.synchronize()
+    step_est = time.perf_counter() - t_probe
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    want_vendor = rank == 0 and world == 1 and not args.no_vendor and args.workload == "c2" and not args.seq_parallel
+    plan = {"timed_steps": args.steps * step_est, "eager_profile_steps": 8 * step_est * 1.05, "vae": 0.0 if args.no_vae else 6.0,
+            "full_clips": 2.0 * (spc * step_est + 1.5) + 3.0 if (args.full_clip and not args.no_vae and not wl.get("pose")) else 0.0,
+            "window": (args.window * (2 if args.window_ab else 1) / max(world, 1)) * (spc * step_est + 1.5) if args.window > 0 else 0.0,
+            "cpu_baseline": 110.0 if want_cpu else 0.0, "vendor_yardstick": 45.0 if want_vendor else 0.0}
+    used = time.perf_counter() - T_PROCESS_START
+    trimmed = []
+    if args.budget_s > 0:
+        def over():
+            return used + sum(plan.values()) > args.budget_s
+        if over() and plan["full_clips"]:
+            plan["full_clips"] = 0.0
+            args.full_clip = False
+            trimmed.append("full clips")
+        if over() and plan["vendor_yardstick"]:
+            plan["vendor_yardstick"] = 0.0
+            want_vendor = False
+            trimmed.append("vendor yardstick")
+    if dist is not None:            # every rank drops the same parts (the full clips hold collectives): the slowest rank's plan decides
+        tv = torch.tensor([0.0 if args.full_clip else 1.0], device=dev)
+        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        if tv.item() > 0 and args.full_clip:
+            args.full_clip = False
+            plan["full_clips"] = 0.0
+            trimmed.append("full clips (another rank's plan)")
+    wall_expected = used + sum(plan.values())
+    print(f"bench.py[rank {rank}/{world}]: {used:.0f} s used, step ~{step_est * 1e3:.0f} ms, expected total ~{wall_expected:.0f} s of --budget-s {args.budget_s:.0f}"
+          + (f" (trimmed: {', '.join(trimmed)})" if trimmed else ""), file=sys.stderr, flush=True)
     # Over the timed region only the dominant kernel is bracketed by HIP events (`roofline`): every event record is a packet between two
     # kernels of the stream it measures, and the ~1440 records of a fully instrumented C2 step cost that step about 1 % (profiles/r3m_prof_events_ab.txt).
     # The breakdown over all kernel families (`roofline_all`, `kernel_ms_per_step`) comes from `prof_steps` fully instrumented steps run
@@ -540,6 +651,16 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     finite = bool(torch.isfinite(lat.float()).all().item())
+    # the last self-attention launch of the eager steps above: how many of its workgroups the optimistic pass handed to the second pass (0 on every
+    # random-init forward measured so far; --attn-gain makes the logits peaky)
+    second_pass = None
+    if L_TOKENS(T, H, W) >= 2048 and not sp:
+        import ctypes as _C
+        fa, fb = _C.c_int32(), _C.c_int32()
+        if _lib.lib().svi_attention_last_flagged(_lib.current_stream(), _C.byref(fa), _C.byref(fb)) == 0 and fb.value > 0:
+            second_pass = {"flagged_workgroups": fa.value, "workgroups": fb.value, "fraction": round(fa.value / fb.value, 5), "attn_gain": args.attn_gain,
+                           "what": "last self-attention launch of the instrumented eager steps: workgroups (256 query rows of one head) whose row sums left the range the "
+                                   "first key tile's reference maximum covers and were recomputed by the complete kernel"}
 
     # VAE decode of the finished clip (fp32, as pipelines/svi_video.py:385-389), timed once on the same stream; for the I2V
     # model also the per-clip conditioning encode y = mask | VAE.encode([motion frame | zeros]) (svi_video.py:291-350)
@@ -848,7 +969,8 @@ def main() -> None:
                    "dit_tflops": round(flops_step / (dist.get_world_size(sp_group) if sp else 1) / (ms_per_step * 1e-3) / 1e12, 1),
                    "flop_per_step_executed": flops_step, "flop_per_forward_reference": flops_forward,
                    "ranks": who, "rccl": rccl,
-                   "transport": None if world == 1 else ("nccl (RCCL), one GPU per rank" if args.transport == "nccl" else
+                   "transport": ("nccl (RCCL), ONE rank (--rccl-probe): a live communicator beside the step graph; barrier, tail all-gather and MAX-reduce go through it, "
+                                 "degenerate — a code-path probe, not a scaling figure") if (world == 1 and args.rccl_probe) else None if world == 1 else ("nccl (RCCL), one GPU per rank" if args.transport == "nccl" else
                                                          f"gloo through the host, {len({w.get('pci_bus_id') for w in who})} distinct device(s) under {world} ranks: a probe of "
                                                          "the multi-rank code path, NOT a scaling measurement"),
                    "hip_graph": bool(args.graph),
@@ -865,9 +987,41 @@ def main() -> None:
                              f"{prof_steps} fully instrumented eager steps behind the timed region" + (" (which replays one hipGraph per step)" if args.graph else
                              " (inside it only the dominant kernel is bracketed by events; `roofline` is from those)")),
     }
+    line["config"].update({"attention_second_pass": second_pass, "prompt_tokens": [args.prompt_tokens, max(1, args.prompt_tokens // 2)],
+                           "hip_graph_note": graph_note, "rccl_probe": bool(args.rccl_probe) or None,
+                           "budget_s": args.budget_s, "budget_trimmed": trimmed or None, "wall_s_expected": round(wall_expected, 1)})
+    if rank == 0 and want_vendor:
+        # the vendor libraries on the same shapes, same box, same job (after every timed part of this process; the child has the GPU to itself)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        y = vendor_yardstick()
+        line["vendor_yardstick"] = y
+        by = {r["shape"]: r for r in y.get("rows", [])} if isinstance(y, dict) else {}
+
+        def vend(fam_name, shapes, eq_per_step, note):
+            f = roof_all.get(fam_name)
+            if not f or not all(sh in by for sh in shapes):
+                return
+            key = "vendor_bare_ms" if "vendor_bare_ms" in by[shapes[0]] else next((k for k in ("vendor_sdpa_flash_ms", "vendor_sdpa_efficient_ms", "vendor_sdpa_default_ms") if k in by[shapes[0]]), None)
+            if key is None:
+                return
+            v_ms = sum(by[sh][key] for sh in shapes)
+            o_ms = sum(by[sh]["ours_ms"] for sh in shapes)
+            f["vendor"] = {"ms_per_step": round(v_ms * eq_per_step, 3), "isolated_ms_per_L_row_launch": round(v_ms, 4), "ours_isolated_ms_per_L_row_launch": round(o_ms, 4),
+                           "ours_over_vendor_time": round(o_ms / v_ms, 3), "what": note}
+        bare = "torch.matmul = hipBLASLt, NOTHING fused (no bias, activation, gate or residual: ours does all of them in the same launch)"
+        vend("gemm_qkv", ["qk", "v"], S_eq, bare + "; q|k [L,1536]x[3072,1536]^T + v [L,1536]x[1536,1536]^T per self-attention third")
+        vend("gemm_attn_out", ["attn_out"], S_eq, bare)
+        vend("gemm_cross", ["v"], 2 * R_eq, bare + "; the 1536^2 projection, twice per block and branch (cross-attention q and o)")
+        vend("gemm_ffn1", ["ffn1"], R_eq, bare)
+        vend("gemm_ffn2", ["ffn2"], R_eq, bare)
+        vend("flash_self", ["self_attention"], S_eq, "F.scaled_dot_product_attention [1, 12, L, 128] bf16 (PyTorch-ROCm's flash backend); ours through the public seam "
+             "(v transposed by a launch of its own and the softmax scale applied inside the kernel: the DiT's instance needs neither)")
+    line["config"]["wall_s"] = round(time.perf_counter() - T_PROCESS_START, 1)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            line["config"]["wall_s"] = round(time.perf_counter() - T_PROCESS_START, 1)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -56,6 +56,7 @@ static SviSwitches parse_switches() {
     s.rms_rows = env_int("SVI_RMS_ROWS", 0, 1);
     s.flash_split = env_int("SVI_FLASH_SPLIT", 0, 0);
     if (s.flash_split > 4) s.flash_split = 4;
+    s.ws_limit_mb = env_int("SVI_WS_LIMIT_MB", 1, 0);
     { const char* v = getenv("SVI_T5_BUCKETS"); s.t5_host_buckets = v && strcmp(v, "host") == 0; }
 #ifdef SVI_ABLATIONS
     s.flash_abl = env_int("SVI_FLASH_ABL", 0, 0);

@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const bf16* __restric
 //     accumulated from zero, the tail key's bias added to the finished score, p = 2^(s - max), o = (P V) / l): up to 64 keys the two kernels agree bit for
 //     bit, which is what lets a step with the prompt's key count known on the host (this kernel) and one without (the streaming kernel) be compared with
 //     torch.equal (tests/test_gpu_attn_qk8.py, test_gpu_dit.py).
-// A prompt with more than 128 distinct keys returns at once; the streaming kernel launched beside it (long_keys_only) serves it.
+// NKB is chosen on the HOST from its copy of the prompt's key count (read_key_blocks); a prompt with more than 128 distinct keys, or an unknown count, takes
+// the streaming kernel instead (svi_launch_cross).  The device copy is checked against NKB here: a launch made for another key count (a stale host copy
+// behind a replayed graph, a future writer of the tail that forgets the generation) TRAPS instead of silently dropping keys.
 // =================================================================================================
 #define CR_ROWS 256       // rows a workgroup has in work at a time: 8 waves x 32
 #define CR_MASK_OFF (2 * CR_KEYS * 256 + CR_ROWS * 256)
@@ -336,7 +338,9 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
                                                                       const bf16* __restrict__ q_gain, float q_out_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // NKB = 32-key blocks walked, known to the launcher (the host's copy of key_tail[0]); the exact count is read here
-    const int Lk = min(key_tail ? min(max(key_tail[0], 1), Lk_full) : Lk_full, 32 * NKB);
+    const int Lk_dev = key_tail ? min(max(key_tail[0], 1), Lk_full) : Lk_full;
+    if (Lk_dev > 32 * NKB || Lk_dev <= 32 * (NKB - 1)) __builtin_trap();          // uniform: this launch was made for another number of key blocks
+    const int Lk = Lk_dev;
     const float tail_bias = (key_tail && key_tail[1] > 1) ? __builtin_amdgcn_logf((float)key_tail[1]) : 0.f;      // (q carries softmax_scale * log2e: scores are exponents)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform, and said so: the unit loop below is scalar control flow)

@@ -91,6 +91,8 @@ struct SviSwitches {
                                  // identical (the prompter's zero padding); default: m identical keys = one key counted m times (same softmax)
     int t5_host_buckets = 0;     // SVI_T5_BUCKETS = host : the text encoder's relative-position bucket table in the HOST's fp32 arithmetic (what the
                                  // reference module computes on a CPU — the arithmetic the committed fixtures were made with) instead of the device's
+    int ws_limit_mb = 0;         // SVI_WS_LIMIT_MB = n : a DiT workspace beyond n MiB is refused as if the allocation had failed (SVI_ERR_OOM): a budget for callers who
+                                 // share the device, and the way tests reach the stacked CFG pair's out-of-memory fall-back without exhausting a 288 GB part
 #ifdef SVI_ABLATIONS
     int flash_abl = 0, gemm_epi_abl = 0, vae_abl = 0, flash_assume_prescaled = 0;
 #endif

@@ -101,6 +101,10 @@ struct svi_dit {
     // bumped whenever a device pointer a captured hipGraph may have baked in stops being valid (workspace / context-entry
     // (re)allocation, context-cache reset, re-bind): svi_dit_generation
     unsigned long long generation = 0;
+    // forward_pair: the smallest stacked row count (2 L) whose doubled workspace did not fit.  Sticky for the handle's life (the workspace only grows, and
+    // the memory that was missing belongs to the caller's weights): later steps of that size go straight to the unstacked form instead of freeing and
+    // re-allocating per step — and a capture pass behind the eager step no longer meets "the workspace must grow while captured" (ADVICE r5).
+    int pair_stack_oom_rows = 0;
     bool ffn_mx8 = false;             // opt-in: the MLP GEMMs on the block-scaled fp8 matrix path (svi_dit_ffn_mx8)
     // context cache
     bool ctx_cache_on = false;
@@ -375,6 +379,10 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
         const int gl = L > w.capL ? L : w.capL, glc = Lc > w.capLc ? Lc : w.capLc;
         size_t bytes = layout(gl, glc);
         if (bytes < need) bytes = need;
+        if (svi_switches().ws_limit_mb && bytes > (size_t)svi_switches().ws_limit_mb << 20) {          // the caller's budget: refused BEFORE the workspace that is there is given up
+            svi_set_error("DiT workspace of %zu B is beyond SVI_WS_LIMIT_MB=%d", bytes, svi_switches().ws_limit_mb);
+            return SVI_ERR_OOM;
+        }
         if (w.base) { SVI_CHECK_HIP(hipFree(w.base)); w.base = nullptr; w.bytes = 0; }
         hipError_t e = hipMalloc((void**)&w.base, bytes);
         if (e != hipSuccess) { svi_set_error("hipMalloc(%zu B workspace) failed: %s", bytes, hipGetErrorString(e)); return SVI_ERR_OOM; }
@@ -980,11 +988,13 @@ static svi_status forward_pair(svi_dit* h, const bf16* x, const float* timestep,
     // The 2 GiB bound covers every buffer the stacked form addresses with 32-bit byte offsets: the widest activation [2 L, max(ffn_dim, 2 dim)] (the GEMMs'
     // buffer descriptors; the q | k buffer is [2 L, 2 dim]) and V^T [dim, ldvt >= 2 L] (the attention kernel's int row offsets: dim * 2 L * 2 bytes, never
     // more than the q | k buffer's).  The MX-fp8 scale tables are smaller than either.
-    bool stacked = h->ctx_cache_on && L <= SVI_PAIR_STACK_MAX && L % 8 == 0 && ctx_a != ctx_b && (size_t)2 * L * widest * 2 < ((size_t)1 << 31);
+    bool stacked = h->ctx_cache_on && L <= SVI_PAIR_STACK_MAX && L % 8 == 0 && ctx_a != ctx_b && (size_t)2 * L * widest * 2 < ((size_t)1 << 31) &&
+                   !(h->pair_stack_oom_rows && 2 * L >= h->pair_stack_oom_rows);
     svi_status ws = ensure_workspace(h, stacked ? 2 * L : L, Lc, st);
     if (ws == SVI_ERR_OOM && stacked) {          // the doubled workspace does not fit (about 5 GB more at the 14B widths): the unstacked form gives the same bits
         (void)hipGetLastError();
         stacked = false;
+        if (!h->pair_stack_oom_rows || 2 * L < h->pair_stack_oom_rows) h->pair_stack_oom_rows = 2 * L;      // remembered: see the member's comment
         ws = ensure_workspace(h, L, Lc, st);
     }
     SVI_TRY(ws);

@@ -240,8 +240,14 @@ class DenoiseLoop:
         if self.sequence_parallel:
             import torch.distributed as dist
             from .sequence_parallel import forward_distributed_pair
+            world = dist.get_world_size(self.sp_group)
+            pt, ph, pw = self.dit.patch_size
+            tokens = (latents.shape[2] // pt) * (latents.shape[3] // ph) * (latents.shape[4] // pw)
+            # svi_dit_sp_begin_pair's hard bound, decided here from shapes alone (the same answer on every rank, before any collective): 2 x the shard's
+            # rows of the widest activation must stay under 2 GiB (32-bit buffer offsets); beyond it the two-forwards form runs, as before the stacking
+            fits = 2 * -(-tokens // world) * max(self.dit.ffn_dim, 2 * self.dit.dim) * 2 < (1 << 31)
             stackable = (cfg_scale != 1.0 and not split and self.dit._ctx_cache_on and ctx_neg is not None and ctx_neg.shape == ctx_pos.shape
-                         and ctx_neg is not ctx_pos and self.dit.num_heads % dist.get_world_size(self.sp_group) == 0)
+                         and ctx_neg is not ctx_pos and self.dit.num_heads % world == 0 and fits)
             if stackable:
                 # both branches stacked on this rank's rows: half the launches of two shard forwards, each twice as long; no CFG exchange
                 cpred, upred = forward_distributed_pair(self.dit, latents, timestep, ctx_pos, ctx_neg, group=self.sp_group, **cond)

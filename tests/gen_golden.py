@@ -308,6 +308,47 @@ def gen_c1_e2e(dit_mod, vae_mod, fm):
              video_absmean=np.array(float(video.abs().mean())))
 
 
+def gen_c1_50step(dit_mod, fm):
+    """The headline's HORIZON on the reference itself: the C1 latent grid [1,16,5,32,32] (1 280 tokens), the full
+    30-layer 1.3B architecture (the C1 fixture's seeded weights, noise and prompts), FIFTY flow-match steps with CFG 5 — the loop of
+    svi_video.py:392-421 with flow_match.py:53-64's update — once in fp32 and once the way the pipelines run it (bf16 weights,
+    activations and latents).  Latents are kept after steps 1, 5, 10, 20, 30, 40 and 50 so the drift of bf16 Euler updates against the
+    fp32 trajectory is a curve, not one number; the reference's own bf16-vs-fp32 gap at each of them is the yardstick."""
+    import time
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    m = build_ref_dit(dit_mod, cfg, seed)
+    noise = torch.randn((1, 16, 5, 32, 32), generator=torch.Generator("cpu").manual_seed(0), dtype=torch.float32)   # base.py:140-143
+    pos = t(synth.text_context(seed + 1, 512, cfg["text_dim"], 64))
+    neg = t(synth.text_context(seed + 2, 512, cfg["text_dim"], 64))
+    keep = synth.C1_50_KEEP
+
+    def loop(model, lat, pos, neg):
+        s = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        s.set_timesteps(50, shift=5.0)
+        kept = []
+        with torch.no_grad():
+            for i, ts in enumerate(s.timesteps):
+                tt = ts.unsqueeze(0)
+                c = model(lat, tt, pos)
+                u = model(lat, tt, neg)
+                lat = s.step(u + 5.0 * (c - u), s.timesteps[i], lat)
+                if i + 1 in keep:
+                    kept.append(lat[0].float().numpy().copy())
+        return np.stack(kept)
+
+    t0 = time.time()
+    l32 = loop(m, noise, pos, neg)
+    print(f"c1_50step: fp32 loop {time.time() - t0:.0f} s")
+    t0 = time.time()
+    mb = m.to(torch.bfloat16)
+    l16 = loop(mb, noise.to(torch.bfloat16), pos.to(torch.bfloat16), neg.to(torch.bfloat16))
+    print(f"c1_50step: bf16 loop {time.time() - t0:.0f} s")
+    gaps = [float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64))) for a, b in zip(l16, l32)]
+    print("c1_50step: reference bf16-vs-fp32 rel-L2 after steps", dict(zip(keep, [f"{g:.3e}" for g in gaps])))
+    np.savez(os.path.join(OUT, "c1_50step.npz"), steps=np.array(keep), latents_fp32=l32,
+             latents_bf16_bits=synth.bf16_bits(l16), ref_gap=np.array(gaps))
+
+
 def gen_dit_depth(dit_mod, fm):
     """The headline kernels at depth against the reference itself: the full 30-layer Wan2.1-T2V-1.3B architecture
     (the C1 fixture's seeded weights) on a (5,30,52) token grid = 7800 tokens — past the 2048-key threshold, so the HIP path takes the
@@ -918,6 +959,7 @@ def main(argv=None):
         "t5_encoder": gen_t5,
         "clip_encoder": gen_clip,
         "c1_e2e": lambda: gen_c1_e2e(dit_mod, vae_mod, fm),
+        "c1_50step": lambda: gen_c1_50step(dit_mod, fm),
         "dit_c4_4blocks": lambda: gen_c4_blocks(dit_mod),
         "dit_depth": lambda: gen_dit_depth(dit_mod, fm),
         "dit_block_c2": lambda: gen_block_c2(dit_mod),

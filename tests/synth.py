@@ -224,6 +224,7 @@ TEA_TIMESTEPS = [500.0, 500.01, 500.03, 500.035, 500.075, 500.08, 500.15, 500.15
 
 # ----------------------------------------------------------------------------------- fixtures at BASELINE sizes (gen_golden.py)
 C1_SEED, C1_VIDEO_STRIDE = 900, 5            # golden/c1_e2e.npz: 1.3B weights seed; decoded video kept on a stride-5 lattice
+C1_50_KEEP = (1, 5, 10, 20, 30, 40, 50)      # golden/c1_50step.npz: the C1 grid through FIFTY CFG-5 steps; latents kept after these steps
 C2_VIDEO_STRIDE = 7                          # golden/vae_c2.npz
 B14_SEED, B14_GRID = 950, (3, 20, 36)        # golden/dit_block_14b.npz: one 14B-I2V block on 2160 tokens
 

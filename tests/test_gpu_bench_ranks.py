@@ -82,3 +82,33 @@ def test_full_clip_single_rank():
     assert c["full_clip_s"] > c["full_clip_steady_s"] * 0.5 and c["full_clip_breakdown"]["step_graph_captures_over_both_clips"] == 1
     # the steady clip is the extrapolation's twin: 10 replayed steps + decode (+ 8-bit frames, input copies); generous bound on the tiny workload
     assert 0.8 < c["full_clip_steady_vs_extrapolated"] < 2.0, c
+
+
+def test_one_rank_rccl_communicator_beside_the_step_graph():
+    """--rccl-probe: what a one-GPU box can run of the RCCL path on hardware — the process group is RCCL (one rank), the barrier / tail all-gather / MAX-reduce of
+    the timed region go through it, and the step's hipGraph is captured and replayed beside the live communicator behind the guarded probe step that the
+    multi-GPU default uses (VERDICT r5 next #7b).  Either outcome of the guard is legal; the line must say which ran."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, "--rccl-probe", "--workload", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-vae", "--no-vendor"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = line["config"]
+    assert line["n_gpus"] == 1 and c["rccl"] is not None and c["rccl_probe"] is True and "ONE rank" in c["transport"]
+    assert c["hip_graph_note"] and (c["hip_graph"] is True) == ("captured and replayed" in c["hip_graph_note"])
+    assert c["outputs_finite"] and line["ms_per_step"] > 0
+    assert c["wall_s_expected"] > 0 and c["wall_s"] > 0 and c["budget_s"] == 600.0
+
+
+def test_peaky_attention_and_long_prompt_lines():
+    """--attn-gain / --prompt-tokens: the line carries the second-pass census of the last self-attention and the prompt's valid tokens."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, "--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-vae", "--no-full-clip", "--attn-gain", "3",
+                        "--prompt-tokens", "200"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = line["config"]
+    assert c["prompt_tokens"] == [200, 100] and c["outputs_finite"]
+    assert "keys walked: [201, 101]" in line["roofline_all"]["flash_cross"]["what"]
+    # c1 has 1280 tokens: below the long-sequence kernel's threshold, so there is no second pass to count
+    assert c["attention_second_pass"] is None

@@ -428,3 +428,52 @@ def test_identical_trailing_context_rows_count_as_one_key(hip, name):
     mid = full.copy()
     mid[0, 2] = mid[0, -1]                                                     # a twin of the last row far from the end
     assert torch.equal(fwd(mid, True), fwd(mid, False))
+
+
+def test_stacked_pair_falls_back_once_when_its_workspace_does_not_fit(hip):
+    """the stacked CFG pair needs a workspace of 2 L rows; when that allocation fails, forward_pair runs the unstacked form (same bits)
+    — and REMEMBERS it: the next step neither frees and re-allocates (the handle's generation stands still) nor, on the capture pass that follows the eager
+    step of a graphed loop, asks a capturing stream to grow the workspace (which was refused as INVALID, so the 14B-width case this targets could not run
+    the graphed loop at all).  SVI_WS_LIMIT_MB turns a budget into the same SVI_ERR_OOM a failed hipMalloc gives."""
+    from svi_hip import _lib as L
+    c, seed = synth.SMALL_DIT, 150
+    f, h, w = 4, 24, 32                                                # 3072 tokens: the workspace is MiBs, so a MiB budget separates L rows from 2 L
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
+    ctx = synth.text_context(seed + 2, 24, c["text_dim"], 24)
+    cp, cn = dev(ctx), dev(-np.asarray(ctx))
+    lat = hip.generate_noise((1, 16, f, 2 * h, 2 * w), seed=9, device="cpu", dtype=torch.float32)
+
+    def model():
+        m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+        m.context_cache(True)
+        return m
+
+    want = hip.DenoiseLoop(model(), graph=False).sample(dev(lat), cp, cn, num_inference_steps=4, cfg_scale=5.0)     # no budget: the stacked pair
+    try:
+        # the smallest whole-MiB budget under which ONE forward of L rows still runs
+        fit = None
+        for mb in range(1, 200):
+            L.set_switch("SVI_WS_LIMIT_MB", mb)
+            try:
+                model().forward(dev(lat), torch.tensor([500.0]), cp)
+                fit = mb
+                break
+            except RuntimeError as e:
+                assert "SVI_WS_LIMIT_MB" in str(e)
+        assert fit is not None and fit >= 4, fit                        # (2 L rows then need nearly twice that: beyond the budget)
+        m = model()
+        with pytest.raises(RuntimeError):                              # the budget really refuses the doubled workspace
+            m2 = model()
+            m2.forward(torch.cat([dev(lat), dev(lat)], dim=3), torch.tensor([500.0]), cp)
+        x = dev(lat).to(torch.bfloat16)
+        t = torch.tensor([637.5], device="cuda")
+        eager = hip.DenoiseLoop(m, graph=False)
+        eager.step(x, t, -0.04, cp, cn, 5.0)                           # stacked refused -> unstacked, remembered
+        g1 = m.generation()
+        eager.step(x, t, -0.04, cp, cn, 5.0)
+        assert m.generation() == g1                                    # no free + re-allocation per step any more
+        for graph in (False, True):                                    # graph=True: the capture pass behind the eager first step succeeds
+            got = hip.DenoiseLoop(m, graph=graph).sample(dev(lat), cp, cn, num_inference_steps=4, cfg_scale=5.0)
+            assert torch.equal(got, want), graph
+    finally:
+        L.set_switch("SVI_WS_LIMIT_MB", None)
