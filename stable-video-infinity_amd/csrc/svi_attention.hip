@@ -577,6 +577,8 @@ __global__ __launch_bounds__(512, 2) void flash_cross_resident_kernel(const bf16
 // =================================================================================================
 #define QB2 256
 #define SVI_RESCALE_THR 8.0f
+#define SVI_OPT_HEADROOM 64.0f            // log2 units the optimistic pass's fixed reference sits above the tile-0 row maximum (see the prologue of flash_fwd2_kernel)
+#define SVI_OPT_FLAG_SUM 7.9228163e28f    // 2^96: a row sum at or beyond it (or inf / NaN) sends the workgroup to the second pass
 #ifndef SVI_FLASH_BALANCED
 #define SVI_FLASH_BALANCED 1
 #endif
@@ -887,10 +889,10 @@ __device__ __forceinline__ void pv_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) 
 // MODE: 0 = the complete kernel (reference maximum tracked per tile, deferred rescale).
 //       1 = OPTIMISTIC: the reference maximum of a row is fixed after tile 0 and never moves, so the per-score v_max3 stream (34 of the
 //           ~200 VALU instructions of a tile) and the per-tile decision disappear: -3.7 % on the C2 shape (tools/attn_abl.py, ABL 1024).
-//           That is the same softmax as long as no exponential leaves fp32: with a row's scores up to 64 log2 units above its tile-0
-//           maximum, P <= 2^64, the sums and O stay far inside fp32 (bf16 P keeps 8 exponent bits), and numerator and denominator
-//           carry the same reference.  A row group whose sum ends beyond 2^64 (or is not a number: an exponential overflowed) raises
-//           the workgroup's flag ...
+//           That is the same softmax as long as no exponential leaves fp32: the reference is the tile-0 maximum + SVI_OPT_HEADROOM (64), so with a
+//           row's scores up to 160 log2 units above its tile-0 maximum, P <= 2^96, the sums and O stay inside fp32 (bf16 P keeps 8 exponent bits),
+//           and numerator and denominator carry the same reference.  A row group whose sum reaches 2^96 (or is not a number: an exponential
+//           overflowed) raises the workgroup's flag ...
 //       2 = ... and the complete kernel is launched behind it over the same grid: a workgroup whose flag is clear exits at once,
 //           a flagged one recomputes its 256 rows with the tracked maximum and overwrites the optimistic result.
 //       On benign operands (every DiT forward measured so far) no flag is ever raised and modes 1 + 2 give the bits of mode 0 (the
@@ -1410,7 +1412,15 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
             qk_mfma<QREG0 + (8 + kk) * 4, kk == 0>(tok, sA[1][tt], kf[f & 3], kaddr[f3 & 7], cneg[1]);
         });
         phase2(sA, sB, I0{}, I1{}, 0, std::true_type{}, std::false_type{}, std::true_type{});
-        const float d0[2] = {row_max(0), row_max(1)};                  // first reference = the row maxima of tile 0 (any sign)
+        // first reference = the row maxima of tile 0 (any sign).  The optimistic pass sets it SVI_OPT_HEADROOM log2 units HIGHER (round 6): the reference never
+        // moves there, and a row's true maximum can only lie above its tile-0 maximum — so the window the fixed reference covers, which was
+        // [tile-0 max, tile-0 max + 64], becomes [tile-0 max, tile-0 max + 64 + 96 - 32 = 160] for free: every P, l and O of the row is scaled by the same
+        // 2^-64 (exact: powers of two; bf16 P and the fp32 sums keep their relative precision, the row's largest P is >= 2^-64, and what the flush of
+        // P < 2^-126 drops lies 2^-62 below it), the flag is raised at l >= 2^96 (O <= 2^96 * 32760 * |v| stays inside fp32).  tools/attn_stats.py: with
+        // the reference at the tile-0 maximum a neighbourhood-peaked q / k with learned gains of 2.5 flagged 80 % of the workgroups (outgrowth 75) and the
+        // launch took 9.7 ms instead of 4.8.
+        const float hr = OPT ? SVI_OPT_HEADROOM / cs : 0.f;
+        const float d0[2] = {row_max(0) + hr, row_max(1) + hr};
         commit(sA, d0);
         alpha[0] = alpha[1] = 1.0f;                                    // O and l are still 0
         if constexpr (BAL) {      // the four pairs a later tile handles on statements 24..31 of its own phase 2 (kb 0, g 0), for tile 0
@@ -1481,8 +1491,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
 
     if constexpr (MODE == 1) {
         // did some exponential of this wave's rows leave the range the fixed reference covers?  (l holds a lane's half of the row sum;
-        // !(l < 2^64) also catches inf and NaN)
-        const bool bad = !(l_run[0] < 1.8446744e19f) || !(l_run[1] < 1.8446744e19f);
+        // !(l < 2^96) also catches inf and NaN)
+        const bool bad = !(l_run[0] < SVI_OPT_FLAG_SUM) || !(l_run[1] < SVI_OPT_FLAG_SUM);
         if (__any(bad) && lane == 0) atomicOr(&flags[wg_linear], 1);
     }
     // ---- normalise and store: a[(g*4+d)*16 + r] is O[row][32 d + (r&3) + 8 (r>>2) + 4 hi] ----------------------

@@ -451,6 +451,115 @@ def _hip_sample_with_regular_video(self, latents, prompt_emb_posi, prompt_emb_ne
     return lat.clone() if resident else lat
 
 
+# ------------------------------------------------------------------------------------------------------
+# WanVideoPipeline (pipelines/wan_video.py): its step loop is INLINE in __call__ (:266-278), so there is no sampler method to rebind.  Everything around
+# the loop — parameter check, scheduler, seeded noise, prompt / image encoding, TeaCache construction, decode, tensor2video (:197-264, :280-290) — must keep
+# running as the reference wrote it.  So the reference's own __call__ still runs, whole, and is steered from outside through the seams it already has:
+#   * the values the loop needs are picked up where the reference's lines produce them — `self.encode_prompt`, `self.encode_image`,
+#     `self.prepare_extra_input(latents)` (the last statement before the loop that sees the initial latents) are shadowed on the instance for the duration
+#     of the call by wrappers that call the class's own method and remember what it returned;
+#   * `progress_bar_cmd` — called exactly once, with `self.scheduler.timesteps`, to make the loop's iterable (:267) — is replaced by a function that runs
+#     the clip's steps on DenoiseLoop (both forwards of a step in one C call, fused CFG + Euler, hipGraph replay; the caller's own progress bar is driven
+#     from there) and hands the reference's `for` an EMPTY iterable: its body never runs;
+#   * `self.decode_video(latents, ...)` (:281) is shadowed by a wrapper that passes the denoised latents instead of the initial ones.
+# Python looks `pipe(...)` up on the TYPE, so the instance gets a subclass of its own class whose __call__ is the steering function (the class itself, and
+# other instances, are untouched).  Anything the fast loop does not cover (CPU / non-bf16 latents, extra inputs) passes through: the reference's loop runs
+# over the swapped model_fn_wan_video, as install(sampler=False) leaves it.
+def _hip_wan_pipeline_call(self, *args, **kwargs):
+    import inspect
+    cls = type(self).__mro__[1]                      # the pipeline's real class (type(self) is install()'s one-method subclass)
+    orig = cls.__call__
+    hip = getattr(self, "_svi_hip_dit", None)
+    loop = getattr(self, "_svi_hip_loop", None)
+    try:
+        bound = inspect.signature(orig).bind(self, *args, **kwargs)
+        bound.apply_defaults()
+        p = bound.arguments
+    except TypeError:
+        return orig(self, *args, **kwargs)            # let the reference raise its own TypeError
+    if hip is None or loop is None or "progress_bar_cmd" not in p:
+        return orig(self, *args, **kwargs)
+    user_bar = p["progress_bar_cmd"]
+    cfg_scale = float(p.get("cfg_scale", 5.0))
+    seen = {}
+
+    def remember(name, key_fn=None):
+        inner = getattr(cls, name)
+
+        def wrapper(*a, **k):
+            out = inner(self, *a, **k)
+            seen[key_fn(a, k) if key_fn else name] = out
+            if name == "prepare_extra_input":
+                seen["latents"] = a[0] if a else k.get("latents")
+            return out
+        return wrapper
+
+    def steps(timesteps):
+        lat, posi, nega, img, extra = seen.get("latents"), seen.get("posi"), seen.get("nega"), seen.get("encode_image") or {}, seen.get("prepare_extra_input")
+        plain = (isinstance(lat, torch.Tensor) and lat.is_cuda and lat.dtype == torch.bfloat16 and not extra and isinstance(posi, dict) and set(posi) == {"context"}
+                 and (cfg_scale == 1.0 or (isinstance(nega, dict) and set(nega) == {"context"})) and set(img) <= {"clip_feature", "y"}
+                 and timesteps is self.scheduler.timesteps)
+        if not plain:
+            return user_bar(timesteps)                 # the reference's loop, over the swapped model_fn_wan_video
+        _assert_resident(self, hip, full=True)
+        if not hip._ctx_cache_on:
+            hip.context_cache(True)
+        tea = {}
+        if p.get("tea_cache_l1_thresh") is not None:  # as :262-263 builds them: the defining module's own TeaCache, one per branch
+            TC = sys.modules[cls.__module__].TeaCache
+            mk = lambda: TC(p["num_inference_steps"], rel_l1_thresh=p["tea_cache_l1_thresh"], model_id=p.get("tea_cache_model_id", ""))      # noqa: E731
+            tea = dict(tea_cache_posi=mk(), tea_cache_nega=mk())
+        cond = {k: img[k] for k in ("clip_feature", "y") if img.get(k) is not None}
+        resident = loop.resident and not tea
+        ctx_n = nega["context"] if cfg_scale != 1.0 else None
+        if resident:
+            x, ctx_p, ctx_n, cond = loop.adopt(lat, posi["context"], ctx_n, cond)
+        else:
+            x, ctx_p, ctx_n = lat.contiguous().clone(), _stable_bf16(hip, posi["context"]), _stable_bf16(hip, ctx_n)
+            cond = {k: _stable_bf16(hip, v) for k, v in cond.items()}
+        # :267 hands the model the timestep in the pipeline's dtype: the bf16-ROUNDED value is what the time embedding sees
+        ts_dev = self.scheduler.timesteps.to(dtype=getattr(self, "torch_dtype", torch.float32)).to(device=x.device, dtype=torch.float32)
+        try:
+            for i, t in enumerate(user_bar(timesteps)):
+                loop.step(x, ts_dev[i:i + 1], _step_delta_of(self.scheduler, self.scheduler.timesteps[i]), ctx_p, ctx_n, cfg_scale, **tea, **cond)
+        finally:
+            if not resident:
+                loop.drop_graph()
+        seen["denoised"] = x.clone() if resident else x
+        return ()
+
+    def decode_video(latents, *a, **k):
+        return getattr(cls, "decode_video")(self, seen.get("denoised", latents), *a, **k)
+
+    shadows = {"encode_prompt": remember("encode_prompt", lambda a, k: "posi" if (k.get("positive", a[1] if len(a) > 1 else True)) else "nega"),
+               "prepare_extra_input": remember("prepare_extra_input"), "decode_video": decode_video}
+    if hasattr(cls, "encode_image"):
+        shadows["encode_image"] = remember("encode_image")
+    p["progress_bar_cmd"] = steps
+    for name, fn in shadows.items():
+        self.__dict__[name] = fn
+    try:
+        return orig(*bound.args, **bound.kwargs)
+    finally:
+        for name in shadows:
+            self.__dict__.pop(name, None)
+
+
+def _route_wan_call(pipe, hip) -> bool:
+    """install()'s sampler swap for a pipeline whose loop is inline in __call__ (WanVideoPipeline): see _hip_wan_pipeline_call."""
+    cls = type(pipe)
+    if getattr(cls, "_svi_hip_call_subclass", False):
+        cls = cls.__mro__[1]
+    need = ("encode_prompt", "prepare_extra_input", "decode_video", "__call__")
+    if hasattr(cls, "_sample_with_regular_video") or not all(callable(getattr(cls, n, None)) for n in need):
+        return False
+    pipe._svi_hip_loop = DenoiseLoop(hip, scheduler=getattr(pipe, "scheduler", None), resident=True)
+    sub = type(cls.__name__, (cls,), {"__call__": _hip_wan_pipeline_call, "_svi_hip_call_subclass": True, "__module__": cls.__module__,
+                                      "__doc__": cls.__doc__})
+    pipe.__class__ = sub
+    return True
+
+
 def _route_dit(pipe, hip, sampler: bool = True) -> None:
     """The swaps of install() that concern the DiT, with the reference's own idioms: the module-level `model_fn_wan_video` (and the talk
     pipeline's `model_fn_wan_talk_video`) of the pipeline's defining module are replaced — every call statement of that module looks the
@@ -459,7 +568,7 @@ def _route_dit(pipe, hip, sampler: bool = True) -> None:
     dit_module = pipe.dit
     _INSTALLED[id(dit_module)] = hip
     pipe._svi_hip_dit = hip
-    mod = sys.modules[type(pipe).__module__]
+    mod = sys.modules[type(pipe).__module__]              # (install()'s __call__ subclass keeps the real class's __module__)
     if not hasattr(mod, "_svi_hip_original_model_fn"):
         mod._svi_hip_original_model_fn = getattr(mod, "model_fn_wan_video", None)
     mod.model_fn_wan_video = _hip_model_fn
@@ -471,6 +580,8 @@ def _route_dit(pipe, hip, sampler: bool = True) -> None:
         pipe._svi_hip_original_sampler = types.MethodType(type(pipe)._sample_with_regular_video, pipe)
         pipe._svi_hip_loop = DenoiseLoop(hip, scheduler=getattr(pipe, "scheduler", None), resident=True)
         pipe._sample_with_regular_video = types.MethodType(_hip_sample_with_regular_video, pipe)
+    elif sampler:
+        _route_wan_call(pipe, hip)                     # WanVideoPipeline: the loop is inline in __call__ (wan_video.py:266-278)
 
 
 _OFFLOAD_NOTE = ("svi_hip: pipe.{}() is a no-op on an installed pipeline — every model stays resident in HBM (288 GB per MI355X holds the 14B DiT, "
@@ -551,7 +662,9 @@ def install(pipe, vae: bool = True, encoders: bool = True, sampler: bool = True,
     * `model_fn_wan_video` in the pipeline's defining module is replaced by the HIP-backed function
       (every call site in that module — the cond/uncond forwards of the sampler — picks it up);
     * with `sampler`: `pipe._sample_with_regular_video` (svi_video.py:392-421) is rebound to the DenoiseLoop-backed sampler of the same
-      signature — one C call for the two forwards of a step, fused CFG + Euler kernel: the loop bench.py times;
+      signature — one C call for the two forwards of a step, fused CFG + Euler kernel: the loop bench.py times; a WanVideoPipeline, whose loop is
+      inline in `__call__` (wan_video.py:266-278), gets the same loop through `_hip_wan_pipeline_call` (the reference's own `__call__` keeps running
+      around it: every line outside the loop is the reference's);
     * `pipe.vae.encode/decode` are rebound to the HIP VAE (same signatures), when `vae` is true;
     * `pipe.dit` stays the reference nn.Module: weights are borrowed, so call `install` again (or
       `pipe._svi_hip_dit.rebind()`) after `load_lora_v2`, `.to()` or any offload that moves storage.

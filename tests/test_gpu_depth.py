@@ -7,7 +7,7 @@ drives through their second pass.
                       <= max(2e-2, 2 x the reference's own bf16-vs-fp32 gap) vs its fp32 run; loop <= 5e-2.
   dit_c4_4blocks.npz  4 of the 40 blocks of Wan2.1-I2V-14B end to end (in_dim-36 patchify, img_emb, head) on 2160 tokens.
   second pass         svi_dit_block_forward / the sequence-parallel gather mode with self_attn.norm_q / norm_k gains scaled so that
-                      late keys outgrow a row's tile-0 maximum by > 64 log2 units: the optimistic pass raises its flags
+                      late keys outgrow a row's tile-0 maximum by > 160 log2 units (64 of headroom above the tile-0 maximum + sums up to 2^96): the optimistic pass raises its flags
                       (svi_attention_last_flagged > 0), the complete kernel recomputes those workgroups, and the result meets the
                       block tolerance against the CPU oracle and agrees with the single complete pass (SVI_FLASH_TWO_PASS=0).
   two streams         two attention calls on two streams, one with adversarial operands: each keeps its own flag words.
@@ -120,7 +120,7 @@ def robust_rows(sdb, bx, btm, grid, cfg, min_gap=8.0):
     return ((top[..., 0] - top[..., 1]).amin(dim=0) > min_gap), float((top[..., 0] - first64).max())
 
 
-@pytest.mark.parametrize("gain,expect_flags", [(7.0, True), (1.5, False)])
+@pytest.mark.parametrize("gain,expect_flags", [(9.0, True), (1.5, False)])
 def test_block_forward_takes_the_second_pass_on_the_dit_seam(hip, gain, expect_flags):
     """flash_fwd2_kernel<0, 0, false, 1 / 2> (q pre-scaled, Lq == Lk: the instance that runs 59 times per headline step)."""
     from oracle import wan_dit_oracle as wdo
@@ -150,7 +150,7 @@ def test_block_forward_takes_the_second_pass_on_the_dit_seam(hip, gain, expect_f
     with torch.no_grad():
         want = wdo.dit_block(sdb, "blocks.0.", bf16r(bx), bf16r(bctx), bf16r(btm), wdo.rope_table_3d(128, grid), cfg, "bf16")
         rows, outgrowth = robust_rows(sdb, bf16r(bx), bf16r(btm), grid, cfg)
-    assert (outgrowth > 64.0) == expect_flags, outgrowth          # the operands are what the test says they are
+    assert (outgrowth > 160.0) == expect_flags, outgrowth          # the operands are what the test says they are
     r_all, mx, _ = errs(got, want)
     r_rob = errs(got[0, rows], want[0, rows])[0] if int(rows.sum()) else float("nan")     # benign gains: hardly any row is that peaked
     rs = errs(got, single)[0]
@@ -176,7 +176,7 @@ def test_gather_mode_takes_the_second_pass(hip):
     c = dict(dim=512, in_dim=16, ffn_dim=1024, out_dim=16, text_dim=64, freq_dim=256, patch_size=(1, 2, 2), num_layers=2, has_image_input=False)
     sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(900, **c).items()}
     for k in ("blocks.1.self_attn.norm_q.weight", "blocks.1.self_attn.norm_k.weight"):      # the LAST block: its launch is the one the flag words describe,
-        sd[k] = sd[k] * 7.0                                                                    # and block 0 stays benign (bit-identical across the two schedules)
+        sd[k] = sd[k] * 9.0                                                                    # and block 0 stays benign (bit-identical across the two schedules)
     sdd = {k: v.to("cuda", torch.bfloat16).contiguous() for k, v in sd.items()}
     ms = []
     for _ in range(9):
@@ -215,8 +215,8 @@ def test_two_streams_keep_their_own_flag_words(hip):
         q = torch.randn((1, Lq, n * d), generator=g, device="cuda")
         k = torch.randn((1, Lq, n * d), generator=g, device="cuda")
         v = torch.randn((1, Lq, n * d), generator=g, device="cuda")
-        if adversarial:            # a late giant key every row projects on: raw score 3 * 2 * 128 = 768 -> 98 log2 units, ~90 above any tile-0 maximum
-            k[:, 3000] = 3.0
+        if adversarial:            # a late giant key every row projects on: raw score 6 * 2 * 128 = 1536 -> 196 log2 units, ~185 above any tile-0 maximum (the
+            k[:, 3000] = 6.0       # optimistic pass covers 160)
             q = q + 2.0
         return [a.to(torch.bfloat16).contiguous() for a in (q, k, v)]
     qa, ka, va = operands(True)

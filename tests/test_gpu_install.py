@@ -381,3 +381,145 @@ def test_install_refuses_offload_behind_its_back_and_rebinds_moved_parameters(pi
     pipe.cpu_offload = True                                  # the flag alone (the class's own enable_cpu_offload reached around the rebind)
     with pytest.raises(RuntimeError, match="install"):
         pipeline._assert_resident(pipe, hip)
+
+
+# WanVideoPipeline (pipelines/wan_video.py): the step loop is inline in __call__.  The double keeps the reference's signature (:197-219), the order of its
+# statements and — verbatim, checked against the reference's own source with ast on the build box (tests/test_reference_keys.py) — its `for` loop (:266-278),
+# including the timestep cast to the pipeline's dtype; the model-side methods around it are reduced to what the loop needs.
+WAN_CALL_SRC = '''
+import torch
+
+
+def model_fn_wan_video(dit, x, timestep, context, clip_feature=None, y=None, **kwargs):
+    raise AssertionError("the PyTorch model_fn was called: install() did not take effect")
+
+
+class TeaCache:
+    def __init__(self, num_inference_steps, rel_l1_thresh, model_id):
+        raise AssertionError("not used by this test")
+
+
+class WanVideoPipeline:
+    def __init__(self, dit, scheduler, prompts):
+        self.dit, self.vae, self.scheduler, self.device, self.torch_dtype, self.prompts = dit, None, scheduler, "cuda", torch.bfloat16, prompts
+        self.image_encoder = None
+        self.decoded = []
+
+    def check_resize_height_width(self, height, width):
+        return height, width
+
+    def generate_noise(self, shape, seed=None, device="cpu", dtype=torch.float16):
+        generator = None if seed is None else torch.Generator(device).manual_seed(seed)
+        return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+    def load_models_to_device(self, names):
+        pass
+
+    def encode_prompt(self, prompt, positive=True):
+        return {"context": self.prompts[prompt]}
+
+    def prepare_extra_input(self, latents=None):
+        return {}
+
+    def decode_video(self, latents, tiled=True, tile_size=(34, 34), tile_stride=(18, 16)):
+        self.decoded.append(latents)
+        return [latents]
+
+    def tensor2video(self, frames):
+        return frames
+
+    @torch.no_grad()
+    def __call__(self, prompt, negative_prompt="", input_image=None, input_video=None, denoising_strength=1.0, seed=None, rand_device="cpu", height=480, width=832,
+                 num_frames=81, cfg_scale=5.0, num_inference_steps=50, sigma_shift=5.0, tiled=True, tile_size=(30, 52), tile_stride=(15, 26),
+                 tea_cache_l1_thresh=None, tea_cache_model_id="", progress_bar_cmd=lambda x: x, progress_bar_st=None):
+        height, width = self.check_resize_height_width(height, width)
+        tiler_kwargs = {"tiled": tiled, "tile_size": tile_size, "tile_stride": tile_stride}
+        self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
+        noise = self.generate_noise((1, 16, (num_frames - 1) // 4 + 1, height//8, width//8), seed=seed, device=rand_device, dtype=torch.float32)
+        noise = noise.to(dtype=self.torch_dtype, device=self.device)
+        latents = noise
+        self.load_models_to_device(["text_encoder"])
+        prompt_emb_posi = self.encode_prompt(prompt, positive=True)
+        if cfg_scale != 1.0:
+            prompt_emb_nega = self.encode_prompt(negative_prompt, positive=False)
+        image_emb = {}
+        extra_input = self.prepare_extra_input(latents)
+        tea_cache_posi = {"tea_cache": TeaCache(num_inference_steps, rel_l1_thresh=tea_cache_l1_thresh, model_id=tea_cache_model_id) if tea_cache_l1_thresh is not None else None}
+        tea_cache_nega = {"tea_cache": TeaCache(num_inference_steps, rel_l1_thresh=tea_cache_l1_thresh, model_id=tea_cache_model_id) if tea_cache_l1_thresh is not None else None}
+        self.load_models_to_device(["dit"])
+        for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
+            timestep = timestep.unsqueeze(0).to(dtype=self.torch_dtype, device=self.device)
+
+            # Inference
+            noise_pred_posi = model_fn_wan_video(self.dit, latents, timestep=timestep, **prompt_emb_posi, **image_emb, **extra_input, **tea_cache_posi)
+            if cfg_scale != 1.0:
+                noise_pred_nega = model_fn_wan_video(self.dit, latents, timestep=timestep, **prompt_emb_nega, **image_emb, **extra_input, **tea_cache_nega)
+                noise_pred = noise_pred_nega + cfg_scale * (noise_pred_posi - noise_pred_nega)
+            else:
+                noise_pred = noise_pred_posi
+
+            # Scheduler
+            latents = self.scheduler.step(noise_pred, self.scheduler.timesteps[progress_id], latents)
+        self.load_models_to_device(['vae'])
+        frames = self.decode_video(latents, **tiler_kwargs)
+        self.load_models_to_device([])
+        frames = self.tensor2video(frames[0])
+        return frames
+'''
+
+
+@pytest.mark.parametrize("scale", [5.0, 1.0])
+def test_wan_video_pipeline_call_runs_the_fused_loop_and_keeps_the_reference_bits(scale):
+    """VERDICT r5 missing 3 / next 5: WanVideoPipeline's step loop is inline in __call__ (wan_video.py:266-278), so install() gives the instance a one-method
+    subclass whose __call__ steers the reference's own __call__ (svi_hip.pipeline._hip_wan_pipeline_call): every statement outside the loop is the
+    reference's, the loop's steps run on DenoiseLoop.  Bits equal to the reference's own loop over the swapped model_fn_wan_video (install(sampler=False)) —
+    including the bf16-ROUNDED timestep its :267 feeds the model — the caller's progress bar is driven, the shadows are gone after the call, and a second
+    clip replays the step graph captured for the first."""
+    import svi_hip
+    c, grid, nt, nv, ts, seed = CASES["tiny_t2v"]
+    f, h, w = grid
+    modname = "wan_video_double"
+    mod = types.ModuleType(modname)
+    sys.modules[modname] = mod
+    try:
+        exec(compile(WAN_CALL_SRC, modname + ".py", "exec"), mod.__dict__)
+        mod.WanVideoPipeline.__module__ = modname
+        dit, sd = wan_model_double(c, seed)
+        _, ctx, _ = inputs(c, grid, nt, nv, seed)
+        prompts = {"a": dev(ctx), "b": dev(np.asarray(ctx) * 0.7), "neg": dev(-np.asarray(ctx))}
+        kw = dict(negative_prompt="neg", height=16 * h, width=16 * w, num_frames=4 * (f - 1) + 1, cfg_scale=scale, num_inference_steps=5)
+
+        def pipeline(**inst):
+            sch = svi_hip.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+            p = mod.WanVideoPipeline(dit, sch, prompts)
+            svi_hip.install(p, vae=False, encoders=False, resident=False, **inst)
+            return p
+        slow = pipeline(sampler=False)
+        assert type(slow) is mod.WanVideoPipeline
+        want = [slow("a", seed=3, **kw), slow("b", seed=4, **kw)]
+        # the bf16 timestep is a different number: the test is only meaningful if rounding it changes the schedule's values
+        assert not torch.equal(slow.scheduler.timesteps.to(torch.bfloat16).float(), slow.scheduler.timesteps.float())
+        fast = pipeline()
+        assert type(fast) is not mod.WanVideoPipeline and isinstance(fast, mod.WanVideoPipeline) and type(fast).__call__ is svi_hip.pipeline._hip_wan_pipeline_call
+        assert type(fast).__module__ == modname and mod.WanVideoPipeline.__call__ is not svi_hip.pipeline._hip_wan_pipeline_call      # the class itself is untouched
+        seen = []
+
+        def bar(it):
+            for v in it:
+                seen.append(float(v))
+                yield v
+        got = fast("a", seed=3, progress_bar_cmd=bar, **kw)
+        assert torch.equal(got, want[0]) and got.dtype == torch.bfloat16
+        assert seen == [float(t) for t in fast.scheduler.timesteps]                    # the caller's progress bar walked the clip's steps
+        assert len(fast.decoded) == 1 and fast.decoded[0] is got                       # decode_video saw the denoised latents
+        assert not any(n in fast.__dict__ for n in ("encode_prompt", "prepare_extra_input", "decode_video", "encode_image"))
+        loop = fast._svi_hip_loop
+        caps = loop.captures
+        assert loop.resident and caps >= 1
+        assert torch.equal(fast("b", seed=4, **kw), want[1])
+        assert loop.captures == caps                                                   # the next clip replays the first clip's step graph
+        # what the fast loop does not cover passes through to the reference's own loop (float32 latents: the pipeline's dtype switched)
+        fast.torch_dtype = slow.torch_dtype = torch.float32
+        assert torch.equal(fast("a", seed=3, **kw).float(), slow("a", seed=3, **kw).float())
+    finally:
+        del sys.modules[modname]

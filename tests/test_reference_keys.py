@@ -475,3 +475,119 @@ def test_example_launcher_has_the_reference_cli_surface():
             assert ours[name] == default, (name, ours[name], default)
     assert mod.COMMON_NEGATIVE_PROMPT in open(os.path.join(REF, "test_svi.py")).read()       # the negative prompt is the reference's string
     assert mod.calculate_dimensions(1920, 1080, 832) == (464, 832) and mod.calculate_dimensions(640, 480, 832) == (480, 640)
+
+
+def _wan_call_ast():
+    import ast
+    tree = ast.parse(open(os.path.join(REF, "diffsynth/pipelines/wan_video.py")).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "WanVideoPipeline")
+    return next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__call__")
+
+
+def test_wan_pipeline_double_has_the_reference_loop_and_signature():
+    """tests/test_gpu_install.py's WanVideoPipeline double (the GPU box has no reference): its __call__ takes the reference's parameters, in order, with the
+    reference's defaults (but for the progress bar), and its step loop is the reference's `for` statement node for node (wan_video.py:266-278)."""
+    import ast
+    import test_gpu_install as tgi
+    ref_call = _wan_call_ast()
+    dbl_cls = next(n for n in ast.parse(tgi.WAN_CALL_SRC).body if isinstance(n, ast.ClassDef) and n.name == "WanVideoPipeline")
+    dbl_call = next(n for n in dbl_cls.body if isinstance(n, ast.FunctionDef) and n.name == "__call__")
+    assert [a.arg for a in dbl_call.args.args] == [a.arg for a in ref_call.args.args]
+    ref_defaults = {a.arg: ast.dump(d) for a, d in zip(ref_call.args.args[-len(ref_call.args.defaults):], ref_call.args.defaults)}
+    dbl_defaults = {a.arg: ast.dump(d) for a, d in zip(dbl_call.args.args[-len(dbl_call.args.defaults):], dbl_call.args.defaults)}
+    ref_defaults.pop("progress_bar_cmd"), dbl_defaults.pop("progress_bar_cmd")            # tqdm there, identity here
+    assert dbl_defaults == ref_defaults
+    loops = [[n for n in ast.walk(fn) if isinstance(n, ast.For)] for fn in (ref_call, dbl_call)]
+    assert len(loops[0]) == len(loops[1]) == 1 and ast.dump(loops[0][0]) == ast.dump(loops[1][0])
+    # every self.<method>(...) the reference's __call__ makes outside the branches the double leaves out exists on the double under the same name
+    called = {n.func.attr for n in ast.walk(ref_call) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)
+              and isinstance(n.func.value, ast.Name) and n.func.value.id == "self"}
+    have = {n.name for n in dbl_cls.body if isinstance(n, ast.FunctionDef)}
+    assert called - have <= {"preprocess_images", "encode_video", "encode_image"}, called - have
+
+
+def test_wan_pipeline_call_steering_on_the_reference_source(ref):
+    """_hip_wan_pipeline_call around the reference's REAL WanVideoPipeline.__call__ (compiled from its source with ast): the values the loop needs are picked up
+    where the reference's own statements produce them, the shadows are gone afterwards, and — CPU latents are not the fused loop's case — the reference's own
+    loop runs over the swapped model_fn_wan_video and sees the timestep in the pipeline's dtype (bf16-rounded)."""
+    import ast
+    import sys
+    import types
+    from svi_hip import pipeline
+    dit_mod, _, fm = ref
+    call = _wan_call_ast()
+    name = "wan_video_compiled"
+    stubs = ast.parse('''
+def check_resize_height_width(self, height, width):
+    return height, width
+def generate_noise(self, shape, seed=None, device="cpu", dtype=None):
+    import torch
+    return torch.randn(shape, generator=torch.Generator(device).manual_seed(seed), device=device, dtype=dtype)
+def load_models_to_device(self, names):
+    self.loaded.append(list(names))
+def encode_prompt(self, prompt, positive=True):
+    return {"context": self.prompts[prompt]}
+def prepare_extra_input(self, latents=None):
+    return {}
+def decode_video(self, latents, tiled=True, tile_size=(34, 34), tile_stride=(18, 16)):
+    return [latents]
+def tensor2video(self, frames):
+    return frames
+''').body
+    cls = ast.ClassDef(name="WanVideoPipeline", bases=[], keywords=[], body=stubs + [call], decorator_list=[])
+    mod_ast = ast.Module(body=[cls], type_ignores=[])
+    ast.fix_missing_locations(mod_ast)
+    mod = types.ModuleType(name)
+    sys.modules[name] = mod
+    try:
+        mod.torch, mod.tqdm = torch, (lambda x: x)
+
+        def never(*a, **k):
+            raise AssertionError("the PyTorch model_fn_wan_video ran: the swap did not take effect")
+        mod.model_fn_wan_video = never
+        mod.TeaCache = None
+        exec(compile(mod_ast, name + ".py", "exec"), mod.__dict__)
+        mod.WanVideoPipeline.__module__ = name
+        calls = []
+
+        class FakeHip:
+            _ctx_cache_on = False
+            dim, patch_size, ffn_dim, num_heads = 8, (1, 2, 2), 16, 1
+
+            def context_cache(self, on):
+                self._ctx_cache_on = bool(on)
+
+            def forward(self, x, timestep, context, clip_feature=None, y=None, add_condition=None, **kw):
+                calls.append(dict(timestep=timestep, context=context))
+                return x * 0.5 + context.float().mean().to(x.dtype)
+
+        with torch.device("meta"):
+            real_dit = dit_mod.WanModel(**CONFIGS["1.3B-T2V"])
+        pipe = mod.WanVideoPipeline.__new__(mod.WanVideoPipeline)
+        pipe.dit, pipe.device, pipe.torch_dtype, pipe.image_encoder, pipe.loaded = real_dit, "cpu", torch.bfloat16, None, []
+        pipe.prompts = {"p": torch.randn(1, 6, 8).to(torch.bfloat16), "n": torch.randn(1, 6, 8).to(torch.bfloat16)}
+        pipe.scheduler = fm.FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+        hip = FakeHip()
+        pipeline._route_dit(pipe, hip, sampler=True)
+        assert type(pipe) is not mod.WanVideoPipeline and type(pipe).__call__ is pipeline._hip_wan_pipeline_call and type(pipe).__mro__[1] is mod.WanVideoPipeline
+        bar_saw = []
+        out = pipe("p", negative_prompt="n", seed=7, height=32, width=32, num_frames=5, num_inference_steps=3, tiled=False,
+                   progress_bar_cmd=lambda it: (bar_saw.append(it), it)[1])
+        assert bar_saw and bar_saw[0] is pipe.scheduler.timesteps                         # pass-through: the reference's loop took the caller's bar
+        assert len(calls) == 6 and all(c["context"] is pipe.prompts["p" if i % 2 == 0 else "n"] for i, c in enumerate(calls))
+        assert all(c["timestep"].dtype == torch.bfloat16 for c in calls)                 # :267 — the pipeline's dtype
+        assert [float(c["timestep"]) for c in calls[::2]] == [float(t.to(torch.bfloat16)) for t in pipe.scheduler.timesteps]
+        assert not any(n in pipe.__dict__ for n in ("encode_prompt", "prepare_extra_input", "decode_video", "encode_image"))
+        # the reference's arithmetic by hand around the recorded forwards
+        want = torch.randn((1, 16, 2, 4, 4), generator=torch.Generator("cpu").manual_seed(7), dtype=torch.float32).to(torch.bfloat16)
+        for i, t in enumerate(pipe.scheduler.timesteps):
+            c = want * 0.5 + pipe.prompts["p"].float().mean().to(want.dtype)
+            u = want * 0.5 + pipe.prompts["n"].float().mean().to(want.dtype)
+            want = pipe.scheduler.step(u + 5.0 * (c - u), pipe.scheduler.timesteps[i], want)
+        assert torch.equal(out, want)
+        assert pipe.loaded[-1] == [] and ["dit"] in pipe.loaded                          # the reference's own statements around the loop ran
+        # a second install() does not stack subclasses
+        pipeline._route_dit(pipe, hip, sampler=True)
+        assert type(pipe).__mro__[1] is mod.WanVideoPipeline
+    finally:
+        sys.modules.pop(name, None)
