@@ -35,7 +35,12 @@ static SviSwitches parse_switches() {
     s.flash_kernel = env_int("SVI_FLASH_KERNEL", 1, 0);
     if (s.flash_kernel > 2) s.flash_kernel = 0;
     s.gemm_kernel = env_int("SVI_GEMM_KERNEL", 128, 0);
-    if (s.gemm_kernel != 128 && s.gemm_kernel != 192 && s.gemm_kernel != 259 && s.gemm_kernel != 260) {
+#ifdef SVI_GEMM_EXPERIMENTS
+    const bool experiment = s.gemm_kernel == 264 || s.gemm_kernel == 265;      // the four-wave tiles of round 6 (variant builds only)
+#else
+    const bool experiment = false;
+#endif
+    if (s.gemm_kernel != 128 && s.gemm_kernel != 192 && s.gemm_kernel != 259 && s.gemm_kernel != 260 && !experiment) {
         if (s.gemm_kernel != 0)      // 256 / 257 / 258 were kernels of rounds 1-3: an old A/B script must not silently measure "auto" instead
             fprintf(stderr, "libsvi_hip: ignoring SVI_GEMM_KERNEL=%d (kernels: 128, 192, 259 = 256^2 four phases, 260 = 256^2 two phases; 256 / 257 / 258 are retired)\n", s.gemm_kernel);
         s.gemm_kernel = 0;

@@ -313,14 +313,16 @@ __device__ __forceinline__ void gemm256_apply(float (&y)[8], const u32x4& res, c
 
 // MI x NI: 32x32 accumulator blocks per wave along M / N (wave grid (256 / 32 MI) x (TNV / 32 NI)); TNV: tile width.  The 256^2 kernels are
 // <4, 2, 256>; the 256 x 192 kernel <2, 3, 192> (read-back threads whose column chunk lies past the tile's 192 columns sit idle).
-template <int EPI, int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false>
+// NT: threads of the workgroup (512: eight waves, 16 rows per read-back iteration; 256: the four-wave kernel, 8 rows per iteration)
+template <int EPI, int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false, int NT = 512>
 __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, int m0, int n0, int tid,
                                                    int wm, int wn, int l31, int hi, int abl) {
+    constexpr int RPI = NT / 32, ITS = TM / RPI;          // rows per read-back iteration, iterations
     const bool interior = (m0 + TM <= g.M) && (n0 + TNV <= g.N);
     // gate·y + residual: the 16 residual chunks this thread will need are requested NOW (64 registers, the accumulators
     // are about to die) so that their latency runs under the LDS round trip; the column block (and so the gate values)
     // is the same for all 16 chunks of a thread.
-    u32x4 resv[16];
+    u32x4 resv[ITS];
     float gatev[8];
     const int ecc = tid & 31, er = tid >> 5, en = n0 + ecc * 8;
     const bool active = TNV == TN || ecc * 8 < TNV;          // this thread's column chunk belongs to the tile
@@ -330,11 +332,11 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
         } else if (interior) {
             const bf16* rp = g.res + (size_t)(m0 + er) * g.ldres + en;
 #pragma unroll
-            for (int it = 0; it < 16; ++it) resv[it] = *reinterpret_cast<const u32x4*>(rp + (size_t)(16 * it) * g.ldres);
+            for (int it = 0; it < ITS; ++it) resv[it] = *reinterpret_cast<const u32x4*>(rp + (size_t)(RPI * it) * g.ldres);
         } else {
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int m = m0 + er + 16 * it;
+            for (int it = 0; it < ITS; ++it) {
+                const int m = m0 + er + RPI * it;
                 if (m < g.M && efull) resv[it] = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + en);
             }
         }
@@ -404,10 +406,10 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
         const bf16* lp = Cs + er * C2_LD + ecc * 8;
         bf16* cp = g.C + (size_t)(m0 + er) * g.ldc + en;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < ITS / 4; ++b) {
             u32x4 yv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) yv[j] = *reinterpret_cast<const u32x4*>(lp + (16 * (4 * b + j)) * C2_LD);
+            for (int j = 0; j < 4; ++j) yv[j] = *reinterpret_cast<const u32x4*>(lp + (RPI * (4 * b + j)) * C2_LD);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int it = 4 * b + j;
@@ -423,25 +425,25 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
                     float vq[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) vq[e] = (float)o[e];
-                    mx8_quant8(vq, true, m0 + er + 16 * it, en >> 3, g.q8, g.ldq8, g.q8s, g.q8_sc_rows);
+                    mx8_quant8(vq, true, m0 + er + RPI * it, en >> 3, g.q8, g.ldq8, g.q8s, g.q8_sc_rows);
                     continue;
                 }
                 if (abl == 2) { if (y[0] == 123.456f && y[7] == 1.f) cp[0] = o[3]; }
                 // abl 4: non-temporal stores.  Alone the GEMM gains (attn_o 153 -> 140 us, ffn1 861 -> 841 us: the tile no longer
                 // pushes operand panels out of L2), but in the block the next kernel (LN / the next GEMM) then finds its input in
                 // HBM instead of L2 / MALL and gives the time back: step 470.3 vs 469.7 ms.  Ordinary stores stay.
-                else if (abl == 4) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(cp + (size_t)(16 * it) * g.ldc));
-                else st_bf16x8(cp + (size_t)(16 * it) * g.ldc, o);
+                else if (abl == 4) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(cp + (size_t)(RPI * it) * g.ldc));
+                else st_bf16x8(cp + (size_t)(RPI * it) * g.ldc, o);
                 if constexpr (EPI == SVI_EPI_BIAS && !Q8OUT) {
-                    if (g.rowss) gemm_rowss_store(g, o, m0 + er + 16 * it, en, ecc);
+                    if (g.rowss) gemm_rowss_store(g, o, m0 + er + RPI * it, en, ecc);
                 }
             }
         }
         return;
     }
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int ml = er + 16 * it;
+    for (int it = 0; it < ITS; ++it) {
+        const int ml = er + RPI * it;
         const int m = m0 + ml, n = en;
         if (m >= g.M || n >= g.N) continue;
         const bf16x8 yv = *reinterpret_cast<const bf16x8*>(Cs + ml * C2_LD + ecc * 8);
@@ -480,7 +482,7 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
     }
 }
 
-template <int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false>
+template <int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false, int NT = 512>
 __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, int m0, int n0, int tid,
                                                  int wm, int wn, int l31, int hi, int abl = 0) {
     if (abl == 1) {
@@ -488,12 +490,12 @@ __device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&
         return;
     }
     switch (g.epi) {        // uniform: one scalar branch per tile
-        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        default:                     gemm256_epilogue_t<SVI_EPI_BIAS, MI, NI, TNV, Q8OUT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        default:                     gemm256_epilogue_t<SVI_EPI_BIAS, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
     }
 }
 
@@ -753,6 +755,350 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g
     __syncthreads();                                       // every wave is done with the operand buffers: the C tile may overwrite them
     gemm256_epilogue<MI, NI, TNW>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl == 5 ? 0 : abl == 6 ? 1 : abl);
 }
+
+// =================================================================================================
+// Round 6 experiment, NOT part of the product build (-DSVI_GEMM_EXPERIMENTS, tools/build_gemm_variant.py; kinds 264 / 265 of SVI_GEMM_KERNEL): the vendor library's
+// shape for these problems — a 256 x 256 x 64 tile on FOUR waves, 128 x 128 per wave, one wave per SIMD with the whole 512-register file (hipBLASLt's
+// MT256x256x64 kernel: 256 threads; 1230-1290 TFLOP/s at K = 1536 and 1485 at K = 8960 against 1156-1195 / 1380 for the eight-wave kernel above, same box,
+// profiles/r6a_yardstick.txt).  Both forms below are bit-identical to the kernels above (tools/gemm_ab.py, tools/gemm_race_screen.py clean) and SLOWER:
+//                                   q|k|v    attn-out   ffn1     ffn2 (K = 8960)      [TFLOP/s, profiles/r6e_gemm_ab_w4.txt, r6f_gemm_ab_w4r.txt]
+//   eight waves (kind 259)          1148     1029       1163     1368
+//   w4,  LDS-DMA fed (264)          1070      898       1069     1199
+//   w4r, fed through registers (265) 825      763        927     1076
+//   w4 with its global loads REMOVED 1096     1025       1237     1504      (results wrong: the multiply-and-LDS-read ceiling of the structure = the vendor's rate)
+// Reading: the four-wave structure itself reaches the vendor's rate, but a lone wave pays for every memory instruction it issues with matrix-pipe idle time
+// — a `buffer_load ... lds` holds the wave's issue ~60 cycles against the 32 an MFMA covers, sixteen per K tile and wave; moving them earlier, spreading them
+// (1 per 2 MFMAs) or replacing them by buffer_load + ds_write_b128 through two register sets (a ~3000-cycle prefetch window, 32 memory instructions per
+// tile) changes nothing or makes it worse.  In the eight-wave kernel the SIMD's other wave multiplies during those issue slots, which is why it stays the
+// product kernel.  What the vendor's hand-written loop does differently was not found from outside.
+// =================================================================================================
+#ifdef SVI_GEMM_EXPERIMENTS
+// =================================================================================================
+// 256 x 256 x 64 tile on FOUR waves ("w4", round 6): one wave per SIMD, each owning a 128 x 128 quarter of the tile (MI = NI = 4: sixteen 32x32 accumulator
+// blocks = 256 registers, the kernel runs at the full 512-register budget of a lone wave) — the shape the vendor library picks for these problems
+// (tools/yardstick.py + rocprofv3: hipBLASLt's MT256x256x64 kernel is 256 threads per workgroup; 1230-1290 TFLOP/s at K = 1536, 1485 at K = 8960 against
+// 1156-1195 / 1380 for the eight-wave kernel above, same box, same job).  Why it can be faster where the chip is POWER-limited (tools/attn_stats.py: the same
+// instruction stream runs 0.83 of peak on zeros and 0.56 on Gaussian operands): a 128 x 128 wave tile feeds 64 MFMAs from 32 fragment reads per K tile
+// (0.5 per MFMA; the 128 x 64 wave tiles above need 0.75), there is ONE barrier per K tile instead of eight, and no priority flips.
+// Same LDS image (two 64 KiB stages, A | W tiles of 128-byte rows, source-side XOR swizzle), the same MFMA and operand roles and the same k order per
+// accumulator as every other kernel of this file: the same bits.
+// One K tile t (buffer b = t & 1), per wave — fragments are double-buffered in registers, k-step kk + 1 is read from LDS while k-step kk multiplies:
+//   k-step 0   read k-step 1 of tile t          DMA: the wave's 8 W pieces of tile t+1 -> buffer b^1      16 MFMAs
+//   k-step 1   read k-step 2                                                                           16 MFMAs
+//   k-step 2   read k-step 3                                                                           16 MFMAs
+//   s_waitcnt lgkmcnt(0) (every read of buffer b by this wave is complete) vmcnt(0) (its pieces of tile t+1 have landed), s_barrier
+//   k-step 3   read k-step 0 of tile t+1 (b^1)  DMA: the wave's 8 A pieces of tile t+2 -> buffer b        16 MFMAs
+// A DMA piece is requested at least two k-steps (>= 1000 cycles) before the wait that retires it; a buffer is overwritten only behind the barrier that
+// follows its last read; a staged tile is read only behind the barrier that follows every wave's wait for its pieces (cdna_hip_programming.md "read a
+// staged buffer one phase after the wait that retires it").  Within a k-step the source alternates one MFMA with one LDS read / one DMA piece, pinned
+// by sched_barrier, so the matrix pipe is never left waiting behind a burst of memory instructions (a lone wave has no partner to cover one).
+// =================================================================================================
+#define W4_KSTEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+__global__ __launch_bounds__(256, 1) void gemm_bf16_nt_w4_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
+    constexpr int MI = 4, NI = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    const int group = swz / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = swz - group * GM * tiles_n;
+    const int tile_n = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n * gm);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+    if (g.W2 && n0 >= g.n_split) {                          // q | k side by side: this tile's columns belong to the second matrix
+        g.W = g.W2 - (size_t)g.n_split * g.ldw;
+        g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
+    }
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, (int)(((unsigned)(g.M - 1) * (unsigned)g.lda + (unsigned)g.K) * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, (int)(((unsigned)(g.N - 1) * (unsigned)g.ldw + (unsigned)g.K) * 2u), 0x00020000);
+    // a wave's DMA instruction covers 8 rows x 128 B; piece j (0..7) of this wave holds rows j * 32 + wave * 8 + lane / 8 of an operand tile; the bank
+    // swizzle sits on the SOURCE chunk (as in the kernels above; (row >> 1) & 7 does not depend on j)
+    const int r8 = wave * 8 + (lane >> 3);
+    const int c8 = (lane & 7) ^ ((r8 >> 1) & 7);
+    const int a_vo = (r8 * g.lda + c8 * 8) * 2, w_vo = (r8 * g.ldw + c8 * 8) * 2;
+    const unsigned a_so0 = (unsigned)m0 * (unsigned)g.lda * 2u, w_so0 = (unsigned)n0 * (unsigned)g.ldw * 2u;
+    const unsigned a_j = 32u * (unsigned)g.lda * 2u, w_j = 32u * (unsigned)g.ldw * 2u;
+    const int nk = g.K / BK;
+    auto dma = [&](auto opc, int j, int kt, int b) {      // piece j of the A (op 0) / W (op 1) tile of K tile kt -> buffer b
+        constexpr int op = decltype(opc)::value;
+        char* dst = smem + b * E_BUF + op * (2 * E_HALF) + j * 4096 + wave * 1024;
+        if constexpr (op == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)dst, 16, a_vo, (int)(a_so0 + (unsigned)kt * (BK * 2) + (unsigned)j * a_j), 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)dst, 16, w_vo, (int)(w_so0 + (unsigned)kt * (BK * 2) + (unsigned)j * w_j), 0, 0);
+    };
+    std::integral_constant<int, 0> OPA;
+    std::integral_constant<int, 1> OPW;
+
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][i][r] = 0.f;
+
+    int a_addr[4], w_addr[4];          // this lane's fragment of k-step kk, block 0 of the wave's rows (A) / columns (W), buffer 0; block i: + i * 4096
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
+        w_addr[kk] = lds0 + 2 * E_HALF + lds_tile_off(wn * 128 + l31, 2 * kk + hi);
+    }
+    u32x4 fa[2][MI], fw[2][NI];        // fragment registers: set kk & 1 holds k-step kk
+    // one k-step: 16 MFMAs on fragment set CUR, between them the 8 LDS reads of the next k-step into the other set (from `rbuf` — buffer offset 0 / E_BUF —
+    // at k-step index RK) and, where DMAOP >= 0, the wave's 8 pieces of that operand of K tile dkt into buffer db
+    auto kstep = [&](auto curc, auto rkc, int rbuf, auto readc, auto dmaopc, int dkt, int db) __attribute__((always_inline)) {
+        constexpr bool do_read = decltype(readc)::value;
+        constexpr int CUR = decltype(curc)::value, RK = decltype(rkc)::value, DMAOP = decltype(dmaopc)::value;
+        constexpr int NXT = CUR ^ 1;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int j = n * MI + i;
+                acc[n][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[CUR][n]), __builtin_bit_cast(bf16x8, fa[CUR][i]), acc[n][i], 0, 0, 0);
+                if constexpr (do_read) {
+                    // reads in the order the next k-step consumes them: W(0), A(0..3), W(1..3)
+                    if (j == 0) fw[NXT][0] = *(lds_u32x4_t)(w_addr[RK] + rbuf);
+                    else if (j >= 1 && j <= 4) fa[NXT][j - 1] = *(lds_u32x4_t)(a_addr[RK] + rbuf + (j - 1) * 4096);
+                    else if (j >= 5 && j <= 7) fw[NXT][j - 4] = *(lds_u32x4_t)(w_addr[RK] + rbuf + (j - 4) * 4096);
+                }
+#ifndef SVI_W4_NODMA
+                if constexpr (DMAOP >= 0) {
+#if defined(SVI_W4_SPREAD)
+                    if (j & 1) dma(std::integral_constant<int, DMAOP < 0 ? 0 : DMAOP>{}, j >> 1, dkt, db);
+#elif defined(SVI_W4_EARLY)
+                    if (j < 8) dma(std::integral_constant<int, DMAOP < 0 ? 0 : DMAOP>{}, j, dkt, db);
+#else
+                    if (j >= 8) dma(std::integral_constant<int, DMAOP < 0 ? 0 : DMAOP>{}, j - 8, dkt, db);
+#endif
+                }
+#endif
+                W4_KSTEP_FENCE();
+            }
+        }
+    };
+    std::integral_constant<int, 0> C0, K0;
+    std::integral_constant<int, 1> C1, K1;
+    std::integral_constant<int, 2> K2;
+    std::integral_constant<int, 3> K3;
+    std::integral_constant<int, -1> NODMA;
+
+    std::true_type YES;
+    std::false_type NO;
+    // one K tile.  H1: tile t+1 exists (its W is staged here, its first fragments are read here);  H2: tile t+2 exists (its A is staged here)
+    auto ktile = [&](int t, auto h1c, auto h2c) __attribute__((always_inline)) {
+        constexpr bool H1 = decltype(h1c)::value, H2 = decltype(h2c)::value;
+        const int b = t & 1;
+        const int cur = b * E_BUF, oth = (b ^ 1) * E_BUF;
+        if constexpr (H1) kstep(C0, K1, cur, YES, OPW, t + 1, b ^ 1);      // W of tile t+1 -> the other buffer (its A went there one tile ago / in the prologue)
+        else kstep(C0, K1, cur, YES, NODMA, 0, 0);
+        kstep(C1, K2, cur, YES, NODMA, 0, 0);
+        kstep(C0, K3, cur, YES, NODMA, 0, 0);
+        E_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)");          // this wave's reads of buffer b are complete; its pieces of tile t+1 have landed
+        E_BAR();
+        if constexpr (H2) kstep(C1, K0, oth, YES, OPA, t + 2, b);
+        else if constexpr (H1) kstep(C1, K0, oth, YES, NODMA, 0, 0);
+        else kstep(C1, K0, oth, NO, NODMA, 0, 0);
+    };
+
+    // prologue: tile 0 whole, the A tile of tile 1 behind it (W of tile 1 is staged by tile 0's first k-step)
+    for (int j = 0; j < 8; ++j) dma(OPA, j, 0, 0);
+    for (int j = 0; j < 8; ++j) dma(OPW, j, 0, 0);
+    if (nk > 1) {
+        for (int j = 0; j < 8; ++j) dma(OPA, j, 1, 1);
+        E_WAIT("s_waitcnt vmcnt(8)");          // tile 0 has landed (this wave's pieces); A of tile 1 may still fly
+    } else {
+        E_WAIT("s_waitcnt vmcnt(0)");
+    }
+    E_BAR();
+    fw[0][0] = *(lds_u32x4_t)(w_addr[0]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[0][i] = *(lds_u32x4_t)(a_addr[0] + i * 4096);
+#pragma unroll
+    for (int n = 1; n < NI; ++n) fw[0][n] = *(lds_u32x4_t)(w_addr[0] + n * 4096);
+    W4_KSTEP_FENCE();
+    int t = 0;
+    for (; t + 2 < nk; ++t) ktile(t, YES, YES);
+    if (nk >= 2) { ktile(t, YES, NO); ++t; }
+    ktile(t, NO, NO);
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("s_nop 7" : "+v"(acc[n][i]));      // MFMA result -> VALU read
+    __syncthreads();                                       // every wave is done with the operand buffers: the C tile may overwrite them
+    gemm256_epilogue<MI, NI, TN, false, 256>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// "w4r": the four-wave tile fed THROUGH REGISTERS.  What the w4 kernel above showed (tools/gemm_ab.py, profiles/r6e_*): with its global loads taken out the
+// loop runs 1504 TFLOP/s on the K = 8960 shape (the eight-wave kernel: 1344; hipBLASLt: 1485) — with them 1200: a `buffer_load ... lds` costs its wave ~60
+// cycles of issue (MI355X_MICROARCH.md), a lone wave has no partner to multiply meanwhile, and sixteen pieces per K tile leave the matrix pipe idle a fifth of
+// the time wherever they are placed.  Here the operands take the detour the vendor kernels take: plain buffer_load_dwordx4 into registers (two sets of 64 —
+// a wave's 16 KiB share of a K tile — beside 256 accumulators and 64 fragment registers), written to LDS with ds_write_b128 one tile later.  The staging
+// registers are a third and fourth pipeline stage: tile t+3 is requested while tile t multiplies (a window of ~3000 cycles instead of ~1000), and no wait at
+// the barrier concerns vector memory at all.  Same LDS image (the source-side swizzle: lane-linear 16-byte writes), same MFMA order: the same bits.
+//   tile t (parity P = t & 1; LDS buffer P holds it; register set P holds tile t+2, requested during tile t-1):
+//   k-step 0   read k-step 1          request A of tile t+3 -> set P^1 (8 loads, one per MFMA of the second half)
+//   k-step 1   read k-step 2          request W of tile t+3 -> set P^1
+//   k-step 2   read k-step 3
+//   s_waitcnt lgkmcnt(0) (this wave's reads of buffer P and its writes of tile t+1 into buffer P^1 are complete), s_barrier
+//   k-step 3   read k-step 0 of tile t+1 (buffer P^1)          write set P (tile t+2) -> buffer P, one ds_write_b128 per MFMA
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gemm_bf16_nt_w4r_kernel(SviGemmArgs g, int tiles_m, int tiles_n, int GM) {
+    constexpr int MI = 4, NI = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    const int group = swz / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = swz - group * GM * tiles_n;
+    const int tile_n = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n * gm);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+    if (g.W2 && n0 >= g.n_split) {
+        g.W = g.W2 - (size_t)g.n_split * g.ldw;
+        g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
+    }
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, (int)(((unsigned)(g.M - 1) * (unsigned)g.lda + (unsigned)g.K) * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, (int)(((unsigned)(g.N - 1) * (unsigned)g.ldw + (unsigned)g.K) * 2u), 0x00020000);
+    const int r8 = wave * 8 + (lane >> 3);
+    const int c8 = (lane & 7) ^ ((r8 >> 1) & 7);
+    const int a_vo = (r8 * g.lda + c8 * 8) * 2, w_vo = (r8 * g.ldw + c8 * 8) * 2;
+    const unsigned a_so0 = (unsigned)m0 * (unsigned)g.lda * 2u, w_so0 = (unsigned)n0 * (unsigned)g.ldw * 2u;
+    const unsigned a_j = 32u * (unsigned)g.lda * 2u, w_j = 32u * (unsigned)g.ldw * 2u;
+    const int nk = g.K / BK;
+    const int st_addr = lds0 + wave * 1024 + lane * 16;          // this lane's 16 bytes of piece 0 of the A tile of buffer 0 (piece j: + j * 4096; W: + 2 * E_HALF)
+    u32x4 sa[2][8], sw[2][8];                                    // the two staging sets: a wave's 8 + 8 pieces of one K tile each
+    auto gload = [&](auto opc, auto setc, int j, int kt) __attribute__((always_inline)) {
+        constexpr int op = decltype(opc)::value, S = decltype(setc)::value;
+        // a K tile past the last one is requested at an offset beyond the descriptor's range: the request returns zeros without touching memory, so the
+        // loop's last tiles run the same instruction stream as every other (what they stage is never read)
+        const unsigned kb = kt < nk ? (unsigned)kt * (BK * 2) : 0x80000000u;
+        if constexpr (op == 0) sa[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_vo, (int)(a_so0 + kb + (unsigned)j * a_j), 0);
+        else sw[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo, (int)(w_so0 + kb + (unsigned)j * w_j), 0);
+    };
+    typedef __attribute__((address_space(3))) u32x4* lds_w_u32x4_t;
+    auto swrite = [&](auto opc, auto setc, int j, int boff) __attribute__((always_inline)) {
+        constexpr int op = decltype(opc)::value, S = decltype(setc)::value;
+        if constexpr (op == 0) *(lds_w_u32x4_t)(st_addr + boff + j * 4096) = sa[S][j];
+        else *(lds_w_u32x4_t)(st_addr + boff + 2 * E_HALF + j * 4096) = sw[S][j];
+    };
+    std::integral_constant<int, 0> OPA, S0;
+    std::integral_constant<int, 1> OPW, S1;
+
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][i][r] = 0.f;
+    int a_addr[4], w_addr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_addr[kk] = lds0 + lds_tile_off(wm * 128 + l31, 2 * kk + hi);
+        w_addr[kk] = lds0 + 2 * E_HALF + lds_tile_off(wn * 128 + l31, 2 * kk + hi);
+    }
+    u32x4 fa[2][MI], fw[2][NI];
+    // one k-step: 16 MFMAs on fragment set CUR; MFMAs 0..7 are each followed by one LDS read of the next k-step (set CUR^1, from buffer offset rbuf at k-step
+    // RK).  MODE: 0 nothing more; 1 / 2: MFMAs 8..15 each request one A / W piece of K tile xkt into staging set SET; 3: every MFMA is followed by one
+    // ds_write_b128 of staging set SET (A pieces behind MFMAs 0..7, W pieces behind 8..15) into the buffer at offset xoff
+    auto kstep = [&](auto curc, auto rkc, int rbuf, auto readc, auto modec, auto setc, int xkt, int xoff) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(curc)::value, RK = decltype(rkc)::value, MODE = decltype(modec)::value;
+        constexpr bool do_read = decltype(readc)::value;
+        constexpr int NXT = CUR ^ 1;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int j = n * MI + i;
+                acc[n][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[CUR][n]), __builtin_bit_cast(bf16x8, fa[CUR][i]), acc[n][i], 0, 0, 0);
+                if constexpr (do_read) {
+                    if (j == 0) fw[NXT][0] = *(lds_u32x4_t)(w_addr[RK] + rbuf);
+                    else if (j >= 1 && j <= 4) fa[NXT][j - 1] = *(lds_u32x4_t)(a_addr[RK] + rbuf + (j - 1) * 4096);
+                    else if (j >= 5 && j <= 7) fw[NXT][j - 4] = *(lds_u32x4_t)(w_addr[RK] + rbuf + (j - 4) * 4096);
+                }
+                if constexpr (MODE == 1) { if (j >= 8) gload(OPA, setc, j - 8, xkt); }
+                if constexpr (MODE == 2) { if (j >= 8) gload(OPW, setc, j - 8, xkt); }
+                if constexpr (MODE == 3) {
+                    if (j < 8) swrite(OPA, setc, j, xoff);
+                    else swrite(OPW, setc, j - 8, xoff);
+                }
+                W4_KSTEP_FENCE();
+            }
+        }
+    };
+    std::integral_constant<int, 0> C0, K0, M0_;
+    std::integral_constant<int, 1> C1, K1, M1_;
+    std::integral_constant<int, 2> K2, M2_;
+    std::integral_constant<int, 3> K3, M3_;
+    std::true_type YES;
+    std::false_type NO;
+    // one K tile of parity P (every tile runs this one stream: requests for tiles past the end return zeros, what is written or read for them is never used)
+    auto ktile = [&](int t, auto pc) __attribute__((always_inline)) {
+        constexpr int P = decltype(pc)::value;
+        std::integral_constant<int, P> SP;
+        std::integral_constant<int, P ^ 1> SQ;
+        constexpr int cur = P * E_BUF, oth = (P ^ 1) * E_BUF;
+        kstep(C0, K1, cur, YES, M1_, SQ, t + 3, 0);
+        kstep(C1, K2, cur, YES, M2_, SQ, t + 3, 0);
+        kstep(C0, K3, cur, YES, M0_, SQ, 0, 0);
+        E_WAIT("s_waitcnt lgkmcnt(0)");          // this wave's reads of buffer P are complete, and its writes of tile t+1 into buffer P^1 (previous tile) have landed
+        E_BAR();
+        kstep(C1, K0, oth, YES, M3_, SP, 0, cur);
+    };
+
+    // prologue: tiles 0 and 1 into LDS through the staging sets, tile 2 requested into set 0 (tile 3 is requested by tile 0's first k-steps into set 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gload(OPA, S0, j, 0); gload(OPW, S0, j, 0); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gload(OPA, S1, j, 1); gload(OPW, S1, j, 1); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { swrite(OPA, S0, j, 0); swrite(OPW, S0, j, 0); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gload(OPA, S0, j, 2); gload(OPW, S0, j, 2); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { swrite(OPA, S1, j, E_BUF); swrite(OPW, S1, j, E_BUF); }
+    E_WAIT("s_waitcnt lgkmcnt(0)");
+    E_BAR();
+    fw[0][0] = *(lds_u32x4_t)(w_addr[0]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[0][i] = *(lds_u32x4_t)(a_addr[0] + i * 4096);
+#pragma unroll
+    for (int n = 1; n < NI; ++n) fw[0][n] = *(lds_u32x4_t)(w_addr[0] + n * 4096);
+    W4_KSTEP_FENCE();
+    for (int t = 0; t < nk; t += 2) {                      // both parities per trip: the staging sets and LDS buffers are named at compile time
+        ktile(t, S0);
+        ktile(t + 1, S1);                                   // (the launcher sends an odd number of K tiles to the eight-wave kernel)
+    }
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("s_nop 7" : "+v"(acc[n][i]));
+    __syncthreads();
+    gemm256_epilogue<MI, NI, TN, false, 256>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, 0);
+}
+
+#endif  // SVI_GEMM_EXPERIMENTS
 
 // -------------------------------------------------------------------------------------------------
 // Skinny-M kernel (SviGemmArgs.skinny, M <= 128): the text encoder's projections have 10^1..10^2 rows against 4096..10240 columns —
@@ -1018,6 +1364,10 @@ int svi_gemm_choose(const SviGemmArgs& g, int ncu) {
     const long r256 = ((long)tm_s * ((selN + TN - 1) / TN) + ncu - 1) / ncu, r192 = ((long)tm_s * ((selN + 192 - 1) / 192) + ncu - 1) / ncu;
     const bool better = (double)r192 * 0.75 * 1.08 < (double)r256 * 0.97;
     if (g.N >= 192 && (sw.gemm_kernel == 192 || (sw.gemm_kernel == 0 && better))) return 192;
+#ifdef SVI_GEMM_EXPERIMENTS
+    if (sw.gemm_kernel == 265 && ((g.K / BK) & 1)) return SVI_GEMM_DEFAULT_256;          // the register-fed four-wave loop walks K tiles in pairs
+    if (sw.gemm_kernel == 264 || sw.gemm_kernel == 265) return sw.gemm_kernel;
+#endif
     if (sw.gemm_kernel == 259 || sw.gemm_kernel == 260) return sw.gemm_kernel;
     return SVI_GEMM_DEFAULT_256;
 }
@@ -1100,6 +1450,14 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
             const int tn3 = (g.N + TN3 - 1) / TN3;
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel<2, 192>), LDS256_BYTES));
             hipLaunchKernelGGL((gemm_bf16_nt_256e_kernel<2, 192>), dim3(tm * tn3), dim3(512), LDS256_BYTES, st, g, tm, tn3, sw.gemm_gm ? sw.gemm_gm : (tn3 >= 16 ? 5 : 4), abl);
+#ifdef SVI_GEMM_EXPERIMENTS
+        } else if (kind == 265) {      // four waves, operands staged through registers
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_w4r_kernel), LDS256_BYTES));
+            hipLaunchKernelGGL(gemm_bf16_nt_w4r_kernel, dim3(tm * tn), dim3(256), LDS256_BYTES, st, g, tm, tn, gm_rows);
+        } else if (kind == 264) {      // four waves, 128 x 128 per wave
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_w4_kernel), LDS256_BYTES));
+            hipLaunchKernelGGL(gemm_bf16_nt_w4_kernel, dim3(tm * tn), dim3(256), LDS256_BYTES, st, g, tm, tn, gm_rows);
+#endif
         } else if (kind == 260) {
             SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_256e_kernel<2, 256>), LDS256_BYTES));
             hipLaunchKernelGGL((gemm_bf16_nt_256e_kernel<2, 256>), dim3(tm * tn), dim3(512), LDS256_BYTES, st, g, tm, tn, gm_rows, abl);

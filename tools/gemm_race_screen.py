@@ -25,7 +25,7 @@ for it in range(iters):
     b = torch.randn(N, generator=g, device=dev).to(torch.bfloat16); gate = torch.randn(N, generator=g, device=dev); res = torch.randn((M, N), generator=g, device=dev).to(torch.bfloat16)
     outs = {}
     hog = it % 2 == 1
-    for kind in (128, 259, 260, 192):
+    for kind in (128, 259, 260, 192) + ((264, 265) if os.environ.get("SVI_GEMM_EXPERIMENTS") else ()):
         if kind == 192 and N < 192:
             continue
         L.set_switch("SVI_GEMM_KERNEL", kind)
