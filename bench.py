@@ -951,8 +951,10 @@ def main() -> None:
         "dtype": ("bf16 (" + ", ".join((["MLP GEMMs"] if args.fp8_mfma else []) + (["self-attention QK^T"] if fp8_attn_on else [])) + ": MX fp8 e4m3, opt-in)")
                  if (args.fp8_mfma or fp8_attn_on) else "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
         "config": {"workload": wl["desc"] if window is None else
-                   f"BASELINE configs[2] on {world} GPU(s): rolling window of {window['resident']['clips']} clips (seed = k x 42, 2 prompts cycled, clip k -> rank k mod N), "
-                   f"each {wl['desc']}", "value_is": value_src, **full_cfg, "window": window, "step": (f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; the pose condition enters the conditional branch only, so the two "
+                   f"BASELINE configs[2] on {world} GPU(s), INDEPENDENT-clip form (T2V: a clip depends on its prompt and seed only): rolling window of "
+                   f"{window['resident']['clips']} clips (seed = k x 42, 2 prompts cycled, clip k -> rank k mod N), each {wl['desc']}.  The reference's I2V rolling "
+                   f"window hands clip k's last frames to clip k+1 (test_svi.py:472-476): one stream's clips are sequential there (svi_hip.StreamLoop) and ranks take "
+                   f"whole streams, so this figure is an upper bound for a single I2V stream's multi-GPU throughput", "value_is": value_src, **full_cfg, "window": window, "step": (f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; the pose condition enters the conditional branch only, so the two "
                                                     "forwards share nothing) + CFG + Euler") if wl.get("pose") else
                    f"1 scheduler step = cond+uncond DiT forward ({NL} blocks each; block 0's self-attention, whose operands are identical in both, is computed once — outputs bit-identical to two separate forwards) + CFG + Euler",
                    "cfg_pair_stacked": bool(stacked),       # behind the shared block-0 self-attention, every row-local kernel runs once over both branches' rows (2 L); bit-identical

@@ -27,13 +27,16 @@ def generate_noise(shape, seed=None, device="cpu", dtype=torch.float16):
     return torch.randn(shape, generator=generator, device=device, dtype=dtype)
 
 
-def _release_stream_buffers(stream) -> None:
+def _release_stream_buffers(stream) -> bool:
+    """True when the library's buffers of `stream` were released (False: a capture is running on this thread — the release drains the device — or the
+    device / library is gone)."""
     try:
         if torch.cuda.is_current_stream_capturing():      # the release drains the device: illegal inside another loop's capture — leave the buffers
-            return
+            return False
         L.release_stream_buffers(stream)
+        return True
     except Exception:      # a finalizer must not raise (device gone, library unloaded)
-        pass
+        return False
 
 
 class DenoiseLoop:
@@ -135,17 +138,27 @@ class DenoiseLoop:
         self._slots, self._slot_src = {}, {}
         if self.resident and self.dit._ctx_cache_on:
             self.dit.context_cache(False)
+        self._retire_capture_stream()                    # the stream's end also ends its capture stream and the library's buffers keyed to it
 
     def drop_graph(self) -> None:
         """Forget the captured step (a later graphed step captures again)."""
         self._graph = None
 
-    def _retire_capture_stream(self) -> None:
+    def _retire_capture_stream(self) -> bool:
+        """Release the library's per-stream buffers of this loop's capture stream and forget the stream.  When the release cannot happen now (another loop's
+        capture is running on this thread) the stream AND its finalizer are kept: a later release() / close() / garbage collection still frees the ~100 MB the
+        library holds for it at the C2 size (the finalizer used to be spent by the skipped attempt)."""
         fin = getattr(self, "_stream_finalizer", None)
-        if fin is not None and fin.alive:
-            fin()                                        # releases the library's buffers of that stream, once
+        st = self._capture_stream
+        if st is None:
+            return True
+        if not _release_stream_buffers(st):
+            return False
+        if fin is not None:
+            fin.detach()                                 # the buffers are gone: nothing left for the finalizer to do
         self._stream_finalizer = None
         self._capture_stream = None
+        return True
 
     def release(self) -> None:
         """Retire this loop's capture stream: the captured step and the library's per-stream buffers keyed to that stream are freed

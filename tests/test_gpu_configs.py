@@ -63,6 +63,53 @@ def test_c1_end_to_end_vs_reference(hip, vae, golden):
     assert re2e < 5e-2, (re2e, mxe)
 
 
+def test_c1_fifty_steps_vs_reference(hip, golden):
+    """The headline's HORIZON: fifty CFG-5 flow-match steps — the loop of svi_video.py:392-421 with flow_match.py:53-64's update —
+    on the C1 grid (1280 tokens, the 30-layer 1.3B architecture), against the reference's own fifty steps in fp32 and, as the yardstick, the reference's own
+    bf16 run of the same loop (golden/c1_50step.npz: latents after steps 1, 5, 10, 20, 30, 40, 50).  Stated bound at every kept step:
+        HIP vs the reference's fp32 latents <= max(5e-2, 1.5 x the reference's own bf16-vs-fp32 gap at that step)
+    and the hipGraph-replayed loop gives the eager loop's bits."""
+    g = golden("c1_50step.npz")
+    keep = [int(k) for k in g["steps"]]
+    assert keep == list(synth.C1_50_KEEP)
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **cfg).items()}
+    m = hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=synth.num_heads_of(cfg), **cfg)
+    del sd
+    noise = hip.generate_noise((1, 16, 5, 32, 32), seed=0, device="cpu", dtype=torch.float32)
+    pos = dev(torch.from_numpy(synth.text_context(seed + 1, 512, cfg["text_dim"], 64)))
+    neg = dev(torch.from_numpy(synth.text_context(seed + 2, 512, cfg["text_dim"], 64)))
+    ref16 = synth.bf16_from_bits(g["latents_bf16_bits"])
+
+    def run(graph):
+        loop = hip.DenoiseLoop(m, graph=graph)
+        loop.scheduler.set_timesteps(50, shift=5.0)
+        lat = dev(noise).to(torch.bfloat16).contiguous().clone()
+        ts = loop.scheduler.timesteps.to("cuda", torch.float32)
+        kept = []
+        m.context_cache(True)
+        try:
+            for i, t in enumerate(loop.scheduler.timesteps):
+                loop.step(lat, ts[i:i + 1], loop.scheduler.step_delta(t), pos, neg, 5.0)
+                if i + 1 in keep:
+                    kept.append(lat[0].clone())
+        finally:
+            loop.drop_graph()
+            m.context_cache(False)
+        return kept
+    eager, graphed = run(False), run(True)
+    rows = []
+    for j, step in enumerate(keep):
+        assert torch.equal(eager[j], graphed[j]), step                       # 49 replays of one captured step == 50 eager steps, bit for bit
+        r32, r16 = errs(graphed[j], g["latents_fp32"][j])[0], errs(graphed[j], ref16[j])[0]
+        gap = float(g["ref_gap"][j])
+        assert abs(rel_l2(ref16[j], g["latents_fp32"][j]) - gap) < 1e-6
+        rows.append((step, r32, r16, gap))
+        assert r32 <= max(5e-2, 1.5 * gap), (step, r32, gap)
+    assert torch.isfinite(graphed[-1].float()).all()
+    report("c1_50step", **{f"step_{s}": {"hip_vs_ref_fp32": a, "hip_vs_ref_bf16": b, "ref_bf16_vs_fp32": c} for s, a, b, c in rows})
+
+
 # ------------------------------------------------------------------------------------------------------------------ C2 VAE
 def test_vae_c2_size_vs_reference(vae, golden):
     g = golden("vae_c2.npz")

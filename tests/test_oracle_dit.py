@@ -191,3 +191,18 @@ def test_block_rows_is_the_block_on_those_rows():
         full = wdo.dit_block(sd, "blocks.0.", x, ctx, tm, rope, cfg, rounding=rounding)
         part = wdo.dit_block_rows(sd, "blocks.0.", x, ctx, tm, rope, cfg, rows, rounding=rounding)
         assert float((full[:, rows] - part).abs().max()) <= tol
+
+
+def test_fifty_step_fixture_is_what_the_generator_says(golden):
+    """golden/c1_50step.npz (tests/gen_golden.py gen_c1_50step: the REFERENCE's WanModel through fifty CFG-5 steps, fp32 and bf16): shapes, kept steps, and the
+    reference's own bf16-vs-fp32 drift recomputed from the stored latents — the yardstick of tests/test_gpu_configs.py::test_c1_fifty_steps_vs_reference.  (The
+    oracle's own fifty steps at this size take ~20 minutes of CPU: the oracle is pinned to the reference on the shorter fixtures above.)"""
+    g = golden("c1_50step.npz")
+    assert [int(s) for s in g["steps"]] == list(synth.C1_50_KEEP)
+    l32, l16 = g["latents_fp32"], synth.bf16_from_bits(g["latents_bf16_bits"])
+    assert l32.shape == l16.shape == (len(synth.C1_50_KEEP), 16, 5, 32, 32) and np.isfinite(l32).all() and np.isfinite(l16).all()
+    gaps = [rel_l2(a, b) for a, b in zip(l16, l32)]
+    assert np.allclose(gaps, g["ref_gap"], rtol=1e-6)
+    assert gaps[0] < 5e-3 < gaps[-1] < 5e-2                       # bf16 Euler updates drift: 2e-3 after one step, 3e-2 after fifty — inside the 5e-2 the loops are held to
+    # the first steps of this run are the ten-step fixture's schedule? no — another sigma ladder (50 vs 10 steps): the two fixtures only share weights, noise and prompts
+    assert not np.allclose(l32[2], golden("c1_e2e.npz")["latents_fp32"])
