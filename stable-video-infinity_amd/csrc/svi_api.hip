@@ -54,6 +54,7 @@ static SviSwitches parse_switches() {
     s.vae_dma = env_int("SVI_VAE_DMA", 0, 1);
     s.vae_up_phases = env_int("SVI_VAE_UP_PHASES", 0, 1);
     s.vae_tile_order = env_int("SVI_VAE_TILE_ORDER", 0, 1);
+    s.vae_pair = env_int("SVI_VAE_PAIR", 0, 1);
     s.mx8_fused = env_int("SVI_MX8_FUSED", 0, 1);
     s.qk_fused = env_int("SVI_QK_FUSED", 0, 1);
     s.attn_qk8 = env_int("SVI_ATTN_QK8", 0, 0) != 0;

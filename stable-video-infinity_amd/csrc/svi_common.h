@@ -66,6 +66,8 @@ struct SviSwitches {
     int vae_no_x2h = 0;          // SVI_VAE_X2H = 0 : the three-term bf16 convolution also where the two-term fp16 form applies (same parity bounds)
     int vae_dma = 1;             // SVI_VAE_DMA = 0 : residual-block convolutions split their fp32 input on the fly (conv_igemm_x3_kernel<true>) instead of reading
                                  // the fp16 word pairs the producing RMS_norm wrote, staged by LDS-DMA (conv_dma2h_kernel); bit-identical results
+    int vae_pair = 1;            // SVI_VAE_PAIR = 0 : the residual-block convolutions one 256-pixel tile per workgroup (conv_dma2h_kernel<3>) instead of two tiles that share
+                                 // every K step's weights (conv_dma2h_pair_kernel: 26 % fewer bytes through the LDS fill path per MFMA; bit-identical)
     int vae_tile_order = 1;      // SVI_VAE_TILE_ORDER = 0 : the plane-fed convolution's tiles in pixel order (one frame after the other) instead of groups of ~16 image
                                  // rows walked through all frames (same results bit for bit; which order finds its earlier frames' rows still cached)
     int vae_up_phases = 1;       // SVI_VAE_UP_PHASES = 0 : the convolution behind a nearest x2 upsample as ONE 3x3 convolution reading through the upsample (9 taps)

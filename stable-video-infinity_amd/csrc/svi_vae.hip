@@ -675,6 +675,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_x3_kernel(ConvP p) {
 // channels of the [pixel][ld_out] row as zeros).
 template <int NB>
 __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
+#ifdef SVI_D2_DENSE      // timing experiment (results wrong): every DMA piece reads 1 KiB of CONTIGUOUS memory, as a chunk-major plane layout would give
+    p.ld_in = 32; p.ld_w3 = 32;
+#endif
     constexpr int WP = 2 * NB;                       // 1 KiB weight pieces per (x-tap, plane): 32 NB rows of 64 B
     constexpr int NPIECE = 34 + 6 * WP;              // per K step: 34 activation pieces + the weights of three x-taps x two planes
     constexpr int D2_SLOTS = (NPIECE + 7) / 8;       // DMA instructions per wave and step
@@ -769,11 +772,17 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
         for (int i = 0; i < D2_SLOTS; ++i) {
             const int q = wave + 8 * i;
             if (q < 34) {
+#ifdef SVI_D2_SKIP_A
+                if (it_rt | it_cc) continue;
+#endif
                 const int pl = q / 17, r16 = q % 17;
                 const unsigned off = ((s_mask[i] >> it_rt) & 1u) ? s_off[i] + d_act : OOB;
                 if (pl == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lptr_t)(As + r16 * 1024), 16, off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lptr_t)(As + D2_A_PLANE + r16 * 1024), 16, off, 0, 0, 0);
             } else if (q < NPIECE) {
+#ifdef SVI_D2_SKIP_W
+                if (it_rt | it_cc) continue;
+#endif
                 const int w = q - 34, tc = w / (2 * WP), pl = (w % (2 * WP)) / WP, r16 = w % WP;
                 const unsigned off = s_off[i] == OOB ? OOB : s_off[i] + d_w;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + (tc * 2 + pl) * X3_W_PLANE + r16 * 1024), 16, off, 0, 0, 0);
@@ -883,6 +892,261 @@ __global__ __launch_bounds__(512, 2) void conv_dma2h_kernel(ConvP p) {
     }
 }
 
+// =================================================================================================
+// conv_dma2h_kernel<3> on TWO pixel tiles per workgroup that share every K step's weights (round 6).
+// What the fill ablations say (tools/vae_ab.py on variant builds, profiles/r6i_vae_fill_ablation.txt, C2 decode 948 ms): without the weight pieces after
+// the first step 674 ms, without the activation pieces 829 ms — the 36 KiB of weights every workgroup pulls per step (the same lines, for all 256 CUs at once)
+// cost more than twice the 34 KiB of activations, and the matrix pipe is busy 47 % of the time because a step's 70 KiB take longer to arrive than its 54
+// MFMAs per wave take to run.  Two tiles per workgroup halve the weight traffic per MFMA without more LDS: the weights are double-buffered as before
+// (2 x 36 KiB), the two tiles' activation strips each have ONE buffer (2 x 34 KiB) and take turns — while tile 0's strip multiplies, tile 1's strip of
+// the same step and half of the next step's weights stream in; while tile 1's multiplies, tile 0's strip of the NEXT step and the other half:
+//   phase (k, 0)   MFMAs: tile 0 x W(k) from strip buffer 0      DMA: strip of tile 1, step k   -> buffer 1;  W(k+1) pieces 0..15  -> W[(k+1) & 1]
+//   barrier        (strip buffer 1 and what landed are visible; buffer 0 is free)
+//   phase (k, 1)   MFMAs: tile 1 x W(k) from strip buffer 1      DMA: strip of tile 0, step k+1 -> buffer 0;  W(k+1) pieces 16..35 -> W[(k+1) & 1]
+//   barrier
+// 52 KiB instead of 70 per 54 MFMAs and wave, the same 140 KiB of LDS, the same products in the same order per pixel: bit-identical to conv_dma2h_kernel<3>
+// (SVI_VAE_PAIR=0 runs that one).  Measured (tools/vae_ab.py c2 ab-pair, same job): decode 957 -> 916 ms, encode 622 -> 609 ms — a quarter of what the byte
+// count promised.  Tried on top, bit-identical, and dropped (profiles/r6i_vae_fill_ablation.txt): the SIMD's second wave placing its requests 27 MFMAs into
+// the phase instead of at its start (-0.7 %); the pieces fetched into registers one phase ahead and written with ds_write_b128 (a whole phase more for them to
+// arrive: +12 %, slower — two instructions per piece); every piece reading 1 KiB of contiguous memory, as a chunk-major plane layout would give (-8 % at most,
+// wrong results: not built).  What the step waits for is therefore neither the bytes, nor the issue of the requests, nor their latency alone.
+// =================================================================================================
+#define D2P_W_STAGE (6 * X3_W_PLANE)             // 36 KiB: three x-taps x two planes x [96][64 B]
+#define D2P_LDS (2 * D2P_W_STAGE + 2 * 2 * D2_A_PLANE)
+__global__ __launch_bounds__(512, 2) void conv_dma2h_pair_kernel(ConvP p) {
+    constexpr int NB = 3, WP = 2 * NB;
+    constexpr int A_SLOTS = 5, W_SLOTS = 5;          // per wave: strip pieces q = wave + 8 i < 34, weight pieces w = wave + 8 i < 36
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Wbuf = smem;                         // W[0] | W[1]
+    char* const Sbuf = smem + 2 * D2P_W_STAGE;       // strip buffer 0 | 1, each two planes of [272][64 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long HoWo = (long)p.Ho * p.Wo;
+    const long P_total = (long)p.To * HoWo;
+    const int ncob = (p.Cout + NB * 32 - 1) / (NB * 32);
+    const long pair = blockIdx.x / ncob;
+    const int cob = (int)(blockIdx.x - pair * ncob);
+    const int co0 = cob * NB * 32;
+    const int nchunk = p.Cin >> 5;
+    const int nrow = p.kt * p.kh;
+    const int nk = nrow * nchunk;
+    const unsigned OOB = 0xFFF00000u;
+
+    long p0[2];
+    int t_base = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        long tile = 2 * pair + s;                    // (a pair's second tile may lie past the last one: every pixel of it is masked out, nothing is stored)
+        if (p.ord_T > 0) {
+            const long per_group = (long)p.ord_T * p.ord_G;
+            const long n_tiles = (long)p.ord_T * p.ord_Lf;
+            if (tile < n_tiles) {
+                const int full = p.ord_Lf / p.ord_G;
+                const long g = tile / per_group;
+                int gl = p.ord_G;
+                long r = tile - g * per_group, gbase = g * p.ord_G;
+                if (g >= full) { gl = p.ord_Lf - full * p.ord_G; r = tile - (long)full * per_group; gbase = (long)full * p.ord_G; }
+                const int t = (int)(r / gl), j = (int)(r - (long)t * gl);
+                tile = (long)t * p.ord_Lf + gbase + j;
+            }
+        }
+        p0[s] = (long)p.t_begin * HoWo + tile * X3_PIX;
+        const int t_first = (int)(max(min(p0[s] - 1, P_total - 1), 0L) / HoWo);
+        t_base = min(t_base, max(t_first * p.st - p.pt, 0));
+    }
+    // ---- per-slot DMA bookkeeping
+    unsigned a_off[2][A_SLOTS], a_mask[2][A_SLOTS], w_off[W_SLOTS];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int q = wave + 8 * i;
+            a_off[s][i] = OOB; a_mask[s][i] = 0;
+            if (q < 34) {
+                const int r16 = q % 17, row = r16 * 16 + (lane >> 2);
+                const long pp = p0[s] - 1 + row;
+                const bool pix = pp >= 0 && pp < P_total;
+                const long qq = pix ? pp : 0;
+                const int at = (int)(qq / HoWo);
+                const int rem = (int)(qq - (long)at * HoWo);
+                const int ay = rem / p.Wo, ax = rem - ay * p.Wo;
+                const int bt = at * p.st - p.pt, by = ay - p.ph;
+                unsigned m = 0;
+                for (int rt = 0; rt < nrow; ++rt) {
+                    const int ta = rt / p.kh, tb = rt - ta * p.kh;
+                    const int ti = bt + ta, yi = by + tb;
+                    bool ok = pix && ti >= 0 && ti < p.Ti && yi >= 0 && yi < p.Hi;
+                    if (p.zero_frame0 && ti == 0) ok = false;
+                    if (ok) m |= 1u << rt;
+                }
+                a_mask[s][i] = m;
+                const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+                a_off[s][i] = (unsigned)((((bt - t_base) * p.Hi + by) * p.Wi + ax) * p.ld_in) * 2u + (unsigned)chunk * 16u;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < W_SLOTS; ++i) {
+        const int w = wave + 8 * i;
+        w_off[i] = OOB;
+        if (w < 6 * WP) {
+            const int tc = w / (2 * WP), pl = (w % (2 * WP)) / WP, row = (w % WP) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            if (co0 + row < p.Cout) w_off[i] = (unsigned)((pl * p.plane_w3 + ((long)tc * p.Cout + co0 + row) * p.ld_w3 + chunk * 8) * 2);
+        }
+    }
+    const long base_el = (long)t_base * p.Hi * p.Wi * p.ld_in;
+    const long rem_bytes = ((long)p.Ti * p.Hi * p.Wi * p.ld_in - base_el) * 2;
+    const int win = (int)(unsigned)min(rem_bytes, 0xFFE00000L);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.in_h + base_el), 0, win, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.in_l + base_el), 0, win, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2h), 0, (int)(unsigned)min((long)2 * p.plane_w3 * 2, 0xFFE00000L), 0x00020000);
+    bool left_ok[2], right_ok[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const long pp = min(p0[s] + 32 * wave + l31, P_total - 1);
+        const int ax = (int)(pp % p.Wo);
+        left_ok[s] = ax > 0; right_ok[s] = ax < p.Wo - 1;
+    }
+
+    // K step iterators: `c*` = the step being multiplied, `n*` = the step after it
+    int c_rt = 0, c_cc = 0, c_ta = 0, c_tb = 0, n_rt = 0, n_cc = 0, n_ta = 0, n_tb = 0;
+    auto step_next = [&](int& rt, int& cc, int& ta, int& tb) {
+        if (++cc == nchunk) {
+            cc = 0; ++rt;
+            if (++tb == p.kh) { tb = 0; ++ta; }
+        }
+    };
+    auto request_strip = [&](auto sc, int rt, int cc, int ta, int tb) {          // tile S's strip of step (rt, cc) -> strip buffer S
+        constexpr int S = decltype(sc)::value;
+        char* As = Sbuf + S * 2 * D2_A_PLANE;
+        const unsigned d_act = (unsigned)(((ta * p.Hi + tb) * p.Wi) * p.ld_in) * 2u + (unsigned)cc * 64u;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int q = wave + 8 * i;
+            if (q < 34) {
+                const int pl = q / 17, r16 = q % 17;
+                const unsigned off = ((a_mask[S][i] >> rt) & 1u) ? a_off[S][i] + d_act : OOB;
+                if (pl == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lptr_t)(As + r16 * 1024), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lptr_t)(As + D2_A_PLANE + r16 * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    auto request_w = [&](int half, int rt, int cc, int wb) {                    // weight pieces [0, 16) (half 0) or [16, 36) (half 1) of step (rt, cc) -> W[wb]
+        char* Ws = Wbuf + wb * D2P_W_STAGE;
+        const unsigned d_w = (unsigned)((long)rt * p.kw * p.Cout * p.ld_w3 * 2) + (unsigned)cc * 64u;
+#pragma unroll
+        for (int i = 0; i < W_SLOTS; ++i) {
+            const int w = wave + 8 * i;
+            if ((i < 2) != (half == 0) || w >= 6 * WP) continue;
+            const int tc = w / (2 * WP), pl = (w % (2 * WP)) / WP, r16 = w % WP;
+            const unsigned off = w_off[i] == OOB ? OOB : w_off[i] + d_w;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + (tc * 2 + pl) * X3_W_PLANE + r16 * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][n][r] = 0.f;
+    const f16x8 zero8 = {(f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0};
+    // the 54 MFMAs of one (tile, step): exactly conv_dma2h_kernel's six sub-steps
+    auto multiply = [&](auto sc, int wb) {
+        constexpr int S = decltype(sc)::value;
+        const char* As = Sbuf + S * 2 * D2_A_PLANE;
+        const char* Ws = Wbuf + wb * D2P_W_STAGE;
+        f16x8 ah[2], al[2], wh[2][NB], wl[2][NB];
+        auto frags = [&](int sidx, int set) {
+            const int tc = sidx >> 1, ks = sidx & 1;
+            const bool live = tc == 0 ? left_ok[S] : tc == 2 ? right_ok[S] : true;
+            f16x8 h_ = *reinterpret_cast<const f16x8*>(As + x3_off(32 * wave + l31 + tc, 2 * ks + hi));
+            f16x8 l_ = *reinterpret_cast<const f16x8*>(As + D2_A_PLANE + x3_off(32 * wave + l31 + tc, 2 * ks + hi));
+            if (tc != 1) { h_ = live ? h_ : zero8; l_ = live ? l_ : zero8; }
+            ah[set] = h_; al[set] = l_;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                wh[set][n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
+                wl[set][n] = *reinterpret_cast<const f16x8*>(Ws + (tc * 2 + 1) * X3_W_PLANE + x3_off(32 * n + l31, 2 * ks + hi));
+            }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int sidx = 0; sidx < 6; ++sidx) {
+            const int set = sidx & 1;
+            if (sidx + 1 < 6) frags(sidx + 1, set ^ 1);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[S][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[set][n], ah[set], acc[S][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[S][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[set][n], al[set], acc[S][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[S][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[set][n], ah[set], acc[S][n], 0, 0, 0);
+        }
+    };
+    std::integral_constant<int, 0> T0;
+    std::integral_constant<int, 1> T1;
+
+    request_w(0, 0, 0, 0);
+    request_w(1, 0, 0, 0);
+    request_strip(T0, 0, 0, 0, 0);
+    step_next(n_rt, n_cc, n_ta, n_tb);               // n* = step 1
+    __syncthreads();                                 // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+    for (int k = 0; k < nk; ++k) {
+        const int wb = k & 1;
+        const bool more = k + 1 < nk;
+        request_strip(T1, c_rt, c_cc, c_ta, c_tb);
+        if (more) request_w(0, n_rt, n_cc, wb ^ 1);
+        multiply(T0, wb);
+        __syncthreads();                             // tile 1's strip and the first weight pieces have landed; every wave is done with strip buffer 0
+        if (more) {
+            request_strip(T0, n_rt, n_cc, n_ta, n_tb);
+            request_w(1, n_rt, n_cc, wb ^ 1);
+        }
+        multiply(T1, wb);
+        __syncthreads();                             // tile 0's next strip and W(k+1) have landed; every wave is done with strip buffer 1 and W[wb]
+        step_next(c_rt, c_cc, c_ta, c_tb);
+        step_next(n_rt, n_cc, n_ta, n_tb);
+    }
+
+    // ---- epilogue: conv_dma2h_kernel's, once per tile
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool with_res = p.out_mode == 0 && p.res;
+    const float inv_a = 1.0f / p.in_scale;
+    const int half = p.Cout >> 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const long pp = p0[s] + 32 * wave + l31;
+        if (pp >= P_total) continue;
+        const long po = pp + (long)p.t_out_off * HoWo;
+        long pq0 = 0;
+        if (p.out_mode != 0) {
+            const int t = (int)(pp / HoWo);
+            const long sp = pp - (long)t * HoWo;
+            pq0 = (long)(1 + 2 * (t - 1)) * HoWo + sp;
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i) {
+            const int n = i >> 2, rg = i & 3;
+            const int co = co0 + 32 * n + 8 * rg + 4 * hi;
+            if (co >= p.Cout) continue;
+            const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co) : zero4;
+            const f32x4 rv = with_res ? *reinterpret_cast<const f32x4*>(p.res + po * p.ld_res + co) : zero4;
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(p.w2_inv + co) * inv_a;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc[s][n][4 * rg + e] * sv[e] + bv[e]) + rv[e];
+            if (p.out_mode == 0) {
+                *reinterpret_cast<f32x4*>(p.out + po * p.ld_out + co) = v;
+            } else {
+                const int j = co >= half ? 1 : 0;
+                *reinterpret_cast<f32x4*>(p.out + (pq0 + (long)j * HoWo) * p.ld_out + (co - j * half)) = v;
+            }
+        }
+    }
+}
+
 // Can a convolution take its input as the producer's two fp16 planes (conv_dma2h_kernel)?  Decided BEFORE the producer runs.
 bool conv_planes_ok(const ConvP& p) {
     const bool vec_ok = (((uintptr_t)p.w2_inv | (uintptr_t)p.bias) & 15) == 0;
@@ -921,6 +1185,14 @@ svi_status launch_conv_planes(const ConvP& p, hipStream_t st) {
         const long nwg = ((pixels + X3_PIX - 1) / X3_PIX) * ((p.Cout + X3_CO - 1) / X3_CO);
         SVI_REQUIRE(nwg < (1L << 31), "conv: too many workgroups");
         dim3 grid((unsigned)nwg, 1), block(512);
+        if (svi_switches().vae_pair) {       // two tiles per workgroup sharing every step's weights (conv_dma2h_pair_kernel)
+            const long ntile = (pixels + X3_PIX - 1) / X3_PIX;
+            dim3 gridp((unsigned)(((ntile + 1) / 2) * ((p.Cout + X3_CO - 1) / X3_CO)), 1);
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_pair_kernel), D2P_LDS));
+            hipLaunchKernelGGL(conv_dma2h_pair_kernel, gridp, block, D2P_LDS, st, q);
+            SVI_LAUNCH_CHECK();
+            return SVI_OK;
+        }
         SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(conv_dma2h_kernel<3>), 2 * D2_STAGE));
         hipLaunchKernelGGL(conv_dma2h_kernel<3>, grid, block, 2 * D2_STAGE, st, q);
     }

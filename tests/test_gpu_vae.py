@@ -203,6 +203,26 @@ def test_plane_fed_convolutions_agree_with_the_on_the_fly_split(vae, shape):
     assert rd < 5e-6 and md < 5e-5 and re < 5e-6 and me < 5e-5, (rd, md, re, me)
 
 
+@pytest.mark.parametrize("shape", [(16, 3, 12, 20), (16, 2, 30, 52), (16, 2, 5, 3), (16, 1, 7, 9), (16, 4, 30, 52)])
+def test_two_tiles_per_workgroup_give_the_one_tile_kernels_bits(vae, shape):
+    """conv_dma2h_pair_kernel (round 6, the default: two 256-pixel tiles per workgroup share every K step's weights) against conv_dma2h_kernel<3>
+    (SVI_VAE_PAIR=0): the same products in the same order per pixel — decode and encode bit for bit, on grids with an odd number of tiles (the pair's second
+    tile lies past the end), tiles that straddle image rows and frames, one frame, and the frame-interleaved tile order (whole tiles per frame: 30 x 52 latent
+    = 240 x 416 px = 390 tiles per frame)."""
+    from svi_hip import _lib as L
+    v, _ = vae
+    z = torch.from_numpy(synth.randn(621, *shape)).cuda()
+    vid = torch.from_numpy(np.tanh(synth.randn(622, 3, 4 * (shape[1] - 1) + 1, 8 * shape[2], 8 * shape[3]))).cuda()
+    a_dec, a_enc = v.decode([z], device="cuda")[0], v.encode([vid], device="cuda")[0]
+    L.set_switch("SVI_VAE_PAIR", 0)
+    try:
+        b_dec, b_enc = v.decode([z], device="cuda")[0], v.encode([vid], device="cuda")[0]
+    finally:
+        L.set_switch("SVI_VAE_PAIR", None)
+    assert torch.isfinite(a_dec).all() and torch.isfinite(a_enc).all()
+    assert torch.equal(a_dec, b_dec) and torch.equal(a_enc, b_enc)
+
+
 @pytest.mark.parametrize("shape", [(16, 3, 12, 20), (16, 2, 30, 52), (16, 2, 5, 3), (16, 1, 7, 9)])
 def test_upsample_convolution_phases_agree_with_the_nine_tap_form(vae, shape):
     """The convolution behind a nearest x2 upsample (Resample upsample2d/3d, vae:120-131) as four 2x2 convolutions of the small image with

@@ -27,9 +27,11 @@ if "only-default" in sys.argv[1:]:             # for a kernel trace of the produ
     MODES = MODES[:1]
 if "ab-up" in sys.argv[1:]:
     MODES = [("x2h", {}), ("up9", {"SVI_VAE_UP_PHASES": "0"})]
+if "ab-pair" in sys.argv[1:]:
+    MODES = [("pair", {}), ("single", {"SVI_VAE_PAIR": "0"}), ("pair", {})]
 if "ab-order" in sys.argv[1:]:
     MODES = [("x2h", {}), ("pxord", {"SVI_VAE_TILE_ORDER": "0"}), ("x2h", {})]
-KEYS = ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32", "SVI_VAE_UP_PHASES", "SVI_VAE_TILE_ORDER")
+KEYS = ("SVI_VAE_X2H", "SVI_VAE_EXACT_FP32", "SVI_VAE_UP_PHASES", "SVI_VAE_TILE_ORDER", "SVI_VAE_PAIR")
 res = {}
 for name, env in MODES:
     for k in KEYS:
@@ -46,6 +48,9 @@ for name, env in MODES:
         del out
 for k in KEYS:
     _lib.set_switch(k, None)
+if "ab-pair" in sys.argv[1:]:
+    for what in ("decode", "encode"):
+        print(f"{what}: pair vs single bit-identical: {bool(torch.equal(res[('pair', what)], res[('single', what)]))}")
 base = "exact" if ("exact", "decode") in res else "x3" if ("x3", "decode") in res else MODES[-1][0]
 for what in ("decode", "encode") if len(MODES) > 1 else ():
     a = res[(base, what)]
