@@ -78,8 +78,10 @@ int32_t svi_abi_version(void);
 int32_t svi_device_count(void);
 
 /* A/B tooling: the library reads its environment switches (SVI_FLASH_KERNEL, SVI_FLASH_TWO_PASS, SVI_FLASH_SPLIT, SVI_GEMM_KERNEL, SVI_GEMM_GM,
- * SVI_CROSS_DEDUP, SVI_CROSS_FUSED, SVI_RMS_ROWS, SVI_QK_FUSED, SVI_MX8_FUSED, SVI_QK8_FUSED, SVI_VAE_EXACT_FP32, SVI_VAE_X2H, SVI_VAE_DMA, SVI_VAE_UP_PHASES, SVI_VAE_TILE_ORDER, SVI_T5_BUCKETS — all of them select between kernels that
- * compute the same result, bit for bit or within the stated parity bounds; csrc/svi_common.h SviSwitches) once, at first use; tools that flip them inside one process
+ * SVI_CROSS_DEDUP, SVI_CROSS_FUSED, SVI_RMS_ROWS, SVI_QK_FUSED, SVI_MX8_FUSED, SVI_QK8_FUSED, SVI_VAE_EXACT_FP32, SVI_VAE_X2H, SVI_VAE_DMA, SVI_VAE_UP_PHASES, SVI_VAE_TILE_ORDER, SVI_VAE_PAIR, SVI_T5_BUCKETS — all of them select between kernels that
+ * compute the same result, bit for bit or within the stated parity bounds — and SVI_WS_LIMIT_MB, a budget in MiB beyond which a DiT workspace is refused with
+ * SVI_ERR_OOM as if the allocation had failed (callers that share the device; the stacked CFG pair then falls back to its unstacked form, same bits);
+ * csrc/svi_common.h SviSwitches) once, at first use; tools that flip them inside one process
  * call this afterwards.  Switches that change results exist only in variant builds (-DSVI_ABLATIONS), never in the product — with ONE documented
  * exception, off by default: SVI_ATTN_QK8=1 selects the opt-in quantised-QK^T attention (every long-sequence attention call quantises Q and K to
  * MX e4m3, one E8M0 scale per 32 channels, and takes QK^T on v_mfma_scale_f32_32x32x64_f8f6f4; softmax and P·V unchanged).  Like svi_dit_ffn_mx8
