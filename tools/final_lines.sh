@@ -34,10 +34,19 @@ line default --gpus 1 --steps 20 --warmup 5
 line window --steps 5 --warmup 2 --window 3 --window-ab --no-cpu-baseline --no-full-clip
 line window_gloo_x2 --gpus 2 --transport gloo --steps 3 --warmup 1 --window 2 --no-cpu-baseline --no-full-clip
 line c1_window --workload c1 --steps 10 --warmup 3 --window 6 --window-ab --no-cpu-baseline --no-full-clip
-SVI_CROSS_FUSED=0 line cross_two_kernels --steps 10 --warmup 3 --no-cpu-baseline
-line no_graph --steps 10 --warmup 3 --no-graph --no-cpu-baseline
-line fp8_attn --steps 10 --warmup 3 --fp8-attn --no-cpu-baseline
-line fp8_mfma --steps 10 --warmup 3 --fp8-mfma --no-cpu-baseline
-line fp8_mfma_attn --steps 10 --warmup 3 --fp8-mfma --fp8-attn --no-cpu-baseline
+SVI_CROSS_FUSED=0 line cross_two_kernels --steps 10 --warmup 3 --no-cpu-baseline --no-vendor
+line no_graph --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-vendor
+line fp8_attn --steps 10 --warmup 3 --fp8-attn --no-cpu-baseline --no-vendor
+line fp8_mfma --steps 10 --warmup 3 --fp8-mfma --no-cpu-baseline --no-vendor
+line fp8_mfma_attn --steps 10 --warmup 3 --fp8-mfma --fp8-attn --no-cpu-baseline --no-vendor
 line c1 --workload c1 --steps 10 --warmup 3 --no-cpu-baseline
-line c4 --workload c4 --steps 3 --warmup 1 --no-cpu-baseline
+line c4 --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-vendor
+# round 6: the non-benign lines (peaky attention logits through learned-gain factors, a 200-token prompt on the streaming cross-attention kernel), the step beside a
+# live one-rank RCCL communicator, and the kernel-level sweeps they summarise
+line attn_gain_2 --steps 6 --warmup 2 --no-cpu-baseline --no-full-clip --no-vendor --no-vae --attn-gain 2
+line attn_gain_3 --steps 6 --warmup 2 --no-cpu-baseline --no-full-clip --no-vendor --no-vae --attn-gain 3
+line prompt_tokens_200 --steps 6 --warmup 2 --no-cpu-baseline --no-full-clip --no-vendor --no-vae --prompt-tokens 200
+line rccl_probe --steps 6 --warmup 2 --no-cpu-baseline --no-full-clip --no-vendor --no-vae --rccl-probe
+timeout 600 python tools/attn_stats.py --json gpurun_out/${TAG}_attn_stats.json > gpurun_out/${TAG}_attn_stats.txt 2>&1
+timeout 400 python tools/yardstick.py 7 --json gpurun_out/${TAG}_yardstick.json > gpurun_out/${TAG}_yardstick.txt 2>&1
+tail -8 gpurun_out/${TAG}_yardstick.txt

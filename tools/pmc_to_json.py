@@ -96,7 +96,7 @@ def main(tag):
             print(json.dumps({k: out.get(k) for k in ("kernel", "hbm_bytes", "mfma_busy_in_clock", "l2_hit_rate")}))
     # the fused cross-attention (flash_cross_resident_kernel: q read + o written, HBM-bound) and the VAE's strip convolution, when their passes were collected
     for key, pat, what in (("flash_cross", "flash_cross_resident_kernel", "cross-attention, L = 32760 query rows, 12 heads, 65 keys resident in LDS, q RMS-normalised as it is read"),
-                           ("vae_conv", "conv_dma2h_kernel<3>", "the VAE decoder's residual-block convolution (fp16 two-term, plane-fed strips)")):
+                           ("vae_conv", "conv_dma2h_pair_kernel", "the VAE decoder's residual-block convolution (fp16 two-term, plane-fed strips, two tiles per workgroup)")):
         p = os.path.join(ROOT, "gpurun_out", f"{tag}_{key}_pmc.txt")
         if not os.path.exists(p):
             continue
