@@ -342,6 +342,8 @@ def main() -> None:
     ap.add_argument("--fp8-mfma", action="store_true", help="opt-in MX-fp8 MLP (north_star 'bf16/fp8 MFMA'): FP8 weight storage + both MLP GEMMs of every block on "
                     "v_mfma_scale_f32_32x32x64_f8f6f4 with per-32-element activation scales.  Arithmetic the reference never performs (it computes in bf16): "
                     "a separately toleranced line (tests/test_gpu_mx8.py), never the headline")
+    ap.add_argument("--fp8-all", action="store_true", help="opt-in, same caveats: --fp8-mfma --fp8-attn AND the block's other six projections (self-attention q, k, V^T, o; "
+                    "cross-attention q, o) on the MX block-scaled fp8 matrix path (WanDiT.proj_fp8_mfma): every token-side GEMM of the step and QK^T on fp8")
     ap.add_argument("--fp8-attn", action="store_true", help="opt-in quantised QK^T (SVI_ATTN_QK8=1): every long-sequence self-attention quantises Q and K to MX e4m3 (one E8M0 "
                     "scale per 32 channels) and takes QK^T on v_mfma_scale_f32_32x32x64_f8f6f4; P·V stays bf16.  Arithmetic the reference never performs (its dispatch only "
                     "ACCEPTS a quantised-QK^T backend, wan_video_dit.py:116-147): a separately toleranced line (tests/test_gpu_attn_qk8.py), never the headline")
@@ -387,6 +389,8 @@ def main() -> None:
     if args.cpu_baseline_worker:
         cpu_baseline_worker()
         return
+    if args.fp8_all:
+        args.fp8_mfma = args.fp8_attn = True
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -466,6 +470,8 @@ def main() -> None:
     hb.mark("model-bound")
     if args.fp8_mfma:
         dit.ffn_fp8_mfma(True)
+    if args.fp8_all:
+        dit.proj_fp8_mfma(True)
     if args.fp8_attn:
         from svi_hip import _lib as _L
         _L.set_switch("SVI_ATTN_QK8", 1)
@@ -948,7 +954,7 @@ def main() -> None:
                    "c5": "denoised latent frames/sec, Wan2.1-I2V-14B + pose embedder (dance) 81f@832x480 50-step, FP8 weight storage"}[args.workload],
         "value": round(value, 5), "unit": "latent frames/s", "n_gpus": len(who), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.seq_parallel else "weak", "vs_baseline": None,
-        "dtype": ("bf16 (" + ", ".join((["MLP GEMMs"] if args.fp8_mfma else []) + (["self-attention QK^T"] if fp8_attn_on else [])) + ": MX fp8 e4m3, opt-in)")
+        "dtype": ("bf16 (" + ", ".join((["MLP GEMMs"] if args.fp8_mfma else []) + (["q / k / v / o and cross q / o projections"] if args.fp8_all else []) + (["self-attention QK^T"] if fp8_attn_on else [])) + ": MX fp8 e4m3, opt-in)")
                  if (args.fp8_mfma or fp8_attn_on) else "bf16", "data": "synthetic (random-init weights of the named architecture, seeded noise/context)",
         "config": {"workload": wl["desc"] if window is None else
                    f"BASELINE configs[2] on {world} GPU(s), INDEPENDENT-clip form (T2V: a clip depends on its prompt and seed only): rolling window of "
@@ -978,7 +984,9 @@ def main() -> None:
                    "hip_graph": bool(args.graph),
                    "attention": ("self-attention QK^T on the MX block-scaled fp8 matrix path (Q, K quantised per call: e4m3, one E8M0 scale per 32 channels), P·V and the softmax bf16 / fp32 — "
                                  "NOT the reference's arithmetic, opt-in, separately toleranced (tests/test_gpu_attn_qk8.py)") if fp8_attn_on else "bf16",
-                   "weights": ("float8_e4m3fn storage; MLP GEMMs on the MX block-scaled fp8 matrix path (activations e4m3 with one E8M0 scale per 32 elements), everything else "
+                   "weights": ("float8_e4m3fn storage; EVERY token-side GEMM of the block (MLP, self-attention q / k / V^T / o, cross-attention q / o) on the MX block-scaled fp8 matrix path "
+                               "(activations e4m3 with one E8M0 scale per 32 elements; prompt-side K / V bf16), everything else bf16 — NOT the reference's arithmetic, opt-in, separately toleranced") if args.fp8_all else
+                   ("float8_e4m3fn storage; MLP GEMMs on the MX block-scaled fp8 matrix path (activations e4m3 with one E8M0 scale per 32 elements), everything else "
                                "bf16 — NOT the reference's arithmetic, opt-in, separately toleranced") if args.fp8_mfma else
                    "float8_e4m3fn storage, cast to bf16 at bind (reference FP8 mode)" if args.fp8_storage else "bf16",
                    "outputs_finite": finite},

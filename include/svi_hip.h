@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SVI_HIP_ABI_VERSION 9
+#define SVI_HIP_ABI_VERSION 10
 
 typedef enum {
     SVI_OK = 0,
@@ -301,6 +301,19 @@ svi_status svi_gemm_mx8(const void* A8, int32_t lda, const void* a_scales, int32
                         svi_stream stream);
 svi_status svi_dit_bind_ffn_fp8(svi_dit* h, int32_t layer, int32_t which, const void* e4m3_weight);
 svi_status svi_dit_ffn_mx8(svi_dit* h, int32_t enable);
+/* ABI v10 (round 6) — the same opt-in arithmetic on the block's other six projections ("QKV/out-proj ... on bf16/fp8 MFMA" of the north star):
+ *   svi_gemm_mx8_wscaled   C[M,N] = bf16(A8[M,K] · dequant(W8[N,K])^T + bias): the block scales ([K/128][sc_rows], sc_rows a multiple of 256 covering N) belong to
+ *                          the W operand's rows, A carries unit scales — the transposed value projection V^T = Wv · X^T (A8 = the stored e4m3 weight, W8 = the
+ *                          quantised activation rows, bias along M).
+ *   svi_dit_bind_ffn_fp8   also takes which = 10 self_attn.q, 11 self_attn.k, 12 self_attn.v, 13 self_attn.o, 14 cross_attn.q, 15 cross_attn.o
+ *                          (blocks.<layer>.<module>.weight as stored e4m3 bytes [out, in]).
+ *   svi_dit_proj_mx8       route those six GEMMs of every block through the MX fp8 kernels (plain forwards and the stacked CFG pair; sequence-parallel shards keep
+ *                          bf16): the LayerNorm output is quantised once for q, k and V^T, the attention outputs once for each output projection, the cross-attention
+ *                          query's row statistic comes from the fp8 GEMM's epilogue as it does from the bf16 one.  The prompt-side K / V (context cache) stay bf16.
+ *                          Needs all six weights of every block bound; own oracle and tolerance (tests/test_gpu_mx8.py), bench.py --fp8-all; never a default. */
+svi_status svi_gemm_mx8_wscaled(const void* A8, int32_t lda, const void* W8, int32_t ldw, const void* w_scales, int32_t sc_rows, void* C, int32_t ldc,
+                                int32_t M, int32_t N, int32_t K, const void* bias, int32_t bias_along_m, svi_stream stream);
+svi_status svi_dit_proj_mx8(svi_dit* h, int32_t enable);
 
 /* Classifier-free-guidance combine + FlowMatchScheduler.step, fused (pipelines/svi_video.py:410,420;
  * schedulers/flow_match.py:53-64):  lat += (uncond + s*(cond-uncond)) * (sigma_next - sigma), bf16,

@@ -1,4 +1,4 @@
-"""CPU restatement of the opt-in MX-fp8 MLP path of the HIP backend (csrc/svi_gemm.hip mx8_quantize_kernel / gemm_mx8_nt_256_kernel).
+"""CPU restatement of the opt-in MX-fp8 MLP and projection paths of the HIP backend (csrc/svi_gemm.hip mx8_quantize_kernel / gemm_mx8_nt_256_kernel).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/ (and nothing else).  There is no reference counterpart to pin this to — the reference
 computes in bf16 and only STORES weights as float8_e4m3fn (test_svi.py:337, diffsynth/vram_management/layers.py:65-71) — so this file
@@ -51,3 +51,10 @@ def scale_table(e: Tensor, sc_rows: int) -> Tensor:
     out = torch.zeros((nb // 4, sc_rows), dtype=torch.int64)
     out[:, :r] = d.t()
     return out
+
+
+def mx8_linear_t(w: Tensor, x: Tensor, b=None) -> Tensor:
+    """The transposed projection C[M, N] = w[M, K] · dequant(quant(x[N, K]))^T + b[:, None] (svi_gemm_mx8_wscaled: the block scales belong to the W operand's rows)."""
+    q, e = mx8_quantize(x)
+    y = (w.double() @ mx8_dequantize(q, e).double().t()).float()
+    return y if b is None else y + b[:, None]

@@ -178,22 +178,27 @@ def modulated_norm(x: Tensor, shift: Tensor, scale: Tensor, eps: float, rnd) -> 
     return rnd(rnd(xn * rnd(1.0 + scale)) + shift)
 
 
-def self_attention(sd: Dict[str, Tensor], p: str, x: Tensor, rope: Tensor, cfg: DiTConfig, rnd) -> Tensor:
-    q = rms_norm_full(rnd(linear(x, sd[p + "q.weight"], sd[p + "q.bias"])), sd[p + "norm_q.weight"], cfg.eps, rnd)
-    k = rms_norm_full(rnd(linear(x, sd[p + "k.weight"], sd[p + "k.bias"])), sd[p + "norm_k.weight"], cfg.eps, rnd)
-    v = rnd(linear(x, sd[p + "v.weight"], sd[p + "v.bias"]))
+def self_attention(sd: Dict[str, Tensor], p: str, x: Tensor, rope: Tensor, cfg: DiTConfig, rnd, proj=None) -> Tensor:
+    """proj: the linear layer the token-side projections run on (default: `linear`; the HIP path's opt-in MX-fp8 projections are checked with
+    oracle/mx8_oracle.mx8_linear here, as dit_block's mlp_linear does for the MLP)."""
+    lin = proj or linear
+    q = rms_norm_full(rnd(lin(x, sd[p + "q.weight"], sd[p + "q.bias"])), sd[p + "norm_q.weight"], cfg.eps, rnd)
+    k = rms_norm_full(rnd(lin(x, sd[p + "k.weight"], sd[p + "k.bias"])), sd[p + "norm_k.weight"], cfg.eps, rnd)
+    v = rnd(lin(x, sd[p + "v.weight"], sd[p + "v.bias"]))
     q = rnd(apply_rope(q, rope, cfg.num_heads))
     k = rnd(apply_rope(k, rope, cfg.num_heads))
     a = rnd(attention(q, k, v, cfg.num_heads))
-    return rnd(linear(a, sd[p + "o.weight"], sd[p + "o.bias"]))
+    return rnd(lin(a, sd[p + "o.weight"], sd[p + "o.bias"]))
 
 
-def cross_attention(sd: Dict[str, Tensor], p: str, x: Tensor, context: Tensor, cfg: DiTConfig, rnd) -> Tensor:
+def cross_attention(sd: Dict[str, Tensor], p: str, x: Tensor, context: Tensor, cfg: DiTConfig, rnd, proj=None) -> Tensor:
+    """proj: as in self_attention, for the two token-side projections (q and o); the prompt-side k / v stay on `linear`."""
+    lin = proj or linear
     if cfg.has_image_input:
         img, ctx = context[:, :257], context[:, 257:]
     else:
         img, ctx = None, context
-    q = rms_norm_full(rnd(linear(x, sd[p + "q.weight"], sd[p + "q.bias"])), sd[p + "norm_q.weight"], cfg.eps, rnd)
+    q = rms_norm_full(rnd(lin(x, sd[p + "q.weight"], sd[p + "q.bias"])), sd[p + "norm_q.weight"], cfg.eps, rnd)
     k = rms_norm_full(rnd(linear(ctx, sd[p + "k.weight"], sd[p + "k.bias"])), sd[p + "norm_k.weight"], cfg.eps, rnd)
     v = rnd(linear(ctx, sd[p + "v.weight"], sd[p + "v.bias"]))
     a = rnd(attention(q, k, v, cfg.num_heads))
@@ -202,7 +207,7 @@ def cross_attention(sd: Dict[str, Tensor], p: str, x: Tensor, context: Tensor, c
                            sd[p + "norm_k_img.weight"], cfg.eps, rnd)
         vi = rnd(linear(img, sd[p + "v_img.weight"], sd[p + "v_img.bias"]))
         a = rnd(a + rnd(attention(q, ki, vi, cfg.num_heads)))
-    return rnd(linear(a, sd[p + "o.weight"], sd[p + "o.bias"]))
+    return rnd(lin(a, sd[p + "o.weight"], sd[p + "o.bias"]))
 
 
 def audio_tokens(sd: Dict[str, Tensor], audio_first: Tensor, audio_latter: Tensor, rnd) -> Tensor:
@@ -232,16 +237,16 @@ def audio_cross_attention(sd: Dict[str, Tensor], prefix: str, x: Tensor, audio: 
 
 
 def dit_block(sd: Dict[str, Tensor], prefix: str, x: Tensor, context: Tensor, t_mod: Tensor, rope: Tensor,
-              cfg: DiTConfig, rounding: Optional[str] = None, audio: Optional[Tensor] = None, frames: int = 0, mlp_linear=None) -> Tensor:
+              cfg: DiTConfig, rounding: Optional[str] = None, audio: Optional[Tensor] = None, frames: int = 0, mlp_linear=None, proj_linear=None) -> Tensor:
     """One DiTBlock (dit:354-374).  x [B,L,D], context [B,Lc,D] (already text-embedded),
     t_mod [B,6,D], rope complex128 [L, dh/2]; audio [f, 32, 768] (talk variant) or None."""
     rnd = _rounder(rounding)
     mod = rnd(sd[prefix + "modulation"] + t_mod)                       # [B,6,D]
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = [mod[:, i:i + 1] for i in range(6)]
     h = modulated_norm(x, sh_a, sc_a, cfg.eps, rnd)
-    x = rnd(x + rnd(g_a * self_attention(sd, prefix + "self_attn.", h, rope, cfg, rnd)))
+    x = rnd(x + rnd(g_a * self_attention(sd, prefix + "self_attn.", h, rope, cfg, rnd, proj_linear)))
     h = rnd(layer_norm(x, cfg.eps, sd[prefix + "norm3.weight"], sd[prefix + "norm3.bias"]))
-    x = rnd(x + cross_attention(sd, prefix + "cross_attn.", h, context, cfg, rnd))
+    x = rnd(x + cross_attention(sd, prefix + "cross_attn.", h, context, cfg, rnd, proj_linear))
     if audio is not None:
         x = rnd(x + audio_cross_attention(sd, prefix, x, audio, frames, cfg, rnd))                     # dit:364-366
     h = modulated_norm(x, sh_m, sc_m, cfg.eps, rnd)

@@ -528,6 +528,16 @@ extern "C" svi_status svi_gemm_mx8(const void* A8, int32_t lda, const void* a_sc
     return svi_launch_gemm_mx8(g, reinterpret_cast<const unsigned*>(a_scales), sc_rows, reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" svi_status svi_gemm_mx8_wscaled(const void* A8, int32_t lda, const void* W8, int32_t ldw, const void* w_scales, int32_t sc_rows, void* C, int32_t ldc,
+                                           int32_t M, int32_t N, int32_t K, const void* bias, int32_t bias_along_m, svi_stream stream) {
+    SVI_REQUIRE(A8 && w_scales && W8 && C, "svi_gemm_mx8_wscaled: null argument");
+    SviGemmArgs g{};
+    g.A = reinterpret_cast<const bf16*>(A8); g.lda = lda; g.W = reinterpret_cast<const bf16*>(W8); g.ldw = ldw;
+    g.C = reinterpret_cast<bf16*>(C); g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = reinterpret_cast<const bf16*>(bias); g.bias_along_m = bias_along_m; g.epi = SVI_EPI_BIAS;
+    return svi_launch_gemm_mx8_wscaled(g, reinterpret_cast<const unsigned*>(w_scales), sc_rows, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" svi_status svi_cfg_step(void* latents, const void* cond, const void* uncond, int64_t n, float cfg_scale,
                                    float dsigma, svi_stream stream) {
     SVI_REQUIRE(latents && cond, "svi_cfg_step: null argument");

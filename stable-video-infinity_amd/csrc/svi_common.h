@@ -234,6 +234,8 @@ SviFlashSplit svi_flash_plan(int Lq, int Lk, int heads, int cus, int* kernel_out
 // MX-fp8 (opt-in): bf16 -> e4m3 + E8M0 block scales ([K/128][sc_rows] dwords), and C = epi(A8 W8^T) with g.A / g.W e4m3, lda / ldw in bytes
 svi_status svi_launch_mx8_quantize(const bf16* x, int ldx, int rows, int K, unsigned char* q, int ldq, unsigned* scales, int sc_rows, hipStream_t st);
 svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, int sc_rows, hipStream_t st);
+// the same with the block scales on the W operand's rows and unit scales on A (the transposed value projection; bias epilogue only)
+svi_status svi_launch_gemm_mx8_wscaled(const SviGemmArgs& g, const unsigned* w_scales, int sc_rows, hipStream_t st);
 
 // Q [Lq, ldq], K [Lk, ldk] token-major with head hd at column hd*128; VT [(n*128), ldvt] = V transposed
 // (row = channel, col = key; columns >= Lk up to the next multiple of 8 must be readable and finite).

@@ -37,6 +37,7 @@ struct BlockW {
     const bf16* norm3_w = nullptr;
     const bf16* norm3_b = nullptr;
     Lin ffn0, ffn2;
+    const unsigned char* proj_8[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // sa.q, sa.k, sa.v, sa.o, ca.q, ca.o as stored e4m3 bytes (svi_dit_proj_mx8)
     const unsigned char *ffn0_8 = nullptr, *ffn2_8 = nullptr;      // the same weights as stored e4m3 bytes (FP8 storage mode), for the opt-in MX-fp8 MLP
     // talk variant (enable_multitalk): audio cross-attention (models/attention.py:283-371) and its pre-norm (dit:351)
     Lin aud_q, aud_kv, aud_proj;
@@ -106,6 +107,7 @@ struct svi_dit {
     // re-allocating per step — and a capture pass behind the eager step no longer meets "the workspace must grow while captured" (ADVICE r5).
     int pair_stack_oom_rows = 0;
     bool ffn_mx8 = false;             // opt-in: the MLP GEMMs on the block-scaled fp8 matrix path (svi_dit_ffn_mx8)
+    bool proj_mx8 = false;            // opt-in: the block's other six projections too (svi_dit_proj_mx8)
     // context cache
     bool ctx_cache_on = false;
     CtxEntry ctx_entries[4];
@@ -297,9 +299,23 @@ extern "C" svi_status svi_dit_bind_weight(svi_dit* h, const char* name, const vo
 // through csrc/svi_gemm.hip's block-scaled fp8 kernel (activations quantised per row and 32-element block).  Arithmetic the reference
 // never performs: separately toleranced (tests/test_gpu_mx8.py), a separate bench line, never the default.
 extern "C" svi_status svi_dit_bind_ffn_fp8(svi_dit* h, int32_t layer, int32_t which, const void* e4m3_weight) {
-    SVI_REQUIRE(h && e4m3_weight && layer >= 0 && layer < h->cfg.num_layers && (which == 0 || which == 2), "svi_dit_bind_ffn_fp8: bad argument");
+    SVI_REQUIRE(h && e4m3_weight && layer >= 0 && layer < h->cfg.num_layers && (which == 0 || which == 2 || (which >= 10 && which <= 15)), "svi_dit_bind_ffn_fp8: bad argument");
     SVI_REQUIRE(((uintptr_t)e4m3_weight % 16) == 0, "svi_dit_bind_ffn_fp8: the weight is not 16-byte aligned");
-    (which == 0 ? h->blocks[layer].ffn0_8 : h->blocks[layer].ffn2_8) = reinterpret_cast<const unsigned char*>(e4m3_weight);
+    if (which >= 10) h->blocks[layer].proj_8[which - 10] = reinterpret_cast<const unsigned char*>(e4m3_weight);      // 10..15: sa.q, sa.k, sa.v, sa.o, ca.q, ca.o
+    else (which == 0 ? h->blocks[layer].ffn0_8 : h->blocks[layer].ffn2_8) = reinterpret_cast<const unsigned char*>(e4m3_weight);
+    return SVI_OK;
+}
+// The block's other six projections on the same path (ABI v10; include/svi_hip.h).
+extern "C" svi_status svi_dit_proj_mx8(svi_dit* h, int32_t enable) {
+    SVI_REQUIRE(h, "null handle");
+    if (enable) {
+        SVI_REQUIRE(h->cfg.dim % 256 == 0, "svi_dit_proj_mx8: dim must be a multiple of 256 (dim = %d)", h->cfg.dim);
+        for (int l = 0; l < h->cfg.num_layers; ++l)
+            for (int i = 0; i < 6; ++i)
+                if (!h->blocks[l].proj_8[i]) { svi_set_error("svi_dit_proj_mx8: blocks.%d projection %d was not bound as e4m3 (svi_dit_bind_ffn_fp8, which = %d)", l, i, 10 + i); return SVI_ERR_UNBOUND; }
+    }
+    h->proj_mx8 = enable != 0;
+    ++h->generation;
     return SVI_OK;
 }
 extern "C" svi_status svi_dit_ffn_mx8(svi_dit* h, int32_t enable) {
@@ -340,7 +356,7 @@ static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 // capture; an allocation is not, and is refused there with a message).
 static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     Workspace& w = h->ws;
-    if (w.base && w.L == L && w.Lc == Lc && (w.Q8 != nullptr) == h->ffn_mx8) return SVI_OK;
+    if (w.base && w.L == L && w.Lc == Lc && (w.Q8 != nullptr) == (h->ffn_mx8 || h->proj_mx8)) return SVI_OK;
     const svi_dit_config& c = h->cfg;
     const size_t D = c.dim, F = c.ffn_dim;
     const int img = c.has_image_input ? 257 : 0;
@@ -348,7 +364,7 @@ static svi_status ensure_workspace(svi_dit* h, int L, int Lc, hipStream_t st) {
     const size_t ho = (size_t)c.out_dim * c.patch_t * c.patch_h * c.patch_w;
     const size_t ho_ld = (ho + 7) / 8 * 8;
     size_t oX, oX2, oH, oQK, oVT, oF, oCTX, oCTXH, oCK, oCVT, oCKi, oCVTi, oA2, oP, oHO, oI0, oI1, oID, oe, oh1, ot, ost, otm, omodf, oheadf, otail, oRSS, oRS, oQ8 = 0, oS8 = 0;
-    const bool mx8 = h->ffn_mx8;
+    const bool mx8 = h->ffn_mx8 || h->proj_mx8;
     auto layout = [&](int l, int lc) -> size_t {
         const size_t Lctx = (size_t)lc + img;
         const int ldvt = ((l + 7) / 8) * 8, ldcvt = ((lc + 7) / 8) * 8;
@@ -518,6 +534,21 @@ static svi_status linear_transposed(const bf16* Xin, int ldx, const Lin& l, bf16
     return svi_launch_gemm(g, st);
 }
 
+// Opt-in MX-fp8 projections (svi_dit_proj_mx8): y = epi(quantised(A) · W8^T) for one of the block's square projections.  `A` [R, D] bf16 is quantised into the
+// workspace's e4m3 rows + block scales (when `quantise`; else they still hold the rows a previous call of the same phase quantised), W8 = the stored e4m3 weight
+// [N = D, K = D] with unit scales.  Sequence-parallel shards keep the bf16 kernels (their launches are shaped for the exchange).
+static bool proj_mx8_on(const svi_dit* h) { return h->proj_mx8 && !h->sp_active; }
+static svi_status linear_mx8(svi_dit* h, const bf16* A, bool quantise, const unsigned char* W8, const bf16* bias, bf16* C, int ldc, int R, int epi, hipStream_t st,
+                             const float* gate = nullptr, const bf16* res = nullptr, int ldres = 0, float* rowss = nullptr, int ldss = 0) {
+    Workspace& w = h->ws;
+    const int D = h->cfg.dim;
+    if (quantise) SVI_TRY(svi_launch_mx8_quantize(A, D, R, D, w.Q8, D, w.S8, w.sc_rows, st));
+    SviGemmArgs g{};
+    g.A = reinterpret_cast<const bf16*>(w.Q8); g.lda = D; g.W = reinterpret_cast<const bf16*>(W8); g.ldw = D; g.C = C; g.ldc = ldc; g.M = R; g.N = D; g.K = D;
+    g.bias = bias; g.epi = epi; g.gate = gate; g.res = res; g.ldres = ldres; g.rowss = rowss; g.ldss = ldss;
+    return svi_launch_gemm_mx8(g, w.S8, w.sc_rows, st);
+}
+
 // The self-attention third of a block depends on (x, t) only — not on the prompt.  It is written in three pieces so that a
 // sequence-parallel shard can exchange heads for tokens around the attention (svi_dit_sp_*): (1) q | k (RMSNorm + RoPE applied,
 // q pre-scaled) and V^T of the shard's rows [row0, row0 + L), (2) attention, (3) output projection + gate + residual.
@@ -541,7 +572,16 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
     // q | k as ONE N = 2D launch (dit:227-228 side by side): tile columns below D multiply by Wq, the others by Wk — the LN output is read
     // once for both, the weights stay the bound tensors (nothing is packed).  Per element the kernel and the k order are those of the two
     // separate launches (the kernel choice is pinned to the per-projection shape through sel_n): the same bits.
-    if (!svi_switches().qk_fused) {
+    if (proj_mx8_on(h) && part == 0 && !scatter) {
+        // opt-in MX-fp8: the LayerNorm output is quantised ONCE; q and k are two N = D launches on it, V^T the W-scaled form (the stored weight is the A operand)
+        SviProfScope _p(PROF_GEMM_QKV, st);
+        SVI_TRY(linear_mx8(h, w.Hb, true, b.proj_8[0], b.sa.q.b, QK, 2 * D, L, SVI_EPI_BIAS, st));
+        SVI_TRY(linear_mx8(h, w.Hb, false, b.proj_8[1], b.sa.k.b, QK + D, 2 * D, L, SVI_EPI_BIAS, st));
+        SviGemmArgs g{};
+        g.A = reinterpret_cast<const bf16*>(b.proj_8[2]); g.lda = D; g.W = reinterpret_cast<const bf16*>(w.Q8); g.ldw = D; g.C = VT; g.ldc = ldvt; g.M = D; g.N = L; g.K = D;
+        g.bias = b.sa.v.b; g.bias_along_m = 1; g.epi = SVI_EPI_BIAS;
+        SVI_TRY(svi_launch_gemm_mx8_wscaled(g, w.S8, w.sc_rows, st));
+    } else if (!svi_switches().qk_fused) {
         { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.q, QK, 2 * D, L, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
         { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear(w.Hb, D, b.sa.k, QK + D, 2 * D, L, D, D, SVI_EPI_BIAS, st, nullptr, nullptr, 0, nb)); }
     } else {
@@ -552,7 +592,7 @@ static svi_status block_qkv(svi_dit* h, int layer, const bf16* X, const float* m
       g.W2 = b.sa.k.w; g.bias2 = b.sa.k.b; g.n_split = D;
       g.sel_m = nb > 1 ? L / nb : 0; g.sel_n = D;
       SVI_TRY(svi_launch_gemm(g, st)); }
-    if (part == 0) { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st, nb)); }
+    if (part == 0 && !(proj_mx8_on(h) && !scatter)) { SviProfScope _p(PROF_GEMM_QKV, st); SVI_TRY(linear_transposed(w.Hb, D, b.sa.v, VT, ldvt, L, D, D, st, nb)); }
     // q and k in one launch (grid.y = operand): q additionally carries softmax_scale * log2(e) into its single final rounding
     if (q8) { SviProfScope _p(PROF_RMS_ROPE, st); return svi_launch_rmsnorm_rope2_q8(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st, *q8); }
     { SviProfScope _p(PROF_RMS_ROPE, st); SVI_TRY(svi_launch_rmsnorm_rope2(QK, 2 * D, L, D, b.sa.norm_q, b.sa.norm_k, c.eps, &rope, SVI_QK_SCALE_LOG2E, 1.0f, st, scatter)); }
@@ -564,6 +604,7 @@ static svi_status block_attn_out(svi_dit* h, int layer, bf16* X, const bf16* att
     const BlockW& b = h->blocks[layer];
     const int D = c.dim;
     const float* g_a = modf + 2 * D;
+    if (proj_mx8_on(h)) { SviProfScope _p(PROF_GEMM_O, st); return linear_mx8(h, attn, true, b.proj_8[3], b.sa.o.b, X, D, L, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D); }
     { SviProfScope _p(PROF_GEMM_O, st); SVI_TRY(linear(attn, D, b.sa.o, X, D, L, D, D, SVI_EPI_BIAS_GATE_RES, st, g_a, X, D, nb)); }
     return SVI_OK;
 }
@@ -625,7 +666,10 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
     // (per 64-column group; one tiny kernel folds them into rs[row]), so the normalised q never makes its own trip through HBM.  SVI_CROSS_FUSED=0:
     // normalise in place, then attend (rounds 1-4).  The two differ only where the order of the fp32 sum of squares moves a bf16 rounding of q.
     const bool fused = svi_switches().cross_fused && D % 64 == 0 && D % 8 == 0 && R <= w.ldss;
-    {
+    if (proj_mx8_on(h)) {
+        SviProfScope _p(PROF_GEMM_CROSS, st);
+        SVI_TRY(linear_mx8(h, w.Hb, true, b.proj_8[4], b.ca.q.b, w.QK, 2 * D, R, SVI_EPI_BIAS, st, nullptr, nullptr, 0, fused ? w.RSS : nullptr, fused ? w.ldss : 0));
+    } else {
         SviProfScope _p(PROF_GEMM_CROSS, st);
         SviGemmArgs g{};
         g.A = w.Hb; g.lda = D; g.W = b.ca.q.w; g.ldw = D; g.C = w.QK; g.ldc = 2 * D; g.M = R; g.N = D; g.K = D;
@@ -653,7 +697,8 @@ static svi_status run_block_rest_n(svi_dit* h, int layer, bf16* X, const bf16* c
         }
     }
     if (img) SVI_TRY(svi_launch_add_bf16(w.Hb, w.A2, (int64_t)R * D, st));
-    { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.o, X, D, R, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D, nb)); }
+    if (proj_mx8_on(h)) { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear_mx8(h, w.Hb, true, b.proj_8[5], b.ca.o.b, X, D, R, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D)); }
+    else { SviProfScope _p(PROF_GEMM_CROSS, st); SVI_TRY(linear(w.Hb, D, b.ca.o, X, D, R, D, D, SVI_EPI_BIAS_GATE_RES, st, nullptr, X, D, nb)); }
     // --- talk variant: audio cross-attention between the text cross-attention and the MLP (dit:361-366)
     if (audio_frames > 0) SVI_TRY(block_audio(h, layer, X, L, audio_frames, st));
     // --- MLP: x += gate_mlp * W2 gelu_tanh(W1 modulate(norm2 x))                  dit:372-373,334-335

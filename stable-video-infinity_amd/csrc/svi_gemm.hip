@@ -1200,7 +1200,7 @@ static_assert(MX8_SC_OFF + 2048 <= LDS256_BYTES, "scale slabs must fit the 256^2
 
 struct SviMx8Args {
     SviGemmArgs g;                 // A = e4m3 activations [M, lda bytes], W = e4m3 weights [N, ldw bytes]; C / bias / epilogue as for bf16
-    const unsigned* a_scales;      // [K / 128][sc_rows]
+    const unsigned* a_scales;      // [K / 128][sc_rows]: block scales of the SCALED operand's rows (A's rows; with WSC the W operand's rows)
     int sc_rows;
 };
 
@@ -1230,6 +1230,9 @@ __device__ __forceinline__ i32x8 mx8_frag(int base, int s, int hi, int row) {   
     return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
 }
 
+// WSC (round 6): the block scales belong to the W operand's rows and the A operand carries unit scales — the transposed projection V^T = Wv · X^T, where the
+// stored e4m3 weight is the A operand (output rows = channels) and the quantised activation the W operand (output columns = tokens).
+template <bool WSC>
 __global__ __launch_bounds__(512, 2) void gemm_mx8_nt_256_kernel(SviMx8Args a, int tiles_m, int tiles_n, int GM) {
     const SviGemmArgs& g = a.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1271,8 +1274,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mx8_nt_256_kernel(SviMx8Args a, i
             __builtin_amdgcn_global_load_lds((gptr_t)(A8 + (size_t)kt * 128 + a_off[j]), (lptr_t)(As + (j * 8 + wave) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(W8 + (size_t)kt * 128 + w_off[j]), (lptr_t)(Ws + (j * 8 + wave) * 1024), 16, 0, 0);
         }
-        if (wave == 0)        // the k-tile's scale dwords of rows m0 .. m0+255: one KiB, lane-linear (the scale table is padded to whole tiles)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.a_scales + (size_t)kt * a.sc_rows + m0 + lane * 4), (lptr_t)(smem + MX8_SC_OFF + buf * 1024), 16, 0, 0);
+        if (wave == 0)        // the k-tile's scale dwords of rows m0 .. m0+255 (WSC: of the W operand's rows n0 .. n0+255): one KiB, lane-linear (the scale table is padded to whole tiles)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.a_scales + (size_t)kt * a.sc_rows + (WSC ? n0 : m0) + lane * 4), (lptr_t)(smem + MX8_SC_OFF + buf * 1024), 16, 0, 0);
     };
 
     f32x16 acc[2][4];                       // [ni][mi]
@@ -1289,10 +1292,10 @@ __global__ __launch_bounds__(512, 2) void gemm_mx8_nt_256_kernel(SviMx8Args a, i
         const int cur = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
         const int abase = lds0 + cur * 2 * T_STAGE, wbase = abase + T_STAGE, sbase = lds0 + MX8_SC_OFF + cur * 1024;
-        int xs[4];
+        int xs[4];          // WSC: xs[0..1] are the scales of the wave's two W row blocks
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-            xs[mi] = (int)((*(const __attribute__((address_space(3))) unsigned*)(sbase + (wm * 128 + mi * 32 + l31) * 4)) >> (8 * hi));
+        for (int mi = 0; mi < (WSC ? 2 : 4); ++mi)
+            xs[mi] = (int)((*(const __attribute__((address_space(3))) unsigned*)(sbase + ((WSC ? wn * 64 : wm * 128) + mi * 32 + l31) * 4)) >> (8 * hi));
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             i32x8 xa[4], wb[2];
@@ -1304,8 +1307,13 @@ __global__ __launch_bounds__(512, 2) void gemm_mx8_nt_256_kernel(SviMx8Args a, i
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    if (s == 0) acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 0, xs[mi]);
-                    else acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 2, xs[mi]);
+                    if constexpr (WSC) {
+                        if (s == 0) acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0, xs[ni], 0, 0x7f7f7f7f);
+                        else acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[ni], xa[mi], acc[ni][mi], 0, 0, 2, xs[ni], 0, 0x7f7f7f7f);
+                    } else {
+                        if (s == 0) acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 0, xs[mi]);
+                        else acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 2, xs[mi]);
+                    }
                 }
         }
         __syncthreads();                    // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
@@ -1338,8 +1346,27 @@ svi_status svi_launch_gemm_mx8(const SviGemmArgs& g, const unsigned* a_scales, i
     const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
     const int gm_rows = svi_switches().gemm_gm ? svi_switches().gemm_gm : (tn >= 16 ? 5 : 2);
     SviMx8Args a{g, a_scales, sc_rows};
-    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_mx8_nt_256_kernel), LDS256_BYTES));
-    hipLaunchKernelGGL(gemm_mx8_nt_256_kernel, dim3(tm * tn), dim3(512), LDS256_BYTES, st, a, tm, tn, gm_rows);
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_mx8_nt_256_kernel<false>), LDS256_BYTES));
+    hipLaunchKernelGGL(gemm_mx8_nt_256_kernel<false>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, a, tm, tn, gm_rows);
+    SVI_LAUNCH_CHECK();
+    return SVI_OK;
+}
+
+// The same GEMM with the block scales on the W operand's rows (w_scales [K / 128][sc_rows], sc_rows a multiple of 256 covering N) and unit scales on A:
+// C[M, N] = epi(A8[M, K] · dequant(W8[N, K])^T).  The DiT's transposed value projection: A8 = the stored e4m3 weight [dim, K], W8 = the quantised
+// activation rows [tokens, K], C = V^T [dim, ldc >= tokens], bias along M.
+svi_status svi_launch_gemm_mx8_wscaled(const SviGemmArgs& g, const unsigned* w_scales, int sc_rows, hipStream_t st) {
+    SVI_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 128 == 0, "mx8 gemm (W scaled): K=%d must be a multiple of 128", g.K);
+    SVI_REQUIRE(g.lda % 16 == 0 && g.ldw % 16 == 0 && g.ldc % 8 == 0 && g.lda >= g.K && g.ldw >= g.K && g.ldc >= g.N, "mx8 gemm (W scaled): bad leading dims");
+    SVI_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)w_scales % 16) == 0, "mx8 gemm (W scaled): operands must be 16-byte aligned");
+    SVI_REQUIRE(sc_rows % 256 == 0 && sc_rows >= ((g.N + 255) / 256) * 256, "mx8 gemm (W scaled): the scale table must cover whole 256-row tiles of the W operand (sc_rows %d, N %d)", sc_rows, g.N);
+    SVI_REQUIRE(g.epi == SVI_EPI_BIAS && !g.q8 && !g.rowss && !g.W2, "mx8 gemm (W scaled): the plain bias epilogue only");
+    SVI_REQUIRE((long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldw < (1L << 31), "mx8 gemm (W scaled): operand beyond 2 GiB");
+    const int tm = (g.M + TM - 1) / TM, tn = (g.N + TN - 1) / TN;
+    const int gm_rows = svi_switches().gemm_gm ? svi_switches().gemm_gm : (tn >= 16 ? 5 : 2);
+    SviMx8Args a{g, w_scales, sc_rows};
+    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_mx8_nt_256_kernel<true>), LDS256_BYTES));
+    hipLaunchKernelGGL(gemm_mx8_nt_256_kernel<true>, dim3(tm * tn), dim3(512), LDS256_BYTES, st, a, tm, tn, gm_rows);
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }

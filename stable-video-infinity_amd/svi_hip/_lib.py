@@ -80,6 +80,8 @@ SYMBOLS = [
     ("svi_gemm_mx8", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     ("svi_dit_bind_ffn_fp8", _i32, [_vp, _i32, _i32, _vp]),
     ("svi_dit_ffn_mx8", _i32, [_vp, _i32]),
+    ("svi_gemm_mx8_wscaled", _i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    ("svi_dit_proj_mx8", _i32, [_vp, _i32]),
     ("svi_fp8_e4m3_to_bf16", _i32, [_vp, _vp, _i64, _vp]),
     ("svi_gemm_plan", _i32, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     ("svi_attention_plan", _i32, [_i32, _i32, _i32, _i32, C.POINTER(_i32)]),

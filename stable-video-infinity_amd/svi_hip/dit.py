@@ -96,6 +96,7 @@ class WanDiT:
         self._param_versions = []
         self._epoch = 0                     # host-side: moves on bind / rebind / context_cache(); part of a captured graph's key
         self._ffn_mx8 = False               # opt-in MX-fp8 MLP (ffn_fp8_mfma)
+        self._proj_mx8 = False              # opt-in MX-fp8 q / k / v / o and cross-attention q / o projections (proj_fp8_mfma)
         self._ctx_cache_on = False
         self._ctx_pins = PromptPins()
 
@@ -160,6 +161,8 @@ class WanDiT:
         self._epoch += 1
         if self._ffn_mx8:
             self.ffn_fp8_mfma(True)         # the e4m3 tensors may have moved with the re-bind
+        if self._proj_mx8:
+            self.proj_fp8_mfma(True)
 
     def rebind(self) -> None:
         """Re-read every parameter's address (after a LoRA merge, .to(), an offload round trip ...); drops the context cache.
@@ -183,6 +186,26 @@ class WanDiT:
                     L.check(lib.svi_dit_bind_ffn_fp8(self._h, l, which, t.data_ptr()), f"svi_dit_bind_ffn_fp8 {name}")
         L.check(lib.svi_dit_ffn_mx8(self._h, 1 if enable else 0), "svi_dit_ffn_mx8")
         self._ffn_mx8 = bool(enable)
+        self._epoch += 1
+
+    _PROJ_FP8 = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_attn.q", "cross_attn.o")      # svi_dit_bind_ffn_fp8 which = 10 + index
+
+    def proj_fp8_mfma(self, enable: bool = True) -> None:
+        """Opt-in, with ffn_fp8_mfma's caveats (NOT the reference's arithmetic; own tolerance, tests/test_gpu_mx8.py; bench.py --fp8-all): the block's other six
+        projections — self-attention q, k, v, o and cross-attention q, o — on the MX block-scaled fp8 matrix path (svi_dit_proj_mx8).  Needs the FP8 weight
+        STORAGE mode: the stored e4m3 bytes are used as they are (unit scales); the LayerNorm output is quantised once for q, k and V^T, each attention output once
+        for its output projection.  The prompt-side K / V projections (context cache) and sequence-parallel shards keep bf16."""
+        lib = L.lib()
+        if enable:
+            for l in range(self.num_layers):
+                for i, mod in enumerate(self._PROJ_FP8):
+                    name = f"blocks.{l}.{mod}.weight"
+                    t = self._fp8_sources.get(name)
+                    if t is None:
+                        raise RuntimeError(f"proj_fp8_mfma needs {name} bound as float8_e4m3fn (FP8 weight storage mode)")
+                    L.check(lib.svi_dit_bind_ffn_fp8(self._h, l, 10 + i, t.data_ptr()), f"svi_dit_bind_ffn_fp8 {name}")
+        L.check(lib.svi_dit_proj_mx8(self._h, 1 if enable else 0), "svi_dit_proj_mx8")
+        self._proj_mx8 = bool(enable)
         self._epoch += 1
 
     def epoch(self) -> int:

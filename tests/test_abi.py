@@ -31,7 +31,7 @@ def test_ctypes_table_matches_header():
 
 
 def test_abi_version():
-    assert L.lib().svi_abi_version() == 9
+    assert L.lib().svi_abi_version() == 10
 
 
 def test_dit_handle_lifecycle_and_errors():

@@ -182,3 +182,105 @@ def test_c1_end_to_end_with_the_fp8_mlp(hip, golden):
     r_ref_mx, r_ref_16 = errs(got[0], g["latents_fp32"])[0], errs(base[0], g["latents_fp32"])[0]
     report("c1_e2e_mx8", mx8_vs_bf16_arithmetic=r, mx8_vs_ref_fp32=r_ref_mx, fp8_storage_bf16_arithmetic_vs_ref_fp32=r_ref_16)
     assert torch.isfinite(got.float()).all() and r < 5e-2, (r, r_ref_mx, r_ref_16)
+
+
+# ------------------------------------------------------------------------------------------------------------------ round 6: the other six projections
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1536, 2304, 1536), (512, 300, 256), (96 * 8, 1000, 512)])
+def test_w_scaled_gemm_equals_the_dequantised_product(M, N, K):
+    """svi_gemm_mx8_wscaled: C[M, N] = A8 · dequant(W8)^T + bias[:, None] with the block scales on the W operand's rows (the quantised activation) and unit
+    scales on A (the stored e4m3 weight) — the transposed value projection V^T = Wv · X^T.  Rows of different scale and an asymmetric weight: a scale taken from
+    the wrong operand, row or K block cannot pass."""
+    from oracle import mx8_oracle as mx
+    from svi_hip import _lib as L
+    x = bf16r(torch.from_numpy(synth.randn(31, N, K)) * torch.from_numpy(np.exp(0.7 * synth.randn(32, N, 1))))
+    w8 = (torch.from_numpy(synth.randn(33, M, K)) / np.sqrt(K)).to(torch.float8_e4m3fn)
+    bias = bf16r(torch.from_numpy(0.1 * synth.randn(34, M)))
+    q, tab, sc_rows = quantize_dev(dev(x))
+    wd, bd = w8.cuda(), dev(bias)
+    ldc = (N + 7) // 8 * 8
+    out = torch.zeros((M, ldc), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().svi_gemm_mx8_wscaled(wd.data_ptr(), K, q.data_ptr(), K, tab.data_ptr(), sc_rows, out.data_ptr(), ldc, M, N, K, bd.data_ptr(), 1, L.current_stream()),
+            "svi_gemm_mx8_wscaled")
+    y = bf16r(mx.mx8_linear_t(w8.float(), x, bias))
+    r, mxe, sc = errs(out[:, :N], y)
+    report("gemm_mx8_wscaled", M=M, N=N, K=K, rel_l2=r, max_abs=mxe, scale=sc)
+    assert r < 3e-3, (r, mxe)
+    # and it IS the transpose of the A-scaled form on the same operands
+    out2 = torch.empty((N, M), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().svi_gemm_mx8(q.data_ptr(), K, tab.data_ptr(), sc_rows, wd.data_ptr(), K, out2.data_ptr(), M, N, M, K, bd.data_ptr(), 0, None, None, M, L.current_stream()), "svi_gemm_mx8")
+    assert errs(out[:, :N], out2.t().float())[0] < 1e-3
+
+
+def test_block_with_every_projection_on_fp8_vs_oracle_and_vs_bf16(hip):
+    """svi_dit_proj_mx8 (+ the MX-fp8 MLP): self-attention q, k, V^T, o and cross-attention q, o of the block on the block-scaled fp8 matrix path — against the
+    oracle block whose token-side linears are mx8_linear (<= 1e-2: ten quantised GEMMs instead of two), and against the bf16-arithmetic block (different, by a
+    bounded amount); the switch goes back cleanly, alone and together with the MLP's."""
+    from oracle import mx8_oracle as mx
+    from oracle import wan_dit_oracle as wdo
+    from test_oracle_dit import make_cfg
+    grid, seed, nt = (2, 12, 12), 1400, 24
+    f, h, w = grid
+    Lt = f * h * w
+    sd8 = fp8_state_dict(SEAM, seed)
+    m = hip.WanDiT.from_state_dict(sd8, eps=1e-6, num_heads=2, **SEAM)
+    bx = torch.from_numpy(synth.randn(seed + 5, 1, Lt, SEAM["dim"]))
+    bctx = torch.from_numpy(synth.randn(seed + 6, 1, nt, SEAM["dim"]))
+    btm = torch.from_numpy(0.5 * synth.randn(seed + 7, 1, 6, SEAM["dim"]))
+    ref16 = m.block_forward(0, dev(bx), dev(bctx), dev(btm), grid)
+    sdb = {k: (v.float() if v.dtype == torch.float8_e4m3fn else bf16r(v)) for k, v in sd8.items()}
+    cfg, rope = make_cfg(SEAM), wdo.rope_table_3d(128, grid)
+    m.proj_fp8_mfma(True)
+    got_p = m.block_forward(0, dev(bx), dev(bctx), dev(btm), grid)
+    m.ffn_fp8_mfma(True)
+    got_all = m.block_forward(0, dev(bx), dev(bctx), dev(btm), grid)
+    m.proj_fp8_mfma(False)
+    m.ffn_fp8_mfma(False)
+    assert torch.equal(m.block_forward(0, dev(bx), dev(bctx), dev(btm), grid), ref16)
+    with torch.no_grad():
+        want_p = wdo.dit_block(sdb, "blocks.0.", bf16r(bx), bf16r(bctx), bf16r(btm), rope, cfg, "bf16", proj_linear=mx.mx8_linear)
+        want_all = wdo.dit_block(sdb, "blocks.0.", bf16r(bx), bf16r(bctx), bf16r(btm), rope, cfg, "bf16", mlp_linear=mx.mx8_linear, proj_linear=mx.mx8_linear)
+    rp, ra = errs(got_p, want_p)[0], errs(got_all, want_all)[0]
+    dp, da = errs(got_p, ref16)[0], errs(got_all, ref16)[0]
+    report("dit_block_proj_mx8", proj_vs_oracle=rp, all_vs_oracle=ra, proj_vs_bf16_arithmetic=dp, all_vs_bf16_arithmetic=da)
+    assert rp < 1e-2 and ra < 1e-2, (rp, ra)
+    assert 1e-4 < dp < 4e-2 and 1e-4 < da < 5e-2, (dp, da)
+
+
+def test_forward_pair_and_c1_end_to_end_with_every_gemm_on_fp8(hip, golden):
+    """The whole forward (plain and the stacked CFG pair) and BASELINE config 1's ten-step loop with every token-side GEMM of every block on the MX fp8 path
+    (MLP + the six projections; the prompt-side K / V stay bf16).  Stated tolerance of the opt-in mode, as for the MLP alone: latents within rel-L2 5e-2 of the
+    bf16-arithmetic loop after the 10 steps (random-init weights); the CFG pair takes the same kernels (same bits as the plain forward)."""
+    c, grid, seed = SEAM, (2, 8, 8), 1410
+    f, h, w = grid
+    m = hip.WanDiT.from_state_dict(fp8_state_dict(c, seed), eps=1e-6, num_heads=2, **c)
+    x = dev(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w))
+    ctx = dev(synth.text_context(seed + 2, 24, c["text_dim"], 17))
+    t = torch.tensor([637.5])
+    base = m.forward(x, t, ctx)
+    m.ffn_fp8_mfma(True); m.proj_fp8_mfma(True)
+    got = m.forward(x, t, ctx)
+    m.context_cache(True)
+    try:
+        pc, pu = m.forward_cfg_pair(x, t, ctx, dev(-synth.text_context(seed + 2, 24, c["text_dim"], 17)))
+    finally:
+        m.context_cache(False)
+    r = errs(got, base)[0]
+    assert torch.isfinite(got.float()).all() and r < 6e-2, r
+    pair_vs_plain = float(errs(pc, got)[0])
+    assert pair_vs_plain < 2e-2                             # (stacked rows: the same kernels; the context cache's K / V are the plain forward's)
+    with pytest.raises(RuntimeError, match="float8_e4m3fn"):
+        sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
+        hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=2, **c).proj_fp8_mfma(True)
+    cfg, seed = synth.WAN_1_3B, synth.C1_SEED
+    m = hip.WanDiT.from_state_dict(fp8_state_dict(cfg, seed), eps=1e-6, num_heads=synth.num_heads_of(cfg), **cfg)
+    noise = hip.generate_noise((1, 16, 5, 32, 32), seed=0, device="cpu", dtype=torch.float32)
+    pos = dev(torch.from_numpy(synth.text_context(seed + 1, 512, cfg["text_dim"], 64)))
+    neg = dev(torch.from_numpy(synth.text_context(seed + 2, 512, cfg["text_dim"], 64)))
+    loop = hip.DenoiseLoop(m)
+    base = loop.sample(dev(noise), pos, neg, num_inference_steps=10, cfg_scale=5.0, sigma_shift=5.0)
+    m.ffn_fp8_mfma(True); m.proj_fp8_mfma(True)
+    got = loop.sample(dev(noise), pos, neg, num_inference_steps=10, cfg_scale=5.0, sigma_shift=5.0)
+    r = errs(got, base)[0]
+    g = golden("c1_e2e.npz")
+    report("c1_e2e_fp8_all", all_vs_bf16_arithmetic=r, all_vs_ref_fp32=errs(got[0], g["latents_fp32"])[0], pair_vs_plain_forward=pair_vs_plain)
+    assert torch.isfinite(got.float()).all() and r < 5e-2, r

@@ -39,6 +39,7 @@ line no_graph --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-vendor
 line fp8_attn --steps 10 --warmup 3 --fp8-attn --no-cpu-baseline --no-vendor
 line fp8_mfma --steps 10 --warmup 3 --fp8-mfma --no-cpu-baseline --no-vendor
 line fp8_mfma_attn --steps 10 --warmup 3 --fp8-mfma --fp8-attn --no-cpu-baseline --no-vendor
+line fp8_all --steps 10 --warmup 3 --fp8-all --no-cpu-baseline --no-vendor
 line c1 --workload c1 --steps 10 --warmup 3 --no-cpu-baseline
 line c4 --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-vendor
 # round 6: the non-benign lines (peaky attention logits through learned-gain factors, a 200-token prompt on the streaming cross-attention kernel), the step beside a
