@@ -227,15 +227,21 @@ class DenoiseLoop:
             ucond = dict(cond, add_condition=None)
         split = ucond is not cond                   # the two branches differ in more than the prompt
         if tea_cache_posi is not None:
-            if self.cfg_pair is not None:
-                # each rank of a CFG pair would need only its branch's TeaCache; taking this branch would silently run both forwards on
-                # every rank and skip the exchange
-                raise NotImplementedError("TeaCache together with the CFG pair is not served by the HIP backend")
             from .dit import model_fn_wan_video
             usp = {}
             if self.sequence_parallel:          # as the reference: TeaCache + USP (svi_video.py:112-131), residuals per rank
                 self.dit.sp_group = self.sp_group
                 usp = dict(use_unified_sequence_parallel=True)
+            if self.cfg_pair is not None and cfg_scale != 1.0:
+                # a CFG pair: this rank runs ONE branch with that branch's TeaCache (round 6).  The skip decision is a function of the time modulation alone
+                # (svi_video.py:36-62) — the same numbers on both ranks — so the two caches decide alike, step for step, and the exchange of noise_pred never
+                # waits for a forward the partner skipped differently; each cache's residual covers its own branch, as in the serial loop
+                tea_mine = tea_cache_posi if self.cfg_pair.role == 0 else tea_cache_nega
+                if tea_mine is None:
+                    raise ValueError("a CFG pair with TeaCache needs one TeaCache per branch (tea_cache_posi and tea_cache_nega)")
+                fwd_tea = lambda x, t, c, **kw: model_fn_wan_video(self.dit, x, t, c, tea_cache=tea_mine, **usp, **kw)      # noqa: E731
+                return self.cfg_pair.step(fwd_tea, ops.cfg_step_, latents, timestep, dsigma, ctx_pos, ctx_neg, cfg_scale,
+                                          uncond_overrides=dict(add_condition=None) if split else None, **cond)
             cpred = model_fn_wan_video(self.dit, latents, timestep, ctx_pos, tea_cache=tea_cache_posi, **usp, **cond)
             if cfg_scale != 1.0:
                 upred = model_fn_wan_video(self.dit, latents, timestep, ctx_neg, tea_cache=tea_cache_nega, **usp, **ucond)

@@ -52,13 +52,23 @@ def test_forward_checks_before_touching_the_device():
         m.forward(torch.zeros(1, 16, 3, 8, 12), torch.tensor([1.0]), torch.zeros(1, 20, 64))
 
 
-def test_teacache_with_the_cfg_pair_is_refused():
-    """TeaCache + sequence parallelism is served (as the reference allows it); TeaCache on a CFG pair is not: DenoiseLoop.step must not
-    take the TeaCache branch silently and run both full forwards on every rank."""
+def test_teacache_on_a_cfg_pair_runs_this_ranks_branch_with_its_own_cache():
+    """Round 6 (was a refusal): on a CFG pair DenoiseLoop.step hands the pair ONE forward — this rank's branch through model_fn_wan_video with that branch's
+    TeaCache — instead of running both branches on every rank; without a cache for its branch it refuses with a message."""
     import svi_hip
     m = _dit(synth.TINY_DIT)
     lat, ctx = torch.zeros(1, 16, 3, 8, 12), torch.zeros(1, 20, 64)
     tea = svi_hip.TeaCache(4, 0.1, "Wan2.1-T2V-1.3B")
-    loop = svi_hip.DenoiseLoop(m, cfg_pair=object())
-    with pytest.raises(NotImplementedError):
-        loop.step(lat, torch.tensor([500.0]), -0.1, ctx, ctx, 5.0, tea_cache_posi=tea, tea_cache_nega=tea)
+    seen = {}
+
+    class Pair:
+        role = 1
+
+        def step(self, forward, cfg_step, latents, timestep, dsigma, ctx_pos, ctx_neg, cfg_scale, uncond_overrides=None, **cond):
+            seen.update(forward=forward, cfg_step=cfg_step, scale=cfg_scale)
+            return latents
+    loop = svi_hip.DenoiseLoop(m, cfg_pair=Pair())
+    assert loop.step(lat, torch.tensor([500.0]), -0.1, ctx, ctx, 5.0, tea_cache_posi=tea, tea_cache_nega=tea) is lat
+    assert callable(seen["forward"]) and seen["scale"] == 5.0
+    with pytest.raises(ValueError, match="one TeaCache per branch"):
+        loop.step(lat, torch.tensor([500.0]), -0.1, ctx, ctx, 5.0, tea_cache_posi=tea, tea_cache_nega=None)

@@ -89,3 +89,52 @@ def test_denoise_loop_with_teacache_runs_fewer_block_stacks():
     assert torch.isfinite(tea.float()).all() and not torch.equal(tea, plain)    # everything between first and last step skipped
     with pytest.raises(ValueError):
         loop.sample(lat, cp, cn, num_inference_steps=6, tea_cache_l1_thresh=0.1, tea_cache_model_id="")
+
+
+@pytest.mark.gpu
+def test_teacache_on_a_cfg_pair_gives_the_serial_loops_bits():
+    """TeaCache on a CFG pair (round 6): each rank runs its branch through model_fn_wan_video with that branch's cache, the pair exchanges noise_pred, both
+    apply CFG + Euler.  Emulated in one process — two DenoiseLoops over one WanDiT, a pair object per role whose `step` keeps its branch's prediction until the
+    partner's arrives (what the all-gather does) — against the serial TeaCache loop: the two caches take the same decisions step for step (they are functions
+    of the time modulation), so the latents are the serial loop's, bit for bit, and skipped steps really skip on both 'ranks'."""
+    import svi_hip
+    from svi_hip import ops
+    from gpu_util import dev
+    c, grid, nt, nv, seed = synth.TINY_DIT, (3, 4, 6), 20, 13, 100
+    f, h, w = grid
+    sd = {k: torch.from_numpy(v) for k, v in synth.dit_state_dict(seed, **c).items()}
+    m = svi_hip.WanDiT.from_state_dict(sd, eps=1e-6, num_heads=synth.num_heads_of(c), **c)
+    lat0 = dev(synth.randn(seed + 1, 1, 16, f, 2 * h, 2 * w))
+    cp, cn = dev(synth.text_context(seed + 2, nt, c["text_dim"], nv)), dev(synth.text_context(seed + 3, nt, c["text_dim"], nv))
+    steps, thr = 8, 0.15
+    serial = svi_hip.DenoiseLoop(m, graph=False)
+    serial.scheduler.set_timesteps(steps, shift=5.0)
+    tp, tn = svi_hip.TeaCache(steps, thr, synth.TEA_MODEL), svi_hip.TeaCache(steps, thr, synth.TEA_MODEL)
+    want = lat0.clone()
+    ts = serial.scheduler.timesteps.to("cuda", torch.float32)
+    for i, t in enumerate(serial.scheduler.timesteps):
+        serial.step(want, ts[i:i + 1], serial.scheduler.step_delta(t), cp, cn, 5.0, tea_cache_posi=tp, tea_cache_nega=tn)
+
+    mailbox = {}
+
+    class Pair:
+        def __init__(self, role):
+            self.role = role
+
+        def step(self, forward, cfg_step, latents, timestep, dsigma, ctx_pos, ctx_neg, cfg_scale, uncond_overrides=None, **cond):
+            mailbox[self.role] = (forward(latents, timestep, ctx_pos if self.role == 0 else ctx_neg, **cond).clone(), latents, cfg_scale, dsigma)
+            if len(mailbox) == 2:                    # both branches are in: every rank applies the same update to its own copy of the latents
+                for role in (0, 1):
+                    cfg_step(mailbox[role][1], mailbox[0][0], mailbox[1][0], cfg_scale, dsigma)
+                mailbox.clear()
+            return latents
+    loops = [svi_hip.DenoiseLoop(m, cfg_pair=Pair(r)) for r in (0, 1)]
+    caches = [(svi_hip.TeaCache(steps, thr, synth.TEA_MODEL), svi_hip.TeaCache(steps, thr, synth.TEA_MODEL)) for _ in (0, 1)]
+    lats = [lat0.clone(), lat0.clone()]
+    for i, t in enumerate(serial.scheduler.timesteps):
+        for r in (0, 1):
+            loops[r].step(lats[r], ts[i:i + 1], serial.scheduler.step_delta(t), cp, cn, 5.0, tea_cache_posi=caches[r][0], tea_cache_nega=caches[r][1])
+    assert torch.equal(lats[0], want) and torch.equal(lats[1], want)
+    # rank 0 only ever touched its conditional cache, rank 1 its unconditional one, and both walked the serial caches' steps
+    assert caches[0][0].step == tp.step and caches[1][1].step == tn.step and caches[0][1].step == 0 and caches[1][0].step == 0
+    assert not torch.equal(want, svi_hip.DenoiseLoop(m).sample(lat0, cp, cn, num_inference_steps=steps))       # the threshold does skip steps here
