@@ -25,12 +25,19 @@ The single-rank step replays ONE hipGraph per step (the installed sampler's defa
 step as one; bit-identical); `--no-graph` launches eagerly.  `--transport gloo` runs the multi-rank path with the exchanges through
 the host and the ranks sharing the visible device(s): a probe of that code path on a one-GPU box, never a scaling figure.
 
+Round 6: `--attn-gain G` / `--prompt-tokens N` (the non-benign lines: peaky attention logits through learned-gain factors; a long prompt on the streaming
+cross-attention kernel), `--budget-s S` (wall-clock budget counted from process start, default 600: optional parts are dropped, the K timed steps never; the plan is
+printed after the warm-up), `--rccl-probe` (N = 1 with a live one-rank RCCL communicator), `--fp8-all` (opt-in: every token-side GEMM and QK^T on MX fp8), and beside an
+RCCL communicator the step graph is tried behind a guard and voted on (`config.hip_graph`, `config.hip_graph_note`).
+
 Extra objects on the JSON line:
   roofline      dominant kernel = self-attention flash kernel: algorithmic 4*L^2*D FLOP per launch divided by
                 its mean launch time measured with HIP events on the launch stream — inside the timed region with --no-graph; with
                 the hipGraph (default) over eager steps of the same loop run directly behind it (a replay cannot carry event pairs).
                 `traffic` / `mfma_busy_in_clock` come from the rocprofv3 --pmc summaries under profiles/ and are given only when
                 EVERY kernel source hash recorded with them equals the tree being timed.
+  vendor_yardstick / roofline_all.<family>.vendor   (N = 1, c2) tools/yardstick.py as a child process after the timed parts: hipBLASLt (torch.matmul) and
+                F.scaled_dot_product_attention on the step's six hot shapes beside this repo's launches, same box, same job.  Measurement only.
   cpu_baseline  the reference's own DiTBlock.forward and WanVideoVAE.decode (oracle/_ref, built by oracle/build_ref.py: kind
                 "reference") — or, where that copy is absent, the oracle's restatement (kind "port") — timed on this box's
                 host cores on a bounded sample (one of the 30 blocks of one of the 100 forwards, full size; 2 of the 21 latent
