@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, g4 = lane >> 4;
 
     // XCD-aware, bijective remap of the linear workgroup id
     const int nwg = tiles_m * tiles_n;
@@ -109,13 +109,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
         }
     };
 
-    f32x16 acc[2][2];                       // [ni][mi]
+    f32x4 acc[4][4];                        // [nb][mb]: 16 x 16 blocks, lane l holds n = 4 (l >> 4) + e of row m = l & 15
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     load_tile(0);
     store_tile(0);
@@ -127,45 +127,43 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
         const char* As = smem + cur * 2 * STAGE_BYTES;
         const char* Ws = As + STAGE_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 xa[2], wb[2];
+        for (int kk = 0; kk < 2; ++kk) {          // two k-steps of 32: lane group g4 holds k = 8 g4 .. 8 g4 + 7 of the step
+            bf16x8 xa[4], wb[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                xa[i] = *reinterpret_cast<const bf16x8*>(As + lds_tile_off(wm * 64 + i * 32 + l31, 2 * kk + hi));
-                wb[i] = *reinterpret_cast<const bf16x8*>(Ws + lds_tile_off(wn * 64 + i * 32 + l31, 2 * kk + hi));
+            for (int i = 0; i < 4; ++i) {
+                xa[i] = *reinterpret_cast<const bf16x8*>(As + lds_tile_off(wm * 64 + i * 16 + l15, 4 * kk + g4));
+                wb[i] = *reinterpret_cast<const bf16x8*>(Ws + lds_tile_off(wn * 64 + i * 16 + l15, 4 * kk + g4));
             }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nb], xa[mb], acc[nb][mb], 0, 0, 0);
         }
         if (kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue part 1: y = bf16(acc + bias) -> LDS [128 m][CS_LD] bf16 --------------------------
-    // acc[ni][mi][r] is C[m = m0 + wm*64 + mi*32 + l31][n = n0 + wn*64 + ni*32 + (r&3) + 8*(r>>2) + 4*hi]
+    // acc[nb][mb][e] is C[m = m0 + wm*64 + mb*16 + l15][n = n0 + wn*64 + nb*16 + 4*g4 + e]
     bf16* Cs = reinterpret_cast<bf16*>(smem);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int nb = 0; nb < 4; ++nb) {
+        const int nl = wn * 64 + nb * 16 + 4 * g4;
+        float bn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias && !g.bias_along_m) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int ml = wm * 64 + mi * 32 + l31;
+            for (int e = 0; e < 4; ++e) bn[e] = (n0 + nl + e < g.N) ? (float)g.bias[n0 + nl + e] : 0.f;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int ml = wm * 64 + mb * 16 + l15;
             float bm = 0.f;
             if (g.bias && g.bias_along_m) bm = (m0 + ml < g.M) ? (float)g.bias[m0 + ml] : 0.f;
+            bf16x4 pk;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int nl = wn * 64 + ni * 32 + 8 * rg + 4 * hi;
-                bf16x4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float bv = bm;
-                    if (g.bias && !g.bias_along_m) bv = (n0 + nl + e < g.N) ? (float)g.bias[n0 + nl + e] : 0.f;
-                    pk[e] = (bf16)(acc[ni][mi][rg * 4 + e] + bv);
-                }
-                *reinterpret_cast<bf16x4*>(Cs + ml * CS_LD + nl) = pk;
-            }
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[nb][mb][e] + ((g.bias && g.bias_along_m) ? bm : bn[e]));
+            *reinterpret_cast<bf16x4*>(Cs + ml * CS_LD + nl) = pk;
         }
     }
     __syncthreads();
@@ -314,8 +312,10 @@ __device__ __forceinline__ void gemm256_apply(float (&y)[8], const u32x4& res, c
 // MI x NI: 32x32 accumulator blocks per wave along M / N (wave grid (256 / 32 MI) x (TNV / 32 NI)); TNV: tile width.  The 256^2 kernels are
 // <4, 2, 256>; the 256 x 192 kernel <2, 3, 192> (read-back threads whose column chunk lies past the tile's 192 columns sit idle).
 // NT: threads of the workgroup (512: eight waves, 16 rows per read-back iteration; 256: the four-wave kernel, 8 rows per iteration)
-template <int EPI, int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false, int NT = 512>
-__device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, int m0, int n0, int tid,
+// MF: the MFMA the accumulators come from.  32: f32x16 acc[NI][MI], lane l holds n = 8 rg + 4 (l >> 5) + e (r = 4 rg + e) of row m = l & 31 (the MX fp8 kernel
+// and the four-wave experiments);  16: f32x4 acc[2 NI][2 MI] of v_mfma_f32_16x16x32_bf16, lane l holds n = 4 (l >> 4) + e of row m = l & 15 (the bf16 kernels).
+template <int EPI, int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false, int NT = 512, int MF = 32, class ACC>
+__device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, ACC& acc, char* smem, int m0, int n0, int tid,
                                                    int wm, int wn, int l31, int hi, int abl) {
     constexpr int RPI = NT / 32, ITS = TM / RPI;          // rows per read-back iteration, iterations
     const bool interior = (m0 + TM <= g.M) && (n0 + TNV <= g.N);
@@ -353,10 +353,49 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
         }
     }
     // ---- part 1: y = bf16(acc + bias) -> LDS [256 m][C2_LD] bf16 ---------------------------------------------------------
-    u32x2 bnp[NI][4];
-    float bmv[MI];
     const bool bias_n = g.bias && !g.bias_along_m, bias_m = g.bias && g.bias_along_m;
     const bool bias_vec = bias_n && (n0 + TNV <= g.N) && (((uintptr_t)g.bias & 7) == 0);
+    bf16* Cs = reinterpret_cast<bf16*>(smem);
+    if constexpr (MF == 16) {
+        const int l15 = tid & 15, g4 = (tid & 63) >> 4;
+        u32x2 bnq[2 * NI];
+        float bmq[2 * MI];
+#pragma unroll
+        for (int nb = 0; nb < 2 * NI; ++nb) {
+            const int n = n0 + wn * (32 * NI) + nb * 16 + 4 * g4;
+            if (bias_vec) {
+                bnq[nb] = *reinterpret_cast<const u32x2*>(g.bias + n);
+            } else {
+                unsigned short h4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h4[e] = (bias_n && n + e < g.N) ? reinterpret_cast<const unsigned short*>(g.bias)[n + e] : (unsigned short)0;
+                bnq[nb][0] = (unsigned)h4[0] | ((unsigned)h4[1] << 16);
+                bnq[nb][1] = (unsigned)h4[2] | ((unsigned)h4[3] << 16);
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2 * MI; ++mb) {
+            const int m = m0 + wm * (32 * MI) + mb * 16 + l15;
+            bmq[mb] = (bias_m && m < g.M) ? (float)g.bias[m] : 0.f;
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2 * NI; ++nb) {
+            const int nl = wn * (32 * NI) + nb * 16 + 4 * g4;
+            const unsigned b01 = bnq[nb][0], b23 = bnq[nb][1];
+            const float bn4[4] = {__builtin_bit_cast(float, b01 << 16), __builtin_bit_cast(float, b01 & 0xffff0000u),
+                                  __builtin_bit_cast(float, b23 << 16), __builtin_bit_cast(float, b23 & 0xffff0000u)};
+#pragma unroll
+            for (int mb = 0; mb < 2 * MI; ++mb) {
+                const int ml = wm * (32 * MI) + mb * 16 + l15;
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[nb][mb][e] + (bn4[e] + bmq[mb]));
+                *reinterpret_cast<bf16x4*>(Cs + ml * C2_LD + nl) = pk;
+            }
+        }
+    } else {
+    u32x2 bnp[NI][4];
+    float bmv[MI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -377,7 +416,6 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
         const int m = m0 + wm * (32 * MI) + mi * 32 + l31;
         bmv[mi] = (bias_m && m < g.M) ? (float)g.bias[m] : 0.f;
     }
-    bf16* Cs = reinterpret_cast<bf16*>(smem);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -395,6 +433,7 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
                 *reinterpret_cast<bf16x4*>(Cs + ml * C2_LD + nl) = pk;
             }
         }
+    }
     }
     __syncthreads();
     if (abl == 3) return;
@@ -482,20 +521,20 @@ __device__ __forceinline__ void gemm256_epilogue_t(const SviGemmArgs& g, f32x16 
     }
 }
 
-template <int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false, int NT = 512>
-__device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, int m0, int n0, int tid,
+template <int MI = 4, int NI = 2, int TNV = TN, bool Q8OUT = false, int NT = 512, int MF = 32, class ACC>
+__device__ __forceinline__ void gemm256_epilogue(const SviGemmArgs& g, ACC& acc, char* smem, int m0, int n0, int tid,
                                                  int wm, int wn, int l31, int hi, int abl = 0) {
     if (abl == 1) {
-        if (acc[0][0][0] == 123.456f) g.C[0] = (bf16)acc[1][MI - 1][5];      // keep the accumulators alive
+        if (acc[0][0][0] == 123.456f) g.C[0] = (bf16)acc[1][MI - 1][3];      // keep the accumulators alive
         return;
     }
     switch (g.epi) {        // uniform: one scalar branch per tile
-        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
-        default:                     gemm256_epilogue_t<SVI_EPI_BIAS, MI, NI, TNV, Q8OUT, NT>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_TANH: gemm256_epilogue_t<SVI_EPI_BIAS_GELU_TANH, MI, NI, TNV, Q8OUT, NT, MF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GATE_RES:  gemm256_epilogue_t<SVI_EPI_BIAS_GATE_RES, MI, NI, TNV, Q8OUT, NT, MF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_GELU_ERF:  gemm256_epilogue_t<SVI_EPI_BIAS_GELU_ERF, MI, NI, TNV, Q8OUT, NT, MF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_SILU:      gemm256_epilogue_t<SVI_EPI_BIAS_SILU, MI, NI, TNV, Q8OUT, NT, MF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        case SVI_EPI_BIAS_RELU:      gemm256_epilogue_t<SVI_EPI_BIAS_RELU, MI, NI, TNV, Q8OUT, NT, MF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
+        default:                     gemm256_epilogue_t<SVI_EPI_BIAS, MI, NI, TNV, Q8OUT, NT, MF>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl); break;
     }
 }
 
@@ -609,54 +648,59 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g
     std::integral_constant<int, 4> J4;
     std::integral_constant<int, WP> JW;
 
-    f32x16 acc[NI][MI];
+    // The multiply is v_mfma_f32_16x16x32_bf16 (round 6; tools/probe/run_mfma_power_probe.py: on random operands the part's power limit holds a stream of
+    // v_mfma_f32_32x32x16_bf16 at 1.73 GHz = 1750 TFLOP/s and a stream of 16x16x32 at 1.99 GHz = 1996, same nominal rate): the 32-row / 32-column blocks the
+    // schedule below is written in are two 16-row blocks each, a K tile is two k-steps of 32.  Lane l of a fragment read holds row (l & 15), k = 8 (l >> 4) .. + 7
+    // of the step = 16-byte chunk 4 kk + (l >> 4) of the 128-byte row; accumulator block [nb][mb] holds n = 4 (l >> 4) + e of row m = l & 15.
+    f32x4 acc[2 * NI][2 * MI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < 2 * NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MI; ++j)
+        for (int j = 0; j < 2 * MI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-    int a_addr[4], w_addr[4];          // this lane's fragment of k-step kk: row block 0 of the wave's rows (A) / columns (W), buffer 0
+    const int l15 = lane & 15, g4 = lane >> 4;
+    int a_addr[2], w_addr[2];          // this lane's fragment of k-step kk: 16-row block 0 of the wave's rows (A) / columns (W), buffer 0
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        a_addr[kk] = lds0 + lds_tile_off(wm * (32 * MI) + l31, 2 * kk + hi);
-        w_addr[kk] = lds0 + 2 * E_HALF + lds_tile_off(wn * (32 * NI) + l31, 2 * kk + hi);
+    for (int kk = 0; kk < 2; ++kk) {
+        a_addr[kk] = lds0 + lds_tile_off(wm * (32 * MI) + l15, 4 * kk + g4);
+        w_addr[kk] = lds0 + 2 * E_HALF + lds_tile_off(wn * (32 * NI) + l15, 4 * kk + g4);
     }
-    u32x4 xlo[MH][4], xup[MH][4], xw[NI][4];          // A fragments of the lower / upper MH row blocks, W fragments of the NI column blocks
-    auto read_a = [&](u32x4 (&x)[MH][4], int blk0) {
+    u32x4 xlo[2 * MH][2], xup[2 * MH][2], xw[2 * NI][2];          // A fragments of the lower / upper MH 32-row blocks, W fragments of the NI 32-column blocks
+    auto read_a = [&](u32x4 (&x)[2 * MH][2], int blk0) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < MH; ++i) x[i][kk] = *(lds_u32x4_t)(a_addr[kk] + (blk0 + i) * 32 * 128);
+            for (int i = 0; i < 2 * MH; ++i) x[i][kk] = *(lds_u32x4_t)(a_addr[kk] + (2 * blk0 + i) * 16 * 128);
     };
     auto read_w = [&](auto n0c, auto nnc) {
         constexpr int nb0 = decltype(n0c)::value, NN = decltype(nnc)::value;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = nb0; i < nb0 + NN; ++i) xw[i][kk] = *(lds_u32x4_t)(w_addr[kk] + i * 32 * 128);
+            for (int i = 2 * nb0; i < 2 * (nb0 + NN); ++i) xw[i][kk] = *(lds_u32x4_t)(w_addr[kk] + i * 16 * 128);
     };
-    // acc[n][mb0 + i] += W(n) x A(i) for n in [nb0, nb0 + NN), i in [0, MH), over the tile's four k-steps
-    auto cluster = [&](auto n0c, auto nnc, int mb0, const u32x4 (&xa)[MH][4]) {
+    // acc[n][2 mb0 + i] += W(n) x A(i) for the 16-column blocks n of 32-column blocks [nb0, nb0 + NN), the 16-row blocks i of MH 32-row blocks, over the tile's two k-steps
+    auto cluster = [&](auto n0c, auto nnc, int mb0, const u32x4 (&xa)[2 * MH][2]) {
         constexpr int nb0 = decltype(n0c)::value, NN = decltype(nnc)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int n = nb0; n < nb0 + NN; ++n)
+            for (int n = 2 * nb0; n < 2 * (nb0 + NN); ++n)
 #pragma unroll
-                for (int i = 0; i < MH; ++i)
-                    acc[n][mb0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xw[n][kk]), __builtin_bit_cast(bf16x8, xa[i][kk]), acc[n][mb0 + i], 0, 0, 0);
+                for (int i = 0; i < 2 * MH; ++i)
+                    acc[n][2 * mb0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xw[n][kk]), __builtin_bit_cast(bf16x8, xa[i][kk]), acc[n][2 * mb0 + i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
     std::integral_constant<int, 0> N0;
     std::integral_constant<int, 1> N1;
     std::integral_constant<int, NI> NALL;
-    auto flip = [&](int (&ad)[4]) {
+    auto flip = [&](int (&ad)[2]) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) ad[kk] ^= E_BUF;
+        for (int kk = 0; kk < 2; ++kk) ad[kk] ^= E_BUF;
     };
     // one K tile.  SW: tile t+1 exists (its W is staged here, its lower A fragments are read here);  SA: tile t+2 exists (its A is staged here)
     auto ktile = [&](int t, auto swc, auto sac) {
@@ -749,11 +793,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256e_kernel(SviGemmArgs g
     ktile(t, NO, NO);
     if (grp == 0) E_BAR();
 #pragma unroll
-    for (int n = 0; n < NI; ++n)
+    for (int n = 0; n < 2 * NI; ++n)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("s_nop 7" : "+v"(acc[n][i]));      // MFMA result -> VALU read
+        for (int i = 0; i < 2 * MI; ++i) asm volatile("" : "+v"(acc[n][i]));
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // MFMA result -> VALU read
     __syncthreads();                                       // every wave is done with the operand buffers: the C tile may overwrite them
-    gemm256_epilogue<MI, NI, TNW>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl == 5 ? 0 : abl == 6 ? 1 : abl);
+    gemm256_epilogue<MI, NI, TNW, false, 512, 16>(g, acc, smem, m0, n0, tid, wm, wn, l31, hi, abl == 5 ? 0 : abl == 6 ? 1 : abl);
 }
 
 // =================================================================================================
