@@ -48,6 +48,7 @@ static SviSwitches parse_switches() {
     s.gemm_gm = env_int("SVI_GEMM_GM", 1, 0);
     s.vae_exact_fp32 = getenv("SVI_VAE_EXACT_FP32") != nullptr;
     s.flash_two_pass = env_int("SVI_FLASH_TWO_PASS", 0, 1);
+    s.flash_m16 = env_int("SVI_FLASH_M16", 0, 1);
     s.vae_no_x2h = env_int("SVI_VAE_X2H", 0, 1) == 0;
     s.cross_dedup = env_int("SVI_CROSS_DEDUP", 0, 1);
     s.cross_fused = env_int("SVI_CROSS_FUSED", 0, 1);
@@ -98,6 +99,7 @@ extern "C" int32_t svi_switch_state(const char* name) {
     if (n == "SVI_CROSS_DEDUP") return sw.cross_dedup ? 1 : 0;
     if (n == "SVI_QK_FUSED") return sw.qk_fused ? 1 : 0;
     if (n == "SVI_FLASH_TWO_PASS") return sw.flash_two_pass ? 1 : 0;
+    if (n == "SVI_FLASH_M16") return sw.flash_m16 ? 1 : 0;
     return -1;
 }
 

@@ -1542,6 +1542,443 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
     });
 }
 
+// =================================================================================================
+// v3 — the optimistic pass of v2 rebuilt on v_mfma_f32_16x16x32_bf16 (round 6).
+//
+// Why: on random operands the part's POWER limit, not the instruction stream, holds the matrix pipe, and under that limit the two bf16 shapes are not
+// equal: tools/probe/run_mfma_power_probe.py sustains 1750 TFLOP/s on a bare stream of v_mfma_f32_32x32x16_bf16 (1.73 GHz) and 1996 on 16x16x32 (1.99 GHz); with
+// this kernel's softmax mix beside each flop (one v_exp, one v_add, half a v_cvt_pk, half a ds_read_b128 per 32 Ki flop) 1507 against 1700 — provided the fillers
+// are spread ONE PIECE PER MFMA GAP (exp | M | add | M | exp | M | add, cvt | M): two pieces in one 16-cycle gap stall the pipe (1526).
+//
+// Same workgroup shape, LDS image of V^T, LDS-DMA staging, barriers, optimistic reference, flag protocol and split / piece outputs as flash_fwd2_kernel<.., MODE 1>
+// (the flagged second pass stays flash_fwd2_kernel<.., MODE 2>: same grid, same flag words).  What changes is the lane <-> (key, query) map:
+//   S^T block (kb, qb) = 16 keys x 16 queries, lane l holds query 16 qb + (l & 15), MFMA rows 4 (l >> 4) + e;  64 blocks of QK^T per 64-key tile and wave
+//   (4 kb x 4 qb x 4 channel steps of 32), each K fragment (16 B per lane) feeds the four query blocks.
+//   MFMA row r of block kb is KEY 32 (kb >> 1) + 8 (r >> 2) + 4 (kb & 1) + (r & 3), so the 8 probabilities a lane holds in blocks 2 ks and 2 ks + 1 (its 4 + 4
+//   accumulator registers, packed to bf16) are the 8 CONSECUTIVE keys 32 ks + 8 (l >> 4) .. + 7: exactly the k-block the P·V MFMA wants from this lane, and the
+//   V^T fragment is one plain ds_read_b128 (16 channels x 32 keys).  No cross-lane movement of P.
+//   O^T block (db, qb) = 16 channels x 16 queries: 64 P·V MFMAs per tile and wave (8 db x 4 qb x 2 key steps of 32).
+//   K tile swizzle: the 16 rows a fragment read touches are 8 (r >> 2) + (r & 3) + const, which collide under v2's (row & 15); here slot (row, p) holds chunk
+//   p ^ ((row & 3) | ((row >> 3) & 3) << 2) — for a fragment read that is chunk ^ (l & 15): every ds_read_b128 lane group hits 16 distinct slots.  A DMA piece's
+//   rows lie 16 apart, so odd pieces read their source chunks ^ 8 (a second lane offset, koff[1]).
+// Schedule (the balanced optimistic schedule of v2 with every statement split in two): a phase is 16 fragments x 4 statements (one per query block); the four
+// statements of fragment f carry ONE score pair: exp(x0) | add | exp(x1) | add, pack.  Pairs of tile t: key block 0 on statements 32..63 of phase 2 of tile t
+// (from the tile just multiplied), key blocks 1 and 2 on phase 1 of tile t + 1, key block 3 on statements 0..31 of phase 2 of tile t + 1 — each word complete
+// before the P·V statement that reads it (key step 1 starts at statement 32).  LDS-DMA: V(t) on statements 9, 25, 41, 57 of phase 1, K(t + 3) on statements
+// 49, 53, 57, 61 of phase 2.
+// =================================================================================================
+__device__ __forceinline__ int k3_off(int row, int chunk) { return row * 256 + ((chunk ^ ((row & 3) | (((row >> 3) & 3) << 2))) << 4); }
+// One K fragment's four statements (query blocks 0..3) as ONE asm block.  hipcc treats every vector register an asm block writes as a possible forwarding hazard
+// for the next block that reads it and puts an s_nop between two adjacent blocks; per-statement blocks chained through tok / the exponentials cost 120 s_nop per tile
+// pair.  A fragment-sized block meets its neighbour across the fragment's look-ahead ds_read, so none is needed.
+//   B: the block carries one score pair:  exp(x0) | M | add | M | exp(x1) | M | add, pack | M;   DMA: one LDS-DMA piece behind the second MFMA
+#define SVI3_QK4(M0, M1, M2, M3, PRE0, PRE1, PRE2, PRE3, DMA0, DMA1) DMA0 PRE0 M0 PRE1 M1 DMA1 PRE2 M2 PRE3 M3
+#define SVI3_QF(i) "v_mfma_f32_16x16x32_bf16 %[s" #i "], %[kf], a[%c[q" #i "]:%c[r" #i "]], %[cn" #i "]\n\t"
+#define SVI3_QN(i) "v_mfma_f32_16x16x32_bf16 %[s" #i "], %[kf], a[%c[q" #i "]:%c[r" #i "]], %[s" #i "]\n\t"
+#define SVI3_PM(i) "v_mfma_f32_16x16x32_bf16 a[%c[o" #i "]:%c[u" #i "]], %[vf], %[p" #i "], a[%c[o" #i "]:%c[u" #i "]]\n\t"
+#define SVI3_E0 "v_exp_f32 %[t0], %[x0]\n\t"
+#define SVI3_E1 "v_exp_f32 %[t1], %[x1]\n\t"
+#define SVI3_ME0 "v_mul_f32 %[t0], %[x0], %[c]\n\tv_exp_f32 %[t0], %[t0]\n\t"
+#define SVI3_ME1 "v_mul_f32 %[t1], %[x1], %[c]\n\tv_exp_f32 %[t1], %[t1]\n\t"
+#define SVI3_A0 "v_add_f32 %[a0], %[a0], %[t0]\n\t"
+#define SVI3_A1C "v_add_f32 %[a1], %[a1], %[t1]\n\tv_cvt_pk_bf16_f32 %[w], %[t0], %[t1]\n\t"
+#define SVI3_S_OUT(sc) [s0] sc(s0), [s1] sc(s1), [s2] sc(s2), [s3] sc(s3), [tok] "+v"(tok), [ap] "+v"(apin)
+#define SVI3_B_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(sum0), [a1] "+v"(sum1), [w] "=&v"(w)
+#define SVI3_Q_IN [kf] "v"(kf), [kf2] "v"(kf2), [q0] "n"(R), [r0] "n"(R + 3), [q1] "n"(R + 16), [r1] "n"(R + 19), [q2] "n"(R + 32), [r2] "n"(R + 35), [q3] "n"(R + 48), [r3] "n"(R + 51)
+#define SVI3_CN_IN [cn0] "v"(c0), [cn1] "v"(c1), [cn2] "v"(c2), [cn3] "v"(c3)
+#define SVI3_O_IN [vf] "v"(vf), [vf2] "v"(vf2), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [o0] "n"(R), [u0] "n"(R + 3), [o1] "n"(R + 4), [u1] "n"(R + 7), [o2] "n"(R + 8), [u2] "n"(R + 11), [o3] "n"(R + 12), [u3] "n"(R + 15)
+// R: the Q fragment of query block 0 for this channel step (query block qb: R + 16 qb)
+template <int R, bool FIRST, bool B, bool DMA, bool MULC>
+__device__ __forceinline__ void qk3_frag(int& tok, f32x4& s0, f32x4& s1, f32x4& s2, f32x4& s3, u32x4 kf, u32x4 kf2, int& apin, const f32x4& c0, const f32x4& c1, const f32x4& c2,
+                                         const f32x4& c3, float x0, float x1, float c, float& sum0, float& sum1, unsigned& w, const SviDma& d) {
+    const u32x4 rs = d.rs;
+    const int vo = d.vo, so = d.so, m0v = d.m0v;
+    float t0, t1;
+    static_assert(!(FIRST && DMA) && (!DMA || B), "an LDS-DMA piece rides on a fragment that carries a pair and does not start a chain");
+    if constexpr (!B) {
+        if constexpr (FIRST) asm(SVI3_QK4(SVI3_QF(0), SVI3_QF(1), SVI3_QF(2), SVI3_QF(3), "", "", "", "", "", "") SVI_END : SVI3_S_OUT("=&v") : SVI3_Q_IN, SVI3_CN_IN);
+        else asm(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), "", "", "", "", "", "") SVI_END : SVI3_S_OUT("+v") : SVI3_Q_IN);
+    } else if constexpr (DMA) {
+        if constexpr (MULC) asm volatile(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, SVI_DMA_M0, SVI_DMA) SVI_END
+                                         : SVI3_S_OUT("+v"), SVI3_B_OUT : SVI3_Q_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), SVI_DMA_IN);
+        else asm volatile(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, SVI_DMA_M0, SVI_DMA) SVI_END
+                          : SVI3_S_OUT("+v"), SVI3_B_OUT : SVI3_Q_IN, [x0] "v"(x0), [x1] "v"(x1), SVI_DMA_IN);
+    } else if constexpr (FIRST) {
+        if constexpr (MULC) asm(SVI3_QK4(SVI3_QF(0), SVI3_QF(1), SVI3_QF(2), SVI3_QF(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, "", "") SVI_END
+                                : SVI3_S_OUT("=&v"), SVI3_B_OUT : SVI3_Q_IN, SVI3_CN_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c));
+        else asm(SVI3_QK4(SVI3_QF(0), SVI3_QF(1), SVI3_QF(2), SVI3_QF(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, "", "") SVI_END
+                 : SVI3_S_OUT("=&v"), SVI3_B_OUT : SVI3_Q_IN, SVI3_CN_IN, [x0] "v"(x0), [x1] "v"(x1));
+    } else {
+        if constexpr (MULC) asm(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, "", "") SVI_END
+                                : SVI3_S_OUT("+v"), SVI3_B_OUT : SVI3_Q_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c));
+        else asm(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, "", "") SVI_END
+                 : SVI3_S_OUT("+v"), SVI3_B_OUT : SVI3_Q_IN, [x0] "v"(x0), [x1] "v"(x1));
+    }
+}
+// One V^T fragment's four statements: a[R + 4 qb : + 3] += V^T-fragment x P-fragment of query block qb
+template <int R, bool B, bool DMA, bool MULC>
+__device__ __forceinline__ void pv3_frag(int& tok, u32x4 vf, u32x4 vf2, u32x4 p0, u32x4 p1, u32x4 p2, u32x4 p3, int& apin, float x0, float x1, float c, float& sum0, float& sum1,
+                                         unsigned& w, const SviDma& d) {
+    const u32x4 rs = d.rs;
+    const int vo = d.vo, so = d.so, m0v = d.m0v;
+    float t0, t1;
+    static_assert(!DMA || B, "an LDS-DMA piece rides on a fragment that carries a pair");
+    if constexpr (!B) {
+        asm(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), "", "", "", "", "", "") SVI_END : [tok] "+v"(tok), [ap] "+v"(apin) : SVI3_O_IN);
+    } else if constexpr (DMA) {
+        if constexpr (MULC) asm volatile(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, SVI_DMA_M0, SVI_DMA) SVI_END
+                                         : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), SVI_DMA_IN);
+        else asm volatile(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, SVI_DMA_M0, SVI_DMA) SVI_END
+                          : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1), SVI_DMA_IN);
+    } else {
+        if constexpr (MULC) asm(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, "", "") SVI_END
+                                : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c));
+        else asm(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, "", "") SVI_END
+                 : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1));
+    }
+}
+template <int R>
+__device__ __forceinline__ void pv3_mfma(int& tok, u32x4 vf, u32x4 p, int& apin) {
+    asm("v_mfma_f32_16x16x32_bf16 a[%c[o0]:%c[o1]], %[vf], %[p], a[%c[o0]:%c[o1]]" : [tok] "+v"(tok), [ap] "+v"(apin) : [vf] "v"(vf), [p] "v"(p), [o0] "n"(R), [o1] "n"(R + 3));
+}
+
+// MFMA result -> VALU read: hipcc does not know the asm blocks multiply, so the wait states are written here, and EVERY score tuple is tied to the statement —
+// otherwise the reads of an earlier key block's scores (mask, row maximum) are scheduled right behind that block's last MFMA and see its registers too early
+__device__ __forceinline__ void s3_settle(int& tok, f32x4 (&s)[4][4]) {
+    asm volatile("s_nop 15" : "+v"(tok), "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), "+v"(s[1][3]),
+                              "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[2][2]), "+v"(s[2][3]), "+v"(s[3][0]), "+v"(s[3][1]), "+v"(s[3][2]), "+v"(s[3][3]));
+}
+template <int TAG, bool MULC>
+__global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restrict__ Q, int ldq, const bf16* __restrict__ K, int ldk, const bf16* __restrict__ VT, int ldvt,
+                                                            bf16* __restrict__ O, int ldo, int Lq, int Lk, float scale_log2e, int* __restrict__ flags,
+                                                            float* __restrict__ opart, float2* __restrict__ ml, SviFlashSplit sp) {
+    constexpr int OREG0 = SVI_OREG0, QREG0 = SVI_QREG0;
+    // work items as in flash_fwd2_kernel: (q-block, head) pairs, q-block fastest; a split launch cuts the items past sp.whole along the key axis
+    const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x;
+    int qblock = blockIdx.x, head = blockIdx.y, piece = 0, num_heads = gridDim.y;
+    bool is_piece = false;
+    int vt_skip = 0;
+    if (sp.pieces > 1) {
+        int item = wg_linear;
+        if (wg_linear >= sp.whole) {
+            item = sp.whole + (wg_linear - sp.whole) / sp.pieces;
+            piece = (wg_linear - sp.whole) % sp.pieces;
+            is_piece = true;
+        }
+        qblock = item % sp.qblocks;
+        head = item / sp.qblocks;
+        num_heads = sp.heads;
+        if (is_piece) {
+            const int tiles = (Lk + KB - 1) / KB, per = (tiles + sp.pieces - 1) / sp.pieces;
+            const int k0 = piece * per * KB, k1 = min(Lk, k0 + per * KB);
+            K += (size_t)k0 * ldk;
+            VT += k0;
+            vt_skip = k0;
+            Lk = k1 - k0;
+        }
+    }
+    // clear the flag with an atomic whose return is awaited (flash_fwd2_kernel, MODE 1)
+    if (threadIdx.x == 0) { const int old = atomicExch(&flags[wg_linear], 0); asm volatile("" :: "v"(old)); }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int row0 = qblock * QB2 + wave * 64 + l15;          // query 16 qb + l15 of the wave's 64 rows
+
+    // ---- Q fragments of the four query blocks -> a[192:255] (B operands: channels 32 ds + 8 g4 .. + 7 of the lane's query); O accumulators a[64:191] = 0 ----
+    static_for<0, 4>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qc)::value;
+        const int qr = row0 + 16 * qb;
+        const bf16* qp = Q + (size_t)min(qr, Lq - 1) * ldq + head * DH + g4 * 8;
+        static_for<0, 4>([&](auto dc) __attribute__((always_inline)) {
+            constexpr int ds = decltype(dc)::value;
+            bf16x8 v = ld_bf16x8(qp + ds * 32);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (qr < Lq) ? v[e] : (bf16)0.f;
+            q_put<QREG0 + (qb * 4 + ds) * 4>(v);
+        });
+    });
+    int tok = 0;
+    asm volatile("; reserve the accumulation half" ::: SVI_ALL_AGPRS);
+    static_for<0, 128>([&](auto rc) __attribute__((always_inline)) { o_zero<OREG0 + decltype(rc)::value>(tok); });
+    asm volatile("s_nop 4" : "+v"(tok));
+
+    // ---- LDS-DMA (as v2: a tile is 16 pieces of 1 KiB; wave w moves pieces w, w + 4, w + 8, w + 12) ----
+    const int ntiles = (Lk + KB - 1) / KB;
+    const int npairs = (ntiles + 1) >> 1;
+    const int last = 2 * npairs - 1;
+    const int lds0 = (int)(size_t)(lptr_t)smem;
+    constexpr int VST0 = 4 * KT_BYTES;
+    u32x4 k_rs, v_rs;
+    {
+        const unsigned long long kb_ = (unsigned long long)K, vb_ = (unsigned long long)VT;
+        k_rs[0] = (unsigned)kb_; k_rs[1] = (unsigned)(kb_ >> 32) & 0xffffu;
+        k_rs[2] = (unsigned)(((size_t)(Lk - 1) * ldk + (size_t)(head + 1) * DH) * 2); k_rs[3] = 0x00020000u;
+        v_rs[0] = (unsigned)vb_; v_rs[1] = (unsigned)(vb_ >> 32) & 0xffffu;
+        v_rs[2] = (unsigned)(((size_t)((head + 1) * DH - 1) * ldvt + (size_t)ldvt - (size_t)vt_skip) * 2); v_rs[3] = 0x00020000u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            k_rs[i] = __builtin_amdgcn_readfirstlane(k_rs[i]);
+            v_rs[i] = __builtin_amdgcn_readfirstlane(v_rs[i]);
+        }
+    }
+    int koff[2], voff0;          // koff[j & 1]: this lane's source chunk of K piece j (rows 16 j + 4 wave + (lane >> 4); the swizzle's bit 3 is j & 1)
+    {
+        const int kr_ = 4 * wave + (lane >> 4);
+        const int f0 = (lane >> 4) | ((wave >> 1) << 2);
+        koff[0] = (kr_ * ldk + head * DH + (((lane & 15) ^ f0) << 3)) * 2;
+        koff[1] = (kr_ * ldk + head * DH + (((lane & 15) ^ f0 ^ 8) << 3)) * 2;
+        const int vr_ = 8 * wave + (lane >> 3);
+        voff0 = ((head * DH + vr_) * ldvt + (((lane & 7) ^ ((vr_ >> 1) & 7)) << 3)) * 2;
+    }
+    const int kstep = 16 * ldk * 2, vstep = 32 * ldvt * 2;
+    const int piece0 = lds0 + wave * 1024;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(K), 0, (int)k_rs[2], 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(VT), 0, (int)v_rs[2], 0x00020000);
+    auto stage_k = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(smem + (t & 3) * KT_BYTES + (wave + 4 * j) * 1024), 16, koff[j & 1], t * KB * ldk * 2 + j * kstep, 0, 0);
+    };
+    auto stage_v = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(smem + VST0 + (t & 1) * VT_BYTES + (wave + 4 * j) * 1024), 16, voff0, t * KB * 2 + j * vstep, 0, 0);
+    };
+
+    // ---- softmax state (score units; log2 units when Q carries softmax_scale * log2 e) ----
+    const float cs = MULC ? scale_log2e : 1.0f;
+    float m_ref[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cneg[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) cneg[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 pw[2][4];                              // P as MFMA B operands: [key step of 32][query block]
+    float ps[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // row sums per lane: [query block][first / second score of a pair], over the whole key axis
+    // fragment addresses: K rows 8 (l15 >> 2) + (l15 & 3) of key block 0 (other blocks: + KBO(kb)), chunk 4 ds + g4; V^T rows l15 (+ 16 db), chunk 4 ks + g4
+    int kaddr[4], vaddr[2];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) kaddr[ds] = lds0 + k3_off(8 * (l15 >> 2) + (l15 & 3), 4 * ds + g4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) vaddr[ks] = lds0 + VST0 + v_off(l15, 4 * ks + g4);
+#define SVI3_KBO(kb) ((((kb) >> 1) * 32 + ((kb) & 1) * 4) * 256)
+    f32x4 sA[4][4], sB[4][4];                    // score tiles [kb][qb]: even tiles in sA, odd tiles in sB
+    u32x4 kf[4], vf[4];
+    const SviDma no_dma = {k_rs, 0, 0, 0};
+
+    // phase 1 of tile t: S(t) -> sn from K stage KS; pairs of key blocks 1 and 2 of tile t - 1 (so); V(t) -> V stage VD
+    auto phase1 = [&](f32x4 (&sn)[4][4], f32x4 (&so)[4][4], auto ks_c, auto vs_c, auto vd_c, int t) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_c)::value * KT_BYTES, vs = decltype(vs_c)::value * VT_BYTES;
+        constexpr int vd = VST0 + decltype(vd_c)::value * VT_BYTES;
+        const int so_v = t * KB * 2;
+        static_for<0, 16>([&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int kb = f >> 2, ds = f & 3, f3 = f + 3;
+            constexpr int kbp = f < 8 ? 1 : 2, qbp = (f & 7) >> 1, ep = f & 1;            // this fragment's score pair
+            int& pin = *((f3 < 16) ? &kaddr[f3 & 3] : &vaddr[0]);
+            constexpr bool dma = ds == 2;
+            const SviDma d = {v_rs, voff0, so_v + kb * vstep, piece0 + vd + 4096 * kb};
+            unsigned wd = 0;
+            qk3_frag<QREG0 + ds * 4, ds == 0, true, dma, MULC>(tok, sn[kb][0], sn[kb][1], sn[kb][2], sn[kb][3], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin,
+                                                                cneg[0], cneg[1], cneg[2], cneg[3], so[kbp][qbp][2 * ep], so[kbp][qbp][2 * ep + 1], scale_log2e, ps[qbp][0], ps[qbp][1],
+                                                                wd, dma ? d : no_dma);
+            pw[kbp >> 1][qbp][2 * (kbp & 1) + ep] = wd;
+            if constexpr (f3 < 16) kf[f3 & 3] = *(lds_u32x4_t)(kaddr[f3 & 3] + ks + SVI3_KBO(f3 >> 2));
+            else vf[f3 - 16] = *(lds_u32x4_t)(vaddr[0] + vs + (f3 - 16) * 16 * 128);
+        });
+    };
+    // phase 2 of tile t: O += V(t-1) P(t-1) from V stage VS; pairs of key block 3 of tile t - 1 (statements 0..31, so) and of key block 0 of tile t (32..63, sn);
+    // K(t+3) -> K stage (t+3) & 3; the last three fragments read the first K fragments of tile t + 1 (K stage KN)
+    auto phase2 = [&](f32x4 (&sn)[4][4], f32x4 (&so)[4][4], auto vs_c, auto kn_c, int t, auto masked_tag, auto with_next) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool WITH_NEXT = decltype(with_next)::value;
+        constexpr int vs = decltype(vs_c)::value * VT_BYTES, kn = decltype(kn_c)::value * KT_BYTES;
+        const int kd = ((t + 3) & 3) * KT_BYTES, so_k = (t + 3) * KB * ldk * 2;
+        if constexpr (MASKED) {
+            s3_settle(tok, sn);
+            const int key_base = t * KB + 8 * g4;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (key_base + 32 * (kb >> 1) + 4 * (kb & 1) + e >= Lk) sn[kb][qb][e] = -INFINITY;
+        }
+        static_for<0, 16>([&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int ks2 = f >> 3, db = f & 7, f3 = f + 3;
+            constexpr bool own = f >= 8;
+            constexpr int qbp = (f & 7) >> 1, ep = f & 1;
+            constexpr int nf = f3 < 16 ? 0 : f3 - 16;              // the next tile's K fragment read behind this one
+            int& pin = *((f3 < 16) ? &vaddr[f3 >> 3] : &kaddr[nf]);
+            constexpr bool dma = f >= 12;
+            constexpr int pj = f >= 12 ? f - 12 : 0;              // K piece issued inside this fragment's block
+            const SviDma d = {k_rs, koff[pj & 1], so_k + pj * kstep, piece0 + kd + 4096 * pj};
+            unsigned wd = 0;
+            pv3_frag<OREG0 + db * 16, true, dma, MULC>(tok, vf[f & 3], vf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pw[ks2][0], pw[ks2][1], pw[ks2][2], pw[ks2][3], pin,
+                                                        own ? sn[0][qbp][2 * ep] : so[3][qbp][2 * ep], own ? sn[0][qbp][2 * ep + 1] : so[3][qbp][2 * ep + 1], scale_log2e,
+                                                        ps[qbp][0], ps[qbp][1], wd, dma ? d : no_dma);
+            pw[own ? 0 : 1][qbp][(own ? 0 : 2) + ep] = wd;
+            if constexpr (f3 < 16) vf[f3 & 3] = *(lds_u32x4_t)(vaddr[f3 >> 3] + vs + (f3 & 7) * 16 * 128);
+            else if constexpr (WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
+        });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto tile_odd = [&](int t, auto masked_tag, auto with_next) __attribute__((always_inline)) {
+        phase1(sB, sA, I1{}, I0{}, I1{}, t);
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) kaddr[ds] ^= 2 * KT_BYTES;
+        phase2(sB, sA, I0{}, I0{}, t, masked_tag, with_next);
+        tile_barrier<4>(tok);
+    };
+    auto tile_even = [&](int t, auto masked_tag, auto with_next) __attribute__((always_inline)) {
+        phase1(sA, sB, I0{}, I1{}, I0{}, t);
+        phase2(sA, sB, I1{}, I1{}, t, masked_tag, with_next);
+        tile_barrier<4>(tok);
+    };
+
+    // ---- prologue: K(0..3) and V(0) staged; tile 0: scores, the rows' reference, its first key block's pairs ----
+    stage_k(0); stage_k(1); stage_k(2); stage_k(3); stage_v(0);
+    __syncthreads();
+    kf[0] = *(lds_u32x4_t)(kaddr[0]);
+    kf[1] = *(lds_u32x4_t)(kaddr[1]);
+    kf[2] = *(lds_u32x4_t)(kaddr[2]);
+    {
+        float dummy_s = 0.f;
+        unsigned dummy_w = 0;
+        static_for<0, 16>([&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int kb = f >> 2, ds = f & 3, f3 = f + 3;
+            int& pin = kaddr[f3 & 3];
+            qk3_frag<QREG0 + ds * 4, ds == 0, false, false, MULC>(tok, sA[kb][0], sA[kb][1], sA[kb][2], sA[kb][3], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin,
+                                                                   cneg[0], cneg[1], cneg[2], cneg[3], 0.f, 0.f, scale_log2e, dummy_s, dummy_s, dummy_w, no_dma);
+            if constexpr (f3 < 16) kf[f3 & 3] = *(lds_u32x4_t)(kaddr[f3 & 3] + SVI3_KBO(f3 >> 2));
+        });
+        s3_settle(tok, sA);
+        {
+            const int key_base = 8 * g4;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (key_base + 32 * (kb >> 1) + 4 * (kb & 1) + e >= Lk) sA[kb][qb][e] = -INFINITY;
+        }
+        // reference = the row maximum of tile 0 + SVI_OPT_HEADROOM (flash_fwd2_kernel's prologue says why); it never moves
+        const float hr = SVI_OPT_HEADROOM / cs;
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) mx = fmaxf(mx, fmaxf(fmaxf(sA[kb][qb][0], sA[kb][qb][1]), fmaxf(sA[kb][qb][2], sA[kb][qb][3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            m_ref[qb] = mx + hr;
+            cneg[qb] = f32x4{-m_ref[qb], -m_ref[qb], -m_ref[qb], -m_ref[qb]};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sA[kb][qb][e] -= m_ref[qb];
+#pragma unroll
+            for (int ep = 0; ep < 2; ++ep) {          // key block 0 of tile 0 (a later tile does these on statements 32..63 of its own phase 2)
+                const float p0 = __builtin_amdgcn_exp2f(sA[0][qb][2 * ep] * cs);
+                const float p1 = __builtin_amdgcn_exp2f(sA[0][qb][2 * ep + 1] * cs);
+                ps[qb][0] += p0;
+                ps[qb][1] += p1;
+                pw[0][qb][ep] = pack_bf16x2(p0, p1);
+            }
+        }
+        kf[0] = *(lds_u32x4_t)(kaddr[0] + KT_BYTES);          // tile 1, key block 0
+        kf[1] = *(lds_u32x4_t)(kaddr[1] + KT_BYTES);
+        kf[2] = *(lds_u32x4_t)(kaddr[2] + KT_BYTES);
+        asm volatile("s_nop 4" : "+v"(tok), "+v"(cneg[0]), "+v"(cneg[1]), "+v"(cneg[2]), "+v"(cneg[3]));      // VALU-written C operand -> MFMA
+    }
+    __syncthreads();
+
+    // ---- tiles 1 .. last (odd): pairs (odd, even); the last two tiles may hold keys past Lk ----
+    int t = 1;
+    for (; last - t >= 4; t += 2) {
+        tile_odd(t, std::false_type{}, std::true_type{});
+        tile_even(t + 1, std::false_type{}, std::true_type{});
+    }
+    if (last - t == 2) {
+        tile_odd(t, std::false_type{}, std::true_type{});
+        tile_even(t + 1, std::true_type{}, std::true_type{});
+        t += 2;
+    }
+    tile_odd(t, std::true_type{}, std::false_type{});          // t == last: S(last) in sB, its key block 0 already exponentiated
+    // ---- drain: the pairs of key blocks 1..3 of the last tile, then O += V(last) P(last) ----
+    float l_run[4];
+    {
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            float psd = 0.f;
+#pragma unroll
+            for (int kb = 1; kb < 4; ++kb)
+#pragma unroll
+                for (int ep = 0; ep < 2; ++ep) {
+                    const float p0 = __builtin_amdgcn_exp2f(sB[kb][qb][2 * ep] * cs);
+                    const float p1 = __builtin_amdgcn_exp2f(sB[kb][qb][2 * ep + 1] * cs);
+                    psd += p0 + p1;
+                    pw[kb >> 1][qb][2 * (kb & 1) + ep] = pack_bf16x2(p0, p1);
+                }
+            l_run[qb] = (ps[qb][0] + ps[qb][1]) + psd;
+        }
+        asm("s_nop 1" : "+v"(tok), "+v"(pw[0][0]), "+v"(pw[0][1]), "+v"(pw[0][2]), "+v"(pw[0][3]));
+        asm("s_nop 1" : "+v"(tok), "+v"(pw[1][0]), "+v"(pw[1][1]), "+v"(pw[1][2]), "+v"(pw[1][3]));
+        static_for<0, 16>([&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int ks2 = f >> 3, db = f & 7;
+            const u32x4 vfr = *(lds_u32x4_t)(vaddr[ks2] + VT_BYTES + db * 16 * 128);          // V(last) sits in stage last & 1 == 1
+            pv3_mfma<OREG0 + (db * 4 + 0) * 4>(tok, vfr, pw[ks2][0], vaddr[0]);
+            pv3_mfma<OREG0 + (db * 4 + 1) * 4>(tok, vfr, pw[ks2][1], vaddr[0]);
+            pv3_mfma<OREG0 + (db * 4 + 2) * 4>(tok, vfr, pw[ks2][2], vaddr[0]);
+            pv3_mfma<OREG0 + (db * 4 + 3) * 4>(tok, vfr, pw[ks2][3], vaddr[0]);
+        });
+    }
+    {   // did some exponential of this wave's rows leave the range the fixed reference covers?  (l_run: a lane's quarter of the row sum; !(l < 2^96) also catches inf / NaN)
+        const bool bad = !(l_run[0] < SVI_OPT_FLAG_SUM) || !(l_run[1] < SVI_OPT_FLAG_SUM) || !(l_run[2] < SVI_OPT_FLAG_SUM) || !(l_run[3] < SVI_OPT_FLAG_SUM);
+        if (__any(bad) && lane == 0) atomicOr(&flags[wg_linear], 1);
+    }
+    // ---- normalise and store: a[(db * 4 + qb) * 4 + e] is O[16 qb + l15][16 db + 4 g4 + e] ----
+    asm("s_nop 15" : "+v"(tok));
+    static_for<0, 4>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qc)::value;
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const int qr = row0 + 16 * qb;
+        if (is_piece) {
+            const int ldp = num_heads * DH;
+            if (qr < Lq && g4 == 0) ml[((size_t)piece * num_heads + head) * Lq + qr] = make_float2(m_ref[qb], l);
+            float* op = opart + ((size_t)piece * Lq + min(qr, Lq - 1)) * ldp + head * DH + 4 * g4;
+            static_for<0, 8>([&](auto dc) __attribute__((always_inline)) {
+                constexpr int db = decltype(dc)::value;
+                f32x4 v;
+                v[0] = o_get<OREG0 + (db * 4 + qb) * 4 + 0>(tok);
+                v[1] = o_get<OREG0 + (db * 4 + qb) * 4 + 1>(tok);
+                v[2] = o_get<OREG0 + (db * 4 + qb) * 4 + 2>(tok);
+                v[3] = o_get<OREG0 + (db * 4 + qb) * 4 + 3>(tok);
+                if (qr < Lq) *reinterpret_cast<f32x4*>(op + 16 * db) = v;
+            });
+        } else {
+            const float inv = 1.0f / l;
+            bf16* op = O + (size_t)min(qr, Lq - 1) * ldo + head * DH + 4 * g4;
+            static_for<0, 8>([&](auto dc) __attribute__((always_inline)) {
+                constexpr int db = decltype(dc)::value;
+                bf16x4 pk;
+                pk[0] = (bf16)(o_get<OREG0 + (db * 4 + qb) * 4 + 0>(tok) * inv);
+                pk[1] = (bf16)(o_get<OREG0 + (db * 4 + qb) * 4 + 1>(tok) * inv);
+                pk[2] = (bf16)(o_get<OREG0 + (db * 4 + qb) * 4 + 2>(tok) * inv);
+                pk[3] = (bf16)(o_get<OREG0 + (db * 4 + qb) * 4 + 3>(tok) * inv);
+                if (qr < Lq) *reinterpret_cast<bf16x4*>(op + 16 * db) = pk;
+            });
+        }
+    });
+}
+
 // Merge the pieces of the key axis for the items that were cut: O = sum_s w_s O_s / sum_s w_s l_s with w_s = 2^((M_s - max M) cs) — the same
 // softmax, each piece's exponentials re-referenced to the common maximum.  One workgroup per cut item (256 rows of one head); a thread
 // owns 4 channels of 32 rows.
@@ -1837,8 +2274,20 @@ svi_status svi_launch_flash(const bf16* Q, int ldq, const bf16* K, int ldk, cons
             default: break;
         }
 #endif
+        // the optimistic pass on v_mfma_f32_16x16x32_bf16 (flash_fwd3_kernel; SVI_FLASH_M16 = 0: flash_fwd2_kernel<.., 1>, the 32x32x16 form): same grid, flags and outputs
+        bool m16 = two_pass && !qk8 && sw.flash_m16 != 0;
+#ifdef SVI_ABLATIONS
+        if (sw.flash_abl) m16 = false;
+#endif
+        if (m16) {
+            typedef void (*kern3_t)(const bf16*, int, const bf16*, int, const bf16*, int, bf16*, int, int, int, float, int*, float*, float2*, SviFlashSplit);
+            const kern3_t k3 = q_prescaled ? (Lq == Lk ? flash_fwd3_kernel<0, false> : flash_fwd3_kernel<1, false>) : (Lq == Lk ? flash_fwd3_kernel<0, true> : flash_fwd3_kernel<1, true>);
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(k3), lds2));
+            hipLaunchKernelGGL(k3, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml, sp);
+        } else {
         SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(kern), lds2));
         hipLaunchKernelGGL(kern, grid2, block2, lds2, st, Q, ldq, K, ldk, VT, ldvt, O, ldo, Lq, Lk, scale_log2e, flags, opart, ml, sp, qsc, ksc, qs_rows, ks_rows);
+        }
         SVI_LAUNCH_CHECK();
         if (two_pass) {
             kern_t safe = q_prescaled ? (Lq == Lk ? flash_fwd2_kernel<0, 0, false, 2> : flash_fwd2_kernel<1, 0, false, 2>)

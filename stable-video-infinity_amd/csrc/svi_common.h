@@ -74,6 +74,9 @@ struct SviSwitches {
                                  // instead of four 2x2 convolutions of the small image with pre-summed kernels (4 taps; same sum up to fp32 rounding of the weights)
     int flash_two_pass = 1;      // SVI_FLASH_TWO_PASS = 0 : the long-sequence attention as ONE complete pass (tracked maximum) instead of the
                                  // optimistic pass + flagged second pass (same result within the attention tolerance; bit-identical on benign operands)
+    int flash_m16 = 1;           // SVI_FLASH_M16 = 0 : the optimistic attention pass on v_mfma_f32_32x32x16_bf16 (flash_fwd2_kernel, rounds 2-6) instead of 16x16x32
+                                 // (flash_fwd3_kernel: the shape the part's power limit favours); same softmax, results equal within the attention tolerance (the
+                                 // matrix instruction sums a row's 128 channels in another order)
     int flash_split = 0;         // SVI_FLASH_SPLIT = 1 : never cut the key axis of the long-sequence attention (bit-identical to the unsplit kernel); 2..4: that many
                                  // pieces wherever the key axis allows; 0 (default): where the workgroup count fills the chip's last round poorly (svi_attention.hip)
     int rms_rows = 1;            // SVI_RMS_ROWS = 0 : RMSNorm (+RoPE) and LayerNorm (+modulate) with one row per wave (the generic kernels) also for the DiT's shapes, instead of four rows per wave
