@@ -1553,7 +1553,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(const bf16* __restri
 // Same workgroup shape, LDS image of V^T, LDS-DMA staging, barriers, optimistic reference, flag protocol and split / piece outputs as flash_fwd2_kernel<.., MODE 1>
 // (the flagged second pass stays flash_fwd2_kernel<.., MODE 2>: same grid, same flag words).  What changes is the lane <-> (key, query) map:
 //   S^T block (kb, qb) = 16 keys x 16 queries, lane l holds query 16 qb + (l & 15), MFMA rows 4 (l >> 4) + e;  64 blocks of QK^T per 64-key tile and wave
-//   (4 kb x 4 qb x 4 channel steps of 32), each K fragment (16 B per lane) feeds the four query blocks.
+//   (4 kb x 4 qb x 4 channel steps of 32), each K fragment (16 B per lane) feeds the four query blocks; fragments are requested five ahead (rings of six).
 //   MFMA row r of block kb is KEY 32 (kb >> 1) + 8 (r >> 2) + 4 (kb & 1) + (r & 3), so the 8 probabilities a lane holds in blocks 2 ks and 2 ks + 1 (its 4 + 4
 //   accumulator registers, packed to bf16) are the 8 CONSECUTIVE keys 32 ks + 8 (l >> 4) .. + 7: exactly the k-block the P·V MFMA wants from this lane, and the
 //   V^T fragment is one plain ds_read_b128 (16 channels x 32 keys).  No cross-lane movement of P.
@@ -1573,6 +1573,8 @@ __device__ __forceinline__ int k3_off(int row, int chunk) { return row * 256 + (
 // pair.  A fragment-sized block meets its neighbour across the fragment's look-ahead ds_read, so none is needed.
 //   B: the block carries one score pair:  exp(x0) | M | add | M | exp(x1) | M | add, pack | M;   DMA: one LDS-DMA piece behind the second MFMA
 #define SVI3_QK4(M0, M1, M2, M3, PRE0, PRE1, PRE2, PRE3, DMA0, DMA1) DMA0 PRE0 M0 PRE1 M1 DMA1 PRE2 M2 PRE3 M3
+#define SVI3_DMA_M0 "s_add_u32 m0, %[m0v], %c[m0i]\n\t"          /* LDS address of the piece = the stage's base for this wave + 4096 x piece, formed in m0 itself */
+#define SVI3_DMA_IN SVI_DMA_IN, [m0i] "n"(M0I)
 #define SVI3_QF(i) "v_mfma_f32_16x16x32_bf16 %[s" #i "], %[kf], a[%c[q" #i "]:%c[r" #i "]], %[cn" #i "]\n\t"
 #define SVI3_QN(i) "v_mfma_f32_16x16x32_bf16 %[s" #i "], %[kf], a[%c[q" #i "]:%c[r" #i "]], %[s" #i "]\n\t"
 #define SVI3_PM(i) "v_mfma_f32_16x16x32_bf16 a[%c[o" #i "]:%c[u" #i "]], %[vf], %[p" #i "], a[%c[o" #i "]:%c[u" #i "]]\n\t"
@@ -1588,7 +1590,7 @@ __device__ __forceinline__ int k3_off(int row, int chunk) { return row * 256 + (
 #define SVI3_CN_IN [cn0] "v"(c0), [cn1] "v"(c1), [cn2] "v"(c2), [cn3] "v"(c3)
 #define SVI3_O_IN [vf] "v"(vf), [vf2] "v"(vf2), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [o0] "n"(R), [u0] "n"(R + 3), [o1] "n"(R + 4), [u1] "n"(R + 7), [o2] "n"(R + 8), [u2] "n"(R + 11), [o3] "n"(R + 12), [u3] "n"(R + 15)
 // R: the Q fragment of query block 0 for this channel step (query block qb: R + 16 qb)
-template <int R, bool FIRST, bool B, bool DMA, bool MULC>
+template <int R, bool FIRST, bool B, bool DMA, bool MULC, int M0I = 0>
 __device__ __forceinline__ void qk3_frag(int& tok, f32x4& s0, f32x4& s1, f32x4& s2, f32x4& s3, u32x4 kf, u32x4 kf2, int& apin, const f32x4& c0, const f32x4& c1, const f32x4& c2,
                                          const f32x4& c3, float x0, float x1, float c, float& sum0, float& sum1, unsigned& w, const SviDma& d) {
     const u32x4 rs = d.rs;
@@ -1599,10 +1601,10 @@ __device__ __forceinline__ void qk3_frag(int& tok, f32x4& s0, f32x4& s1, f32x4& 
         if constexpr (FIRST) asm(SVI3_QK4(SVI3_QF(0), SVI3_QF(1), SVI3_QF(2), SVI3_QF(3), "", "", "", "", "", "") SVI_END : SVI3_S_OUT("=&v") : SVI3_Q_IN, SVI3_CN_IN);
         else asm(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), "", "", "", "", "", "") SVI_END : SVI3_S_OUT("+v") : SVI3_Q_IN);
     } else if constexpr (DMA) {
-        if constexpr (MULC) asm volatile(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, SVI_DMA_M0, SVI_DMA) SVI_END
-                                         : SVI3_S_OUT("+v"), SVI3_B_OUT : SVI3_Q_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), SVI_DMA_IN);
-        else asm volatile(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, SVI_DMA_M0, SVI_DMA) SVI_END
-                          : SVI3_S_OUT("+v"), SVI3_B_OUT : SVI3_Q_IN, [x0] "v"(x0), [x1] "v"(x1), SVI_DMA_IN);
+        if constexpr (MULC) asm volatile(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, SVI3_DMA_M0, SVI_DMA) SVI_END
+                                         : SVI3_S_OUT("+v"), SVI3_B_OUT : SVI3_Q_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), SVI3_DMA_IN : "scc");
+        else asm volatile(SVI3_QK4(SVI3_QN(0), SVI3_QN(1), SVI3_QN(2), SVI3_QN(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, SVI3_DMA_M0, SVI_DMA) SVI_END
+                          : SVI3_S_OUT("+v"), SVI3_B_OUT : SVI3_Q_IN, [x0] "v"(x0), [x1] "v"(x1), SVI3_DMA_IN : "scc");
     } else if constexpr (FIRST) {
         if constexpr (MULC) asm(SVI3_QK4(SVI3_QF(0), SVI3_QF(1), SVI3_QF(2), SVI3_QF(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, "", "") SVI_END
                                 : SVI3_S_OUT("=&v"), SVI3_B_OUT : SVI3_Q_IN, SVI3_CN_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c));
@@ -1616,7 +1618,7 @@ __device__ __forceinline__ void qk3_frag(int& tok, f32x4& s0, f32x4& s1, f32x4& 
     }
 }
 // One V^T fragment's four statements: a[R + 4 qb : + 3] += V^T-fragment x P-fragment of query block qb
-template <int R, bool B, bool DMA, bool MULC>
+template <int R, bool B, bool DMA, bool MULC, int M0I = 0>
 __device__ __forceinline__ void pv3_frag(int& tok, u32x4 vf, u32x4 vf2, u32x4 p0, u32x4 p1, u32x4 p2, u32x4 p3, int& apin, float x0, float x1, float c, float& sum0, float& sum1,
                                          unsigned& w, const SviDma& d) {
     const u32x4 rs = d.rs;
@@ -1626,10 +1628,10 @@ __device__ __forceinline__ void pv3_frag(int& tok, u32x4 vf, u32x4 vf2, u32x4 p0
     if constexpr (!B) {
         asm(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), "", "", "", "", "", "") SVI_END : [tok] "+v"(tok), [ap] "+v"(apin) : SVI3_O_IN);
     } else if constexpr (DMA) {
-        if constexpr (MULC) asm volatile(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, SVI_DMA_M0, SVI_DMA) SVI_END
-                                         : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), SVI_DMA_IN);
-        else asm volatile(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, SVI_DMA_M0, SVI_DMA) SVI_END
-                          : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1), SVI_DMA_IN);
+        if constexpr (MULC) asm volatile(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, SVI3_DMA_M0, SVI_DMA) SVI_END
+                                         : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c), SVI3_DMA_IN : "scc");
+        else asm volatile(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_E0, SVI3_A0, SVI3_E1, SVI3_A1C, SVI3_DMA_M0, SVI_DMA) SVI_END
+                          : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1), SVI3_DMA_IN : "scc");
     } else {
         if constexpr (MULC) asm(SVI3_QK4(SVI3_PM(0), SVI3_PM(1), SVI3_PM(2), SVI3_PM(3), SVI3_ME0, SVI3_A0, SVI3_ME1, SVI3_A1C, "", "") SVI_END
                                 : [tok] "+v"(tok), [ap] "+v"(apin), SVI3_B_OUT : SVI3_O_IN, [x0] "v"(x0), [x1] "v"(x1), [c] "s"(c));
@@ -1648,6 +1650,9 @@ __device__ __forceinline__ void s3_settle(int& tok, f32x4 (&s)[4][4]) {
     asm volatile("s_nop 15" : "+v"(tok), "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), "+v"(s[1][3]),
                               "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[2][2]), "+v"(s[2][3]), "+v"(s[3][0]), "+v"(s[3][1]), "+v"(s[3][2]), "+v"(s[3][3]));
 }
+#ifndef SVI3_ABL
+#define SVI3_ABL 0          // timing ablations of variant builds (tools/build_variant.py attn_ablN -DSVI3_ABL=N; results WRONG): 1 no LDS-DMA in the tile loop, 2 no softmax fillers (and no LDS-DMA), 4 no tile barrier, 8 no look-ahead fragment reads
+#endif
 template <int TAG, bool MULC>
 __global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restrict__ Q, int ldq, const bf16* __restrict__ K, int ldk, const bf16* __restrict__ VT, int ldvt,
                                                             bf16* __restrict__ O, int ldo, int Lq, int Lk, float scale_log2e, int* __restrict__ flags,
@@ -1733,6 +1738,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restri
     }
     const int kstep = 16 * ldk * 2, vstep = 32 * ldvt * 2;
     const int piece0 = lds0 + wave * 1024;
+    const int kvo[4] = {koff[0], koff[1] + kstep, koff[0] + 2 * kstep, koff[1] + 3 * kstep};      // lane offsets of the four pieces (one scalar offset per tile is left)
+    const int vvo[4] = {voff0, voff0 + vstep, voff0 + 2 * vstep, voff0 + 3 * vstep};
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(K), 0, (int)k_rs[2], 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(VT), 0, (int)v_rs[2], 0x00020000);
     auto stage_k = [&](int t) __attribute__((always_inline)) {
@@ -1762,7 +1769,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restri
     for (int ks = 0; ks < 2; ++ks) vaddr[ks] = lds0 + VST0 + v_off(l15, 4 * ks + g4);
 #define SVI3_KBO(kb) ((((kb) >> 1) * 32 + ((kb) & 1) * 4) * 256)
     f32x4 sA[4][4], sB[4][4];                    // score tiles [kb][qb]: even tiles in sA, odd tiles in sB
-    u32x4 kf[4], vf[4];
+    u32x4 kf[6], vf[6];                          // fragment rings: fragment n of a phase lives in slot n % 6 and is requested five fragments (320 matrix cycles) ahead
     const SviDma no_dma = {k_rs, 0, 0, 0};
 
     // phase 1 of tile t: S(t) -> sn from K stage KS; pairs of key blocks 1 and 2 of tile t - 1 (so); V(t) -> V stage VD
@@ -1772,17 +1779,18 @@ __global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restri
         const int so_v = t * KB * 2;
         static_for<0, 16>([&](auto fc) __attribute__((always_inline)) {
             constexpr int f = decltype(fc)::value;
-            constexpr int kb = f >> 2, ds = f & 3, f3 = f + 3;
+            constexpr int kb = f >> 2, ds = f & 3, f3 = f + 5;
             constexpr int kbp = f < 8 ? 1 : 2, qbp = (f & 7) >> 1, ep = f & 1;            // this fragment's score pair
             int& pin = *((f3 < 16) ? &kaddr[f3 & 3] : &vaddr[0]);
-            constexpr bool dma = ds == 2;
-            const SviDma d = {v_rs, voff0, so_v + kb * vstep, piece0 + vd + 4096 * kb};
+            constexpr bool dma = ds == 2 && !(SVI3_ABL & 3);
+            const SviDma d = {v_rs, vvo[kb], so_v, piece0 + vd};
             unsigned wd = 0;
-            qk3_frag<QREG0 + ds * 4, ds == 0, true, dma, MULC>(tok, sn[kb][0], sn[kb][1], sn[kb][2], sn[kb][3], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin,
+            qk3_frag<QREG0 + ds * 4, ds == 0, !(SVI3_ABL & 2), dma, MULC, 4096 * kb>(tok, sn[kb][0], sn[kb][1], sn[kb][2], sn[kb][3], kf[f % 6], kf[((f & 1) || f == 15) ? (f % 6) : ((f + 1) % 6)], pin,
                                                                 cneg[0], cneg[1], cneg[2], cneg[3], so[kbp][qbp][2 * ep], so[kbp][qbp][2 * ep + 1], scale_log2e, ps[qbp][0], ps[qbp][1],
                                                                 wd, dma ? d : no_dma);
             pw[kbp >> 1][qbp][2 * (kbp & 1) + ep] = wd;
-            if constexpr (f3 < 16) kf[f3 & 3] = *(lds_u32x4_t)(kaddr[f3 & 3] + ks + SVI3_KBO(f3 >> 2));
+            if constexpr (SVI3_ABL & 8) return;
+            if constexpr (f3 < 16) kf[f3 % 6] = *(lds_u32x4_t)(kaddr[f3 & 3] + ks + SVI3_KBO(f3 >> 2));
             else vf[f3 - 16] = *(lds_u32x4_t)(vaddr[0] + vs + (f3 - 16) * 16 * 128);
         });
     };
@@ -1806,21 +1814,22 @@ __global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restri
         }
         static_for<0, 16>([&](auto fc) __attribute__((always_inline)) {
             constexpr int f = decltype(fc)::value;
-            constexpr int ks2 = f >> 3, db = f & 7, f3 = f + 3;
+            constexpr int ks2 = f >> 3, db = f & 7, f3 = f + 5;
             constexpr bool own = f >= 8;
             constexpr int qbp = (f & 7) >> 1, ep = f & 1;
-            constexpr int nf = f3 < 16 ? 0 : f3 - 16;              // the next tile's K fragment read behind this one
-            int& pin = *((f3 < 16) ? &vaddr[f3 >> 3] : &kaddr[nf]);
-            constexpr bool dma = f >= 12;
+            constexpr int nf = f3 < 16 ? 0 : f3 - 16;              // the next tile's K fragment read behind this one (key block nf >> 2, channel step nf & 3)
+            int& pin = *((f3 < 16) ? &vaddr[f3 >> 3] : &kaddr[nf & 3]);
+            constexpr bool dma = f >= 12 && !(SVI3_ABL & 3);
             constexpr int pj = f >= 12 ? f - 12 : 0;              // K piece issued inside this fragment's block
-            const SviDma d = {k_rs, koff[pj & 1], so_k + pj * kstep, piece0 + kd + 4096 * pj};
+            const SviDma d = {k_rs, kvo[pj], so_k, piece0 + kd};
             unsigned wd = 0;
-            pv3_frag<OREG0 + db * 16, true, dma, MULC>(tok, vf[f & 3], vf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pw[ks2][0], pw[ks2][1], pw[ks2][2], pw[ks2][3], pin,
+            pv3_frag<OREG0 + db * 16, !(SVI3_ABL & 2), dma, MULC, 4096 * pj>(tok, vf[f % 6], vf[((f & 1) || f == 15) ? (f % 6) : ((f + 1) % 6)], pw[ks2][0], pw[ks2][1], pw[ks2][2], pw[ks2][3], pin,
                                                         own ? sn[0][qbp][2 * ep] : so[3][qbp][2 * ep], own ? sn[0][qbp][2 * ep + 1] : so[3][qbp][2 * ep + 1], scale_log2e,
                                                         ps[qbp][0], ps[qbp][1], wd, dma ? d : no_dma);
             pw[own ? 0 : 1][qbp][(own ? 0 : 2) + ep] = wd;
-            if constexpr (f3 < 16) vf[f3 & 3] = *(lds_u32x4_t)(vaddr[f3 >> 3] + vs + (f3 & 7) * 16 * 128);
-            else if constexpr (WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf] + kn);
+            if constexpr (SVI3_ABL & 8) return;
+            if constexpr (f3 < 16) vf[f3 % 6] = *(lds_u32x4_t)(vaddr[f3 >> 3] + vs + (f3 & 7) * 16 * 128);
+            else if constexpr (WITH_NEXT) kf[nf] = *(lds_u32x4_t)(kaddr[nf & 3] + kn + SVI3_KBO(nf >> 2));
         });
     };
     using I0 = std::integral_constant<int, 0>;
@@ -1830,12 +1839,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restri
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) kaddr[ds] ^= 2 * KT_BYTES;
         phase2(sB, sA, I0{}, I0{}, t, masked_tag, with_next);
-        tile_barrier<4>(tok);
+        if constexpr (!(SVI3_ABL & 4)) tile_barrier<(SVI3_ABL & 3) ? 0 : 4>(tok);
     };
     auto tile_even = [&](int t, auto masked_tag, auto with_next) __attribute__((always_inline)) {
         phase1(sA, sB, I0{}, I1{}, I0{}, t);
         phase2(sA, sB, I1{}, I1{}, t, masked_tag, with_next);
-        tile_barrier<4>(tok);
+        if constexpr (!(SVI3_ABL & 4)) tile_barrier<(SVI3_ABL & 3) ? 0 : 4>(tok);
     };
 
     // ---- prologue: K(0..3) and V(0) staged; tile 0: scores, the rows' reference, its first key block's pairs ----
@@ -1844,16 +1853,18 @@ __global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restri
     kf[0] = *(lds_u32x4_t)(kaddr[0]);
     kf[1] = *(lds_u32x4_t)(kaddr[1]);
     kf[2] = *(lds_u32x4_t)(kaddr[2]);
+    kf[3] = *(lds_u32x4_t)(kaddr[3]);
+    kf[4] = *(lds_u32x4_t)(kaddr[0] + SVI3_KBO(1));
     {
         float dummy_s = 0.f;
         unsigned dummy_w = 0;
         static_for<0, 16>([&](auto fc) __attribute__((always_inline)) {
             constexpr int f = decltype(fc)::value;
-            constexpr int kb = f >> 2, ds = f & 3, f3 = f + 3;
+            constexpr int kb = f >> 2, ds = f & 3, f3 = f + 5;
             int& pin = kaddr[f3 & 3];
-            qk3_frag<QREG0 + ds * 4, ds == 0, false, false, MULC>(tok, sA[kb][0], sA[kb][1], sA[kb][2], sA[kb][3], kf[f & 3], kf[((f & 1) || f == 15) ? (f & 3) : ((f + 1) & 3)], pin,
+            qk3_frag<QREG0 + ds * 4, ds == 0, false, false, MULC>(tok, sA[kb][0], sA[kb][1], sA[kb][2], sA[kb][3], kf[f % 6], kf[((f & 1) || f == 15) ? (f % 6) : ((f + 1) % 6)], pin,
                                                                    cneg[0], cneg[1], cneg[2], cneg[3], 0.f, 0.f, scale_log2e, dummy_s, dummy_s, dummy_w, no_dma);
-            if constexpr (f3 < 16) kf[f3 & 3] = *(lds_u32x4_t)(kaddr[f3 & 3] + SVI3_KBO(f3 >> 2));
+            if constexpr (f3 < 16) kf[f3 % 6] = *(lds_u32x4_t)(kaddr[f3 & 3] + SVI3_KBO(f3 >> 2));
         });
         s3_settle(tok, sA);
         {
@@ -1890,9 +1901,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(const bf16* __restri
                 pw[0][qb][ep] = pack_bf16x2(p0, p1);
             }
         }
-        kf[0] = *(lds_u32x4_t)(kaddr[0] + KT_BYTES);          // tile 1, key block 0
+        kf[0] = *(lds_u32x4_t)(kaddr[0] + KT_BYTES);          // tile 1: key block 0, then the first fragment of key block 1
         kf[1] = *(lds_u32x4_t)(kaddr[1] + KT_BYTES);
         kf[2] = *(lds_u32x4_t)(kaddr[2] + KT_BYTES);
+        kf[3] = *(lds_u32x4_t)(kaddr[3] + KT_BYTES);
+        kf[4] = *(lds_u32x4_t)(kaddr[0] + KT_BYTES + SVI3_KBO(1));
         asm volatile("s_nop 4" : "+v"(tok), "+v"(cneg[0]), "+v"(cneg[1]), "+v"(cneg[2]), "+v"(cneg[3]));      // VALU-written C operand -> MFMA
     }
     __syncthreads();

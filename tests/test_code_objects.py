@@ -59,6 +59,8 @@ def test_hot_kernels_have_no_scratch_and_fit_their_occupancy(tmp_path):
         clean.update(family(prefix))
     main_pass = {k: v for k, v in family("flash_fwd2_kernel<").items() if re.match(r"flash_fwd2_kernel<\d+, \d+, (true|false), 1, ", k)}
     assert len(main_pass) >= 4
+    main_pass.update(family("flash_fwd3_kernel<"))          # round 6: the optimistic pass on v_mfma_f32_16x16x32_bf16 (what the step launches by default)
+    assert len(main_pass) >= 8
     clean.update(main_pass)
     # (scalar registers parked in the lanes of a vector register — sgpr_spill_count, a few in the convolution and the Q8 attention — cost no memory)
     bad = {k: v for k, v in clean.items() if v["private_segment_fixed_size"] or v["vgpr_spill_count"]}

@@ -137,6 +137,8 @@ for name, scale in (("zeros", 0.0), ("small (x 1e-3)", 1e-3), ("unit Gaussian (t
     print(json.dumps(row), flush=True)
     del q, k, vt
 
+if "--a-only" in args:
+    sys.exit(0)
 # ---- part B: peaky logits ----------------------------------------------------------------------------------------------------------------------
 cluster = 1560                                   # one latent frame of the C2 grid (30 x 52 tokens): a query's own frame is its neighbourhood
 ncl = Ltok // cluster
