@@ -850,8 +850,8 @@ def main() -> None:
         pmc = pmc_summaries() if args.workload == "c2" else {"why": "the PMC summaries are collected on the c2 workload"}
         fp = pmc.get("flash") or {}
         traffic, traffic_src = fp.get("hbm_bytes"), pmc.get("flash_file") or pmc.get("why")
-        roof = {"kernel": "flash_fwd2_kernel (self-attention; one launch = the optimistic pass <...,1> + the flagged second pass <...,2>, which exits "
-                          "at once unless a row's exponentials left the optimistic range)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+        roof = {"kernel": "flash_fwd3_kernel + flash_fwd2_kernel<.., 2> (self-attention; one launch = the optimistic pass, on v_mfma_f32_16x16x32_bf16 since round 6 "
+                          "(SVI_FLASH_M16=0: flash_fwd2_kernel<.., 1>), + the flagged second pass, which exits at once unless a row's exponentials left the optimistic range)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "mfma_busy_in_clock": fp.get("mfma_busy_in_clock"), "l2_hit_rate": fp.get("l2_hit_rate"),
                 "algorithmic_flop_per_launch": alg, "launches": fl["count"], "ms_per_launch": round(per_launch_ms, 4), "source": roof_source}

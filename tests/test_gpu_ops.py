@@ -315,6 +315,32 @@ def test_flash_attention(hip, Lq, Lk, heads):
     assert r < 6e-3, (r, mx)
 
 
+@pytest.mark.parametrize("Lq,Lk,heads", [(64, 64, 1), (100, 100, 1), (192, 192, 2), (300, 1000, 1), (1000, 130, 2), (2304, 2304, 1), (4096, 4096, 1)])
+def test_flash_attention_16x16x32_pass_matches_the_32x32x16_pass(hip, Lq, Lk, heads):
+    """Round 6: the optimistic pass of the long-sequence attention runs on v_mfma_f32_16x16x32_bf16 (flash_fwd3_kernel; SVI_FLASH_M16=0 is the rounds 2-6 kernel on
+    32x32x16).  Forced onto short and ragged key axes (one real tile, masked last tiles, Lq != Lk: every prologue / drain path of the tile loop): against fp64 within
+    the attention tolerance, and against the 32x32x16 pass far inside it (same softmax, same bf16 rounding points; only the matrix instruction's summation order
+    differs)."""
+    L = hip._lib
+    D = heads * 128
+    q = dev(synth.randn(71, 1, Lq, D)); k = dev(synth.randn(72, 1, Lk, D)); v = dev(synth.randn(73, 1, Lk, D))
+    want = wdo.attention(q.double().cpu(), k.double().cpu(), v.double().cpu(), heads).float()
+    outs = {}
+    try:
+        L.set_switch("SVI_FLASH_KERNEL", 2)
+        for m16 in (1, 0):
+            L.set_switch("SVI_FLASH_M16", m16)
+            outs[m16] = hip.flash_attention(q, k, v, heads).float().cpu()
+    finally:
+        L.set_switch("SVI_FLASH_M16", None)
+        L.set_switch("SVI_FLASH_KERNEL", None)
+    r16, mx16, _ = errs(outs[1], want)
+    r32, _, _ = errs(outs[0], want)
+    rab, _, _ = errs(outs[1], outs[0])
+    report("flash_attention_m16", Lq=Lq, Lk=Lk, heads=heads, rel_l2=r16, rel_l2_32x32=r32, rel_l2_between=rab, max_abs=mx16)
+    assert r16 < 6e-3 and r32 < 6e-3 and rab < 3e-3, (r16, r32, rab)
+
+
 def test_flash_attention_online_softmax_rescale(hip):
     """Force the running max to jump late in the key axis (a spiked key in the last tile) and early (first tile):
     exercises the O/l rescale branch that bounded random data barely touches."""

@@ -59,12 +59,12 @@ def main(tag):
     # self-attention: one call = optimistic pass + flagged second pass (two instantiations of flash_fwd2_kernel): their counters are added
     p = os.path.join(ROOT, "gpurun_out", f"{tag}_flash_pmc.txt")
     if os.path.exists(p):
-        ks = {k: v for k, v in parse(p).items() if "flash_fwd2_kernel" in k}
+        ks = {k: v for k, v in parse(p).items() if "flash_fwd2_kernel" in k or "flash_fwd3_kernel" in k}
         vals = {}
         for v in ks.values():
             for c, x in v.items():
                 vals[c] = vals.get(c, 0.0) + x
-        out = {"kernel": "flash_fwd2_kernel (self-attention, L=32760, 12 heads; optimistic pass + flagged second pass)", "kernels_summed": sorted(ks),
+        out = {"kernel": "flash_fwd3_kernel + flash_fwd2_kernel<.., 2> (self-attention, L=32760, 12 heads; optimistic pass on v_mfma_f32_16x16x32_bf16 + flagged second pass)", "kernels_summed": sorted(ks),
                "counters_per_launch": vals, "attention_src_sha": hashes["svi_attention.hip"], "source_hashes": hashes, **derive(vals), "note": note}
         json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_flash_pmc.json"), "w"), indent=1)
         print(json.dumps({k: out.get(k) for k in ("hbm_bytes", "mfma_busy_in_clock", "l2_hit_rate")}))
