@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 #define TN 256
 #define TN3 192
 #ifndef SVI_GEMM_DEFAULT_256
-#define SVI_GEMM_DEFAULT_256 259      // which schedule of the 256^2 tile runs by default: 259 = four phases per K tile, 260 = two (see gemm_bf16_nt_256e_kernel); SVI_GEMM_KERNEL overrides per process
+#define SVI_GEMM_DEFAULT_256 260      // which schedule of the 256^2 tile runs by default: 260 = two phases per K tile (clusters of 32 MFMAs; the faster one since the 16x16x32 instruction: q|k +6 %, ffn +1 %, profiles/r6v_gemm_phases_ab.txt), 259 = four; SVI_GEMM_KERNEL overrides per process
 #endif
 #define T_STAGE (TM * BK * 2)          // 32 KiB per operand tile
 #define C2_LD 264

@@ -70,6 +70,21 @@ def gen() -> str:
                 out.append("v_cvt_pk_bf16_f32 %[w0], %[t0], %[x0]")
         out.append("s_waitcnt lgkmcnt(0)")
         return out
+    def mix_pk(lines):            # as mix_fine, the pair's two row-sum adds as ONE v_pk_add_f32 on fixed register pairs: exp | M | - | M | exp | M | pk_add, cvt | M
+        out = []
+        for n, l in enumerate(lines):
+            if n % 4 == 0:
+                out.append("v_exp_f32 v200, %[x0]")
+            if n % 4 == 2:
+                out.append("v_exp_f32 v201, %[x0]")
+            if n % 4 == 3:
+                out.append("v_pk_add_f32 v[202:203], v[202:203], v[200:201]")
+                out.append("v_cvt_pk_bf16_f32 %[w0], v200, v201")
+            if n % 8 == 5:
+                out.append("ds_read_b128 %[fr], %[ad]")
+            out.append(l)
+        out.append("s_waitcnt lgkmcnt(0)")
+        return out
     ins = ", ".join([f'[a{i}] "v"(a[{i}])' for i in range(8)] + [f'[b{i}] "v"(b[{i}])' for i in range(8)])
 
     def body(lines):
@@ -95,6 +110,7 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* __restrict__ opa, c
         else if constexpr (SHAPE == 16) asm volatile({body(s16)} :: {ins} : {agprs});
         else if constexpr (SHAPE == 17) asm volatile({body(s16t)} :: {ins} : {agprs});
         else if constexpr (SHAPE == 132) asm volatile({body(mix(s32, 1))} : [t0] "=&v"(t0), [s0] "+v"(s0), [w0] "=&v"(w0), [fr] "=&v"(fr) : {ins}, [x0] "v"(x0), [ad] "v"(ad) : {agprs});
+        else if constexpr (SHAPE == 118) asm volatile({body(mix_pk(s16))} : [t0] "=&v"(t0), [s0] "+v"(s0), [w0] "=&v"(w0), [fr] "=&v"(fr) : {ins}, [x0] "v"(x0), [ad] "v"(ad) : {agprs}, "v200", "v201", "v202", "v203");
         else if constexpr (SHAPE == 117) asm volatile({body(mix_fine(s16))} : [t0] "=&v"(t0), [s0] "+v"(s0), [w0] "=&v"(w0), [fr] "=&v"(fr) : {ins}, [x0] "v"(x0), [ad] "v"(ad) : {agprs});
         else asm volatile({body(mix(s16, 2))} : [t0] "=&v"(t0), [s0] "+v"(s0), [w0] "=&v"(w0), [fr] "=&v"(fr) : {ins}, [x0] "v"(x0), [ad] "v"(ad) : {agprs});
     }}
@@ -109,6 +125,7 @@ extern "C" int probe_run(int shape, int blocks, int loops, const void* opa, cons
     if (shape == 32) hipLaunchKernelGGL(probe<32>, dim3(blocks), dim3(256), 0, 0, (const u32x4*)opa, (const u32x4*)opb, (float*)out, loops);
     else if (shape == 16) hipLaunchKernelGGL(probe<16>, dim3(blocks), dim3(256), 0, 0, (const u32x4*)opa, (const u32x4*)opb, (float*)out, loops);
     else if (shape == 132) hipLaunchKernelGGL(probe<132>, dim3(blocks), dim3(256), 0, 0, (const u32x4*)opa, (const u32x4*)opb, (float*)out, loops);
+    else if (shape == 118) hipLaunchKernelGGL(probe<118>, dim3(blocks), dim3(256), 0, 0, (const u32x4*)opa, (const u32x4*)opb, (float*)out, loops);
     else if (shape == 117) hipLaunchKernelGGL(probe<117>, dim3(blocks), dim3(256), 0, 0, (const u32x4*)opa, (const u32x4*)opb, (float*)out, loops);
     else if (shape == 116) hipLaunchKernelGGL(probe<116>, dim3(blocks), dim3(256), 0, 0, (const u32x4*)opa, (const u32x4*)opb, (float*)out, loops);
     else hipLaunchKernelGGL(probe<17>, dim3(blocks), dim3(256), 0, 0, (const u32x4*)opa, (const u32x4*)opb, (float*)out, loops);
@@ -160,7 +177,7 @@ try:
         opa = (torch.randn((4 * 8 * 64, 8), generator=g, device=dev) * sc).to(torch.bfloat16).contiguous()
         opb = (torch.randn((4 * 8 * 64, 8), generator=g, device=dev) * sc).to(torch.bfloat16).contiguous()
         for shape, name in ((32, "32x32x16"), (16, "16x16x32 (B fastest)"), (17, "16x16x32 (A fastest)"), (32, "32x32x16 (again)"),
-                            (132, "32x32x16 + softmax mix"), (116, "16x16x32 + softmax mix"), (117, "16x16x32 + mix, one piece per gap"), (132, "32x32x16 + mix (again)")):
+                            (132, "32x32x16 + softmax mix"), (116, "16x16x32 + softmax mix"), (117, "16x16x32 + mix, one piece per gap"), (118, "16x16x32 + mix, row sums by v_pk_add_f32"), (132, "32x32x16 + mix (again)")):
             loops = 2000
             lib.probe_run(shape, BLOCKS, loops, C.c_void_p(opa.data_ptr()), C.c_void_p(opb.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(ms))
             loops = max(500, int(loops * 350.0 / max(ms.value, 1e-3)))          # ~0.35 s per launch
