@@ -52,7 +52,13 @@ __device__ __forceinline__ void gemm_rowss_store(const SviGemmArgs& g, const bf1
     if ((lane_chunk & 7) == 0) g.rowss[(size_t)(n >> 6) * g.ldss + m] = ss;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
+// PF = K tiles of global loads in flight (a register ring of PF slots, the K loop unrolled by PF so that every slot is a fixed register set and the compiler
+// counts vmcnt itself).  PF = 1 is the loop as rounds 1-6 had it (two workgroups per CU share a SIMD's issue slots).  PF = 4 serves launches of at most one
+// workgroup per CU — the C1-size step, where M = 2560 rows make 240 tiles of a projection: a lone wave per SIMD covers only 512 cycles of matrix work per
+// K tile, a quarter of an L2 round trip, and the PF = 1 loop ran at that latency (1.2 us per K tile; ffn2 at C1: 169 us for 70 GFLOP).  Same MFMA and k
+// order in both: bit-identical.
+template <int PF>
+__global__ __launch_bounds__(256, PF == 1 ? 2 : 1) void gemm_bf16_nt_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -86,26 +92,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
         w_ptr[j] = g.W + (size_t)(w_ok[j] ? (n0 + r) : 0) * g.ldw + ld_chunk * 8;
     }
     const int nk = (g.K + BK - 1) / BK;
-    u32x4 ra[4], rw[4];
+    u32x4 ra[PF][4], rw[PF][4];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](u32x4 (&xa)[4], u32x4 (&xw)[4], int kt) {
+        if constexpr (PF > 1) {          // K % 64 == 0 (the launcher's condition): no k tail, and a row past the edge reads row 0 (its results are never stored) —
+#pragma unroll                           // no predicate, no branch around a load: the compiler's vmcnt arithmetic keeps PF - 1 tiles in flight
+            for (int j = 0; j < 4; ++j) {
+                xa[j] = *reinterpret_cast<const u32x4*>(a_ptr[j] + kt * BK);
+                xw[j] = *reinterpret_cast<const u32x4*>(w_ptr[j] + kt * BK);
+            }
+            return;
+        }
         const int kbase = kt * BK + ld_chunk * 8;
         const bool kin = kbase < g.K;          // K % 8 == 0: a chunk is entirely inside or outside
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ra[j] = (a_ok[j] && kin) ? *reinterpret_cast<const u32x4*>(a_ptr[j] + kt * BK) : zero4;
-            rw[j] = (w_ok[j] && kin) ? *reinterpret_cast<const u32x4*>(w_ptr[j] + kt * BK) : zero4;
+            xa[j] = (a_ok[j] && kin) ? *reinterpret_cast<const u32x4*>(a_ptr[j] + kt * BK) : zero4;
+            xw[j] = (w_ok[j] && kin) ? *reinterpret_cast<const u32x4*>(w_ptr[j] + kt * BK) : zero4;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const u32x4 (&xa)[4], const u32x4 (&xw)[4], int buf) {
         char* As = smem + buf * 2 * STAGE_BYTES;
         char* Ws = As + STAGE_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int off = lds_tile_off(ld_row + 32 * j, ld_chunk);
-            *reinterpret_cast<u32x4*>(As + off) = ra[j];
-            *reinterpret_cast<u32x4*>(Ws + off) = rw[j];
+            *reinterpret_cast<u32x4*>(As + off) = xa[j];
+            *reinterpret_cast<u32x4*>(Ws + off) = xw[j];
         }
     };
 
@@ -117,13 +131,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load_tile(ra[s], rw[s], s);          // (PF > 1: the launcher guarantees nk >= PF; PF = 1: nk >= 1)
+    store_tile(ra[0], rw[0], 0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K tile: slot s of the ring held tile kt (in LDS since the step before; tile 0: the prologue) and takes tile kt + PF; tile kt + 1 moves to LDS behind the MFMAs
+    auto kstep = [&](u32x4 (&la)[4], u32x4 (&lw)[4], const u32x4 (&sa)[4], const u32x4 (&sw_)[4], int kt, bool ld, bool st) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (ld) load_tile(la, lw, kt + PF);
         const char* As = smem + cur * 2 * STAGE_BYTES;
         const char* Ws = As + STAGE_BYTES;
 #pragma unroll
@@ -140,8 +156,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(SviGemmArgs g, int
                 for (int mb = 0; mb < 4; ++mb)
                     acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nb], xa[mb], acc[nb][mb], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (st) store_tile(sa, sw_, cur ^ 1);
         __syncthreads();
+    };
+    // steady state: every step loads and stores — no branch between a load and the wait that counts it, so PF - 1 tiles stay in flight (a conditional
+    // load makes the compiler's vmcnt arithmetic assume the shorter path: vmcnt(0) every step, which is what the PF = 1 loop pays by construction)
+    int kt0 = 0;
+    for (; kt0 + 2 * PF <= nk; kt0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) kstep(ra[s], rw[s], ra[(s + 1) % PF], rw[(s + 1) % PF], kt0 + s, true, true);
+    }
+    for (; kt0 < nk; kt0 += PF) {                 // the last PF .. 2 PF - 1 tiles
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int kt = kt0 + s;
+            if (kt < nk) kstep(ra[s], rw[s], ra[(s + 1) % PF], rw[(s + 1) % PF], kt, kt + PF < nk, kt + 1 < nk);
+        }
     }
 
     // ---- epilogue part 1: y = bf16(acc + bias) -> LDS [128 m][CS_LD] bf16 --------------------------
@@ -1543,9 +1573,15 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
         return SVI_OK;
     }
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel), 4 * STAGE_BYTES));
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m,
-                       tiles_n);
+    // at most one workgroup per CU (the C1-size step's projections: 240 tiles): the loop with four K tiles of loads in flight; SVI_GEMM_PF = 1 | 4 forces one
+    const bool deep = g.K % BK == 0 && g.K >= 4 * BK && (sw.gemm_pf ? sw.gemm_pf > 1 : (long)tiles_m * tiles_n <= gemm_device_cus());
+    if (deep) {
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<4>), 4 * STAGE_BYTES));
+        hipLaunchKernelGGL(gemm_bf16_nt_kernel<4>, dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m, tiles_n);
+    } else {
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<1>), 4 * STAGE_BYTES));
+        hipLaunchKernelGGL(gemm_bf16_nt_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m, tiles_n);
+    }
     SVI_LAUNCH_CHECK();
     return SVI_OK;
 }
