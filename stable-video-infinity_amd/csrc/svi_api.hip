@@ -47,7 +47,7 @@ static SviSwitches parse_switches() {
     }
     s.gemm_gm = env_int("SVI_GEMM_GM", 1, 0);
     s.gemm_pf = env_int("SVI_GEMM_PF", 1, 0);
-    if (s.gemm_pf != 0 && s.gemm_pf != 1 && s.gemm_pf != 4) s.gemm_pf = 0;
+    if (s.gemm_pf != 0 && s.gemm_pf != 1 && s.gemm_pf != 4 && s.gemm_pf != 8) s.gemm_pf = 0;
     s.vae_exact_fp32 = getenv("SVI_VAE_EXACT_FP32") != nullptr;
     s.flash_two_pass = env_int("SVI_FLASH_TWO_PASS", 0, 1);
     s.flash_m16 = env_int("SVI_FLASH_M16", 0, 1);

@@ -61,7 +61,7 @@ void svi_set_error(const char* fmt, ...);
 struct SviSwitches {
     int flash_kernel = 0;        // SVI_FLASH_KERNEL = 1 | 2 : force flash_fwd_kernel / flash_fwd2_kernel (0: by key count)
     int gemm_kernel = 0;         // SVI_GEMM_KERNEL = 128 | 192 | 259 | 260 : force the 128^2 kernel / the 256 x 192 tile / the 256^2 tile with four / two phases per K tile (0: by tile count)
-    int gemm_pf = 0;             // SVI_GEMM_PF = 1 | 4 : K tiles of loads the 128^2 kernel keeps in flight (0: 4 when the launch is at most one workgroup per CU)
+    int gemm_pf = 0;             // SVI_GEMM_PF = 1 | 4 | 8 : the 128^2 kernel's loop — 1 = one K tile of loads in flight, 4 = four, 8 = four on eight waves (0: 8 when the launch is at most one workgroup per CU, else 1)
     int gemm_gm = 0;             // SVI_GEMM_GM = n >= 1 : row panels per tile group (0: per shape)
     int vae_exact_fp32 = 0;      // SVI_VAE_EXACT_FP32 : fp32-MFMA convolution everywhere
     int vae_no_x2h = 0;          // SVI_VAE_X2H = 0 : the three-term bf16 convolution also where the two-term fp16 form applies (same parity bounds)

@@ -57,12 +57,21 @@ __device__ __forceinline__ void gemm_rowss_store(const SviGemmArgs& g, const bf1
 // workgroup per CU — the C1-size step, where M = 2560 rows make 240 tiles of a projection: a lone wave per SIMD covers only 512 cycles of matrix work per
 // K tile, a quarter of an L2 round trip, and the PF = 1 loop ran at that latency (1.2 us per K tile; ffn2 at C1: 169 us for 70 GFLOP).  Same MFMA and k
 // order in both: bit-identical.
-template <int PF>
-__global__ __launch_bounds__(256, PF == 1 ? 2 : 1) void gemm_bf16_nt_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
+#ifndef SVI_GEMM_DEEP_PF
+#define SVI_GEMM_DEEP_PF 4
+#endif
+// NT = 256: four waves as 2 x 2, 64 x 64 per wave.  NT = 512 (with PF = 4): eight waves as 2 x 4, 64 x 32 per wave — the same tile, the same LDS image, the same
+// k order per element (bit-identical), two waves per SIMD from ONE workgroup: while one waits for its fragments or its staging writes the other multiplies.
+template <int PF, int NT = 256>
+__global__ __launch_bounds__(NT, (PF == 1 && NT == 256) ? 2 : 1) void gemm_bf16_nt_kernel(SviGemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int WNC = NT / 128;           // wave columns (2 or 4)
+    constexpr int NBW = 8 / WNC;            // 16-column blocks per wave (4 or 2)
+    constexpr int LJ = 1024 / NT;           // 16-byte chunks of an operand tile per thread (4 or 2)
+    constexpr int LR = NT / 8;              // tile rows one pass of the staging assignment covers (32 or 64)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNC, wn = wave % WNC;
     const int l15 = lane & 15, g4 = lane >> 4;
 
     // XCD-aware, bijective remap of the linear workgroup id
@@ -77,28 +86,28 @@ __global__ __launch_bounds__(256, PF == 1 ? 2 : 1) void gemm_bf16_nt_kernel(SviG
         g.bias = g.bias2 ? g.bias2 - g.n_split : nullptr;
     }
 
-    // global -> register staging assignment: 1024 16-byte chunks per operand tile, 4 per thread
-    const int ld_row = tid >> 3;            // + 32*j
+    // global -> register staging assignment: 1024 16-byte chunks per operand tile, LJ per thread
+    const int ld_row = tid >> 3;            // + LR*j
     const int ld_chunk = tid & 7;
-    const bf16* a_ptr[4];
-    const bf16* w_ptr[4];
-    bool a_ok[4], w_ok[4];
+    const bf16* a_ptr[LJ];
+    const bf16* w_ptr[LJ];
+    bool a_ok[LJ], w_ok[LJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = ld_row + 32 * j;
+    for (int j = 0; j < LJ; ++j) {
+        const int r = ld_row + LR * j;
         a_ok[j] = (m0 + r) < g.M;
         w_ok[j] = (n0 + r) < g.N;
         a_ptr[j] = g.A + (size_t)(a_ok[j] ? (m0 + r) : 0) * g.lda + ld_chunk * 8;
         w_ptr[j] = g.W + (size_t)(w_ok[j] ? (n0 + r) : 0) * g.ldw + ld_chunk * 8;
     }
     const int nk = (g.K + BK - 1) / BK;
-    u32x4 ra[PF][4], rw[PF][4];
+    u32x4 ra[PF][LJ], rw[PF][LJ];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    auto load_tile = [&](u32x4 (&xa)[4], u32x4 (&xw)[4], int kt) {
+    auto load_tile = [&](u32x4 (&xa)[LJ], u32x4 (&xw)[LJ], int kt) {
         if constexpr (PF > 1) {          // K % 64 == 0 (the launcher's condition): no k tail, and a row past the edge reads row 0 (its results are never stored) —
 #pragma unroll                           // no predicate, no branch around a load: the compiler's vmcnt arithmetic keeps PF - 1 tiles in flight
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < LJ; ++j) {
                 xa[j] = *reinterpret_cast<const u32x4*>(a_ptr[j] + kt * BK);
                 xw[j] = *reinterpret_cast<const u32x4*>(w_ptr[j] + kt * BK);
             }
@@ -107,25 +116,25 @@ __global__ __launch_bounds__(256, PF == 1 ? 2 : 1) void gemm_bf16_nt_kernel(SviG
         const int kbase = kt * BK + ld_chunk * 8;
         const bool kin = kbase < g.K;          // K % 8 == 0: a chunk is entirely inside or outside
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < LJ; ++j) {
             xa[j] = (a_ok[j] && kin) ? *reinterpret_cast<const u32x4*>(a_ptr[j] + kt * BK) : zero4;
             xw[j] = (w_ok[j] && kin) ? *reinterpret_cast<const u32x4*>(w_ptr[j] + kt * BK) : zero4;
         }
     };
-    auto store_tile = [&](const u32x4 (&xa)[4], const u32x4 (&xw)[4], int buf) {
+    auto store_tile = [&](const u32x4 (&xa)[LJ], const u32x4 (&xw)[LJ], int buf) {
         char* As = smem + buf * 2 * STAGE_BYTES;
         char* Ws = As + STAGE_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int off = lds_tile_off(ld_row + 32 * j, ld_chunk);
+        for (int j = 0; j < LJ; ++j) {
+            const int off = lds_tile_off(ld_row + LR * j, ld_chunk);
             *reinterpret_cast<u32x4*>(As + off) = xa[j];
             *reinterpret_cast<u32x4*>(Ws + off) = xw[j];
         }
     };
 
-    f32x4 acc[4][4];                        // [nb][mb]: 16 x 16 blocks, lane l holds n = 4 (l >> 4) + e of row m = l & 15
+    f32x4 acc[NBW][4];                      // [nb][mb]: 16 x 16 blocks, lane l holds n = 4 (l >> 4) + e of row m = l & 15
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NBW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -137,21 +146,20 @@ __global__ __launch_bounds__(256, PF == 1 ? 2 : 1) void gemm_bf16_nt_kernel(SviG
     __syncthreads();
 
     // one K tile: slot s of the ring held tile kt (in LDS since the step before; tile 0: the prologue) and takes tile kt + PF; tile kt + 1 moves to LDS behind the MFMAs
-    auto kstep = [&](u32x4 (&la)[4], u32x4 (&lw)[4], const u32x4 (&sa)[4], const u32x4 (&sw_)[4], int kt, bool ld, bool st) {
+    auto kstep = [&](u32x4 (&la)[LJ], u32x4 (&lw)[LJ], const u32x4 (&sa)[LJ], const u32x4 (&sw_)[LJ], int kt, bool ld, bool st) {
         const int cur = kt & 1;
         if (ld) load_tile(la, lw, kt + PF);
         const char* As = smem + cur * 2 * STAGE_BYTES;
         const char* Ws = As + STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {          // two k-steps of 32: lane group g4 holds k = 8 g4 .. 8 g4 + 7 of the step
-            bf16x8 xa[4], wb[4];
+            bf16x8 xa[4], wb[NBW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xa[i] = *reinterpret_cast<const bf16x8*>(As + lds_tile_off(wm * 64 + i * 16 + l15, 4 * kk + g4));
-                wb[i] = *reinterpret_cast<const bf16x8*>(Ws + lds_tile_off(wn * 64 + i * 16 + l15, 4 * kk + g4));
-            }
+            for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(As + lds_tile_off(wm * 64 + i * 16 + l15, 4 * kk + g4));
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int i = 0; i < NBW; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(Ws + lds_tile_off(wn * (16 * NBW) + i * 16 + l15, 4 * kk + g4));
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
                     acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nb], xa[mb], acc[nb][mb], 0, 0, 0);
@@ -175,11 +183,11 @@ __global__ __launch_bounds__(256, PF == 1 ? 2 : 1) void gemm_bf16_nt_kernel(SviG
     }
 
     // ---- epilogue part 1: y = bf16(acc + bias) -> LDS [128 m][CS_LD] bf16 --------------------------
-    // acc[nb][mb][e] is C[m = m0 + wm*64 + mb*16 + l15][n = n0 + wn*64 + nb*16 + 4*g4 + e]
+    // acc[nb][mb][e] is C[m = m0 + wm*64 + mb*16 + l15][n = n0 + wn*(16 NBW) + nb*16 + 4*g4 + e]
     bf16* Cs = reinterpret_cast<bf16*>(smem);
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int nl = wn * 64 + nb * 16 + 4 * g4;
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int nl = wn * (16 * NBW) + nb * 16 + 4 * g4;
         float bn[4] = {0.f, 0.f, 0.f, 0.f};
         if (g.bias && !g.bias_along_m) {
 #pragma unroll
@@ -200,8 +208,8 @@ __global__ __launch_bounds__(256, PF == 1 ? 2 : 1) void gemm_bf16_nt_kernel(SviG
 
     // ---- epilogue part 2: row-contiguous read-back, activation / gate / residual, coalesced store ----
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int id = tid + 256 * it;
+    for (int it = 0; it < 2048 / NT; ++it) {
+        const int id = tid + NT * it;
         const int ml = id >> 4, cc = id & 15;
         const int m = m0 + ml, n = n0 + cc * 8;
         if (m >= g.M || n >= g.N) continue;
@@ -1574,13 +1582,18 @@ svi_status svi_launch_gemm(const SviGemmArgs& g, hipStream_t st) {
     }
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     // at most one workgroup per CU (the C1-size step's projections: 240 tiles): the loop with four K tiles of loads in flight; SVI_GEMM_PF = 1 | 4 forces one
-    const bool deep = g.K % BK == 0 && g.K >= 4 * BK && (sw.gemm_pf ? sw.gemm_pf > 1 : (long)tiles_m * tiles_n <= gemm_device_cus());
+    const bool deep = g.K % BK == 0 && g.K >= SVI_GEMM_DEEP_PF * BK && (sw.gemm_pf ? sw.gemm_pf > 1 : (long)tiles_m * tiles_n <= gemm_device_cus());
     if (deep) {
-        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<4>), 4 * STAGE_BYTES));
-        hipLaunchKernelGGL(gemm_bf16_nt_kernel<4>, dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m, tiles_n);
+        if (sw.gemm_pf == 4) {          // (A/B: the four-wave form of the deep loop)
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<SVI_GEMM_DEEP_PF>), 4 * STAGE_BYTES));
+            hipLaunchKernelGGL(gemm_bf16_nt_kernel<SVI_GEMM_DEEP_PF>, dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m, tiles_n);
+        } else {
+            SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>((gemm_bf16_nt_kernel<SVI_GEMM_DEEP_PF, 512>)), 4 * STAGE_BYTES));
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<SVI_GEMM_DEEP_PF, 512>), dim3(tiles_m * tiles_n), dim3(512), 4 * STAGE_BYTES, st, g, tiles_m, tiles_n);
+        }
     } else {
-        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<1>), 4 * STAGE_BYTES));
-        hipLaunchKernelGGL(gemm_bf16_nt_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m, tiles_n);
+        SVI_TRY(svi_ensure_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<1, 256>), 4 * STAGE_BYTES));
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 256>), dim3(tiles_m * tiles_n), dim3(256), 4 * STAGE_BYTES, st, g, tiles_m, tiles_n);
     }
     SVI_LAUNCH_CHECK();
     return SVI_OK;

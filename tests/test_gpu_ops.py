@@ -131,9 +131,9 @@ def test_gemm_tile_256x192_bit_identical(hip, M, N, K, epi):
     (2560, 1536, 8960, "gate_res"), (2560, 1536, 1536, "bias"), (1283, 1536, 1536, "gate_res"), (1280, 1000, 256, "gelu_tanh"), (640, 3072, 320, "bias"),
     (1536, 2560, 1536, "transposed"), (300, 200, 448, "bias")])
 def test_gemm_128_tile_deep_prefetch_bit_identical(hip, M, N, K, epi):
-    """The 128^2 kernel with four K tiles of loads in flight (what a launch of at most one workgroup per CU takes: the C1-size step's projections, 240 tiles
-    of M = 2560 stacked rows) against the same kernel with one (SVI_GEMM_PF = 4 / 1, both forced onto the 128^2 tile): same MFMA and k order, so the same
-    bits — K of 4 (no steady-state iteration), 5, 7, 24 and 140 tiles, ragged row and column edges, every epilogue of the block; and against fp64."""
+    """The 128^2 kernel with four K tiles of loads in flight, on four waves and on eight (64 x 32 per wave, two per SIMD: what a launch of at most one
+    workgroup per CU takes — the C1-size step's projections, 240 tiles of M = 2560 stacked rows) against the same kernel with one (SVI_GEMM_PF = 4 / 8 / 1,
+    all forced onto the 128^2 tile): same k order per element, so the same bits — K of 4 (no steady-state iteration), 5, 7, 24 and 140 tiles, ragged row and column edges, every epilogue of the block; and against fp64."""
     L = hip._lib
     x = dev(synth.randn(41, M, K)); w = dev(synth.randn(42, N, K) / math.sqrt(K))
     b = dev(synth.randn(43, N))
@@ -145,16 +145,16 @@ def test_gemm_128_tile_deep_prefetch_bit_identical(hip, M, N, K, epi):
     outs = {}
     try:
         L.set_switch("SVI_GEMM_KERNEL", 128)
-        for pf in (1, 4):
+        for pf in (1, 4, 8):
             L.set_switch("SVI_GEMM_PF", pf)
             outs[pf] = hip.linear(x, w, b, transpose_out=True)[:, :M].clone() if epi == "transposed" else hip.linear(x, w, b, **kw)
     finally:
         L.set_switch("SVI_GEMM_KERNEL", None)
         L.set_switch("SVI_GEMM_PF", None)
-    assert torch.equal(outs[4], outs[1])
+    assert torch.equal(outs[4], outs[1]) and torch.equal(outs[8], outs[1])
     if epi == "bias":
         want = (x.double().cpu() @ w.double().cpu().t() + b.double().cpu()).float()
-        r, mx, _ = errs(outs[4], want)
+        r, mx, _ = errs(outs[8], want)
         report("gemm_128_deep_prefetch", M=M, N=N, K=K, rel_l2=r, max_abs=mx)
         assert r < 4e-3, r
 
