@@ -77,7 +77,7 @@ int32_t svi_abi_version(void);
 /* Number of visible HIP devices (0 => every compute entry point will fail with SVI_ERR_HIP). */
 int32_t svi_device_count(void);
 
-/* A/B tooling: the library reads its environment switches (SVI_FLASH_KERNEL, SVI_FLASH_TWO_PASS, SVI_FLASH_M16, SVI_FLASH_SPLIT, SVI_GEMM_KERNEL, SVI_GEMM_GM,
+/* A/B tooling: the library reads its environment switches (SVI_FLASH_KERNEL, SVI_FLASH_TWO_PASS, SVI_FLASH_M16, SVI_FLASH_SPLIT, SVI_GEMM_KERNEL, SVI_GEMM_GM, SVI_GEMM_PF,
  * SVI_CROSS_DEDUP, SVI_CROSS_FUSED, SVI_RMS_ROWS, SVI_QK_FUSED, SVI_MX8_FUSED, SVI_QK8_FUSED, SVI_VAE_EXACT_FP32, SVI_VAE_X2H, SVI_VAE_DMA, SVI_VAE_UP_PHASES, SVI_VAE_TILE_ORDER, SVI_VAE_PAIR, SVI_T5_BUCKETS — all of them select between kernels that
  * compute the same result, bit for bit or within the stated parity bounds — and SVI_WS_LIMIT_MB, a budget in MiB beyond which a DiT workspace is refused with
  * SVI_ERR_OOM as if the allocation had failed (callers that share the device; the stacked CFG pair then falls back to its unstacked form, same bits);
