@@ -69,6 +69,12 @@ def test_hot_kernels_have_no_scratch_and_fit_their_occupancy(tmp_path):
         assert v["vgpr_count"] <= 256 and v["group_segment_fixed_size"] == 0, (k, v)          # two waves per SIMD; LDS is dynamic (128 KiB + the mask table)
     for k, v in family("gemm_bf16_nt_256e_kernel<").items():
         assert v["vgpr_count"] <= 256, (k, v)
+    # round 6: the 128^2 tile's loops — <1, 256> shares a SIMD with a second workgroup, <4, 512> (the C1-size step's projections: at most one workgroup per CU)
+    # brings its own second wave per SIMD, <4, 256> (A/B only) owns the file
+    g128 = family("gemm_bf16_nt_kernel<")
+    assert {re.sub(r"\s", "", k) for k in g128} >= {"gemm_bf16_nt_kernel<1,256>", "gemm_bf16_nt_kernel<4,256>", "gemm_bf16_nt_kernel<4,512>"}, sorted(g128)
+    for k, v in g128.items():
+        assert v["vgpr_count"] <= (512 if re.sub(r"\s", "", k).endswith("<4,256>") else 256), (k, v)
     for k, v in main_pass.items():
         assert 256 < v["vgpr_count"] <= 512, (k, v)                                             # one wave per SIMD, by design
     other_passes = {k: v for k, v in family("flash_fwd2_kernel<").items() if k not in main_pass}
