@@ -6,12 +6,14 @@ import torch
 import svi_hip as hip
 L = hip._lib
 label = sys.argv[1] if len(sys.argv) > 1 else os.environ.get("SVI_HIP_LIB", "default")
+M0 = int(os.environ.get("PROBE_M", "2560"))          # PROBE_M=65520: the C2-size stacked pair (tools/patches/gemm256_loop_ablation.patch builds are timed with it)
 shapes = [("ffn2", 2560, 1536, 8960, L.EPI_BIAS_GATE_RES), ("attn_out", 2560, 1536, 1536, L.EPI_BIAS_GATE_RES), ("q", 2560, 1536, 1536, L.EPI_BIAS),
           ("ffn1", 2560, 8960, 1536, L.EPI_BIAS_GELU_TANH), ("qk480", 2560, 3072, 1536, L.EPI_BIAS), ("t720", 2560, 4608, 1536, L.EPI_BIAS)]
 if os.environ.get("SVI_GEMM_KERNEL"):
     shapes = [s for s in shapes if s[0] != "ffn1"] + [("ffn1_128", 2560, 8960, 1536, L.EPI_BIAS_GELU_TANH)]
 row = []
 for name, M, N, K, epi in shapes:
+    M = M0
     g = torch.Generator().manual_seed(1)
     x = torch.randn(M, K, generator=g).bfloat16().cuda(); w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().cuda(); b = torch.randn(N, generator=g).bfloat16().cuda()
     kw = dict(epilogue=epi)
@@ -21,7 +23,7 @@ for name, M, N, K, epi in shapes:
         hip.linear(x, w, b, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 50
+    n = 50 if M0 <= 4096 else 10
     e0.record()
     for _ in range(n):
         hip.linear(x, w, b, **kw)
