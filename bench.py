@@ -58,6 +58,8 @@ for p in (ROOT, os.path.join(ROOT, "stable-video-infinity_amd"), os.path.join(RO
         sys.path.insert(0, p)
 
 T_PROCESS_START = time.perf_counter()      # --budget-s and config.wall_s count from here (the interpreter's own start-up is ahead of it)
+# the pool's host driver only supports dmabuf IPC: RCCL between processes needs this before the HSA runtime starts (a launcher that did not export it, e.g. a bare torchrun)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 WORKLOADS = {
